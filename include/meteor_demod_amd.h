@@ -1,0 +1,228 @@
+/*
+ * meteor_demod_amd.h — C-ABI of the MI355X-native LRPT demodulator.
+ *
+ * Drop-in boundary for ONE path of dbdexter-dev/meteor_demod: IQ samples in ->
+ * 8-bit soft QPSK/OQPSK symbols out.  Citations are reference file:line.
+ *
+ * The reference's seam is a per-sample function pointer
+ *     int (*demod)(float complex *sample)            main.c:22-29,72,104,304
+ * bound to demod_qpsk (demod.c:24) or demod_oqpsk (demod.c:51) and configured by
+ *     void demod_init(float pll_bw, float sym_bw, int samplerate, int symrate,
+ *                     int interp_factor, int rrc_order, int oqpsk,
+ *                     float freq_max)                 demod.h:29, demod.c:8-15
+ * with state in file-static globals.  A GPU needs batches and explicit state, so
+ * the same seam is exported here as a context object that demodulates BLOCKS of
+ * samples for N independent streams (recordings, or tiles of one recording):
+ *
+ *   reference                                  this library
+ *   ---------                                  ------------
+ *   demod_init(...)            demod.h:29      mdemod_create(&params, &ctx)
+ *   demod_deinit()             demod.h:34      mdemod_destroy(ctx)
+ *   demod_qpsk / demod_oqpsk   demod.h:42,50   mdemod_process_device[_uniform], mdemod_process_host
+ *   ring quantise  main.c:305-306              done on device: soft = int8 I,Q pairs
+ *   pll_get_freq / pll_get_locked /
+ *   pll_did_lock_once          pll.h:20,27,34  mdemod_status.{pll_freq,locked,locked_once}
+ *   mm_omega                   timing.h:32     mdemod_status.omega
+ *   agc_get_gain               agc.h:18        mdemod_status.gain
+ *   lock gating    main.c:312                  mdemod_status.first_lock_symbol + lock events
+ *
+ * Results are bit-identical, stream by stream, to the reference compiled with
+ * -ffp-contract=off (the only compiler-independent build of it).
+ * State persists in the context between calls exactly as the reference's
+ * globals persist between per-sample calls, so feeding a recording in blocks of
+ * any size gives the same bytes as feeding it in one call.
+ *
+ * Plain C: pointers and sizes only.  Device pointers are raw HIP device
+ * addresses; `hip_stream` is a hipStream_t passed as void* (NULL = default).
+ * There is no CPU fallback: every entry fails with MDEMOD_ERR_HIP if no gfx950
+ * device / kernel image is available.
+ */
+#ifndef METEOR_DEMOD_AMD_H
+#define METEOR_DEMOD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDEMOD_ABI_VERSION 1
+
+/* Error codes (the reference surfaces none: demod_init returns void and drops
+ * filter_init_rrc's status, demod.c:14). */
+enum {
+	MDEMOD_OK            =  0,
+	MDEMOD_ERR_PARAM     = -1,   /* bad argument / unsupported configuration */
+	MDEMOD_ERR_NOMEM     = -2,   /* host or device allocation failed         */
+	MDEMOD_ERR_HIP       = -3,   /* HIP runtime / launch failure             */
+	MDEMOD_ERR_OVERFLOW  = -4,   /* soft-symbol capacity too small           */
+	MDEMOD_ERR_RANGE     = -5    /* stream index out of range                */
+};
+
+/* Defaults of the reference CLI (demod.h:8-15). */
+#define MDEMOD_DEFAULT_SYM_RATE   72000
+#define MDEMOD_DEFAULT_RRC_ORDER  32
+#define MDEMOD_DEFAULT_INTERP     5
+#define MDEMOD_DEFAULT_SYM_BW     0.00005f
+#define MDEMOD_DEFAULT_PLL_BW     1.0f
+
+typedef struct mdemod_ctx mdemod_ctx;
+
+/* The eight demod_init arguments (same meaning, same order: demod.h:17-29),
+ * plus what the GPU boundary needs in addition. */
+typedef struct {
+	float    pll_bw;        /* -b  carrier loop bandwidth                (main.c:88)  */
+	float    sym_bw;        /* SYM_BW, fixed 5e-5 upstream               (main.c:187) */
+	int32_t  samplerate;    /* -s / WAV header                           (main.c:121) */
+	int32_t  symrate;       /* -r                                        (main.c:118) */
+	int32_t  interp_factor; /* -O                                        (main.c:109) */
+	int32_t  rrc_order;     /* -f  (taps = 2*order+1)                    (main.c:97)  */
+	int32_t  oqpsk;         /* -m oqpsk                                  (main.c:103) */
+	float    freq_max;      /* -d already scaled by 2*pi/symrate (main.c:136);
+	                           negative selects the 0.3 default (pll.c:31)            */
+	int32_t  bps;           /* input format: 8 (u8 offset-128), 16 (s16), 32 (f32):
+	                           wavfile.c:58-69                                        */
+	int32_t  device;        /* HIP device ordinal                                     */
+	uint32_t n_streams;     /* independent streams held by this context               */
+	uint32_t reserved;
+} mdemod_params;
+
+/* Value snapshot of one stream after a call (replaces the reference's racy
+ * getters polled from the UI thread, main.c:231-237,250-258). */
+typedef struct {
+	uint64_t n_samples;          /* samples consumed since create/reset           */
+	uint64_t n_symbols;          /* symbols emitted since create/reset            */
+	int64_t  first_lock_symbol;  /* symbol whose PLL update set locked_once; -1   */
+	uint32_t symbols_this_call;  /* symbols written to soft by the last call      */
+	uint32_t lock_events_this_call; /* lock transitions in the last call (may
+	                                exceed MDEMOD_MAX_LOCK_EVENTS; extra dropped) */
+	float    pll_freq;           /* pll_get_freq()      rad/symbol                */
+	float    omega;              /* mm_omega()          rad/interpolated sample   */
+	float    gain;               /* agc_get_gain()                                */
+	int32_t  locked;             /* pll_get_locked()                              */
+	int32_t  locked_once;        /* pll_did_lock_once()                           */
+	int32_t  overflow;           /* 1 if soft capacity was exceeded (symbols past
+	                                the capacity are dropped, state still advances)*/
+} mdemod_status;
+
+#define MDEMOD_MAX_LOCK_EVENTS 32
+typedef struct {
+	uint64_t symbol;             /* absolute symbol index of the transition       */
+	int32_t  locked;             /* new lock state                                */
+	int32_t  pad;
+} mdemod_lock_event;
+
+/* Complete loop state of one stream, for chaining tiles, seeding
+ * tiles with converged state, checkpoints and tests.  History is exchanged
+ * separately (mdemod_get_history / mdemod_set_history). */
+typedef struct {
+	float    agc_gain, agc_bias_re, agc_bias_im;      /* agc.c:9-10              */
+	float    pll_phase, pll_freq, pll_err;            /* pll.c:16,20             */
+	int32_t  pll_locked, pll_locked_once, pll_updown; /* pll.c:20,112            */
+	float    t_phase, t_freq, t_prev;                 /* timing.c:13-14          */
+	int32_t  t_dual_state;                            /* timing.c:43             */
+	float    oqpsk_inphase;                           /* demod.c:54              */
+	uint64_t n_samples, n_symbols;
+	int64_t  first_lock_symbol;
+} mdemod_stream_state;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+
+uint32_t mdemod_abi_version(void);
+const char *mdemod_strerror(int code);
+
+/* Replaces demod_init (demod.c:8-15).  Derives loop constants, RRC taps and the
+ * tanh LUT on the host with the reference's exact mixed float/double
+ * expressions, uploads them, allocates per-stream state. */
+int  mdemod_create(const mdemod_params *params, mdemod_ctx **out);
+/* Replaces demod_deinit (demod.c:18-21). */
+void mdemod_destroy(mdemod_ctx *ctx);
+/* Put every stream back into the reference's power-on state. */
+int  mdemod_reset(mdemod_ctx *ctx, void *hip_stream);
+
+/* Soft-symbol capacity (in SYMBOLS) that is always enough for n input samples. */
+uint64_t mdemod_max_symbols(const mdemod_ctx *ctx, uint64_t n_samples);
+
+/* ---- the hot path (replaces the main.c:303-306 loop body) ---------------- */
+
+/*
+ * All streams share one layout: stream s reads n_samples IQ samples starting at
+ * iq_dev + s*iq_stride_samples (in units of one IQ sample) and writes its int8
+ * I,Q pairs at soft_dev + s*soft_stride_symbols*2.  Asynchronous on hip_stream.
+ */
+int  mdemod_process_device_uniform(mdemod_ctx *ctx,
+                                   const void *iq_dev, uint64_t iq_stride_samples,
+                                   uint32_t n_samples,
+                                   int8_t *soft_dev, uint64_t soft_stride_symbols,
+                                   uint32_t soft_cap_symbols,
+                                   void *hip_stream);
+
+/*
+ * Ragged batch: per-stream sample offsets (from iq_dev, in IQ samples) and
+ * counts, both arrays of n_streams entries in DEVICE memory.  count 0 is legal.
+ */
+int  mdemod_process_device(mdemod_ctx *ctx,
+                           const void *iq_dev,
+                           const uint64_t *iq_offset_dev, const uint32_t *n_samples_dev,
+                           int8_t *soft_dev, uint64_t soft_stride_symbols,
+                           uint32_t soft_cap_symbols,
+                           void *hip_stream);
+
+/*
+ * Host-buffer convenience (PCIe inclusive, synchronous): iq_host[s] points at
+ * n_samples[s] IQ samples of stream s; soft_host[s] receives up to soft_cap[s]
+ * symbols (2 bytes each); n_symbols[s] is set to the number produced.
+ */
+int  mdemod_process_host(mdemod_ctx *ctx,
+                         const void *const *iq_host, const uint32_t *n_samples,
+                         int8_t *const *soft_host, const uint32_t *soft_cap,
+                         uint32_t *n_symbols);
+
+/* ---- status / state (synchronise with the last call on hip_stream first) -- */
+
+int  mdemod_get_status(mdemod_ctx *ctx, uint32_t first, uint32_t count,
+                       mdemod_status *out, void *hip_stream);
+int  mdemod_get_lock_events(mdemod_ctx *ctx, uint32_t stream,
+                            mdemod_lock_event *out, uint32_t cap, uint32_t *n,
+                            void *hip_stream);
+int  mdemod_get_state(mdemod_ctx *ctx, uint32_t stream, mdemod_stream_state *out,
+                      void *hip_stream);
+int  mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in,
+                      void *hip_stream);
+/* Filter history: the last mdemod_history_len() input samples, oldest first,
+ * as float I,Q pairs (filter.h:6). */
+uint32_t mdemod_history_len(const mdemod_ctx *ctx);
+int  mdemod_get_history(mdemod_ctx *ctx, uint32_t stream, float *iq_pairs, void *hip_stream);
+int  mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs, void *hip_stream);
+
+/* ---- init-time tables, exposed for known-answer tests -------------------- */
+
+/* Host-only: derive the init-time tables for `params` without touching a device
+ * (what demod_init computes through pll_init / timing_init / filter_init_rrc).
+ * rrc_out (may be NULL) receives interp*taps floats, consts_out the 8 loop
+ * constants (order below), lut_out the 32-entry tanh LUT.  Returns the number
+ * of RRC floats, or <0. */
+int  mdemod_derive_tables(const mdemod_params *params, float *rrc_out, uint32_t rrc_cap,
+                          float consts_out[8], float lut_out[32]);
+
+/* RRC polyphase table as filter_init_rrc lays it out (filter.c:18-22):
+ * interp*taps floats, bank-major.  Returns number of floats, or <0. */
+int  mdemod_get_rrc_table(const mdemod_ctx *ctx, float *out, uint32_t cap);
+/* Derived loop constants in the order:
+ * pll_alpha, pll_beta, pll_fmax, t_alpha, t_beta, t_center, t_maxdev, osf */
+int  mdemod_get_loop_constants(const mdemod_ctx *ctx, float out[8]);
+/* tanh LUT (pll.c:40-42), 32 floats. */
+int  mdemod_get_tanh_lut(const mdemod_ctx *ctx, float out[32]);
+
+/* Device self-test of the scalar primitives (fixed-point sine, hypot, wrap):
+ * evaluates them on `n` inputs on the GPU.  x: n floats in; sin_out/cos_out: n
+ * floats each; for hypot: pairs (x[2i], x[2i+1]) -> n/2 results in sin_out. */
+int  mdemod_selftest_sincos(mdemod_ctx *ctx, const float *x, uint32_t n,
+                            float *sin_out, float *cos_out);
+int  mdemod_selftest_hypot(mdemod_ctx *ctx, const float *xy, uint32_t n_pairs, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

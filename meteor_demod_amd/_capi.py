@@ -1,0 +1,125 @@
+"""ctypes binding of include/meteor_demod_amd.h (the C-ABI shared library).
+
+Loading fails loudly if the library has not been built: there is no Python or
+CPU implementation of the demodulator to fall back to.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_DIR = Path(__file__).resolve().parent / "lib"
+LIB_PATH = LIB_DIR / "libmeteor_demod_amd.so"
+
+MDEMOD_OK = 0
+MDEMOD_ERR_PARAM = -1
+MDEMOD_ERR_NOMEM = -2
+MDEMOD_ERR_HIP = -3
+MDEMOD_ERR_OVERFLOW = -4
+MDEMOD_ERR_RANGE = -5
+MDEMOD_MAX_LOCK_EVENTS = 32
+
+
+class MdemodParams(C.Structure):
+    _fields_ = [
+        ("pll_bw", C.c_float), ("sym_bw", C.c_float),
+        ("samplerate", C.c_int32), ("symrate", C.c_int32),
+        ("interp_factor", C.c_int32), ("rrc_order", C.c_int32),
+        ("oqpsk", C.c_int32), ("freq_max", C.c_float),
+        ("bps", C.c_int32), ("device", C.c_int32),
+        ("n_streams", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class MdemodStatus(C.Structure):
+    _fields_ = [
+        ("n_samples", C.c_uint64), ("n_symbols", C.c_uint64),
+        ("first_lock_symbol", C.c_int64),
+        ("symbols_this_call", C.c_uint32), ("lock_events_this_call", C.c_uint32),
+        ("pll_freq", C.c_float), ("omega", C.c_float), ("gain", C.c_float),
+        ("locked", C.c_int32), ("locked_once", C.c_int32), ("overflow", C.c_int32),
+    ]
+
+
+class MdemodLockEvent(C.Structure):
+    _fields_ = [("symbol", C.c_uint64), ("locked", C.c_int32), ("pad", C.c_int32)]
+
+
+class MdemodStreamState(C.Structure):
+    _fields_ = [
+        ("agc_gain", C.c_float), ("agc_bias_re", C.c_float), ("agc_bias_im", C.c_float),
+        ("pll_phase", C.c_float), ("pll_freq", C.c_float), ("pll_err", C.c_float),
+        ("pll_locked", C.c_int32), ("pll_locked_once", C.c_int32), ("pll_updown", C.c_int32),
+        ("t_phase", C.c_float), ("t_freq", C.c_float), ("t_prev", C.c_float),
+        ("t_dual_state", C.c_int32), ("oqpsk_inphase", C.c_float),
+        ("n_samples", C.c_uint64), ("n_symbols", C.c_uint64),
+        ("first_lock_symbol", C.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what the symbol-export test walks.
+_P = C.POINTER
+SIGNATURES = {
+    "mdemod_abi_version": (C.c_uint32, []),
+    "mdemod_strerror": (C.c_char_p, [C.c_int]),
+    "mdemod_create": (C.c_int, [_P(MdemodParams), _P(C.c_void_p)]),
+    "mdemod_destroy": (None, [C.c_void_p]),
+    "mdemod_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mdemod_max_symbols": (C.c_uint64, [C.c_void_p, C.c_uint64]),
+    "mdemod_process_device_uniform": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                                C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "mdemod_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "mdemod_process_host": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_uint32),
+                                      _P(C.c_void_p), _P(C.c_uint32), _P(C.c_uint32)]),
+    "mdemod_get_status": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(MdemodStatus), C.c_void_p]),
+    "mdemod_get_lock_events": (C.c_int, [C.c_void_p, C.c_uint32, _P(MdemodLockEvent), C.c_uint32,
+                                         _P(C.c_uint32), C.c_void_p]),
+    "mdemod_get_state": (C.c_int, [C.c_void_p, C.c_uint32, _P(MdemodStreamState), C.c_void_p]),
+    "mdemod_set_state": (C.c_int, [C.c_void_p, C.c_uint32, _P(MdemodStreamState), C.c_void_p]),
+    "mdemod_history_len": (C.c_uint32, [C.c_void_p]),
+    "mdemod_get_history": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_float), C.c_void_p]),
+    "mdemod_set_history": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_float), C.c_void_p]),
+    "mdemod_derive_tables": (C.c_int, [_P(MdemodParams), _P(C.c_float), C.c_uint32,
+                                       _P(C.c_float), _P(C.c_float)]),
+    "mdemod_get_rrc_table": (C.c_int, [C.c_void_p, _P(C.c_float), C.c_uint32]),
+    "mdemod_get_loop_constants": (C.c_int, [C.c_void_p, _P(C.c_float)]),
+    "mdemod_get_tanh_lut": (C.c_int, [C.c_void_p, _P(C.c_float)]),
+    "mdemod_selftest_sincos": (C.c_int, [C.c_void_p, _P(C.c_float), C.c_uint32, _P(C.c_float), _P(C.c_float)]),
+    "mdemod_selftest_hypot": (C.c_int, [C.c_void_p, _P(C.c_float), C.c_uint32, _P(C.c_float)]),
+}
+
+_lib = None
+
+
+class MdemodError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        self.code = code
+        super().__init__(f"{what}: error {code} ({strerror(code)})")
+
+
+def lib() -> C.CDLL:
+    """The loaded C-ABI library; raises if the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -m meteor_demod_amd.build). There is no CPU fallback.")
+        handle = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def strerror(code: int) -> str:
+    return lib().mdemod_strerror(code).decode()
+
+
+def check(code: int, what: str) -> int:
+    if code < 0:
+        raise MdemodError(code, what)
+    return code

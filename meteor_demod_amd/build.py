@@ -1,0 +1,94 @@
+"""Builds the native pieces IN-TREE with hipcc for gfx950.
+
+    meteor_demod_amd/lib/libmeteor_demod_amd.so   the product: HIP kernels + C-ABI
+    meteor_demod_amd/lib/libmdemod_synth.so       synthetic IQ generator (host + device)
+    meteor_demod_amd/lib/meteor_demod_amd         the C host CLI (drop-in for the reference's main.c)
+
+The oracle (test infrastructure) is built separately by oracle/Makefile; this
+module never touches it.  `python -m meteor_demod_amd.build` rebuilds everything.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIB = PKG / "lib"
+ARCH = "gfx950"
+
+# -ffp-contract=off is part of the numerical specification: the
+# reference's output is only reproducible without FMA contraction.
+COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
+          f"--offload-arch={ARCH}", f"-I{ROOT / 'include'}"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def _stale(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def _run(cmd: list[str]) -> None:
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout + proc.stderr)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+
+
+def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
+    LIB.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    headers = sorted(CSRC.glob("*.h")) + [ROOT / "include" / "meteor_demod_amd.h"]
+    out: dict[str, Path] = {}
+
+    # --- product library ---------------------------------------------------
+    srcs = [CSRC / "demod_kernel.hip", CSRC / "demod_aux.hip", CSRC / "demod_api.cpp", CSRC / "demod_host.cpp"]
+    objs = []
+    for src in srcs:
+        obj = LIB / (src.stem + ".o")
+        if force or _stale(obj, [src] + headers):
+            if verbose:
+                print("hipcc", src.name, flush=True)
+            _run([hipcc, *COMMON, "-x", "hip", "-c", str(src), "-o", str(obj)])
+        objs.append(obj)
+    so = LIB / "libmeteor_demod_amd.so"
+    if force or _stale(so, objs):
+        _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(so), *map(str, objs)])
+    out["lib"] = so
+
+    # --- synthetic signal generator -----------------------------------------
+    synth = LIB / "libmdemod_synth.so"
+    if force or _stale(synth, [CSRC / "synth.hip", CSRC / "synth_core.h"]):
+        if verbose:
+            print("hipcc synth.hip", flush=True)
+        _run([hipcc, *COMMON, "-shared", str(CSRC / "synth.hip"), "-o", str(synth)])
+    out["synth"] = synth
+
+    # --- C host CLI -----------------------------------------------------------
+    host_src = ROOT / "host" / "meteor_demod_amd.c"
+    if host_src.exists():
+        exe = LIB / "meteor_demod_amd"
+        if force or _stale(exe, [host_src, ROOT / "include" / "meteor_demod_amd.h", so]):
+            cc = shutil.which("gcc") or shutil.which("cc")
+            _run([cc, "-std=gnu11", "-O2", "-Wall", f"-I{ROOT / 'include'}", str(host_src), "-o", str(exe),
+                  f"-L{LIB}", "-lmeteor_demod_amd", f"-Wl,-rpath,$ORIGIN", "-lm"])
+        out["cli"] = exe
+    return out
+
+
+if __name__ == "__main__":
+    for k, v in build(force="--force" in sys.argv, verbose=True).items():
+        print(f"{k}: {v}")

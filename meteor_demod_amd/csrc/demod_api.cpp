@@ -1,0 +1,583 @@
+/*
+ * demod_api.cpp — implementation of the C-ABI declared in
+ * include/meteor_demod_amd.h: context lifecycle, device buffers, launches.
+ * There is no CPU fallback anywhere in this file: without a HIP device every
+ * entry that needs one returns MDEMOD_ERR_HIP.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "demod_host.h"
+#include "demod_internal.h"
+
+struct mdemod_ctx {
+	mdemod_params params;
+	HostTables    tab;
+	int           block_threads;
+	size_t        lds_bytes;
+	size_t        sample_bytes;
+
+	/* device */
+	DemodStateSoA st;
+	float        *d_ctab;
+	float        *d_lut;
+	std::vector<void *> allocs;
+
+	/* host-buffer path staging (grow only) */
+	void   *d_iq;      size_t d_iq_bytes;
+	int8_t *d_soft;    size_t d_soft_bytes;
+	uint64_t *d_off;   uint32_t *d_cnt;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                   \
+	do {                                                                                \
+		hipError_t e_ = (expr);                                                         \
+		if (e_ != hipSuccess) {                                                         \
+			fprintf(stderr, "meteor_demod_amd: %s failed: %s (%s:%d)\n", #expr,         \
+			        hipGetErrorString(e_), __FILE__, __LINE__);                         \
+			return e_ == hipErrorOutOfMemory ? MDEMOD_ERR_NOMEM : MDEMOD_ERR_HIP;       \
+		}                                                                               \
+	} while (0)
+
+template <typename T>
+int
+dev_alloc(mdemod_ctx *ctx, T **ptr, size_t count)
+{
+	void *p = nullptr;
+	HIP_TRY(hipMalloc(&p, count * sizeof(T) + 16));
+	ctx->allocs.push_back(p);
+	*ptr = static_cast<T *>(p);
+	return MDEMOD_OK;
+}
+
+template <typename T>
+int
+fetch(const T *dev, uint32_t first, uint32_t count, std::vector<T> &host, hipStream_t st)
+{
+	host.resize(count);
+	HIP_TRY(hipMemcpyAsync(host.data(), dev + first, sizeof(T) * count, hipMemcpyDeviceToHost, st));
+	return MDEMOD_OK;
+}
+
+int
+env_int(const char *name, int dflt)
+{
+	const char *v = getenv(name);
+	return (v && *v) ? atoi(v) : dflt;
+}
+
+int
+select_device(const mdemod_ctx *ctx)
+{
+	HIP_TRY(hipSetDevice(ctx->params.device));
+	return MDEMOD_OK;
+}
+
+int
+launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
+{
+	L.c = ctx->tab.c;
+	L.st = ctx->st;
+	L.n_streams = ctx->params.n_streams;
+	L.ctab = ctx->d_ctab;
+	L.ctab_floats = static_cast<uint32_t>(ctx->tab.ctab.size());
+	L.tanh_lut = ctx->d_lut;
+	HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->lds_bytes, stream));
+	return MDEMOD_OK;
+}
+
+} /* namespace */
+
+extern "C" {
+
+uint32_t
+mdemod_abi_version(void)
+{
+	return MDEMOD_ABI_VERSION;
+}
+
+const char *
+mdemod_strerror(int code)
+{
+	switch (code) {
+	case MDEMOD_OK: return "ok";
+	case MDEMOD_ERR_PARAM: return "bad parameter or unsupported configuration";
+	case MDEMOD_ERR_NOMEM: return "out of memory";
+	case MDEMOD_ERR_HIP: return "HIP runtime failure (no gfx950 device, or launch error)";
+	case MDEMOD_ERR_OVERFLOW: return "soft-symbol capacity too small";
+	case MDEMOD_ERR_RANGE: return "stream index out of range";
+	default: return "unknown error";
+	}
+}
+
+int
+mdemod_derive_tables(const mdemod_params *params, float *rrc_out, uint32_t rrc_cap,
+                     float consts_out[8], float lut_out[32])
+{
+	if (!params) return MDEMOD_ERR_PARAM;
+	HostTables t;
+	int rc = mdemod_host_derive(*params, t);
+	if (rc) return rc;
+	if (rrc_out) {
+		if (rrc_cap < t.rrc.size()) return MDEMOD_ERR_PARAM;
+		memcpy(rrc_out, t.rrc.data(), t.rrc.size() * sizeof(float));
+	}
+	if (consts_out) {
+		const float v[8] = { t.c.pll_alpha, t.c.pll_beta, t.c.pll_fmax, t.c.t_alpha,
+		                     t.c.t_beta, t.c.t_center, t.c.t_maxdev, t.osf };
+		memcpy(consts_out, v, sizeof(v));
+	}
+	if (lut_out) memcpy(lut_out, t.tanh_lut, sizeof(t.tanh_lut));
+	return static_cast<int>(t.rrc.size());
+}
+
+int
+mdemod_create(const mdemod_params *params, mdemod_ctx **out)
+{
+	if (!params || !out || params->n_streams == 0) return MDEMOD_ERR_PARAM;
+	*out = nullptr;
+	mdemod_ctx *ctx = new (std::nothrow) mdemod_ctx();
+	if (!ctx) return MDEMOD_ERR_NOMEM;
+	ctx->params = *params;
+	ctx->d_iq = nullptr; ctx->d_iq_bytes = 0;
+	ctx->d_soft = nullptr; ctx->d_soft_bytes = 0;
+	ctx->d_off = nullptr; ctx->d_cnt = nullptr;
+
+	int rc = mdemod_host_derive(*params, ctx->tab);
+	if (rc) { delete ctx; return rc; }
+	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
+
+	/* tunables (experiments only; defaults are the measured best) */
+	DemodConsts &c = ctx->tab.c;
+	c.ring_granules = c.hpad / 4 + env_int("MDEMOD_RING_EXTRA", 8);
+	if (c.ring_granules < c.hpad / 4 + 4) c.ring_granules = c.hpad / 4 + 4;
+	const int waves = env_int("MDEMOD_WAVES_PER_BLOCK", 3);
+	ctx->block_threads = 64 * (waves < 1 ? 1 : (waves > 16 ? 16 : waves));
+
+	auto lds_need = [&](int threads) {
+		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
+		       static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes;
+	};
+	while (ctx->block_threads > 64 && lds_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
+	ctx->lds_bytes = lds_need(ctx->block_threads);
+	if (ctx->lds_bytes > 160 * 1024) { delete ctx; return MDEMOD_ERR_PARAM; }
+
+#define CREATE_TRY(expr) do { rc = (expr); if (rc) { mdemod_destroy(ctx); return rc; } } while (0)
+	{
+		hipError_t e = hipSetDevice(params->device);
+		if (e != hipSuccess) {
+			fprintf(stderr, "meteor_demod_amd: no usable HIP device %d: %s\n", params->device, hipGetErrorString(e));
+			delete ctx;
+			return MDEMOD_ERR_HIP;
+		}
+	}
+	const size_t n = params->n_streams;
+	DemodStateSoA &s = ctx->st;
+	CREATE_TRY(dev_alloc(ctx, &s.agc_gain, n));   CREATE_TRY(dev_alloc(ctx, &s.agc_bias_re, n));
+	CREATE_TRY(dev_alloc(ctx, &s.agc_bias_im, n)); CREATE_TRY(dev_alloc(ctx, &s.pll_phase, n));
+	CREATE_TRY(dev_alloc(ctx, &s.pll_freq, n));   CREATE_TRY(dev_alloc(ctx, &s.pll_err, n));
+	CREATE_TRY(dev_alloc(ctx, &s.t_phase, n));    CREATE_TRY(dev_alloc(ctx, &s.t_freq, n));
+	CREATE_TRY(dev_alloc(ctx, &s.t_prev, n));     CREATE_TRY(dev_alloc(ctx, &s.inphase, n));
+	CREATE_TRY(dev_alloc(ctx, &s.flags, n));
+	CREATE_TRY(dev_alloc(ctx, &s.n_samples, n));  CREATE_TRY(dev_alloc(ctx, &s.n_symbols, n));
+	CREATE_TRY(dev_alloc(ctx, &s.first_lock, n));
+	CREATE_TRY(dev_alloc(ctx, &s.sym_this_call, n)); CREATE_TRY(dev_alloc(ctx, &s.ev_this_call, n));
+	CREATE_TRY(dev_alloc(ctx, &s.overflow, n));
+	{
+		unsigned char *h = nullptr;
+		CREATE_TRY(dev_alloc(ctx, &h, static_cast<size_t>(c.hpad) * n * ctx->sample_bytes));
+		s.hist = h;
+	}
+	CREATE_TRY(dev_alloc(ctx, &s.events, n * MDEMOD_MAX_LOCK_EVENTS));
+	CREATE_TRY(dev_alloc(ctx, &ctx->d_ctab, ctx->tab.ctab.size()));
+	CREATE_TRY(dev_alloc(ctx, &ctx->d_lut, 32));
+	{
+		hipError_t e = hipMemcpy(ctx->d_ctab, ctx->tab.ctab.data(), ctx->tab.ctab.size() * sizeof(float), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(ctx->d_lut, ctx->tab.tanh_lut, sizeof(ctx->tab.tanh_lut), hipMemcpyHostToDevice);
+		if (e != hipSuccess) { mdemod_destroy(ctx); return MDEMOD_ERR_HIP; }
+	}
+	CREATE_TRY(mdemod_reset(ctx, nullptr));
+	{
+		hipError_t e = hipDeviceSynchronize();
+		if (e != hipSuccess) { mdemod_destroy(ctx); return MDEMOD_ERR_HIP; }
+	}
+#undef CREATE_TRY
+	*out = ctx;
+	return MDEMOD_OK;
+}
+
+void
+mdemod_destroy(mdemod_ctx *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->params.device);
+	for (void *p : ctx->allocs) (void)hipFree(p);
+	if (ctx->d_iq) (void)hipFree(ctx->d_iq);
+	if (ctx->d_soft) (void)hipFree(ctx->d_soft);
+	if (ctx->d_off) (void)hipFree(ctx->d_off);
+	if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
+	delete ctx;
+}
+
+int
+mdemod_reset(mdemod_ctx *ctx, void *hip_stream)
+{
+	if (!ctx) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	HIP_TRY(hipMemsetAsync(ctx->st.events, 0, sizeof(mdemod_lock_event) * MDEMOD_MAX_LOCK_EVENTS * ctx->params.n_streams,
+	                       static_cast<hipStream_t>(hip_stream)));
+	HIP_TRY(mdemod_launch_reset(ctx->st, ctx->tab.c, ctx->params.bps, ctx->params.n_streams,
+	                            static_cast<hipStream_t>(hip_stream)));
+	return MDEMOD_OK;
+}
+
+uint64_t
+mdemod_max_symbols(const mdemod_ctx *ctx, uint64_t n_samples)
+{
+	if (!ctx) return 0;
+	/* The symbol clock can run at most center*(1+2^-12) rad per interpolated
+	 * step and fires every 2*pi (pi for the OQPSK half symbols, but only every
+	 * second firing emits): a generous closed-form bound plus slack for the
+	 * phase the stream starts with. */
+	const double steps = static_cast<double>(n_samples) * ctx->tab.c.interp;
+	const double per_step = static_cast<double>(ctx->tab.c.t_center) * (1.0 + 1.0 / 4096.0) / 6.283185307179586;
+	return static_cast<uint64_t>(steps * per_step * 1.01) + 16;
+}
+
+int
+mdemod_process_device_uniform(mdemod_ctx *ctx, const void *iq_dev, uint64_t iq_stride_samples,
+                              uint32_t n_samples, int8_t *soft_dev, uint64_t soft_stride_symbols,
+                              uint32_t soft_cap_symbols, void *hip_stream)
+{
+	if (!ctx || (!iq_dev && n_samples) || !soft_dev) return MDEMOD_ERR_PARAM;
+	if (n_samples > 0x3FFFFF00u) return MDEMOD_ERR_PARAM;
+	if (soft_cap_symbols > soft_stride_symbols) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	DemodLaunch L;
+	memset(&L, 0, sizeof(L));
+	L.iq = iq_dev; L.iq_stride = iq_stride_samples; L.n_samples = n_samples;
+	L.soft = soft_dev; L.soft_stride = soft_stride_symbols; L.soft_cap = soft_cap_symbols;
+	return launch(ctx, L, static_cast<hipStream_t>(hip_stream));
+}
+
+int
+mdemod_process_device(mdemod_ctx *ctx, const void *iq_dev, const uint64_t *iq_offset_dev,
+                      const uint32_t *n_samples_dev, int8_t *soft_dev, uint64_t soft_stride_symbols,
+                      uint32_t soft_cap_symbols, void *hip_stream)
+{
+	if (!ctx || !iq_dev || !iq_offset_dev || !n_samples_dev || !soft_dev) return MDEMOD_ERR_PARAM;
+	if (soft_cap_symbols > soft_stride_symbols) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	DemodLaunch L;
+	memset(&L, 0, sizeof(L));
+	L.iq = iq_dev; L.iq_offset = iq_offset_dev; L.n_samples_arr = n_samples_dev;
+	L.soft = soft_dev; L.soft_stride = soft_stride_symbols; L.soft_cap = soft_cap_symbols;
+	return launch(ctx, L, static_cast<hipStream_t>(hip_stream));
+}
+
+int
+mdemod_process_host(mdemod_ctx *ctx, const void *const *iq_host, const uint32_t *n_samples,
+                    int8_t *const *soft_host, const uint32_t *soft_cap, uint32_t *n_symbols)
+{
+	if (!ctx || !iq_host || !n_samples || !soft_host || !soft_cap) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	const uint32_t ns = ctx->params.n_streams;
+	const size_t sb = ctx->sample_bytes;
+
+	std::vector<uint64_t> off(ns);
+	uint64_t total = 0;
+	uint32_t cap_max = 1;
+	for (uint32_t s = 0; s < ns; s++) {
+		if (n_samples[s] > 0x3FFFFF00u) return MDEMOD_ERR_PARAM;
+		off[s] = total;
+		total += (static_cast<uint64_t>(n_samples[s]) + 7) & ~7ull;   /* keep streams 16-B aligned */
+		if (soft_cap[s] > cap_max) cap_max = soft_cap[s];
+	}
+	const size_t iq_bytes = static_cast<size_t>(total) * sb + 64;
+	const size_t soft_bytes = static_cast<size_t>(cap_max) * 2 * ns;
+	if (iq_bytes > ctx->d_iq_bytes) {
+		if (ctx->d_iq) (void)hipFree(ctx->d_iq);
+		ctx->d_iq = nullptr; ctx->d_iq_bytes = 0;
+		HIP_TRY(hipMalloc(&ctx->d_iq, iq_bytes));
+		ctx->d_iq_bytes = iq_bytes;
+	}
+	if (soft_bytes > ctx->d_soft_bytes) {
+		if (ctx->d_soft) (void)hipFree(ctx->d_soft);
+		ctx->d_soft = nullptr; ctx->d_soft_bytes = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_soft), soft_bytes));
+		ctx->d_soft_bytes = soft_bytes;
+	}
+	if (!ctx->d_off) {
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_off), sizeof(uint64_t) * ns));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_cnt), sizeof(uint32_t) * ns));
+	}
+
+	/* one packed H2D transfer */
+	std::vector<unsigned char> pack(static_cast<size_t>(total) * sb);
+	for (uint32_t s = 0; s < ns; s++)
+		if (n_samples[s]) memcpy(&pack[off[s] * sb], iq_host[s], static_cast<size_t>(n_samples[s]) * sb);
+	if (!pack.empty()) HIP_TRY(hipMemcpy(ctx->d_iq, pack.data(), pack.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(ctx->d_off, off.data(), sizeof(uint64_t) * ns, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(ctx->d_cnt, n_samples, sizeof(uint32_t) * ns, hipMemcpyHostToDevice));
+
+	/* per-stream capacities differ: run with the max and clip on the way back */
+	rc = mdemod_process_device(ctx, ctx->d_iq, ctx->d_off, ctx->d_cnt, ctx->d_soft, cap_max, cap_max, nullptr);
+	if (rc) return rc;
+	HIP_TRY(hipDeviceSynchronize());
+
+	std::vector<int8_t> soft(soft_bytes);
+	std::vector<uint32_t> produced(ns);
+	HIP_TRY(hipMemcpy(soft.data(), ctx->d_soft, soft_bytes, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(produced.data(), ctx->st.sym_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost));
+	int result = MDEMOD_OK;
+	for (uint32_t s = 0; s < ns; s++) {
+		uint32_t m = produced[s];
+		if (m > soft_cap[s]) { m = soft_cap[s]; result = MDEMOD_ERR_OVERFLOW; }
+		if (m) memcpy(soft_host[s], &soft[static_cast<size_t>(s) * cap_max * 2], static_cast<size_t>(m) * 2);
+		if (n_symbols) n_symbols[s] = m;
+	}
+	return result;
+}
+
+/* ---- status / state ---------------------------------------------------------- */
+
+
+int
+mdemod_get_status(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_status *out, void *hip_stream)
+{
+	if (!ctx || !out) return MDEMOD_ERR_PARAM;
+	if (static_cast<uint64_t>(first) + count > ctx->params.n_streams) return MDEMOD_ERR_RANGE;
+	if (!count) return MDEMOD_OK;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	const DemodStateSoA &s = ctx->st;
+	std::vector<uint64_t> nsamp, nsym; std::vector<int64_t> fl;
+	std::vector<uint32_t> symc, evc; std::vector<float> pf, om, gn; std::vector<int32_t> flags, ovf;
+	if ((rc = fetch(s.n_samples, first, count, nsamp, st))) return rc;
+	if ((rc = fetch(s.n_symbols, first, count, nsym, st))) return rc;
+	if ((rc = fetch(s.first_lock, first, count, fl, st))) return rc;
+	if ((rc = fetch(s.sym_this_call, first, count, symc, st))) return rc;
+	if ((rc = fetch(s.ev_this_call, first, count, evc, st))) return rc;
+	if ((rc = fetch(s.pll_freq, first, count, pf, st))) return rc;
+	if ((rc = fetch(s.t_freq, first, count, om, st))) return rc;
+	if ((rc = fetch(s.agc_gain, first, count, gn, st))) return rc;
+	if ((rc = fetch(s.flags, first, count, flags, st))) return rc;
+	if ((rc = fetch(s.overflow, first, count, ovf, st))) return rc;
+	HIP_TRY(hipStreamSynchronize(st));
+	for (uint32_t i = 0; i < count; i++) {
+		mdemod_status &o = out[i];
+		o.n_samples = nsamp[i]; o.n_symbols = nsym[i]; o.first_lock_symbol = fl[i];
+		o.symbols_this_call = symc[i]; o.lock_events_this_call = evc[i];
+		o.pll_freq = pf[i]; o.omega = om[i]; o.gain = gn[i];
+		o.locked = (flags[i] & MDEMOD_FLAG_LOCKED) ? 1 : 0;
+		o.locked_once = (flags[i] & MDEMOD_FLAG_LOCKED_ONCE) ? 1 : 0;
+		o.overflow = ovf[i];
+	}
+	return MDEMOD_OK;
+}
+
+int
+mdemod_get_lock_events(mdemod_ctx *ctx, uint32_t stream, mdemod_lock_event *out, uint32_t cap,
+                       uint32_t *n, void *hip_stream)
+{
+	if (!ctx || !n) return MDEMOD_ERR_PARAM;
+	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	uint32_t cnt = 0;
+	HIP_TRY(hipMemcpyAsync(&cnt, ctx->st.ev_this_call + stream, sizeof(cnt), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	*n = cnt;
+	uint32_t m = cnt < MDEMOD_MAX_LOCK_EVENTS ? cnt : MDEMOD_MAX_LOCK_EVENTS;
+	if (m > cap) m = cap;
+	if (m && out) {
+		HIP_TRY(hipMemcpyAsync(out, ctx->st.events + static_cast<size_t>(stream) * MDEMOD_MAX_LOCK_EVENTS,
+		                       sizeof(mdemod_lock_event) * m, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+	}
+	return MDEMOD_OK;
+}
+
+#define ONE(field, hostvar, dir)                                                                   \
+	HIP_TRY(hipMemcpyAsync(dir ? static_cast<void *>(ctx->st.field + stream) : static_cast<void *>(&(hostvar)), \
+	                       dir ? static_cast<const void *>(&(hostvar)) : static_cast<const void *>(ctx->st.field + stream), \
+	                       sizeof(hostvar), dir ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st))
+
+int
+mdemod_get_state(mdemod_ctx *ctx, uint32_t stream, mdemod_stream_state *out, void *hip_stream)
+{
+	if (!ctx || !out) return MDEMOD_ERR_PARAM;
+	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	int32_t flags = 0;
+	ONE(agc_gain, out->agc_gain, 0); ONE(agc_bias_re, out->agc_bias_re, 0); ONE(agc_bias_im, out->agc_bias_im, 0);
+	ONE(pll_phase, out->pll_phase, 0); ONE(pll_freq, out->pll_freq, 0); ONE(pll_err, out->pll_err, 0);
+	ONE(t_phase, out->t_phase, 0); ONE(t_freq, out->t_freq, 0); ONE(t_prev, out->t_prev, 0);
+	ONE(inphase, out->oqpsk_inphase, 0); ONE(flags, flags, 0);
+	ONE(n_samples, out->n_samples, 0); ONE(n_symbols, out->n_symbols, 0); ONE(first_lock, out->first_lock_symbol, 0);
+	HIP_TRY(hipStreamSynchronize(st));
+	out->pll_locked = (flags & MDEMOD_FLAG_LOCKED) ? 1 : 0;
+	out->pll_locked_once = (flags & MDEMOD_FLAG_LOCKED_ONCE) ? 1 : 0;
+	out->pll_updown = (flags & MDEMOD_FLAG_UPDOWN_POS) ? 1 : -1;
+	out->t_dual_state = (flags >> MDEMOD_FLAG_DUAL_SHIFT) & 3;
+	return MDEMOD_OK;
+}
+
+int
+mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in, void *hip_stream)
+{
+	if (!ctx || !in) return MDEMOD_ERR_PARAM;
+	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
+	if (in->t_dual_state != 1 && in->t_dual_state != 2) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	mdemod_stream_state v = *in;
+	int32_t flags = (v.pll_locked ? MDEMOD_FLAG_LOCKED : 0) | (v.pll_locked_once ? MDEMOD_FLAG_LOCKED_ONCE : 0) |
+	                (v.pll_updown > 0 ? MDEMOD_FLAG_UPDOWN_POS : 0) | (v.t_dual_state << MDEMOD_FLAG_DUAL_SHIFT);
+	ONE(agc_gain, v.agc_gain, 1); ONE(agc_bias_re, v.agc_bias_re, 1); ONE(agc_bias_im, v.agc_bias_im, 1);
+	ONE(pll_phase, v.pll_phase, 1); ONE(pll_freq, v.pll_freq, 1); ONE(pll_err, v.pll_err, 1);
+	ONE(t_phase, v.t_phase, 1); ONE(t_freq, v.t_freq, 1); ONE(t_prev, v.t_prev, 1);
+	ONE(inphase, v.oqpsk_inphase, 1); ONE(flags, flags, 1);
+	ONE(n_samples, v.n_samples, 1); ONE(n_symbols, v.n_symbols, 1); ONE(first_lock, v.first_lock_symbol, 1);
+	HIP_TRY(hipStreamSynchronize(st));
+	return MDEMOD_OK;
+}
+#undef ONE
+
+uint32_t
+mdemod_history_len(const mdemod_ctx *ctx)
+{
+	return ctx ? static_cast<uint32_t>(ctx->tab.c.hpad) : 0;
+}
+
+int
+mdemod_get_history(mdemod_ctx *ctx, uint32_t stream, float *iq_pairs, void *hip_stream)
+{
+	if (!ctx || !iq_pairs) return MDEMOD_ERR_PARAM;
+	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	const size_t sb = ctx->sample_bytes, ns = ctx->params.n_streams;
+	const int hpad = ctx->tab.c.hpad;
+	std::vector<unsigned char> raw(static_cast<size_t>(hpad) * sb);
+	HIP_TRY(hipMemcpy2DAsync(raw.data(), sb, static_cast<const unsigned char *>(ctx->st.hist) + stream * sb,
+	                         ns * sb, sb, hpad, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	for (int k = 0; k < hpad; k++) {
+		const unsigned char *p = &raw[k * sb];
+		if (ctx->params.bps == 8) { iq_pairs[2*k] = (float)((int)p[0] - 128); iq_pairs[2*k+1] = (float)((int)p[1] - 128); }
+		else if (ctx->params.bps == 16) { int16_t v[2]; memcpy(v, p, 4); iq_pairs[2*k] = v[0]; iq_pairs[2*k+1] = v[1]; }
+		else memcpy(&iq_pairs[2*k], p, 8);
+	}
+	return MDEMOD_OK;
+}
+
+int
+mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs, void *hip_stream)
+{
+	if (!ctx || !iq_pairs) return MDEMOD_ERR_PARAM;
+	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	const size_t sb = ctx->sample_bytes, ns = ctx->params.n_streams;
+	const int hpad = ctx->tab.c.hpad;
+	std::vector<unsigned char> raw(static_cast<size_t>(hpad) * sb);
+	for (int k = 0; k < hpad; k++) {
+		unsigned char *p = &raw[k * sb];
+		const float re = iq_pairs[2*k], im = iq_pairs[2*k+1];
+		if (ctx->params.bps == 8) {
+			if (re != floorf(re) || im != floorf(im) || re < -128 || re > 127 || im < -128 || im > 127) return MDEMOD_ERR_PARAM;
+			p[0] = (unsigned char)((int)re + 128); p[1] = (unsigned char)((int)im + 128);
+		} else if (ctx->params.bps == 16) {
+			if (re != floorf(re) || im != floorf(im) || re < -32768 || re > 32767 || im < -32768 || im > 32767) return MDEMOD_ERR_PARAM;
+			int16_t v[2] = { (int16_t)re, (int16_t)im }; memcpy(p, v, 4);
+		} else memcpy(p, &iq_pairs[2*k], 8);
+	}
+	HIP_TRY(hipMemcpy2DAsync(static_cast<unsigned char *>(ctx->st.hist) + stream * sb, ns * sb, raw.data(), sb,
+	                         sb, hpad, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	return MDEMOD_OK;
+}
+
+/* ---- tables -------------------------------------------------------------------- */
+
+int
+mdemod_get_rrc_table(const mdemod_ctx *ctx, float *out, uint32_t cap)
+{
+	if (!ctx || !out) return MDEMOD_ERR_PARAM;
+	if (cap < ctx->tab.rrc.size()) return MDEMOD_ERR_PARAM;
+	memcpy(out, ctx->tab.rrc.data(), ctx->tab.rrc.size() * sizeof(float));
+	return static_cast<int>(ctx->tab.rrc.size());
+}
+
+int
+mdemod_get_loop_constants(const mdemod_ctx *ctx, float out[8])
+{
+	if (!ctx || !out) return MDEMOD_ERR_PARAM;
+	const DemodConsts &c = ctx->tab.c;
+	const float v[8] = { c.pll_alpha, c.pll_beta, c.pll_fmax, c.t_alpha, c.t_beta, c.t_center, c.t_maxdev, ctx->tab.osf };
+	memcpy(out, v, sizeof(v));
+	return MDEMOD_OK;
+}
+
+int
+mdemod_get_tanh_lut(const mdemod_ctx *ctx, float out[32])
+{
+	if (!ctx || !out) return MDEMOD_ERR_PARAM;
+	memcpy(out, ctx->tab.tanh_lut, sizeof(ctx->tab.tanh_lut));
+	return MDEMOD_OK;
+}
+
+/* ---- device self-tests of the scalar primitives --------------------------------- */
+
+int
+mdemod_selftest_sincos(mdemod_ctx *ctx, const float *x, uint32_t n, float *sin_out, float *cos_out)
+{
+	if (!ctx || !x || !sin_out || !cos_out) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	float *d = nullptr;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(float) * 3 * static_cast<size_t>(n) + 16));
+	hipError_t e = hipMemcpy(d, x, sizeof(float) * n, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = mdemod_launch_selftest_sincos(d, n, d + n, d + 2 * static_cast<size_t>(n), nullptr);
+	if (e == hipSuccess) e = hipMemcpy(sin_out, d + n, sizeof(float) * n, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(cos_out, d + 2 * static_cast<size_t>(n), sizeof(float) * n, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	return e == hipSuccess ? MDEMOD_OK : MDEMOD_ERR_HIP;
+}
+
+int
+mdemod_selftest_hypot(mdemod_ctx *ctx, const float *xy, uint32_t n_pairs, float *out)
+{
+	if (!ctx || !xy || !out) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	float *d = nullptr;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(float) * 3 * static_cast<size_t>(n_pairs) + 16));
+	hipError_t e = hipMemcpy(d, xy, sizeof(float) * 2 * n_pairs, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = mdemod_launch_selftest_hypot(d, n_pairs, d + 2 * static_cast<size_t>(n_pairs), nullptr);
+	if (e == hipSuccess) e = hipMemcpy(out, d + 2 * static_cast<size_t>(n_pairs), sizeof(float) * n_pairs, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	return e == hipSuccess ? MDEMOD_OK : MDEMOD_ERR_HIP;
+}
+
+} /* extern "C" */

@@ -1,0 +1,90 @@
+/*
+ * demod_aux.hip — small support kernels: power-on state reset and the device
+ * self-tests of the scalar primitives (used by the parity tests to pin
+ * fast_sin/fast_cos/cabsf on the GPU against the reference's values).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "demod_internal.h"
+#include "demod_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+/* Power-on state of the reference's file-static globals:
+ * agc.c:9-10, pll.c:33-36,112, timing.c:13-14,21,43, filter.c:16 (calloc). */
+template <typename sample_t>
+__global__ void
+reset_kernel(DemodStateSoA st, float t_center, int hpad, uint32_t n_streams, sample_t zero)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_streams) return;
+	st.agc_gain[s] = 1.0f; st.agc_bias_re[s] = 0.0f; st.agc_bias_im[s] = 0.0f;
+	st.pll_phase[s] = 0.0f; st.pll_freq[s] = 0.0f; st.pll_err[s] = 1000.0f;
+	st.t_phase[s] = 0.0f; st.t_freq[s] = t_center; st.t_prev[s] = 0.0f;
+	st.inphase[s] = 0.0f;
+	st.flags[s] = MDEMOD_FLAG_UPDOWN_POS | (1 << MDEMOD_FLAG_DUAL_SHIFT);
+	st.n_samples[s] = 0; st.n_symbols[s] = 0; st.first_lock[s] = -1;
+	st.sym_this_call[s] = 0; st.ev_this_call[s] = 0; st.overflow[s] = 0;
+	sample_t *hist = reinterpret_cast<sample_t *>(st.hist);
+	for (int k = 0; k < hpad; k++) hist[(size_t)k * n_streams + s] = zero;
+}
+
+__global__ void
+selftest_sincos_kernel(const float *x, uint32_t n, float *s, float *c)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	s[i] = md_fast_sin(x[i]);
+	c[i] = md_fast_cos(x[i]);
+}
+
+__global__ void
+selftest_hypot_kernel(const float *xy, uint32_t n, float *out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	out[i] = md_cabsf(xy[2 * i], xy[2 * i + 1]);
+}
+
+} /* namespace */
+
+hipError_t
+mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, uint32_t n_streams, hipStream_t stream)
+{
+	if (n_streams == 0) return hipSuccess;
+	const dim3 block(256), grid((n_streams + 255) / 256);
+	switch (fmt) {
+	case 16:
+		hipLaunchKernelGGL(reset_kernel<uint32_t>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, (uint32_t)0);
+		break;
+	case 8:   /* raw u8 encoding of 0.0 is 128 (wavfile.c:60) */
+		hipLaunchKernelGGL(reset_kernel<uint16_t>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, (uint16_t)0x8080);
+		break;
+	case 32:
+		hipLaunchKernelGGL(reset_kernel<float2>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, make_float2(0.0f, 0.0f));
+		break;
+	default:
+		return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_selftest_sincos(const float *x, uint32_t n, float *s, float *c, hipStream_t stream)
+{
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(selftest_sincos_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, n, s, c);
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_selftest_hypot(const float *xy, uint32_t n, float *out, hipStream_t stream)
+{
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(selftest_hypot_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, xy, n, out);
+	return hipGetLastError();
+}

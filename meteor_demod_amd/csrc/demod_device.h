@@ -1,0 +1,172 @@
+/*
+ * demod_device.h — scalar stages of the demodulator as gfx950 device functions.
+ *
+ * Every function reproduces, operation by operation and rounding by rounding,
+ * what the reference computes (reference file:line cited at each function).
+ * The file must be compiled with -ffp-contract=off: the reference's output is
+ * only defined without FMA contraction.  Temporaries are typed
+ * explicitly wherever the reference's C expression mixes float and double.
+ */
+#ifndef MDEMOD_DEVICE_H
+#define MDEMOD_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+#define MD_TWO_PI_D 6.283185307179586476925286766559   /* 2*M_PI  (pll.c:61,113; timing.c:80) */
+#define MD_HALF_PI_D 1.5707963267948966192313216916398 /* M_PI/2  (sincos.c:39)                */
+#define MD_TWO_PI_F 6.28318548202514648437500f         /* 2*(float)M_PI (timing.c:37)          */
+#define MD_PI_F     3.14159274101257324218750f         /* (float)M_PI   (timing.c:50)          */
+
+struct cf32 { float re, im; };
+
+/* dsp/sincos.c:13-34 — Q14 parabola on a 16-bit turn code. */
+__device__ __forceinline__ float
+md_fast_sin(float fx)
+{
+	/* sincos.c:24: float*int -> float, division in double, then the narrowing
+	 * double->int16 that x86 compilers implement as cvttsd2si + low 16 bits. */
+	const double xd = (double)(fx * 65536.0f) / MD_TWO_PI_D;
+	const int32_t wide = __double2int_rz(xd);
+	const int32_t sign = (int32_t)(int16_t)(wide & 0xFFFF);
+	int32_t x = (wide & 0x7FFF) - 16384;                    /* sincos.c:26-27 */
+	const int32_t x2 = (x * x) >> 14;                       /* sincos.c:29    */
+	int32_t y = 19900 - ((x2 * 3516) >> 14);                /* sincos.c:31    */
+	y = 16384 - ((x2 * y) >> 14);                           /* sincos.c:32    */
+	return (float)(sign < 0 ? -y : y) * (1.0f / 16384.0f);  /* sincos.c:34 (exact: power of two) */
+}
+
+/* dsp/sincos.c:37-40 */
+__device__ __forceinline__ float
+md_fast_cos(float fx)
+{
+	return md_fast_sin((float)((double)fx + MD_HALF_PI_D));
+}
+
+/* cabsf as glibc 2.35 computes it: one double sqrt of the exact double sum of
+ * squares, narrowed to float (agc.c:21). */
+__device__ __forceinline__ float
+md_cabsf(float re, float im)
+{
+	const double s = (double)re * (double)re + (double)im * (double)im;
+	return (float)__dsqrt_rn(s);
+}
+
+/* dsp/agc.c:13-25 */
+__device__ __forceinline__ cf32
+md_agc(cf32 x, float &gain, float &bias_re, float &bias_im)
+{
+	const float keep = 1.0f - 0.001f;
+	bias_re = bias_re * keep + 0.001f * x.re;
+	bias_im = bias_im * keep + 0.001f * x.im;
+	x.re = x.re - bias_re;
+	x.im = x.im - bias_im;
+	x.re = x.re * gain;
+	x.im = x.im * gain;
+	const float mag = md_cabsf(x.re, x.im);
+	gain = gain + 0.0001f * (190.0f - mag);
+	gain = (0.0f > gain) ? 0.0f : gain;
+	return x;
+}
+
+/* NCO phase advance: pll.c:60-61 */
+__device__ __forceinline__ void
+md_nco_advance(float &phase, float freq)
+{
+	phase = phase + freq;
+	if ((double)phase >= MD_TWO_PI_D)
+		phase = (float)((double)phase - MD_TWO_PI_D);
+}
+
+/* fmod(x, 2*pi) with the dividend's sign (pll.c:113).  |x| < 2*pi needs no work;
+ * one period off is an exact double subtraction; anything larger takes libm's
+ * exact fmod. */
+__device__ __forceinline__ double
+md_wrap_2pi(double x)
+{
+	const double ax = fabs(x);
+	if (ax < MD_TWO_PI_D) return x;
+	if (ax < 2.0 * MD_TWO_PI_D) return (x < 0.0) ? x + MD_TWO_PI_D : x - MD_TWO_PI_D;
+	return fmod(x, MD_TWO_PI_D);
+}
+
+/* pll.c:154-159 */
+__device__ __forceinline__ float
+md_tanh_lut(const float *lut, float v)
+{
+	if (v > 15.0f) return 1.0f;
+	if (v < -16.0f) return -1.0f;
+	return lut[(int)v + 16];
+}
+
+struct PllState {
+	float phase, freq, err;
+	int   locked, locked_once, updown;
+};
+
+/* pll.c:100-130,143-151.  Returns 1 when `locked` changed. */
+__device__ __forceinline__ int
+md_pll_update(PllState &p, const float *lut, float alpha, float beta, float fmax,
+              float i, float q, int &just_locked_first)
+{
+	const float e = md_tanh_lut(lut, i) * q - md_tanh_lut(lut, q) * i;
+
+	const float ph = p.phase + alpha * e;
+	p.phase = (float)md_wrap_2pi((double)ph);
+	p.freq = p.freq + beta * e;
+
+	const float decayed = p.err * (1.0f - 0.001f);
+	p.err = (float)((double)decayed + fabs((double)e) * (double)0.001f);
+
+	int changed = 0;
+	just_locked_first = 0;
+	if (p.err < 85.0f && !p.locked) {
+		p.locked = 1;
+		if (!p.locked_once) just_locked_first = 1;
+		p.locked_once = 1;
+		changed = 1;
+	} else if (p.err > 105.0f && p.locked) {
+		p.locked = 0;
+		changed = 1;
+	}
+
+	if (!p.locked)
+		p.freq = (float)((double)p.freq + 0.000001 * (double)p.updown);
+	if (p.freq >= fmax) p.updown = -1;
+	else if (p.freq <= -fmax) p.updown = 1;
+	p.freq = (fmax < p.freq) ? fmax : p.freq;        /* MIN(fmax, freq)  */
+	p.freq = (-fmax > p.freq) ? -fmax : p.freq;      /* MAX(-fmax, .)    */
+	return changed;
+}
+
+/* timing.c:60-87,90-95 */
+__device__ __forceinline__ void
+md_timing_update(float &t_phase, float &t_freq, float &t_prev,
+                 float alpha, float beta, float center, float maxdev, float q)
+{
+	const float sp = (t_prev < 0.0f) ? -1.0f : 1.0f;
+	const float sq = (q < 0.0f) ? -1.0f : 1.0f;
+	const float e = sp * q - sq * t_prev;
+	t_prev = q;
+
+	float fd = t_freq - center;
+	t_phase = (float)((double)t_phase - (MD_TWO_PI_D + (double)(alpha * e)));
+	fd = fd - beta * e;
+	fd = (maxdev < fd) ? maxdev : fd;
+	fd = (-maxdev > fd) ? -maxdev : fd;
+	t_freq = center + fd;
+}
+
+/* main.c:305-306 */
+__device__ __forceinline__ int
+md_quantise(float v)
+{
+	float h = v * 0.5f;                 /* v/2, exact */
+	h = (127.0f < h) ? 127.0f : h;
+	h = (-127.0f > h) ? -127.0f : h;
+	return (int)h;                      /* truncation toward zero */
+}
+
+#endif

@@ -1,0 +1,125 @@
+/*
+ * demod_host.cpp — init-time arithmetic of the demodulator (host, libm).
+ *
+ * Compile with -ffp-contract=off.  Each block cites the reference lines whose
+ * mixed float/double evaluation it reproduces; values are pinned by the
+ * known-answer fixtures in tests/golden (RRC tables, loop constants, tanh LUT).
+ */
+#include "demod_host.h"
+
+#include <cmath>
+#include <cstdlib>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+const double kPi = 3.14159265358979323846;   /* M_PI */
+
+/* Second-order loop gains from damping and bandwidth: pll.c:133-140 (damp
+ * 1/sqrt2) and timing.c:98-105 (damp 1) evaluate the same float expression. */
+void
+loop_gains(float damp, float bw, float &alpha, float &beta)
+{
+	const float two_d_bw = (2.0f * damp) * bw;
+	const float denom = (1.0f + two_d_bw) + bw * bw;
+	alpha = ((4.0f * damp) * bw) / denom;
+	beta = ((4.0f * bw) * bw) / denom;
+}
+
+/* One prototype tap: filter.c:71-94.  `n_taps` is the prototype length
+ * (taps*interp), `osf` the oversampling of the prototype (osf*interp). */
+float
+rrc_tap(int stage, unsigned n_taps, float osf, float alpha)
+{
+	const float norm = static_cast<float>(2.0 / 5.0);
+	const int centre = static_cast<int>((n_taps - 1) / 2);
+
+	if (stage == centre) {
+		/* filter.c:82-84: (1-a) and 4a are float, the division by pi and the sum are double */
+		const double v = static_cast<double>(1.0f - alpha) + static_cast<double>(4.0f * alpha) / kPi;
+		return static_cast<float>(static_cast<double>(norm) * v);
+	}
+
+	const float t = static_cast<float>(std::abs(centre - stage)) / osf;
+	const double pi_t = kPi * static_cast<double>(t);
+	const float fat = (4.0f * alpha) * t;                                  /* 4*alpha*t, float */
+	const float num = sinf(static_cast<float>(pi_t * static_cast<double>(1.0f - alpha))) +
+	                  fat * cosf(static_cast<float>(pi_t * static_cast<double>(1.0f + alpha)));
+	const float den = static_cast<float>(pi_t * static_cast<double>(1.0f - fat * fat));
+
+	/* filter.c:90-91: Blackman window, cosf of a double argument narrowed to float, sum in double */
+	const double span = static_cast<double>(n_taps - 1);
+	const float c1 = cosf(static_cast<float>((2 * kPi) * static_cast<double>(stage) / span));
+	const float c2 = cosf(static_cast<float>((4 * kPi) * static_cast<double>(stage) / span));
+	const double win = (0.42 - 0.5 * static_cast<double>(c1)) + 0.08 * static_cast<double>(c2);
+	const float shaped = static_cast<float>(static_cast<double>(num) * win);
+
+	return (shaped / den) * norm;
+}
+
+} /* namespace */
+
+int
+mdemod_host_derive(const mdemod_params &p, HostTables &out)
+{
+	if (p.interp_factor < 1 || p.interp_factor > 64) return MDEMOD_ERR_PARAM;
+	if (p.rrc_order < 1 || p.rrc_order > 256) return MDEMOD_ERR_PARAM;
+	if (p.samplerate <= 0 || p.symrate <= 0) return MDEMOD_ERR_PARAM;
+	if (p.bps != 8 && p.bps != 16 && p.bps != 32) return MDEMOD_ERR_PARAM;
+
+	DemodConsts &c = out.c;
+	c.interp = p.interp_factor;
+	c.taps = 2 * p.rrc_order + 1;
+	c.oqpsk = p.oqpsk ? 1 : 0;
+
+	/* demod.c:10-14 */
+	const int mult = p.oqpsk ? 1 : 2;
+	const float pll_bw = static_cast<float>((2 * kPi) * static_cast<double>(p.pll_bw) /
+	                                        static_cast<double>(mult * p.symrate));
+	const float sym_freq = static_cast<float>((2 * kPi) * static_cast<double>(p.symrate) /
+	                                          static_cast<double>(p.samplerate * p.interp_factor));
+	const float sym_bw = p.sym_bw / static_cast<float>(p.interp_factor);
+	out.osf = static_cast<float>(p.samplerate) / static_cast<float>(p.symrate);
+
+	/* pll.c:29-44 */
+	float fmax = p.freq_max;
+	if (fmax < 0) fmax = 0.3f;
+	else fmax = (1.0f < fmax) ? 1.0f : fmax;
+	c.pll_fmax = p.oqpsk ? fmax / 2.0f : fmax;
+	loop_gains(0.7071067811865475f, pll_bw, c.pll_alpha, c.pll_beta);
+	for (int i = 0; i < 32; i++) out.tanh_lut[i] = static_cast<float>(tanh(static_cast<double>(i - 16)));
+
+	/* timing.c:19-27 */
+	c.t_center = sym_freq;
+	c.t_maxdev = sym_freq / static_cast<float>(1 << 12);
+	loop_gains(1.0f, sym_bw, c.t_alpha, c.t_beta);
+
+	/* filter.c:10-28 */
+	const unsigned taps = static_cast<unsigned>(c.taps), banks = static_cast<unsigned>(c.interp);
+	const float rrc_alpha = static_cast<float>(0.6);                       /* demod.h:8 */
+	out.rrc.resize(static_cast<size_t>(taps) * banks);
+	for (unsigned j = 0; j < banks; j++)
+		for (unsigned i = 0; i < taps; i++)
+			out.rrc[j * taps + i] = rrc_tap(static_cast<int>(i * banks + j), taps * banks,
+			                                out.osf * static_cast<float>(banks), rrc_alpha);
+
+	/* ---- kernel geometry ---- */
+	c.hpad = ((c.taps - 1 + 7) / 8) * 8;
+	if (c.hpad < 8) c.hpad = 8;
+	c.win_granules = (c.taps + 6) / 4;                 /* ceil((3 + taps) / 4): any start alignment */
+	c.chunk_granules = 2;
+	c.ring_granules = c.hpad / 4 + 8;
+	c.ctab_row_floats = 4 * c.win_granules;
+	const int stride_granules = (c.win_granules & 1) ? c.win_granules : c.win_granules + 1;   /* odd: distinct bank slots */
+	c.ctab_row_stride = 4 * stride_granules;
+
+	/* aligned coefficient rows: row (a, bank), slot s holds tap s-a or 0 */
+	out.ctab.assign(static_cast<size_t>(4) * banks * c.ctab_row_stride, 0.0f);
+	for (int a = 0; a < 4; a++)
+		for (unsigned b = 0; b < banks; b++) {
+			float *row = &out.ctab[(static_cast<size_t>(a) * banks + b) * c.ctab_row_stride];
+			for (int k = 0; k < c.taps; k++) row[a + k] = out.rrc[b * taps + k];
+		}
+	return MDEMOD_OK;
+}

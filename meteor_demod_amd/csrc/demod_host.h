@@ -1,0 +1,24 @@
+/*
+ * demod_host.h — host-side (init-time) derivations of the demodulator:
+ * demod_init's parameter arithmetic, the RRC polyphase table and the tanh LUT,
+ * computed with the host libm exactly as the reference does at start-up
+ * (CPU and GPU paths must share bit-identical tables).
+ */
+#ifndef MDEMOD_HOST_H
+#define MDEMOD_HOST_H
+
+#include <vector>
+#include "demod_internal.h"
+
+struct HostTables {
+	DemodConsts        c;
+	float              osf;
+	std::vector<float> rrc;       /* interp*taps, bank-major (filter.c:20)     */
+	std::vector<float> ctab;      /* [4 alignments][interp banks][row stride]  */
+	float              tanh_lut[32];
+};
+
+/* Returns MDEMOD_OK or MDEMOD_ERR_PARAM. */
+int mdemod_host_derive(const mdemod_params &p, HostTables &out);
+
+#endif

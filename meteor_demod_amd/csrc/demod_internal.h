@@ -1,0 +1,77 @@
+/*
+ * demod_internal.h — structures shared by the host side (demod_api.cpp) and the
+ * gfx950 kernels (demod_kernel.hip).  Not part of the public C-ABI.
+ */
+#ifndef MDEMOD_INTERNAL_H
+#define MDEMOD_INTERNAL_H
+
+#include <stdint.h>
+#include "../../include/meteor_demod_amd.h"
+
+#define MDEMOD_WAVE            64
+#define MDEMOD_GRANULE_SAMPLES 4      /* ring granule = 4 consecutive IQ samples */
+
+/* Loop constants + geometry, passed to the kernel by value. */
+struct DemodConsts {
+	int32_t interp;          /* polyphase banks (-O)                              */
+	int32_t taps;            /* 2*order+1                                         */
+	int32_t oqpsk;           /* -m oqpsk                                          */
+	int32_t hpad;            /* history samples kept per stream (>= taps-1, %8==0)*/
+	int32_t win_granules;    /* granules covering one FIR window at any alignment */
+	int32_t ring_granules;   /* LDS ring capacity per lane, in granules           */
+	int32_t chunk_granules;  /* granules fetched per refill                       */
+	int32_t ctab_row_floats; /* padded row length of the aligned coefficient table*/
+	int32_t ctab_row_stride; /* floats between rows (bank-conflict-free stride)   */
+	float   pll_alpha, pll_beta, pll_fmax;
+	float   t_alpha, t_beta, t_center, t_maxdev;
+};
+
+/* Per-stream state, structure-of-arrays in HBM so that lane s of a wave touches
+ * element s of each array (fully coalesced state load/store). */
+struct DemodStateSoA {
+	float    *agc_gain, *agc_bias_re, *agc_bias_im;
+	float    *pll_phase, *pll_freq, *pll_err;
+	float    *t_phase, *t_freq, *t_prev;
+	float    *inphase;
+	int32_t  *flags;             /* bit0 locked, bit1 locked_once, bit2 updown>0, bits 4-5 dual_state */
+	uint64_t *n_samples, *n_symbols;
+	int64_t  *first_lock;
+	uint32_t *sym_this_call, *ev_this_call;
+	int32_t  *overflow;
+	void     *hist;              /* [hpad][n_streams] raw samples (format of the ctx) */
+	mdemod_lock_event *events;   /* [n_streams][MDEMOD_MAX_LOCK_EVENTS]               */
+};
+
+#define MDEMOD_FLAG_LOCKED       1
+#define MDEMOD_FLAG_LOCKED_ONCE  2
+#define MDEMOD_FLAG_UPDOWN_POS   4
+#define MDEMOD_FLAG_DUAL_SHIFT   4
+
+/* Launch arguments of the demod kernel. */
+struct DemodLaunch {
+	DemodConsts   c;
+	DemodStateSoA st;
+	const void   *iq;                /* base of all streams                          */
+	const uint64_t *iq_offset;       /* per-stream offsets (samples) or NULL         */
+	const uint32_t *n_samples_arr;   /* per-stream counts or NULL                    */
+	uint64_t      iq_stride;         /* uniform layout: stream s starts at s*stride  */
+	uint32_t      n_samples;         /* uniform count                                */
+	int8_t       *soft;
+	uint64_t      soft_stride;       /* symbols                                      */
+	uint32_t      soft_cap;          /* symbols                                      */
+	uint32_t      n_streams;
+	const float  *ctab;              /* aligned, zero-padded coefficient table in HBM*/
+	uint32_t      ctab_floats;
+	const float  *tanh_lut;          /* 32 floats                                    */
+};
+
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, size_t lds_bytes, hipStream_t stream);
+hipError_t mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, uint32_t n_streams, hipStream_t stream);
+hipError_t mdemod_launch_selftest_sincos(const float *x, uint32_t n, float *s, float *c, hipStream_t stream);
+hipError_t mdemod_launch_selftest_hypot(const float *xy, uint32_t n, float *out, hipStream_t stream);
+#endif
+
+#endif

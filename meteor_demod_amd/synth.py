@@ -1,0 +1,111 @@
+"""Deterministic synthetic LRPT recordings (csrc/synth_core.h) — test/bench input only.
+
+The same per-sample function runs on the host and on gfx950 and is bit-identical
+between the two, so a huge device-resident buffer can be spot-checked tile by
+tile against a CPU-generated copy.  Signal model: random (O)QPSK
+symbols, RRC alpha=0.6, symbol-clock error, carrier offset + phase, AWGN at a
+given Es/N0, DC offset, quantised to u8 / s16 / f32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libmdemod_synth.so"
+
+SPAN, OS, TRIG = 6, 256, 1024
+PULSE_LEN = 2 * SPAN * OS + 2
+
+
+class SynthTables(C.Structure):
+    _fields_ = [("pulse", C.c_double * PULSE_LEN),
+                ("cos_hi", C.c_double * TRIG), ("sin_hi", C.c_double * TRIG),
+                ("cos_lo", C.c_double * TRIG), ("sin_lo", C.c_double * TRIG)]
+
+
+class SynthStream(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("sym_step", C.c_uint64), ("sym_phase0", C.c_uint64),
+                ("car_step", C.c_uint32), ("car_phase0", C.c_uint32),
+                ("amp", C.c_double), ("noise_scale", C.c_double),
+                ("dc_i", C.c_double), ("dc_q", C.c_double),
+                ("oqpsk", C.c_int32), ("fmt", C.c_int32)]
+
+
+_lib = None
+_tables = None
+_NP = {8: np.uint8, 16: np.int16, 32: np.float32}
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} missing: run python -m meteor_demod_amd.build")
+        h = C.CDLL(str(LIB_PATH))
+        h.mdemod_synth_tables_size.restype = C.c_size_t
+        h.mdemod_synth_stream_size.restype = C.c_size_t
+        h.mdemod_synth_tables_init.argtypes = [C.POINTER(SynthTables), C.c_double]
+        h.mdemod_synth_tables_init.restype = None
+        h.mdemod_synth_host.argtypes = [C.POINTER(SynthTables), C.POINTER(SynthStream), C.c_uint64, C.c_uint64, C.c_void_p]
+        h.mdemod_synth_host.restype = None
+        h.mdemod_synth_device.argtypes = [C.POINTER(SynthTables), C.POINTER(SynthStream), C.c_uint32, C.c_uint64,
+                                          C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
+        h.mdemod_synth_device.restype = C.c_int
+        assert h.mdemod_synth_tables_size() == C.sizeof(SynthTables)
+        assert h.mdemod_synth_stream_size() == C.sizeof(SynthStream)
+        _lib = h
+    return _lib
+
+
+def tables() -> SynthTables:
+    global _tables
+    if _tables is None:
+        t = SynthTables()
+        lib().mdemod_synth_tables_init(C.byref(t), 0.6)
+        _tables = t
+    return _tables
+
+
+def make_stream(seed: int, samplerate: float, symrate: float, *, f0_hz: float = 1200.0,
+                phase0_rad: float = 0.7, clock_ppm: float = 0.0, esn0_db: float = 12.0,
+                rms: float = 6000.0, dc=(30.0, -20.0), oqpsk: bool = False, fmt: int = 16,
+                sym_phase0: float = 0.25) -> SynthStream:
+    """Stream descriptor: `rms` is the complex RMS amplitude in LSB of the output format."""
+    sps = samplerate / (symrate * (1.0 + clock_ppm * 1e-6))
+    sym_step = int(round((1.0 / sps) * 2.0 ** 32))
+    car_step = int(round((f0_hz / samplerate) * 2.0 ** 32)) & 0xFFFFFFFF
+    car_phase0 = int(round((phase0_rad / (2 * math.pi)) * 2.0 ** 32)) & 0xFFFFFFFF
+    # unit-energy RRC + +-1 rails: each rail has power 1/1 per symbol period -> complex power 2
+    amp = rms / math.sqrt(2.0)
+    esn0 = 10.0 ** (esn0_db / 10.0)
+    sigma = rms * math.sqrt(sps / (2.0 * esn0))          # per-component noise std
+    ih_std = math.sqrt(8.0 * (65536.0 ** 2 - 1.0) / 12.0)  # std of the 8-uniform integer sum
+    return SynthStream(seed & (2 ** 64 - 1), sym_step, int(sym_phase0 * 2 ** 32) + (SPAN << 32),
+                       car_step, car_phase0, amp, sigma / ih_std, dc[0], dc[1], int(oqpsk), fmt)
+
+
+def generate_host(st: SynthStream, count: int, n0: int = 0) -> np.ndarray:
+    """[count, 2] array in the stream's format, generated on the CPU."""
+    out = np.empty((count, 2), dtype=_NP[st.fmt])
+    lib().mdemod_synth_host(C.byref(tables()), C.byref(st), n0, count, out.ctypes.data)
+    return out
+
+
+def generate_device(streams, count: int, out=None, n0: int = 0, device: int = 0):
+    """torch tensor [n_streams, count, 2] generated on the GPU (all streams same format)."""
+    import torch
+    fmt = streams[0].fmt
+    tdt = {8: torch.uint8, 16: torch.int16, 32: torch.float32}[fmt]
+    ns = len(streams)
+    if out is None:
+        out = torch.empty((ns, count, 2), dtype=tdt, device=f"cuda:{device}")
+    assert out.is_contiguous() or out.stride(1) == 2
+    arr = (SynthStream * ns)(*streams)
+    rc = lib().mdemod_synth_device(C.byref(tables()), arr, ns, n0, count, C.c_void_p(out.data_ptr()),
+                                   out.stride(0) // 2, device)
+    if rc:
+        raise RuntimeError(f"mdemod_synth_device failed ({rc})")
+    return out
