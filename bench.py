@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — IQ Msamples/s demodulated on MI355X (BASELINE.json metric).
+
+Workload at N=1 = BASELINE.json configs[1]: QPSK 72k, 230 kS/s int16, RRC order
+32, oversampling 5, ONE device-resident synthetic IQ buffer cut into T tiles of
+L samples; each tile is an independent stream demodulated bit-exactly by one GPU
+lane (tiles of one recording are independent streams).  A "step"
+is one pass of the fused demod kernel over the whole buffer (T*L samples), input
+already in HBM.  For N>1 each rank owns its own buffer of the same shape (weak
+scaling), no collective on the data path; `--fanin` additionally gathers the
+soft symbols on rank 0 over RCCL (outside the timed region by default).
+
+One JSON line on rank 0, with `roofline` (HBM, algorithmic bytes / measured
+kernel time) and `cpu_baseline` (the reference's own code from oracle/_ref, or
+the oracle port, timed on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse() -> argparse.Namespace:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tiles", type=int, default=262144, help="tiles (= streams = lanes) per GPU")
+    ap.add_argument("--tile-samples", type=int, default=32768, help="IQ samples per tile")
+    ap.add_argument("--config", default="c1", choices=["c1", "c3", "c4"], help="c1 = the headline config")
+    ap.add_argument("--fanin", action="store_true", help="also gather soft symbols on rank 0 (timed separately)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def demod_config(tag: str):
+    from meteor_demod_amd import DemodConfig
+    if tag == "c1":
+        return DemodConfig(samplerate=230000), "configs[1]: QPSK 72k, 230 kS/s s16, RRC order 32, oversamp 5"
+    if tag == "c3":
+        return DemodConfig(samplerate=230000, symrate=80000, oqpsk=True), "configs[2]: OQPSK 80k, 230 kS/s s16"
+    return (DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8),
+            "configs[3]: QPSK 72k, 1 MS/s s16, RRC order 64, oversamp 8")
+
+
+def cpu_baseline(cfg) -> dict:
+    """Reference CPU path on this host: one single-threaded process per core (the reference has
+    exactly one demod thread, main.c:218), each on the same 2^23-sample recording."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import numpy as np
+    import oracle_py as O
+    from meteor_demod_amd import synth
+
+    n = 1 << 23
+    st = synth.make_stream(424242, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0)
+    try:
+        iq = synth.generate_device([st], n).cpu().numpy()[0]
+    except Exception:
+        iq = synth.generate_host(st, n)
+    cores = len(os.sched_getaffinity(0))
+    procs = max(1, min(cores, 64))
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        path = Path(td) / "in.raw"
+        iq.tofile(path)
+        if O.have_ref():
+            kind = "reference"
+            cmd = [str(O.REF_HARNESS), "time", *O._ref_args(cfg), str(path)]
+            t0 = time.time()
+            ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(procs)]
+            outs = [p.communicate()[0] for p in ps]
+            wall = time.time() - t0
+            per = [float(o.split()[0]) for o in outs]
+        else:
+            kind = "port"
+            code = ("import sys,time,numpy as np;sys.path.insert(0,%r);import oracle_py as O;"
+                    "from meteor_demod_amd import DemodConfig;cfg=DemodConfig(**%r);"
+                    "iq=np.fromfile(%r,dtype=np.int16).reshape(-1,2);t=time.time();O.oracle_demod(cfg,iq);print(time.time()-t)"
+                    % (str(ROOT / "tests"), cfg.__dict__, str(path)))
+            t0 = time.time()
+            ps = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, cwd=str(ROOT))
+                  for _ in range(procs)]
+            outs = [p.communicate()[0] for p in ps]
+            wall = time.time() - t0
+            per = [float(o.split()[-1]) for o in outs]
+    agg = procs * n / max(per) / 1e6
+    return {"value": round(agg, 2), "unit": "Msamples/s", "cores": procs, "kind": kind,
+            "per_core_msps": round(n / (sum(per) / len(per)) / 1e6, 2),
+            "sample": f"{procs} processes x 2^23-sample {cfg.symrate // 1000}k recording "
+                      f"({procs * n / 1e6:.0f} M samples, {sum(per):.1f} s CPU, {wall:.1f} s wall), strict -ffp-contract=off build"}
+
+
+def spot_check(cfg, d, x, tiles, L, n_check=4) -> str:
+    """Untimed: reset, one pass, compare sampled tiles byte-for-byte with the oracle."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import numpy as np
+    import torch
+    import oracle_py as O
+    d.reset()
+    soft = d.process(x)
+    torch.cuda.synchronize()
+    for t in np.random.default_rng(0).choice(tiles, n_check, replace=False):
+        st = d.status(int(t), 1)[0]
+        want = O.oracle_demod(cfg, x[int(t)].cpu().numpy())[0]
+        got = soft[int(t), : st.symbols_this_call].cpu().numpy()
+        if got.shape != want.shape or not np.array_equal(got, want):
+            return f"MISMATCH tile {int(t)}"
+    return f"{n_check} sampled tiles byte-identical to oracle"
+
+
+def main() -> None:
+    args = parse()
+    import torch
+    from meteor_demod_amd import Demodulator, synth
+    from meteor_demod_amd.sharding import fanin_soft, init_from_env
+
+    rank, local, world = init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the demodulator has no CPU path")
+    torch.cuda.set_device(local)
+    dist = torch.distributed if world > 1 else None
+
+    cfg, workload = demod_config(args.config)
+    T, L = args.tiles, args.tile_samples
+
+    # ---- one long synthetic recording, generated on the device, cut into T tiles -------------
+    rec = synth.make_stream(1000 * 1 + rank, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0,
+                            clock_ppm=7.0 * (rank - world / 2))
+    buf = torch.empty((T * L, 2), dtype=torch.int16, device=f"cuda:{local}")
+    synth.generate_device([rec], T * L, out=buf.view(1, T * L, 2), device=local)
+    x = buf.view(T, L, 2)
+
+    d = Demodulator(cfg, T, device=local)
+    cap = d.max_symbols(L)
+    soft = torch.empty((T, cap, 2), dtype=torch.int8, device=f"cuda:{local}")
+
+    for _ in range(args.warmup):
+        d.process(x, soft=soft)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        d.process(x, soft=soft)
+        b.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+
+    if dist:
+        tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(tt[0]), float(tt[1])
+
+    fanin_ms = None
+    if args.fanin and dist:
+        st = d.status()
+        counts = torch.tensor([s.symbols_this_call for s in st], dtype=torch.int32, device=f"cuda:{local}")
+        torch.cuda.synchronize(); dist.barrier()
+        t1 = time.perf_counter()
+        fanin_soft(soft, counts, T * world, dst=0)
+        torch.cuda.synchronize(); dist.barrier()
+        fanin_ms = (time.perf_counter() - t1) * 1e3
+
+    if rank != 0:
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    samples_per_step = T * L * world
+    value = samples_per_step * args.steps / elapsed / 1e6
+    bytes_per_sample = cfg.bps / 4 + 2 * cfg.symrate / cfg.samplerate
+    algo_bytes = T * L * bytes_per_sample                                   # per launch, per GPU
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+
+    traffic = None
+    tfile = ROOT / "profiles" / "hbm_traffic.json"
+    if tfile.exists():
+        try:
+            rec_t = json.loads(tfile.read_text())
+            key = f"{args.config}:{T}x{L}"
+            if key in rec_t:
+                traffic = rec_t[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "IQ Msamples/s demodulated (whole node)", "value": round(value, 1), "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload + f"; one device-resident IQ buffer of {T}x{L} samples per GPU, "
+                               "one tile per lane, bit-exact per tile",
+                   "tiles_per_gpu": T, "tile_samples": L, "samples_per_step": samples_per_step,
+                   "input_bytes_per_gpu": T * L * 4},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "demod_kernel", "kernel_ms": round(kernel_ms, 3),
+                     "algorithmic_bytes_per_sample": round(bytes_per_sample, 4)},
+    }
+    if fanin_ms is not None:
+        out["fanin_ms"] = round(fanin_ms, 2)
+    if not args.no_check:
+        out["check"] = spot_check(cfg, d, x, T, L)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

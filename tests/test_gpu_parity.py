@@ -1,0 +1,309 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the
+oracle and the committed golden vectors.  Bar: every soft-symbol byte identical
+(not +-1 LSB), identical lock/unlock events, identical loop state."""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from conftest import load_npz
+from golden_cases import BY_NAME, CASES, sha
+from meteor_demod_amd import DemodConfig, Demodulator, synth
+
+pytestmark = pytest.mark.gpu
+
+C1 = DemodConfig(samplerate=230000)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def gpu_demod(cfg, blocks_per_stream, n_streams=None):
+    """blocks_per_stream: list (per stream) of numpy [n,2] -> list of soft arrays, statuses, demod."""
+    torch = _torch()
+    ns = len(blocks_per_stream)
+    n = blocks_per_stream[0].shape[0]
+    assert all(b.shape[0] == n for b in blocks_per_stream)
+    d = Demodulator(cfg, ns)
+    x = torch.from_numpy(np.stack(blocks_per_stream)).cuda()
+    soft = d.process(x)
+    torch.cuda.synchronize()
+    st = d.status()
+    outs = [soft[s, : st[s].symbols_this_call].cpu().numpy() for s in range(ns)]
+    return outs, st, d
+
+
+# ---- every golden case, byte for byte ------------------------------------------------------
+
+@pytest.mark.parametrize("name", [c.name for c in CASES])
+def test_hip_matches_reference_golden_and_oracle(name, manifest, gpu_device):
+    case = BY_NAME[name]
+    meta = manifest["cases"][name]
+    iq = case.generate()
+    assert sha(iq) == meta["input_sha256"]
+    ost = O.OracleStream(case.cfg)
+    want, trace, ev = ost.run(iq, want_trace=True)
+
+    (got,), (st,), d = gpu_demod(case.cfg, [iq])
+    # vs the reference's own output (golden)
+    assert got.shape[0] == meta["n_symbols"]
+    assert sha(got) == meta["soft_sha256"]
+    if meta["stored_input"]:
+        assert np.array_equal(got, load_npz(name)["soft"])
+    # vs the oracle
+    assert np.array_equal(got, want)
+    # lock behaviour
+    assert st.first_lock_symbol == meta["first_lock_symbol"]
+    assert [list(e) for e in d.lock_events(0)] == meta["lock_events"] == [list(e) for e in ev]
+    assert st.locked == meta["final"]["locked"] and st.locked_once == int(meta["first_lock_symbol"] >= 0)
+    # status getters (pll_get_freq, mm_omega, agc_get_gain) as read after the last SAMPLE:
+    # bit-exact floats (for OQPSK the AGC may have run once more after the last symbol)
+    assert np.float32(st.pll_freq) == np.float32(ost.state.pll_freq) == trace[-1]["pll_freq"]
+    assert np.float32(st.omega) == np.float32(ost.state.t_freq) == trace[-1]["omega"]
+    assert np.float32(st.gain) == np.float32(ost.state.gain)
+    assert st.n_samples == iq.shape[0] and st.n_symbols == want.shape[0] and st.overflow == 0
+    d.close()
+
+
+def test_full_loop_state_matches_oracle(gpu_device):
+    """Every field of the per-stream state after a run, incl. filter history."""
+    for name in ("c1_short", "c3_short"):
+        case = BY_NAME[name]
+        iq = case.generate()[:20011]                      # odd length on purpose
+        ost = O.OracleStream(case.cfg)
+        ost.run(iq)
+        (_,), _, d = gpu_demod(case.cfg, [iq])
+        g, s = d.get_state(0), ost.state
+        for a, b in [(g.agc_gain, s.gain), (g.agc_bias_re, s.bias.re), (g.agc_bias_im, s.bias.im),
+                     (g.pll_phase, s.pll_phase), (g.pll_freq, s.pll_freq), (g.pll_err, s.pll_err),
+                     (g.t_phase, s.t_phase), (g.t_freq, s.t_freq), (g.t_prev, s.t_prev),
+                     (g.oqpsk_inphase, s.inphase)]:
+            assert np.float32(a) == np.float32(b)
+        assert (g.pll_locked, g.pll_locked_once, g.pll_updown, g.t_dual_state) == \
+               (s.locked, s.locked_once, s.updown, s.dual_state)
+        assert (g.n_samples, g.n_symbols, g.first_lock_symbol) == (s.n_samples, s.n_symbols, s.first_lock_symbol)
+        hist = d.get_history(0)
+        want = ost.history()
+        assert np.array_equal(hist[-(case.cfg.taps - 1):], want[-(case.cfg.taps - 1):])
+        d.close()
+
+
+# ---- block chaining: state persists across calls like the reference's globals ----------------
+
+@pytest.mark.parametrize("name", ["c1_short", "c3_short", "u8_short", "f32_short", "odd_cfg"])
+@pytest.mark.parametrize("blocks", [[1, 2, 3, 5, 64, 1000, 4099], [8192], [0, 7, 0, 130, 1]])
+def test_block_chaining_equals_one_shot(name, blocks, gpu_device):
+    torch = _torch()
+    case = BY_NAME[name]
+    iq = case.generate()[:24000]
+    want = O.oracle_demod(case.cfg, iq)[0]
+    with Demodulator(case.cfg, 1) as d:
+        parts, pos, k = [], 0, 0
+        while pos < iq.shape[0]:
+            b = min(blocks[k % len(blocks)], iq.shape[0] - pos)
+            k += 1
+            if b == 0:      # an empty block is legal: state must not move
+                soft = d.process(torch.from_numpy(np.zeros((1, 1, 2), dtype=iq.dtype)).cuda(), n_samples=0)
+            else:
+                soft = d.process(torch.from_numpy(iq[pos:pos + b][None]).cuda())
+            torch.cuda.synchronize()
+            m = d.status()[0].symbols_this_call
+            parts.append(soft[0, :m].cpu().numpy())
+            pos += b
+        got = np.concatenate(parts)
+        assert np.array_equal(got, want)
+        assert d.status()[0].n_samples == iq.shape[0]
+
+
+def test_state_export_import_continues_exactly(gpu_device):
+    """Checkpoint/hand-off: get_state+history from one context, set into another, continue."""
+    torch = _torch()
+    case = BY_NAME["c1_short"]
+    iq = case.generate()[:30000]
+    want = O.oracle_demod(case.cfg, iq)[0]
+    cut = 12345
+    with Demodulator(case.cfg, 1) as a, Demodulator(case.cfg, 3) as b:
+        s1 = a.process(torch.from_numpy(iq[None, :cut]).cuda())
+        torch.cuda.synchronize()
+        m1 = a.status()[0].symbols_this_call
+        b.set_state(2, a.get_state(0))
+        b.set_history(2, a.get_history(0))
+        x = torch.from_numpy(np.stack([iq[cut:]] * 3)).cuda()
+        s2 = b.process(x)
+        torch.cuda.synchronize()
+        st = b.status()
+        got = np.concatenate([s1[0, :m1].cpu().numpy(), s2[2, : st[2].symbols_this_call].cpu().numpy()])
+        assert np.array_equal(got, want)
+        assert st[2].n_samples == iq.shape[0] and st[2].n_symbols == want.shape[0]
+        # streams 0,1 of b started cold: they are a different (valid) demodulation
+        assert st[0].n_samples == iq.shape[0] - cut
+
+
+# ---- batches: many independent streams, one per lane -----------------------------------------
+
+def test_batch_of_distinct_streams_each_matches_oracle(gpu_device):
+    """BASELINE configs[4] in miniature: N independent recordings with different carrier
+    offsets, clock errors and noise; every stream equals its own serial demodulation."""
+    ns, n = 200, 9000
+    streams = [synth.make_stream(5000 + i, 230000, 72000, f0_hz=(i % 13 - 6) * 450.0, clock_ppm=(i % 9 - 4) * 12.5,
+                                 esn0_db=6.0 + (i % 5) * 4.0, rms=3000.0 + 40.0 * i) for i in range(ns)]
+    iqs = [synth.generate_host(s, n) for s in streams]
+    outs, st, d = gpu_demod(C1, iqs)
+    for i in range(ns):
+        want, tr, ev = O.oracle_demod(C1, iqs[i], want_trace=True)
+        assert np.array_equal(outs[i], want), i
+        assert np.float32(st[i].pll_freq) == tr[-1]["pll_freq"] and st[i].locked == tr[-1]["locked"]
+    d.close()
+
+
+def test_result_is_independent_of_lane_and_neighbours(gpu_device):
+    """The same recording placed in different lanes / waves / blocks, next to different
+    neighbours, demodulates to the same bytes."""
+    torch = _torch()
+    n = 8000
+    probe = synth.generate_host(synth.make_stream(77, 230000, 72000, f0_hz=250.0, esn0_db=15.0), n)
+    rng = np.random.default_rng(0)
+    other = [synth.generate_host(synth.make_stream(8000 + i, 230000, 72000, f0_hz=float(rng.integers(-3000, 3000))), n)
+             for i in range(8)]
+    ns = 500
+    slots = [0, 1, 63, 64, 127, 191, 192, 255, 256, 499]
+    batch = [other[i % 8] for i in range(ns)]
+    for s in slots:
+        batch[s] = probe
+    outs, st, d = gpu_demod(C1, batch)
+    want = O.oracle_demod(C1, probe)[0]
+    for s in slots:
+        assert np.array_equal(outs[s], want), s
+    d.close()
+
+
+def test_ragged_batch_with_empty_and_short_streams(gpu_device):
+    torch = _torch()
+    lens = [0, 1, 3, 4, 5, 63, 64, 65, 66, 129, 1000, 4097, 12000, 0, 2, 7777]
+    streams = [synth.make_stream(6000 + i, 230000, 72000, f0_hz=100.0 * i, esn0_db=18.0) for i in range(len(lens))]
+    iqs = [synth.generate_host(s, n) if n else np.zeros((0, 2), np.int16) for s, n in zip(streams, lens)]
+    pad = 3                                              # odd sample offsets: streams are NOT 16-byte aligned
+    offsets, pos = [], pad
+    for a in iqs:
+        offsets.append(pos)
+        pos += a.shape[0] + 1
+    flat = np.zeros((pos + 8, 2), dtype=np.int16)
+    for o, a in zip(offsets, iqs):
+        flat[o:o + a.shape[0]] = a
+    with Demodulator(C1, len(lens)) as d:
+        cap = d.max_symbols(max(lens))
+        soft = torch.zeros((len(lens), cap, 2), dtype=torch.int8, device="cuda")
+        d.process_ragged(torch.from_numpy(flat).cuda(), torch.tensor(offsets, dtype=torch.int64).cuda(),
+                         torch.tensor(lens, dtype=torch.int32).cuda(), soft)
+        torch.cuda.synchronize()
+        st = d.status()
+        for i, a in enumerate(iqs):
+            want = O.oracle_demod(C1, a)[0] if a.shape[0] else np.zeros((0, 2), np.int8)
+            assert st[i].symbols_this_call == want.shape[0], i
+            assert st[i].n_samples == lens[i]
+            assert np.array_equal(soft[i, : want.shape[0]].cpu().numpy(), want), i
+
+
+def test_soft_capacity_overflow_is_reported_not_fatal(gpu_device):
+    torch = _torch()
+    iq = BY_NAME["c1_short"].generate()[:10000]
+    want = O.oracle_demod(C1, iq)[0]
+    with Demodulator(C1, 1) as d:
+        soft = torch.full((1, 100, 2), 99, dtype=torch.int8, device="cuda")
+        d.process(torch.from_numpy(iq[None]).cuda(), soft=soft)
+        torch.cuda.synchronize()
+        st = d.status()[0]
+        assert st.overflow == 1 and st.symbols_this_call == want.shape[0] and st.n_symbols == want.shape[0]
+        assert np.array_equal(soft[0].cpu().numpy(), want[:100])
+
+
+def test_host_buffer_path(gpu_device):
+    """mdemod_process_host: host pointers in, host soft symbols out (PCIe inclusive)."""
+    iqs = [BY_NAME["c1_short"].generate()[:n] for n in (5000, 0, 12001)]
+    with Demodulator(C1, 3) as d:
+        outs = d.process_host(iqs)
+        for a, o in zip(iqs, outs):
+            want = O.oracle_demod(C1, a)[0] if a.shape[0] else np.zeros((0, 2), np.int8)
+            assert np.array_equal(o, want)
+
+
+def test_reset_restores_power_on_state(gpu_device):
+    torch = _torch()
+    iq = BY_NAME["c1_short"].generate()[:15000]
+    x = torch.from_numpy(iq[None]).cuda()
+    with Demodulator(C1, 1) as d:
+        a = d.process(x).clone()
+        d.reset()
+        b = d.process(x)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and d.status()[0].n_samples == iq.shape[0]
+
+
+# ---- scalar primitives on the device, pinned against the reference ------------------------------
+
+def test_device_fast_sin_cos_match_reference(manifest, gpu_device):
+    """fast_sin/fast_cos (sincos.c:13-40) over the same 1.3M-point sweep the reference was run on."""
+    x = np.concatenate([np.linspace(-9.0, 9.0, 1 << 20, dtype=np.float32),
+                        np.random.default_rng(7).uniform(-9, 9, 1 << 18).astype(np.float32),
+                        np.array([0.0, -0.0, 6.2831855, -6.2831855, 3.1415927, 1.5707964], dtype=np.float32)])
+    meta = manifest["tables"]["sincos"]
+    assert sha(x) == meta["x_sha256"]
+    with Demodulator(C1, 1) as d:
+        s, c = d.selftest_sincos(x)
+    assert sha(s) == meta["sin_sha256"]
+    assert sha(c) == meta["cos_sha256"]
+
+
+def test_device_cabsf_is_correctly_rounded(gpu_device):
+    rng = np.random.default_rng(3)
+    xy = np.concatenate([rng.normal(0, 300, (1 << 20, 2)), rng.normal(0, 1e-4, (1 << 16, 2)),
+                         rng.normal(0, 1e6, (1 << 16, 2)), np.array([[0, 0], [3, 4], [-0.0, 1e-30]])]).astype(np.float32)
+    with Demodulator(C1, 1) as d:
+        got = d.selftest_hypot(xy)
+    want = np.sqrt(xy[:, 0].astype(np.float64) ** 2 + xy[:, 1].astype(np.float64) ** 2).astype(np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_device_generator_equals_host_generator(gpu_device):
+    """The synthetic-input generator is bit-identical on gfx950 and on the host (all formats)."""
+    for fmt, rms in ((16, 6000.0), (8, 60.0), (32, 0.5)):
+        streams = [synth.make_stream(300 + i, 230000, 72000, f0_hz=-700.0 + 300 * i, clock_ppm=5.0 * i,
+                                     oqpsk=bool(i & 1), fmt=fmt, rms=rms) for i in range(5)]
+        dev = synth.generate_device(streams, 20000).cpu().numpy()
+        for i, st in enumerate(streams):
+            assert np.array_equal(dev[i], synth.generate_host(st, 20000)), (fmt, i)
+
+
+# ---- full-size properties (BASELINE configs[1]/[4] scale) ------------------------------------------
+
+def test_full_size_batch_properties(gpu_device):
+    """65536 streams x 16384 samples (1.07 G samples): replicas of a recording agree byte for
+    byte wherever they sit, and randomly sampled streams equal the oracle."""
+    torch = _torch()
+    ns, n, distinct = 65536, 16384, 256
+    streams = [synth.make_stream(100 + i, 230000, 72000, f0_hz=(i % 7 - 3) * 400.0, clock_ppm=(i % 11 - 5) * 8.0)
+               for i in range(distinct)]
+    base = synth.generate_device(streams, n)
+    x = base.repeat(ns // distinct, 1, 1)
+    with Demodulator(C1, ns) as d:
+        soft = d.process(x)
+        torch.cuda.synchronize()
+        st = d.status()
+        counts = torch.tensor([s.symbols_this_call for s in st], device="cuda")
+        # checksum of checksums: every replica group identical
+        s3 = soft.view(ns // distinct, distinct, -1)
+        c3 = counts.view(ns // distinct, distinct)
+        assert torch.equal(c3, c3[:1].expand_as(c3))
+        mask = (torch.arange(soft.shape[1], device="cuda")[None, :] < c3[0][:, None]).repeat_interleave(2, dim=1)
+        assert torch.equal(s3 * mask, (s3[:1] * mask).expand_as(s3))
+        # sampled streams against the oracle
+        for i in np.random.default_rng(1).choice(ns, 12, replace=False):
+            iq = synth.generate_host(streams[i % distinct], n)
+            want = O.oracle_demod(C1, iq)[0]
+            assert st[i].symbols_this_call == want.shape[0]
+            assert np.array_equal(soft[i, : want.shape[0]].cpu().numpy(), want), i

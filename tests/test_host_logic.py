@@ -1,0 +1,144 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every
+symbol the header declares, init-time tables equal the reference's, and the
+library fails loudly (no CPU fallback) when no GPU is present."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_npz
+from golden_cases import CASES, sha
+from meteor_demod_amd import DemodConfig, _capi, derive_tables, scale_freq_max, synth
+from meteor_demod_amd._capi import MdemodParams
+
+
+def _declared_symbols() -> list[str]:
+    text = (ROOT / "include" / "meteor_demod_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdemod_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_all_exported():
+    lib = _capi.lib()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/meteor_demod_amd.h but not exported"
+    # and the python binding table covers exactly the header
+    assert sorted(_capi.SIGNATURES) == names
+
+
+def test_abi_version_and_struct_layouts():
+    lib = _capi.lib()
+    assert lib.mdemod_abi_version() == 1
+    assert C.sizeof(_capi.MdemodParams) == 48
+    assert C.sizeof(_capi.MdemodStatus) == 56
+    assert C.sizeof(_capi.MdemodLockEvent) == 16
+    assert C.sizeof(_capi.MdemodStreamState) == 80
+    assert lib.mdemod_strerror(-3).decode().startswith("HIP")
+
+
+def test_product_library_does_not_link_the_oracle():
+    """The shipped path must not depend on oracle/ in any form."""
+    import subprocess
+    out = subprocess.run(["ldd", str(_capi.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "lrpt_oracle" not in out
+    syms = subprocess.run(["nm", "-D", str(_capi.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "orc_" not in syms
+    forbidden = re.compile(r"oracle_py|lrpt_oracle|\borc_[a-z]|oracle/_ref|import\s+oracle|from\s+oracle")
+    for src in list((ROOT / "meteor_demod_amd").rglob("*.py")) + list((ROOT / "meteor_demod_amd" / "csrc").iterdir()) \
+            + list((ROOT / "host").glob("*.c")):
+        assert not forbidden.search(src.read_text()), src
+
+
+@pytest.mark.parametrize("tag", ["c1", "c3", "c4", "odd"])
+def test_product_rrc_table_matches_reference(tag, manifest):
+    """filter_init_rrc known-answer (filter.c:10-28,71-94) for the product's own host code."""
+    cfg = DemodConfig(**manifest["tables"][f"rrc_{tag}"]["cfg"])
+    rrc, consts, lut = derive_tables(cfg)
+    g = load_npz("tables")
+    assert np.array_equal(rrc, g[f"rrc_{tag}"])
+    assert np.array_equal(lut, g["tanh_lut"])
+
+
+def test_product_loop_constants_match_survey_a7():
+    """SURVEY App. A.7 (measured from the reference): derived constants per config."""
+    _, c, _ = derive_tables(DemodConfig(samplerate=230000))
+    assert c["pll_alpha"] == np.float32(1.23405785e-04) and c["pll_beta"] == np.float32(7.61496555e-09)
+    assert c["pll_fmax"] == np.float32(0.3)
+    assert c["t_center"] == np.float32(0.393382043) and c["t_maxdev"] == np.float32(9.60405378e-05)
+    assert c["t_alpha"] == np.float32(3.99991986e-05) and c["t_beta"] == np.float32(3.99991956e-10)
+    _, c, _ = derive_tables(DemodConfig(samplerate=230000, symrate=80000, oqpsk=True))
+    assert c["pll_alpha"] == np.float32(2.22119459e-04) and c["pll_fmax"] == np.float32(0.15)
+    assert c["t_center"] == np.float32(0.437091142)
+    _, c, _ = derive_tables(DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8))
+    assert c["t_center"] == np.float32(0.0565486662) and c["t_alpha"] == np.float32(2.49996865e-05)
+
+
+def test_product_constants_equal_oracle_constants():
+    import oracle_py as O
+    for case in CASES:
+        _, c, lut = derive_tables(case.cfg)
+        st = O.OracleStream(case.cfg)
+        for k in ("pll_alpha", "pll_beta", "pll_fmax", "t_alpha", "t_beta", "t_center", "t_maxdev", "osf"):
+            assert np.float32(getattr(st.consts, k)) == c[k], (case.name, k)
+
+
+def test_bad_parameters_are_rejected():
+    lib = _capi.lib()
+    for bad in (dict(interp_factor=0), dict(rrc_order=0), dict(samplerate=0), dict(symrate=-1), dict(bps=12)):
+        cfg = DemodConfig(samplerate=230000)
+        for k, v in bad.items():
+            setattr(cfg, k, v)
+        p = cfg.to_c()
+        assert lib.mdemod_derive_tables(C.byref(p), None, 0, None, None) == _capi.MDEMOD_ERR_PARAM
+        ctx = C.c_void_p()
+        assert lib.mdemod_create(C.byref(p), C.byref(ctx)) == _capi.MDEMOD_ERR_PARAM
+    p = DemodConfig(samplerate=230000).to_c(n_streams=0)
+    assert lib.mdemod_create(C.byref(p), C.byref(C.c_void_p())) == _capi.MDEMOD_ERR_PARAM
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    """Without a HIP device mdemod_create must fail with MDEMOD_ERR_HIP."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from meteor_demod_amd import Demodulator
+    with pytest.raises(_capi.MdemodError) as ei:
+        Demodulator(DemodConfig(samplerate=230000), 1)
+    assert ei.value.code == _capi.MDEMOD_ERR_HIP
+
+
+def test_freq_max_scaling_follows_main_c():
+    """main.c:136: -d in Hz -> rad/symbol in double then narrowed; default -1 stays negative."""
+    assert scale_freq_max(-1, 72000) < 0
+    assert scale_freq_max(3500.0, 72000.0) == float(np.float32(3500.0 * 2 * np.pi / 72000.0))
+
+
+def test_synth_is_deterministic_and_addressable():
+    st = synth.make_stream(42, 230000, 72000, f0_hz=777.0, clock_ppm=13.0)
+    a = synth.generate_host(st, 5000)
+    b = synth.generate_host(st, 3000, n0=2000)
+    assert np.array_equal(a[2000:], b)
+    assert sha(a) == "%s" % sha(synth.generate_host(st, 5000))
+    # format variants share the same underlying signal
+    st8 = synth.make_stream(42, 230000, 72000, f0_hz=777.0, clock_ppm=13.0, fmt=8, rms=60.0)
+    u = synth.generate_host(st8, 1000)
+    assert u.dtype == np.uint8 and 100 < u.mean() < 156
+
+
+def test_synth_signal_is_what_it_claims():
+    """Power, carrier offset and symbol rate of the synthetic recording."""
+    fs, rs, f0 = 230000.0, 72000.0, 1200.0
+    st = synth.make_stream(7, fs, rs, f0_hz=f0, esn0_db=30.0, dc=(0.0, 0.0))
+    x = synth.generate_host(st, 1 << 16).astype(np.float64)
+    z = x[:, 0] + 1j * x[:, 1]
+    assert abs(np.sqrt(np.mean(np.abs(z) ** 2)) - 6000.0) < 300.0
+    # 4th power removes QPSK modulation: line at 4*f0
+    spec = np.abs(np.fft.fft(z ** 4))
+    peak = np.fft.fftfreq(z.size, 1 / fs)[np.argmax(spec)]
+    assert abs(peak - 4 * f0) < 20.0
