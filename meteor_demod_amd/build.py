@@ -55,14 +55,16 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
     out: dict[str, Path] = {}
 
     # --- product library ---------------------------------------------------
-    srcs = [CSRC / "demod_kernel.hip", CSRC / "demod_aux.hip", CSRC / "demod_api.cpp", CSRC / "demod_host.cpp"]
+    srcs = [CSRC / "demod_kernel.hip", CSRC / "demod_kernel_rw.hip", CSRC / "demod_aux.hip", CSRC / "demod_api.cpp", CSRC / "demod_host.cpp"]
     objs = []
     for src in srcs:
         obj = LIB / (src.stem + ".o")
         if force or _stale(obj, [src] + headers):
             if verbose:
                 print("hipcc", src.name, flush=True)
-            _run([hipcc, *COMMON, "-x", "hip", "-c", str(src), "-o", str(obj)])
+            # the register-window kernel wants scalar f32 ops: packed v_pk_* are slower on gfx950
+            extra = ["-fno-slp-vectorize"] if src.name == "demod_kernel_rw.hip" else []
+            _run([hipcc, *COMMON, *extra, "-x", "hip", "-c", str(src), "-o", str(obj)])
         objs.append(obj)
     so = LIB / "libmeteor_demod_amd.so"
     if force or _stale(so, objs):

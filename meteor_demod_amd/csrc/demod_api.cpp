@@ -90,7 +90,10 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	L.ctab = ctx->d_ctab;
 	L.ctab_floats = static_cast<uint32_t>(ctx->tab.ctab.size());
 	L.tanh_lut = ctx->d_lut;
-	HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->lds_bytes, stream));
+	if (ctx->tab.use_rw)
+		HIP_TRY(mdemod_launch_demod_rw(L, ctx->params.bps, env_int("MDEMOD_RW_PACKED", 1), ctx->lds_bytes, stream));
+	else
+		HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->lds_bytes, stream));
 	return MDEMOD_OK;
 }
 
@@ -151,20 +154,25 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	ctx->d_soft = nullptr; ctx->d_soft_bytes = 0;
 	ctx->d_off = nullptr; ctx->d_cnt = nullptr;
 
-	int rc = mdemod_host_derive(*params, ctx->tab);
+	/* MDEMOD_KERNEL=v1 forces the LDS-ring kernel (tests cover both) */
+	const char *kforce = getenv("MDEMOD_KERNEL");
+	int rc = mdemod_host_derive(*params, ctx->tab, !(kforce && !strcmp(kforce, "v1")));
 	if (rc) { delete ctx; return rc; }
 	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
 
 	/* tunables (experiments only; defaults are the measured best) */
 	DemodConsts &c = ctx->tab.c;
-	c.ring_granules = c.hpad / 4 + env_int("MDEMOD_RING_EXTRA", 8);
-	if (c.ring_granules < c.hpad / 4 + 4) c.ring_granules = c.hpad / 4 + 4;
+	if (!ctx->tab.use_rw) {
+		c.ring_granules = c.hpad / 4 + env_int("MDEMOD_RING_EXTRA", 8);
+		if (c.ring_granules < c.hpad / 4 + 4) c.ring_granules = c.hpad / 4 + 4;
+	}
 	const int waves = env_int("MDEMOD_WAVES_PER_BLOCK", 3);
 	ctx->block_threads = 64 * (waves < 1 ? 1 : (waves > 16 ? 16 : waves));
 
 	auto lds_need = [&](int threads) {
 		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
-		       static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes;
+		       (ctx->tab.use_rw ? static_cast<size_t>(MDEMOD_RW_BLOCK / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
+		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes);
 	};
 	while (ctx->block_threads > 64 && lds_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
 	ctx->lds_bytes = lds_need(ctx->block_threads);
@@ -193,7 +201,7 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	CREATE_TRY(dev_alloc(ctx, &s.overflow, n));
 	{
 		unsigned char *h = nullptr;
-		CREATE_TRY(dev_alloc(ctx, &h, static_cast<size_t>(c.hpad) * n * ctx->sample_bytes));
+		CREATE_TRY(dev_alloc(ctx, &h, static_cast<size_t>(c.hpad) * n * (ctx->tab.use_rw ? 8 : ctx->sample_bytes)));
 		s.hist = h;
 	}
 	CREATE_TRY(dev_alloc(ctx, &s.events, n * MDEMOD_MAX_LOCK_EVENTS));
@@ -235,7 +243,7 @@ mdemod_reset(mdemod_ctx *ctx, void *hip_stream)
 	if (rc) return rc;
 	HIP_TRY(hipMemsetAsync(ctx->st.events, 0, sizeof(mdemod_lock_event) * MDEMOD_MAX_LOCK_EVENTS * ctx->params.n_streams,
 	                       static_cast<hipStream_t>(hip_stream)));
-	HIP_TRY(mdemod_launch_reset(ctx->st, ctx->tab.c, ctx->params.bps, ctx->params.n_streams,
+	HIP_TRY(mdemod_launch_reset(ctx->st, ctx->tab.c, ctx->params.bps, ctx->tab.use_rw ? 1 : 0, ctx->params.n_streams,
 	                            static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
 }
@@ -475,16 +483,21 @@ mdemod_get_history(mdemod_ctx *ctx, uint32_t stream, float *iq_pairs, void *hip_
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
-	const size_t sb = ctx->sample_bytes, ns = ctx->params.n_streams;
+	const int hfmt = ctx->tab.use_rw ? 32 : ctx->params.bps;     /* v2 keeps converted floats */
+	const size_t sb = 2 * static_cast<size_t>(hfmt) / 8, ns = ctx->params.n_streams;
 	const int hpad = ctx->tab.c.hpad;
 	std::vector<unsigned char> raw(static_cast<size_t>(hpad) * sb);
-	HIP_TRY(hipMemcpy2DAsync(raw.data(), sb, static_cast<const unsigned char *>(ctx->st.hist) + stream * sb,
-	                         ns * sb, sb, hpad, hipMemcpyDeviceToHost, st));
+	if (ctx->tab.use_rw)      /* v2 layout: [stream][hpad] */
+		HIP_TRY(hipMemcpyAsync(raw.data(), static_cast<const unsigned char *>(ctx->st.hist) + static_cast<size_t>(stream) * hpad * sb,
+		                       static_cast<size_t>(hpad) * sb, hipMemcpyDeviceToHost, st));
+	else
+		HIP_TRY(hipMemcpy2DAsync(raw.data(), sb, static_cast<const unsigned char *>(ctx->st.hist) + stream * sb,
+		                         ns * sb, sb, hpad, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	for (int k = 0; k < hpad; k++) {
 		const unsigned char *p = &raw[k * sb];
-		if (ctx->params.bps == 8) { iq_pairs[2*k] = (float)((int)p[0] - 128); iq_pairs[2*k+1] = (float)((int)p[1] - 128); }
-		else if (ctx->params.bps == 16) { int16_t v[2]; memcpy(v, p, 4); iq_pairs[2*k] = v[0]; iq_pairs[2*k+1] = v[1]; }
+		if (hfmt == 8) { iq_pairs[2*k] = (float)((int)p[0] - 128); iq_pairs[2*k+1] = (float)((int)p[1] - 128); }
+		else if (hfmt == 16) { int16_t v[2]; memcpy(v, p, 4); iq_pairs[2*k] = v[0]; iq_pairs[2*k+1] = v[1]; }
 		else memcpy(&iq_pairs[2*k], p, 8);
 	}
 	return MDEMOD_OK;
@@ -498,22 +511,27 @@ mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs, void
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
-	const size_t sb = ctx->sample_bytes, ns = ctx->params.n_streams;
+	const int hfmt = ctx->tab.use_rw ? 32 : ctx->params.bps;
+	const size_t sb = 2 * static_cast<size_t>(hfmt) / 8, ns = ctx->params.n_streams;
 	const int hpad = ctx->tab.c.hpad;
 	std::vector<unsigned char> raw(static_cast<size_t>(hpad) * sb);
 	for (int k = 0; k < hpad; k++) {
 		unsigned char *p = &raw[k * sb];
 		const float re = iq_pairs[2*k], im = iq_pairs[2*k+1];
-		if (ctx->params.bps == 8) {
+		if (hfmt == 8) {
 			if (re != floorf(re) || im != floorf(im) || re < -128 || re > 127 || im < -128 || im > 127) return MDEMOD_ERR_PARAM;
 			p[0] = (unsigned char)((int)re + 128); p[1] = (unsigned char)((int)im + 128);
-		} else if (ctx->params.bps == 16) {
+		} else if (hfmt == 16) {
 			if (re != floorf(re) || im != floorf(im) || re < -32768 || re > 32767 || im < -32768 || im > 32767) return MDEMOD_ERR_PARAM;
 			int16_t v[2] = { (int16_t)re, (int16_t)im }; memcpy(p, v, 4);
 		} else memcpy(p, &iq_pairs[2*k], 8);
 	}
-	HIP_TRY(hipMemcpy2DAsync(static_cast<unsigned char *>(ctx->st.hist) + stream * sb, ns * sb, raw.data(), sb,
-	                         sb, hpad, hipMemcpyHostToDevice, st));
+	if (ctx->tab.use_rw)
+		HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(ctx->st.hist) + static_cast<size_t>(stream) * hpad * sb, raw.data(),
+		                       static_cast<size_t>(hpad) * sb, hipMemcpyHostToDevice, st));
+	else
+		HIP_TRY(hipMemcpy2DAsync(static_cast<unsigned char *>(ctx->st.hist) + stream * sb, ns * sb, raw.data(), sb,
+		                         sb, hpad, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	return MDEMOD_OK;
 }

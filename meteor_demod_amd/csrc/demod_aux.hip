@@ -18,7 +18,7 @@ namespace {
  * agc.c:9-10, pll.c:33-36,112, timing.c:13-14,21,43, filter.c:16 (calloc). */
 template <typename sample_t>
 __global__ void
-reset_kernel(DemodStateSoA st, float t_center, int hpad, uint32_t n_streams, sample_t zero)
+reset_kernel(DemodStateSoA st, float t_center, int hpad, uint32_t n_streams, sample_t zero, int stream_major)
 {
 	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n_streams) return;
@@ -30,7 +30,7 @@ reset_kernel(DemodStateSoA st, float t_center, int hpad, uint32_t n_streams, sam
 	st.n_samples[s] = 0; st.n_symbols[s] = 0; st.first_lock[s] = -1;
 	st.sym_this_call[s] = 0; st.ev_this_call[s] = 0; st.overflow[s] = 0;
 	sample_t *hist = reinterpret_cast<sample_t *>(st.hist);
-	for (int k = 0; k < hpad; k++) hist[(size_t)k * n_streams + s] = zero;
+	for (int k = 0; k < hpad; k++) hist[stream_major ? (size_t)s * hpad + k : (size_t)k * n_streams + s] = zero;
 }
 
 __global__ void
@@ -53,19 +53,20 @@ selftest_hypot_kernel(const float *xy, uint32_t n, float *out)
 } /* namespace */
 
 hipError_t
-mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, uint32_t n_streams, hipStream_t stream)
+mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int float_history, uint32_t n_streams, hipStream_t stream)
 {
 	if (n_streams == 0) return hipSuccess;
 	const dim3 block(256), grid((n_streams + 255) / 256);
+	if (float_history) fmt = 32;        /* the v2 kernel keeps its history as converted floats */
 	switch (fmt) {
 	case 16:
-		hipLaunchKernelGGL(reset_kernel<uint32_t>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, (uint32_t)0);
+		hipLaunchKernelGGL(reset_kernel<uint32_t>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, (uint32_t)0, float_history);
 		break;
 	case 8:   /* raw u8 encoding of 0.0 is 128 (wavfile.c:60) */
-		hipLaunchKernelGGL(reset_kernel<uint16_t>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, (uint16_t)0x8080);
+		hipLaunchKernelGGL(reset_kernel<uint16_t>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, (uint16_t)0x8080, float_history);
 		break;
 	case 32:
-		hipLaunchKernelGGL(reset_kernel<float2>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, make_float2(0.0f, 0.0f));
+		hipLaunchKernelGGL(reset_kernel<float2>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, make_float2(0.0f, 0.0f), float_history);
 		break;
 	default:
 		return hipErrorInvalidValue;

@@ -61,7 +61,7 @@ rrc_tap(int stage, unsigned n_taps, float osf, float alpha)
 } /* namespace */
 
 int
-mdemod_host_derive(const mdemod_params &p, HostTables &out)
+mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 {
 	if (p.interp_factor < 1 || p.interp_factor > 64) return MDEMOD_ERR_PARAM;
 	if (p.rrc_order < 1 || p.rrc_order > 256) return MDEMOD_ERR_PARAM;
@@ -104,11 +104,45 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out)
 			out.rrc[j * taps + i] = rrc_tap(static_cast<int>(i * banks + j), taps * banks,
 			                                out.osf * static_cast<float>(banks), rrc_alpha);
 
-	/* ---- kernel geometry ---- */
+	/* ---- symbol-clock fast path constants ---- */
+	{
+		const double f_hi = (static_cast<double>(c.t_center) + static_cast<double>(c.t_maxdev)) * (1.0 + 1e-6);
+		c.step_fmax = nextafterf(static_cast<float>(f_hi), 1e30f);
+		const double thr_min = p.oqpsk ? kPi : 2 * kPi;          /* first threshold a fresh symbol meets */
+		int ks = static_cast<int>(floor((thr_min - 0.6 - 1e-3) / f_hi)) - 1;
+		c.step_safe = ks < 0 ? 0 : ks;
+		const double f_lo = static_cast<double>(c.t_center) - static_cast<double>(c.t_maxdev);
+		int kc = static_cast<int>(ceil(1.1 / f_lo)) + 3;
+		c.step_check = kc > 24 ? 24 : kc;
+		c.interp_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(c.interp)) + 1u;
+	}
+
+	/* ---- kernel selection + geometry ---- */
+	const double per_firing = static_cast<double>(out.osf) / (p.oqpsk ? 2.0 : 1.0);   /* samples consumed per firing */
+	out.use_rw = allow_rw && c.taps <= 65 && per_firing <= 3.6;
+	c.chunk_granules = 2;
+	if (out.use_rw) {
+		/* v2: 80-slot register window, filter embedded as 65 taps (leading zeros), 16 alignments */
+		const int kTaps = 65, NW = 80, AL = NW - kTaps + 1;
+		c.hpad = kTaps - 1;
+		c.win_granules = NW / 4;
+		c.ring_granules = 0;
+		c.ctab_row_floats = NW;
+		c.ctab_row_stride = NW + 2;                       /* 41 x 8 B: odd => consecutive rows hit distinct b64 bank slots */
+		out.ctab.assign(static_cast<size_t>(AL) * banks * c.ctab_row_stride, 0.0f);
+		const int lead = kTaps - c.taps;
+		for (int a = 0; a < AL; a++)
+			for (unsigned b = 0; b < banks; b++) {
+				float *row = &out.ctab[(static_cast<size_t>(a) * banks + b) * c.ctab_row_stride];
+				for (int k = 0; k < c.taps; k++) row[a + lead + k] = out.rrc[b * taps + k];
+			}
+		return MDEMOD_OK;
+	}
+
+	/* v1: LDS ring */
 	c.hpad = ((c.taps - 1 + 7) / 8) * 8;
 	if (c.hpad < 8) c.hpad = 8;
 	c.win_granules = (c.taps + 6) / 4;                 /* ceil((3 + taps) / 4): any start alignment */
-	c.chunk_granules = 2;
 	c.ring_granules = c.hpad / 4 + 8;
 	c.ctab_row_floats = 4 * c.win_granules;
 	const int stride_granules = (c.win_granules & 1) ? c.win_granules : c.win_granules + 1;   /* odd: distinct bank slots */

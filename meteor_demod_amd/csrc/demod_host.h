@@ -16,9 +16,10 @@ struct HostTables {
 	std::vector<float> rrc;       /* interp*taps, bank-major (filter.c:20)     */
 	std::vector<float> ctab;      /* [4 alignments][interp banks][row stride]  */
 	float              tanh_lut[32];
+	bool               use_rw;    /* v2 register-window kernel eligible (taps <= 65, <= 3.6 samples per firing) */
 };
 
 /* Returns MDEMOD_OK or MDEMOD_ERR_PARAM. */
-int mdemod_host_derive(const mdemod_params &p, HostTables &out);
+int mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw = true);
 
 #endif

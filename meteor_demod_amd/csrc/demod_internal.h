@@ -10,6 +10,8 @@
 
 #define MDEMOD_WAVE            64
 #define MDEMOD_GRANULE_SAMPLES 4      /* ring granule = 4 consecutive IQ samples */
+#define MDEMOD_RW_STATE_SLOTS   11     /* per-lane LDS state words of the v2 kernel */
+#define MDEMOD_RW_BLOCK         256    /* threads per block of the v2 kernel        */
 
 /* Loop constants + geometry, passed to the kernel by value. */
 struct DemodConsts {
@@ -24,6 +26,11 @@ struct DemodConsts {
 	int32_t ctab_row_stride; /* floats between rows (bank-conflict-free stride)   */
 	float   pll_alpha, pll_beta, pll_fmax;
 	float   t_alpha, t_beta, t_center, t_maxdev;
+	/* symbol-clock fast path (v2 kernel): see demod_host.cpp */
+	int32_t  step_safe;      /* blind steps that provably cannot fire            */
+	int32_t  step_check;     /* predicated checked steps after them              */
+	float    step_fmax;      /* upper bound of the per-step phase increment      */
+	uint32_t interp_magic;   /* floor(2^32/interp)+1: x/interp == mulhi(x, magic) */
 };
 
 /* Per-stream state, structure-of-arrays in HBM so that lane s of a wave touches
@@ -69,7 +76,8 @@ struct DemodLaunch {
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, size_t lds_bytes, hipStream_t stream);
-hipError_t mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, uint32_t n_streams, hipStream_t stream);
+hipError_t mdemod_launch_demod_rw(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream);
+hipError_t mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int float_history, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_selftest_sincos(const float *x, uint32_t n, float *s, float *c, hipStream_t stream);
 hipError_t mdemod_launch_selftest_hypot(const float *xy, uint32_t n, float *out, hipStream_t stream);
 #endif

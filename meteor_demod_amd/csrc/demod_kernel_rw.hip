@@ -1,0 +1,474 @@
+/*
+ * demod_kernel_rw.hip — v2 "register window" demodulator kernel for gfx950.
+ *
+ * Same contract as demod_kernel.hip (one lane = one stream, bit-exact serial
+ * recurrence per stream, reference citations in demod_device.h), different data
+ * movement, chosen from measurements on MI355X (profiles/r01_v1_baseline.md,
+ * tools/ubench/valu_rates.hip):
+ *
+ *   - v1 was latency bound at 6 waves/CU because its 24 KB-per-wave LDS ring
+ *     capped occupancy, and its FIR paid 2 SDWA converts (4.2 cycles each) plus
+ *     packed f32 ops (6.3 cycles each) per tap.
+ *   - Here the FIR window lives in VGPRs (the register file is 3.2x the LDS) as
+ *     ALREADY CONVERTED floats: NW = 80 samples x (re, im).  One tap is two
+ *     scalar v_mul_f32 + two v_add_f32 (2.3 cycles each): 9.2 cycles instead of
+ *     17.6, and LDS holds only the coefficient rows.
+ *   - All lanes of a wave slide their windows TOGETHER, by 8 slots (two
+ *     granules) at a time, with plain register moves: 144 v_mov_b32 every ~2.5
+ *     symbols (~130 cycles per symbol against ~740 for the FIR).  Per-lane
+ *     position differences are absorbed by the coefficient row: a lane whose
+ *     65 samples start `a` slots into the register window reads row (a, bank),
+ *     zero padded (exact: acc + (+-0) == acc and acc is never -0).  A lane that
+ *     runs ahead of the window idles one iteration, a lane that lags gates the
+ *     slide.  (A rotate-by-renaming variant with 19 unrolled FIR copies was
+ *     tried first: hipcc merged the copies behind PHI moves and spilled.)
+ *   - Coefficient rows are read with ds_read_b64 and an odd 8-byte row stride:
+ *     the <= 32 consecutive rows a wave uses map to distinct LDS bank slots.
+ *   - The symbol clock is stepped branch-free: K blind float adds that provably
+ *     cannot fire, then a few predicated checked steps; a generic loop remains
+ *     for block ends and unusual states.  Every add is the reference's add.
+ *   - Soft symbols are collected 8 per lane and written as one 16-byte store.
+ *   - The 160 window registers leave ~95 VGPRs at 2 waves/SIMD (the minimum that
+ *     reaches full VALU issue rate); the compiler needed 293 and spilled to scratch
+ *     (= HBM: 140 GB of spill traffic per launch).  The per-symbol loop state
+ *     (AGC, PLL, lock flags, counters: 11 values) therefore lives in per-lane LDS
+ *     slots [field][lane] (conflict free) and is only in registers while the
+ *     scalar part of a symbol runs.
+ *   - Filters shorter than 65 taps are embedded as 65-tap filters with leading
+ *     zero coefficients (exact for the same reason as the padding).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "demod_internal.h"
+#include "demod_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kTaps = 65;                 /* embedded filter length          */
+constexpr int kBack = kTaps - 1;          /* 64 = history length             */
+
+template <int FMT> struct Fmt;
+template <> struct Fmt<16> {
+	typedef uint32_t sample_t;
+	__device__ static __forceinline__ cf32 decode(uint32_t w) {
+		cf32 r; r.re = (float)(int)(int16_t)(w & 0xFFFFu); r.im = (float)((int)w >> 16); return r;
+	}
+};
+template <> struct Fmt<8> {
+	typedef uint16_t sample_t;
+	__device__ static __forceinline__ cf32 decode(uint16_t w) {
+		cf32 r; r.re = (float)((int)(w & 0xFFu) - 128); r.im = (float)((int)(w >> 8) - 128); return r;
+	}
+};
+template <> struct Fmt<32> {
+	typedef float2 sample_t;
+	__device__ static __forceinline__ cf32 decode(float2 w) { cf32 r; r.re = w.x; r.im = w.y; return r; }
+};
+
+template <int FMT> struct Gran { typename Fmt<FMT>::sample_t s[4]; };
+
+/* Window element: either the raw sample (PACKED: one VGPR for s16/u8, converted at every use)
+ * or the converted float pair (two VGPRs, converted once). */
+template <int FMT, bool PACKED> struct Win;
+template <int FMT> struct Win<FMT, true> {
+	typedef typename Fmt<FMT>::sample_t elem_t;
+	__device__ static __forceinline__ elem_t pack(typename Fmt<FMT>::sample_t raw) { return raw; }
+	__device__ static __forceinline__ cf32 get(elem_t e) { return Fmt<FMT>::decode(e); }
+	__device__ static __forceinline__ elem_t from_float(float2 h);
+};
+template <> __device__ __forceinline__ uint32_t Win<16, true>::from_float(float2 h) {
+	return ((uint32_t)(int)h.x & 0xFFFFu) | ((uint32_t)(int)h.y << 16);
+}
+template <> __device__ __forceinline__ uint16_t Win<8, true>::from_float(float2 h) {
+	return (uint16_t)((((int)h.x + 128) & 0xFF) | ((((int)h.y + 128) & 0xFF) << 8));
+}
+template <> __device__ __forceinline__ float2 Win<32, true>::from_float(float2 h) { return h; }
+template <int FMT> struct Win<FMT, false> {
+	typedef float2 elem_t;
+	__device__ static __forceinline__ elem_t pack(typename Fmt<FMT>::sample_t raw) {
+		const cf32 s = Fmt<FMT>::decode(raw); return make_float2(s.re, s.im);
+	}
+	__device__ static __forceinline__ cf32 get(elem_t e) { cf32 r; r.re = e.x; r.im = e.y; return r; }
+	__device__ static __forceinline__ elem_t from_float(float2 h) { return h; }
+};
+
+/* 4 consecutive samples starting at block sample m0 (zeros past the end). */
+template <int FMT>
+__device__ __forceinline__ Gran<FMT>
+fetch_granule(const typename Fmt<FMT>::sample_t *src, int m0, int n)
+{
+	Gran<FMT> g;
+	if (m0 + 3 < n) {
+		__builtin_memcpy(&g, src + m0, sizeof(g));
+	} else {
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			if (m0 + u < n) g.s[u] = src[m0 + u];
+			else __builtin_memset(&g.s[u], 0, sizeof(g.s[u]));
+		}
+	}
+	return g;
+}
+
+/* ---- FIR over the rotated register window (filter.c:46-65) --------------------- */
+
+/* filter.c:55-62: sequential, oldest first, unfused.  Coefficients arrive in chunks of CH
+ * taps, one chunk ahead of the arithmetic; the scheduling barrier between chunks keeps the
+ * scheduler from hoisting every ds_read to the top (80 live VGPRs of coefficients would
+ * spill the window). */
+template <int NW, typename W>
+__device__ __forceinline__ void
+fir_window(const typename W::elem_t (&win)[NW], const float *row, float &out_re, float &out_im)
+{
+	constexpr int CH = 8;
+	static_assert(NW % CH == 0, "window is a whole number of chunks");
+	float ar = 0.0f, ai = 0.0f;
+	float2 cur[CH / 2], nxt[CH / 2];
+#pragma unroll
+	for (int j = 0; j < CH / 2; j++) cur[j] = *reinterpret_cast<const float2 *>(row + 2 * j);
+#pragma unroll
+	for (int c = 0; c < NW / CH; c++) {
+		if (c + 1 < NW / CH) {
+#pragma unroll
+			for (int j = 0; j < CH / 2; j++) nxt[j] = *reinterpret_cast<const float2 *>(row + (c + 1) * CH + 2 * j);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int j = 0; j < CH / 2; j++) {
+			const int s = c * CH + 2 * j;
+			const cf32 x0 = W::get(win[s]), x1 = W::get(win[s + 1]);
+			ar = ar + x0.re * cur[j].x;
+			ai = ai + x0.im * cur[j].x;
+			ar = ar + x1.re * cur[j].y;
+			ai = ai + x1.im * cur[j].y;
+		}
+#pragma unroll
+		for (int j = 0; j < CH / 2; j++) cur[j] = nxt[j];
+	}
+	out_re = ar;
+	out_im = ai;
+}
+
+/* ---- the kernel ------------------------------------------------------------------ */
+
+template <int FMT, int OQPSK, bool PACKED>
+__global__ void __launch_bounds__(256, 2)
+demod_kernel_rw(const DemodLaunch L)
+{
+	typedef Fmt<FMT> F;
+	typedef Win<FMT, PACKED> W;
+	typedef typename F::sample_t sample_t;
+	constexpr int NW = 80;                       /* window slots                       */
+	constexpr int SLIDE = 8;                     /* slots per slide (two granules)     */
+	constexpr int AMAX = NW - kTaps;             /* alignments 0..15                   */
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	float *ctab = reinterpret_cast<float *>(lds);
+	float *lut = ctab + L.ctab_floats;
+	/* per-lane state slots: field f of this lane is sl[f * 64] */
+	enum { S_GAIN, S_BIAS_RE, S_BIAS_IM, S_PHASE, S_FREQ, S_ERR, S_FLAGS, S_TPREV, S_INPHASE, S_EVCALL, S_FIRSTLOCK, S_COUNT };
+	static_assert(S_COUNT == MDEMOD_RW_STATE_SLOTS, "host LDS sizing");
+	float *sl = lut + 32 + (threadIdx.x >> 6) * (S_COUNT * 64) + (threadIdx.x & 63);
+	int *sli = reinterpret_cast<int *>(sl);
+
+	const DemodConsts &C = L.c;
+	const uint32_t stream = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool valid = stream < L.n_streams;
+
+	for (uint32_t i = threadIdx.x; i < L.ctab_floats; i += blockDim.x) ctab[i] = L.ctab[i];
+	if (threadIdx.x < 32) lut[threadIdx.x] = L.tanh_lut[threadIdx.x];
+
+	/* ---- per-stream geometry ---- */
+	int n = 0;
+	const sample_t *src = nullptr;
+	if (valid) {
+		n = (int)(L.n_samples_arr ? L.n_samples_arr[stream] : L.n_samples);
+		const uint64_t off = L.iq_offset ? L.iq_offset[stream] : (uint64_t)stream * L.iq_stride;
+		src = reinterpret_cast<const sample_t *>(L.iq) + off;
+	}
+	const int v_end = kBack + n;                 /* virtual stream = 64 history samples ++ block */
+	const int interp = C.interp;
+
+	/* ---- state: symbol-clock variables in registers, everything else in the LDS slots ---- */
+	float t_phase = 0.0f, t_freq = C.t_center;
+	int dual_state = 1;
+	{
+		float gain = 1.0f, bias_re = 0.0f, bias_im = 0.0f, phase = 0.0f, freq = 0.0f, err = 1000.0f, t_prev = 0.0f, inph = 0.0f;
+		int fl = MDEMOD_FLAG_UPDOWN_POS | (1 << MDEMOD_FLAG_DUAL_SHIFT);
+		if (valid) {
+			gain = L.st.agc_gain[stream]; bias_re = L.st.agc_bias_re[stream]; bias_im = L.st.agc_bias_im[stream];
+			phase = L.st.pll_phase[stream]; freq = L.st.pll_freq[stream]; err = L.st.pll_err[stream];
+			fl = L.st.flags[stream];
+			t_phase = L.st.t_phase[stream]; t_freq = L.st.t_freq[stream]; t_prev = L.st.t_prev[stream];
+			inph = L.st.inphase[stream];
+		}
+		dual_state = (fl >> MDEMOD_FLAG_DUAL_SHIFT) & 3;
+		sl[S_GAIN * 64] = gain; sl[S_BIAS_RE * 64] = bias_re; sl[S_BIAS_IM * 64] = bias_im;
+		sl[S_PHASE * 64] = phase; sl[S_FREQ * 64] = freq; sl[S_ERR * 64] = err;
+		sli[S_FLAGS * 64] = fl & 7;                     /* locked | locked_once | updown>0; bit 3 = overflow */
+		sl[S_TPREV * 64] = t_prev; sl[S_INPHASE * 64] = inph;
+		sli[S_EVCALL * 64] = 0; sli[S_FIRSTLOCK * 64] = -1;
+	}
+
+	/* ---- window: slots 0..63 = history, 64..79 = first four granules of the block ---- */
+	typename W::elem_t win[NW];
+	{
+		/* v2 history layout is [stream][64] float2: one base address + immediate offsets */
+		const float2 *hist = reinterpret_cast<const float2 *>(L.st.hist) + (size_t)(valid ? stream : 0) * kBack;
+#pragma unroll
+		for (int k = 0; k < kBack; k++) {
+			float2 h = hist[k];
+			if (!valid) h = make_float2(0.0f, 0.0f);
+			win[k] = W::from_float(h);
+		}
+#pragma unroll
+		for (int g = 0; g < (NW - kBack) / 4; g++) {
+			const Gran<FMT> gr = fetch_granule<FMT>(src, 4 * g, n);
+#pragma unroll
+			for (int u = 0; u < 4; u++) win[kBack + 4 * g + u] = W::pack(gr.s[u]);
+		}
+	}
+	/* the two granules that enter at the next slide are fetched right after the previous one */
+	int g_load = (NW - kBack) / 4;                         /* next block granule to fetch (wave-uniform) */
+	Gran<FMT> st0 = fetch_granule<FMT>(src, 4 * g_load, n);
+	Gran<FMT> st1 = fetch_granule<FMT>(src, 4 * g_load + 4, n);
+	g_load += 2;
+
+	__syncthreads();                                       /* coefficient rows + LUT visible */
+
+	int base = 0;                                          /* virtual index of logical slot 0 */
+	int v_cur = kBack - 1;
+	int isub = 0, fire_sub = 0;
+	bool fired = false;
+	bool done = !valid || n == 0;
+	uint32_t sym_call = 0;
+	uint32_t ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0;           /* 8 buffered soft symbols          */
+	const int k_safe = C.step_safe, k_check = C.step_check;
+	const float f_hi = C.step_fmax;
+	const uint32_t magic = C.interp_magic;
+
+	while (true) {
+		/* ---- (1) symbol clock: timing.c:32-57 ---- */
+		if (!fired && !done) {
+			const float thr = OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F;
+			const int steps_left = (v_end - 1 - v_cur) * interp + (isub ? interp - isub : 0);
+			const bool fast = (t_phase < thr - (float)k_safe * f_hi - 1e-3f) && (steps_left >= k_safe + k_check);
+			if (fast) {
+				float p = t_phase;
+				for (int k = 0; k < k_safe; k++) p = p + t_freq;       /* cannot reach thr: no compare needed */
+				int m = k_safe;
+				bool hit = false;
+				for (int j = 0; j < k_check; j++) {
+					const float q = p + t_freq;
+					const bool take = !hit;
+					p = take ? q : p;
+					m += take ? 1 : 0;
+					hit = hit || (q >= thr);
+				}
+				t_phase = p;
+				const uint32_t w = (uint32_t)(isub + m);
+				const uint32_t qd = __umulhi(w + (uint32_t)interp - 1u, magic);        /* ceil(w / interp)  */
+				v_cur += (int)qd - (isub > 0 ? 1 : 0);
+				const uint32_t q1 = __umulhi(w - 1u, magic);
+				fire_sub = (int)(w - 1u - q1 * (uint32_t)interp);
+				const uint32_t q0 = __umulhi(w, magic);
+				isub = (int)(w - q0 * (uint32_t)interp);
+				fired = hit;
+			}
+			while (!fired && !done) {                                   /* generic path */
+				if (isub == 0) {
+					if (v_cur + 1 >= v_end) { done = true; break; }
+					v_cur++;
+				}
+				t_phase = t_phase + t_freq;
+				fire_sub = isub;
+				isub = (isub + 1 == interp) ? 0 : isub + 1;
+				if (t_phase >= thr) fired = true;
+			}
+		}
+		if (__all(done)) break;
+
+		/* ---- (2) slide the window by 8 slots when nobody needs slots 0..7 any more ---- */
+		{
+			const int a_now = v_cur - kBack - base;
+			if (__all(done || a_now >= SLIDE)) {
+#pragma unroll
+				for (int k = 0; k < NW - SLIDE; k++) win[k] = win[k + SLIDE];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					win[NW - 8 + u] = W::pack(st0.s[u]);
+					win[NW - 4 + u] = W::pack(st1.s[u]);
+				}
+				base += SLIDE;
+				st0 = fetch_granule<FMT>(src, 4 * g_load, n);
+				st1 = fetch_granule<FMT>(src, 4 * g_load + 4, n);
+				g_load += 2;
+			}
+		}
+
+		/* ---- (3) process the firing if its 65 samples are inside the window ---- */
+		const int a = v_cur - kBack - base;
+		if (fired && a <= AMAX) {
+			fired = false;
+			const int bank = interp - 1 - fire_sub;                     /* filter.c:52 */
+			const float *row = ctab + (a * interp + bank) * C.ctab_row_stride;
+			cf32 y;
+			fir_window<NW, W>(win, row, y.re, y.im);
+
+			/* ---- scalar part: state comes from / goes back to the LDS slots ---- */
+			{
+				float gain = sl[S_GAIN * 64], bias_re = sl[S_BIAS_RE * 64], bias_im = sl[S_BIAS_IM * 64];
+				y = md_agc(y, gain, bias_re, bias_im);
+				sl[S_GAIN * 64] = gain; sl[S_BIAS_RE * 64] = bias_re; sl[S_BIAS_IM * 64] = bias_im;
+			}
+			int fl = sli[S_FLAGS * 64];
+			PllState pll;
+			pll.phase = sl[S_PHASE * 64]; pll.freq = sl[S_FREQ * 64]; pll.err = sl[S_ERR * 64];
+			pll.locked = fl & 1; pll.locked_once = (fl >> 1) & 1; pll.updown = (fl & 4) ? 1 : -1;
+
+			const float sn = md_fast_sin(-pll.phase);
+			const float cs = md_fast_cos(-pll.phase);
+			bool emit = true;
+			float out_re, out_im;
+			if (OQPSK) {
+				float inphase = sl[S_INPHASE * 64];
+				if (dual_state == 1) { inphase = y.re * cs - y.im * sn; emit = false; sl[S_INPHASE * 64] = inphase; }   /* demod.c:66-71 */
+				out_re = inphase;
+				out_im = y.re * sn + y.im * cs;                                          /* demod.c:76    */
+				dual_state = (dual_state % 2) + 1;                                       /* timing.c:52   */
+			} else {
+				out_re = y.re * cs - y.im * sn;
+				out_im = y.re * sn + y.im * cs;
+			}
+			md_nco_advance(pll.phase, pll.freq);
+
+			if (emit) {
+				float t_prev = sl[S_TPREV * 64];
+				md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);
+				sl[S_TPREV * 64] = t_prev;
+				int first = 0;
+				const int changed = md_pll_update(pll, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
+				if (first) sli[S_FIRSTLOCK * 64] = (int)sym_call;
+				if (changed) {
+					const int ev_call = sli[S_EVCALL * 64];
+					if (ev_call < MDEMOD_MAX_LOCK_EVENTS) {
+						mdemod_lock_event ev;
+						ev.symbol = L.st.n_symbols[stream] + sym_call; ev.locked = pll.locked; ev.pad = 0;
+						L.st.events[(size_t)stream * MDEMOD_MAX_LOCK_EVENTS + ev_call] = ev;
+					}
+					sli[S_EVCALL * 64] = ev_call + 1;
+				}
+				const uint32_t sym = (uint32_t)(md_quantise(out_re) & 0xFF) | ((uint32_t)(md_quantise(out_im) & 0xFF) << 8);
+				ob0 = __builtin_amdgcn_alignbit(ob1, ob0, 16);
+				ob1 = __builtin_amdgcn_alignbit(ob2, ob1, 16);
+				ob2 = __builtin_amdgcn_alignbit(ob3, ob2, 16);
+				ob3 = (ob3 >> 16) | (sym << 16);
+				sym_call++;
+				if ((sym_call & 7u) == 0) {
+					const uint32_t sb = sym_call - 8;
+					int8_t *soft_out = L.soft + (size_t)stream * L.soft_stride * 2;
+					if (sym_call <= L.soft_cap) {
+						uint4 v; v.x = ob0; v.y = ob1; v.z = ob2; v.w = ob3;
+						__builtin_memcpy(soft_out + 2 * (size_t)sb, &v, 16);
+					} else {
+						fl |= 8;
+						const uint32_t w4[4] = { ob0, ob1, ob2, ob3 };
+						for (uint32_t i = 0; i < 8 && sb + i < L.soft_cap; i++)
+							*reinterpret_cast<uint16_t *>(soft_out + 2 * (size_t)(sb + i)) =
+							    (uint16_t)(w4[i >> 1] >> ((i & 1) * 16));
+					}
+				}
+			}
+			sl[S_PHASE * 64] = pll.phase; sl[S_FREQ * 64] = pll.freq; sl[S_ERR * 64] = pll.err;
+			sli[S_FLAGS * 64] = (fl & 8) | (pll.locked ? 1 : 0) | (pll.locked_once ? 2 : 0) | (pll.updown > 0 ? 4 : 0);
+		}
+	}
+
+	/* Epilogue addresses are recomputed from an opaque copy of the stream index: otherwise the
+	 * compiler keeps ~30 VGPRs of prologue addresses alive across the main loop. */
+	uint32_t stream_e = stream;
+	asm volatile("" : "+v"(stream_e));
+	int8_t *soft_e = L.soft + (size_t)stream_e * L.soft_stride * 2;
+	int overflow = (sli[S_FLAGS * 64] >> 3) & 1;
+
+	/* ---- flush the partial group of soft symbols ---- */
+	if (valid) {
+		const uint32_t r = sym_call & 7u;
+		const uint32_t sb = sym_call - r;
+		const uint32_t w4[4] = { ob0, ob1, ob2, ob3 };
+		for (uint32_t i = 0; i < r; i++) {
+			const uint32_t hw = 8 - r + i;
+			if (sb + i < L.soft_cap)
+				*reinterpret_cast<uint16_t *>(soft_e + 2 * (size_t)(sb + i)) = (uint16_t)(w4[hw >> 1] >> ((hw & 1) * 16));
+			else
+				overflow = 1;
+		}
+	}
+
+	/* ---- store state ---- */
+	if (valid) {
+		const int fl = sli[S_FLAGS * 64];
+		L.st.agc_gain[stream_e] = sl[S_GAIN * 64]; L.st.agc_bias_re[stream_e] = sl[S_BIAS_RE * 64]; L.st.agc_bias_im[stream_e] = sl[S_BIAS_IM * 64];
+		L.st.pll_phase[stream_e] = sl[S_PHASE * 64]; L.st.pll_freq[stream_e] = sl[S_FREQ * 64]; L.st.pll_err[stream_e] = sl[S_ERR * 64];
+		L.st.flags[stream_e] = (fl & 7) | (dual_state << MDEMOD_FLAG_DUAL_SHIFT);
+		L.st.t_phase[stream_e] = t_phase; L.st.t_freq[stream_e] = t_freq; L.st.t_prev[stream_e] = sl[S_TPREV * 64];
+		L.st.inphase[stream_e] = sl[S_INPHASE * 64];
+		const uint64_t nsym0 = L.st.n_symbols[stream_e];
+		const int first_lock_call = sli[S_FIRSTLOCK * 64];
+		L.st.n_samples[stream_e] += (uint64_t)n;
+		L.st.n_symbols[stream_e] = nsym0 + sym_call;
+		if (first_lock_call >= 0) L.st.first_lock[stream_e] = (int64_t)(nsym0 + (uint32_t)first_lock_call);
+		L.st.sym_this_call[stream_e] = sym_call;
+		L.st.ev_this_call[stream_e] = (uint32_t)sli[S_EVCALL * 64];
+		L.st.overflow[stream_e] = overflow;
+
+		/* history := last 64 samples of (old history ++ block), as floats; ascending k is in-place safe */
+		float2 *hist = reinterpret_cast<float2 *>(L.st.hist);
+		for (int k = 0; k < kBack; k++) {
+			const int idx = n + k;
+			float2 h;
+			if (idx < kBack) h = hist[(size_t)idx * L.n_streams + stream_e];
+			else { const cf32 s = F::decode(src[idx - kBack]); h = make_float2(s.re, s.im); }
+			hist[(size_t)k * L.n_streams + stream_e] = h;
+		}
+	}
+}
+
+template <int FMT, int OQPSK, bool PACKED>
+hipError_t
+launch_rw(const DemodLaunch &L, size_t lds_bytes, hipStream_t stream)
+{
+	const int block = MDEMOD_RW_BLOCK;
+	const uint32_t blocks = (L.n_streams + block - 1) / block;
+	auto kfn = demod_kernel_rw<FMT, OQPSK, PACKED>;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(kfn, dim3(blocks), dim3(block), lds_bytes, stream, L);
+	return hipGetLastError();
+}
+
+template <int FMT>
+hipError_t
+launch_rw_mode(const DemodLaunch &L, bool packed, size_t lds_bytes, hipStream_t stream)
+{
+	if (FMT != 32 && packed)
+		return L.c.oqpsk ? launch_rw<FMT, 1, true>(L, lds_bytes, stream) : launch_rw<FMT, 0, true>(L, lds_bytes, stream);
+	return L.c.oqpsk ? launch_rw<FMT, 1, false>(L, lds_bytes, stream) : launch_rw<FMT, 0, false>(L, lds_bytes, stream);
+}
+
+} /* namespace */
+
+hipError_t
+mdemod_launch_demod_rw(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream)
+{
+	switch (fmt) {
+	case 16: return launch_rw_mode<16>(L, packed != 0, lds_bytes, stream);
+	case 8:  return launch_rw_mode<8>(L, packed != 0, lds_bytes, stream);
+	case 32: return launch_rw_mode<32>(L, false, lds_bytes, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
