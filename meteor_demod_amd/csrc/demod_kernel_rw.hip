@@ -119,34 +119,75 @@ fetch_granule(const typename Fmt<FMT>::sample_t *src, int m0, int n)
  * taps, one chunk ahead of the arithmetic; the scheduling barrier between chunks keeps the
  * scheduler from hoisting every ds_read to the top (80 live VGPRs of coefficients would
  * spill the window). */
+/* Coefficient fetch.  `volatile` keeps hipcc from fusing two ds_read_b64 into one
+ * ds_read2_b64: the fused form is serviced in 16-lane groups over 16 bank slots and measured
+ * 2.7x bank-conflict cycles on the ~40 distinct rows a wave uses; plain b64 has 32 slots. */
+typedef float coef2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2
+ld_coef(const float *row, int s)
+{
+	/* explicit LDS address space: address-space inference does not look through volatile */
+	typedef const volatile coef2_t __attribute__((address_space(3))) *lds_coef_ptr;
+	const coef2_t v = *(lds_coef_ptr)(row + s);
+	return make_float2(v.x, v.y);
+}
+
+/* One chunk of CH taps: filter.c:55-62, sequential, oldest first, unfused. */
+template <int NW, typename W, int CH>
+__device__ __forceinline__ void
+fir_chunk(const typename W::elem_t (&win)[NW], int c, const float2 (&h)[CH / 2], float &ar, float &ai)
+{
+#pragma unroll
+	for (int j = 0; j < CH / 2; j++) {
+		const int s = c * CH + 2 * j;
+		const cf32 x0 = W::get(win[s]), x1 = W::get(win[s + 1]);
+		ar = ar + x0.re * h[j].x;
+		ai = ai + x0.im * h[j].x;
+		ar = ar + x1.re * h[j].y;
+		ai = ai + x1.im * h[j].y;
+	}
+}
+
+/*
+ * FIR over the register window.  Chunks [c_lo, c_hi) of 8 slots are evaluated (the caller
+ * drops an edge chunk whose coefficients are zero for every lane of the wave).  Coefficients
+ * are fetched two chunks ahead; the empty asm ties the fetch address to the accumulator so
+ * the compiler cannot hoist all 40 reads to the top (80 live VGPRs of coefficients was what
+ * capped the kernel at 2 waves/SIMD).
+ */
 template <int NW, typename W>
 __device__ __forceinline__ void
-fir_window(const typename W::elem_t (&win)[NW], const float *row, float &out_re, float &out_im)
+fir_window(const typename W::elem_t (&win)[NW], const float *row, bool skip_first, bool skip_last,
+           float &out_re, float &out_im)
 {
-	constexpr int CH = 8;
+	constexpr int CH = 8, NCH = NW / CH;
 	static_assert(NW % CH == 0, "window is a whole number of chunks");
 	float ar = 0.0f, ai = 0.0f;
-	float2 cur[CH / 2], nxt[CH / 2];
+	float2 h0[CH / 2], h1[CH / 2];
+
+	if (!skip_first) {                                   /* wave-uniform */
 #pragma unroll
-	for (int j = 0; j < CH / 2; j++) cur[j] = *reinterpret_cast<const float2 *>(row + 2 * j);
+		for (int j = 0; j < CH / 2; j++) h0[j] = ld_coef(row, 2 * j);
+		fir_chunk<NW, W, CH>(win, 0, h0, ar, ai);
+	}
 #pragma unroll
-	for (int c = 0; c < NW / CH; c++) {
-		if (c + 1 < NW / CH) {
+	for (int j = 0; j < CH / 2; j++) h0[j] = ld_coef(row, CH + 2 * j);
 #pragma unroll
-			for (int j = 0; j < CH / 2; j++) nxt[j] = *reinterpret_cast<const float2 *>(row + (c + 1) * CH + 2 * j);
+	for (int c = 1; c < NCH - 1; c++) {
+		int tie = 0;                                             /* opaque zero: keeps the LDS address space of `row` */
+		asm volatile("" : "+v"(tie) : "v"(ar), "v"(ai));         /* fetch of chunk c+1 may not pass chunk c-1's sum */
+		if (c + 1 < NCH - 1) {
+#pragma unroll
+			for (int j = 0; j < CH / 2; j++) h1[j] = ld_coef(row + tie, (c + 1) * CH + 2 * j);
 		}
-		__builtin_amdgcn_sched_barrier(0);
+		fir_chunk<NW, W, CH>(win, c, h0, ar, ai);
 #pragma unroll
-		for (int j = 0; j < CH / 2; j++) {
-			const int s = c * CH + 2 * j;
-			const cf32 x0 = W::get(win[s]), x1 = W::get(win[s + 1]);
-			ar = ar + x0.re * cur[j].x;
-			ai = ai + x0.im * cur[j].x;
-			ar = ar + x1.re * cur[j].y;
-			ai = ai + x1.im * cur[j].y;
-		}
+		for (int j = 0; j < CH / 2; j++) h0[j] = h1[j];
+	}
+	if (!skip_last) {
 #pragma unroll
-		for (int j = 0; j < CH / 2; j++) cur[j] = nxt[j];
+		for (int j = 0; j < CH / 2; j++) h0[j] = ld_coef(row, (NCH - 1) * CH + 2 * j);
+		fir_chunk<NW, W, CH>(win, NCH - 1, h0, ar, ai);
 	}
 	out_re = ar;
 	out_im = ai;
@@ -155,7 +196,7 @@ fir_window(const typename W::elem_t (&win)[NW], const float *row, float &out_re,
 /* ---- the kernel ------------------------------------------------------------------ */
 
 template <int FMT, int OQPSK, bool PACKED>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, PACKED ? 3 : 2)
 demod_kernel_rw(const DemodLaunch L)
 {
 	typedef Fmt<FMT> F;
@@ -316,7 +357,11 @@ demod_kernel_rw(const DemodLaunch L)
 			const int bank = interp - 1 - fire_sub;                     /* filter.c:52 */
 			const float *row = ctab + (a * interp + bank) * C.ctab_row_stride;
 			cf32 y;
-			fir_window<NW, W>(win, row, y.re, y.im);
+			/* slots 0..7 carry only zeros for a lane with a >= 8, slots 72..79 only zeros for a < 8:
+			 * when the whole wave agrees the chunk is dropped (exact: acc + 0*x == acc). */
+			const bool skip_first = __all(a >= 8);              /* over the lanes active in this branch */
+			const bool skip_last = __all(a < 8);
+			fir_window<NW, W>(win, row, skip_first, skip_last, y.re, y.im);
 
 			/* ---- scalar part: state comes from / goes back to the LDS slots ---- */
 			{

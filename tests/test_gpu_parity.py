@@ -23,6 +23,25 @@ def _torch():
     return torch
 
 
+KERNEL_VARIANTS = {
+    "v2-packed": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "1"},    # default: register window, raw samples
+    "v2-float": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0"},     # register window, converted floats
+    "v1-ring": {"MDEMOD_KERNEL": "v1", "MDEMOD_RW_PACKED": "1"},    # LDS ring (generic fallback, > 65 taps)
+}
+
+
+@pytest.fixture(params=list(KERNEL_VARIANTS))
+def kernel_variant(request, monkeypatch):
+    """Every kernel implementation must produce the same bytes (selection knobs are env vars
+    read by mdemod_create / launch)."""
+    for k, v in KERNEL_VARIANTS[request.param].items():
+        if v:
+            monkeypatch.setenv(k, v)
+        else:
+            monkeypatch.delenv(k, raising=False)
+    return request.param
+
+
 def gpu_demod(cfg, blocks_per_stream, n_streams=None):
     """blocks_per_stream: list (per stream) of numpy [n,2] -> list of soft arrays, statuses, demod."""
     torch = _torch()
@@ -41,7 +60,7 @@ def gpu_demod(cfg, blocks_per_stream, n_streams=None):
 # ---- every golden case, byte for byte ------------------------------------------------------
 
 @pytest.mark.parametrize("name", [c.name for c in CASES])
-def test_hip_matches_reference_golden_and_oracle(name, manifest, gpu_device):
+def test_hip_matches_reference_golden_and_oracle(name, manifest, gpu_device, kernel_variant):
     case = BY_NAME[name]
     meta = manifest["cases"][name]
     iq = case.generate()
@@ -70,7 +89,7 @@ def test_hip_matches_reference_golden_and_oracle(name, manifest, gpu_device):
     d.close()
 
 
-def test_full_loop_state_matches_oracle(gpu_device):
+def test_full_loop_state_matches_oracle(gpu_device, kernel_variant):
     """Every field of the per-stream state after a run, incl. filter history."""
     for name in ("c1_short", "c3_short"):
         case = BY_NAME[name]
@@ -97,7 +116,7 @@ def test_full_loop_state_matches_oracle(gpu_device):
 
 @pytest.mark.parametrize("name", ["c1_short", "c3_short", "u8_short", "f32_short", "odd_cfg"])
 @pytest.mark.parametrize("blocks", [[1, 2, 3, 5, 64, 1000, 4099], [8192], [0, 7, 0, 130, 1]])
-def test_block_chaining_equals_one_shot(name, blocks, gpu_device):
+def test_block_chaining_equals_one_shot(name, blocks, gpu_device, kernel_variant):
     torch = _torch()
     case = BY_NAME[name]
     iq = case.generate()[:24000]
@@ -120,7 +139,7 @@ def test_block_chaining_equals_one_shot(name, blocks, gpu_device):
         assert d.status()[0].n_samples == iq.shape[0]
 
 
-def test_state_export_import_continues_exactly(gpu_device):
+def test_state_export_import_continues_exactly(gpu_device, kernel_variant):
     """Checkpoint/hand-off: get_state+history from one context, set into another, continue."""
     torch = _torch()
     case = BY_NAME["c1_short"]
@@ -146,7 +165,7 @@ def test_state_export_import_continues_exactly(gpu_device):
 
 # ---- batches: many independent streams, one per lane -----------------------------------------
 
-def test_batch_of_distinct_streams_each_matches_oracle(gpu_device):
+def test_batch_of_distinct_streams_each_matches_oracle(gpu_device, kernel_variant):
     """BASELINE configs[4] in miniature: N independent recordings with different carrier
     offsets, clock errors and noise; every stream equals its own serial demodulation."""
     ns, n = 200, 9000
@@ -182,7 +201,7 @@ def test_result_is_independent_of_lane_and_neighbours(gpu_device):
     d.close()
 
 
-def test_ragged_batch_with_empty_and_short_streams(gpu_device):
+def test_ragged_batch_with_empty_and_short_streams(gpu_device, kernel_variant):
     torch = _torch()
     lens = [0, 1, 3, 4, 5, 63, 64, 65, 66, 129, 1000, 4097, 12000, 0, 2, 7777]
     streams = [synth.make_stream(6000 + i, 230000, 72000, f0_hz=100.0 * i, esn0_db=18.0) for i in range(len(lens))]
@@ -209,7 +228,7 @@ def test_ragged_batch_with_empty_and_short_streams(gpu_device):
             assert np.array_equal(soft[i, : want.shape[0]].cpu().numpy(), want), i
 
 
-def test_soft_capacity_overflow_is_reported_not_fatal(gpu_device):
+def test_soft_capacity_overflow_is_reported_not_fatal(gpu_device, kernel_variant):
     torch = _torch()
     iq = BY_NAME["c1_short"].generate()[:10000]
     want = O.oracle_demod(C1, iq)[0]
@@ -281,7 +300,7 @@ def test_device_generator_equals_host_generator(gpu_device):
 
 # ---- full-size properties (BASELINE configs[1]/[4] scale) ------------------------------------------
 
-def test_full_size_batch_properties(gpu_device):
+def test_full_size_batch_properties(gpu_device, kernel_variant):
     """65536 streams x 16384 samples (1.07 G samples): replicas of a recording agree byte for
     byte wherever they sit, and randomly sampled streams equal the oracle."""
     torch = _torch()
