@@ -221,6 +221,9 @@ int  mdemod_get_tanh_lut(const mdemod_ctx *ctx, float out[32]);
 int  mdemod_selftest_sincos(mdemod_ctx *ctx, const float *x, uint32_t n,
                             float *sin_out, float *cos_out);
 int  mdemod_selftest_hypot(mdemod_ctx *ctx, const float *xy, uint32_t n_pairs, float *out);
+/* Exhaustive on-device check of the division-free turn code of fast_sin against the real
+ * double division over every float with |x| < 16 (see csrc/demod_device.h). */
+int  mdemod_selftest_turncode(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch);
 
 #ifdef __cplusplus
 }

@@ -584,6 +584,24 @@ mdemod_selftest_sincos(mdemod_ctx *ctx, const float *x, uint32_t n, float *sin_o
 }
 
 int
+mdemod_selftest_turncode(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch)
+{
+	if (!ctx || !n_mismatch) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	unsigned long long *d = nullptr, h = 0;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(h)));
+	hipError_t e = hipMemset(d, 0, sizeof(h));
+	if (e == hipSuccess) e = mdemod_launch_selftest_turncode(d, nullptr);
+	if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return MDEMOD_ERR_HIP;
+	*n_mismatch = h;
+	if (n_checked) *n_checked = 2ull * 0x41800000ull;
+	return MDEMOD_OK;
+}
+
+int
 mdemod_selftest_hypot(mdemod_ctx *ctx, const float *xy, uint32_t n_pairs, float *out)
 {
 	if (!ctx || !xy || !out) return MDEMOD_ERR_PARAM;

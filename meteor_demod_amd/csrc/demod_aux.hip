@@ -50,7 +50,28 @@ selftest_hypot_kernel(const float *xy, uint32_t n, float *out)
 	out[i] = md_cabsf(xy[2 * i], xy[2 * i + 1]);
 }
 
+/* Every float with |x| < 16, both signs: division-free turn code vs the real division. */
+__global__ void
+selftest_turncode_kernel(unsigned long long *mismatch)
+{
+	const uint32_t limit = 0x41800000u;                     /* bits of 16.0f */
+	unsigned long long bad = 0;
+	for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < limit; u += (uint64_t)gridDim.x * blockDim.x) {
+		const float a = __uint_as_float((uint32_t)u), b = __uint_as_float((uint32_t)u | 0x80000000u);
+		bad += (md_turn_code(a) != md_turn_code_div(a)) ? 1 : 0;
+		bad += (md_turn_code(b) != md_turn_code_div(b)) ? 1 : 0;
+	}
+	if (bad) atomicAdd(mismatch, bad);
+}
+
 } /* namespace */
+
+hipError_t
+mdemod_launch_selftest_turncode(unsigned long long *mismatch_dev, hipStream_t stream)
+{
+	hipLaunchKernelGGL(selftest_turncode_kernel, dim3(256 * 32), dim3(256), 0, stream, mismatch_dev);
+	return hipGetLastError();
+}
 
 hipError_t
 mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int float_history, uint32_t n_streams, hipStream_t stream)

@@ -224,6 +224,12 @@ class Demodulator:
                                                s.ctypes.data_as(fp), c.ctypes.data_as(fp)), "selftest_sincos")
         return s, c
 
+    def selftest_turncode(self) -> tuple[int, int]:
+        """(floats checked, mismatches) of the division-free fast_sin turn code, exhaustive on the GPU."""
+        n, bad = C.c_uint64(), C.c_uint64()
+        check(self._lib.mdemod_selftest_turncode(self._ctx, C.byref(n), C.byref(bad)), "selftest_turncode")
+        return n.value, bad.value
+
     def selftest_hypot(self, xy: np.ndarray) -> np.ndarray:
         xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
         out = np.empty(xy.shape[0], dtype=np.float32)

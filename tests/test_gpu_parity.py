@@ -278,6 +278,14 @@ def test_device_fast_sin_cos_match_reference(manifest, gpu_device):
     assert sha(c) == meta["cos_sha256"]
 
 
+def test_device_turn_code_shortcut_is_exact_everywhere(gpu_device):
+    """The division-free fast_sin turn code equals the real double division for EVERY float
+    with |x| < 16 (2.2e9 values), on the device."""
+    with Demodulator(C1, 1) as d:
+        n, bad = d.selftest_turncode()
+    assert n == 2 * 0x41800000 and bad == 0
+
+
 def test_device_cabsf_is_correctly_rounded(gpu_device):
     rng = np.random.default_rng(3)
     xy = np.concatenate([rng.normal(0, 300, (1 << 20, 2)), rng.normal(0, 1e-4, (1 << 16, 2)),

@@ -142,3 +142,17 @@ def test_synth_signal_is_what_it_claims():
     spec = np.abs(np.fft.fft(z ** 4))
     peak = np.fft.fftfreq(z.size, 1 / fs)[np.argmax(spec)]
     assert abs(peak - 4 * f0) < 20.0
+
+
+def test_turn_code_shortcut_proof_holds_on_the_host():
+    """tools/proofs/verify_sincos_shortcut.cpp: the division-free turn code of fast_sin equals the
+    reference's double division for every float |x| < 16 (exhaustive, ~10 CPU-seconds)."""
+    import subprocess
+    import tempfile
+    src = ROOT / "tools" / "proofs" / "verify_sincos_shortcut.cpp"
+    with tempfile.TemporaryDirectory() as td:
+        exe = Path(td) / "verify"
+        subprocess.run(["g++", "-O2", "-ffp-contract=off", "-pthread", str(src), "-o", str(exe)], check=True)
+        out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "mismatches 0" in out.stdout
