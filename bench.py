@@ -36,8 +36,10 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tiles", type=int, default=262144, help="tiles (= streams = lanes) per GPU")
-    ap.add_argument("--tile-samples", type=int, default=32768, help="IQ samples per tile")
+    ap.add_argument("--tiles", type=int, default=393216,
+                    help="tiles (= streams = lanes) per GPU; default = 2 residency rounds of the v2 kernel "
+                         "(256 CUs x 12 waves x 64 lanes = 196608 lanes resident)")
+    ap.add_argument("--tile-samples", type=int, default=16384, help="IQ samples per tile")
     ap.add_argument("--config", default="c1", choices=["c1", "c3", "c4"], help="c1 = the headline config")
     ap.add_argument("--fanin", action="store_true", help="also gather soft symbols on rank 0 (timed separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
