@@ -1,0 +1,262 @@
+/*
+ * meteor_demod_amd — C host for the MI355X LRPT demodulator.
+ *
+ * Same command line as the reference's CLI for the path this repository replaces
+ * (main.c:19,35-51,82-152): -b -d -f -m -o -O -q -B -R -r -s -S/--bps --stdout -h -v,
+ * same defaults (demod.h:8-15), k/M suffixes (utils.c:60-86), WAV header overriding
+ * -s/--bps with raw fallback (main.c:164-166, wavfile.c:34-48), and the same file-level
+ * behaviour: input consumed in whole 32768-byte reads (wavfile.c:6,55), 1024-byte
+ * chunks written only once the PLL has locked (main.c:308-315), final flush of
+ * 2*ring_idx bytes (main.c:321).
+ *
+ * All demodulation happens on the GPU through the C-ABI (include/meteor_demod_amd.h);
+ * there is no CPU demodulator in this program.  Extension: several input files are
+ * demodulated as one batch, one stream per file (outputs <input>.s).
+ *
+ * Not reproduced (out of scope): ncurses TUI, the live status thread.
+ * Known deviation: if the final flush would read past the 1024-byte ring (ring_idx >
+ * 512, where the reference reads out of bounds) only the bytes inside the ring are
+ * written.
+ */
+#include <getopt.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "meteor_demod_amd.h"
+
+#define FILE_BUFFER_SIZE 32768          /* wavfile.c:6 */
+#define RINGSIZE 512                    /* main.c:20   */
+#define BLOCK_BUFFERS 128               /* 4 MiB of input per stream per GPU call */
+
+struct stream_io {
+	const char *in_name;
+	char       *out_name;
+	FILE       *in, *out;
+	int8_t      ring[2 * RINGSIZE];      /* main.c:34 (static => zero initialised) */
+	unsigned    ring_idx;
+	uint64_t    symbols;                 /* symbols emitted so far */
+	unsigned long bytes_out;
+	int         eof;
+};
+
+static const struct option longopts[] = {
+	{ "batch", 0, NULL, 'B' },      { "pll-bw", 1, NULL, 'b' },   { "freq-delta", 1, NULL, 'd' },
+	{ "fir-order", 1, NULL, 'f' },  { "help", 0, NULL, 'h' },     { "mode", 1, NULL, 'm' },
+	{ "output", 1, NULL, 'o' },     { "oversamp", 1, NULL, 'O' }, { "quiet", 0, NULL, 'q' },
+	{ "refresh-rate", 1, NULL, 'R' }, { "symrate", 1, NULL, 'r' }, { "stdout", 0, NULL, 0x00 },
+	{ "samplerate", 1, NULL, 's' }, { "bps", 1, NULL, 'S' },      { "version", 0, NULL, 'v' },
+	{ "device", 1, NULL, 0x01 },    { NULL, 0, NULL, 0 }
+};
+
+/* utils.c:60-86: number with optional k/M suffix, truncated to int, returned as float */
+static float
+human_number(const char *s)
+{
+	const float v = (float)atof(s);
+	const char *p = s;
+	int out;
+	while ((*p >= '0' && *p <= '9') || *p == '.') p++;
+	if (*p == 'k' || *p == 'K') out = (int)(v * 1000);
+	else if (*p == 'M') out = (int)(v * 1000000);
+	else out = (int)v;
+	return (float)out;
+}
+
+static void
+usage(const char *prog)
+{
+	fprintf(stderr,
+	        "Usage: %s [options] file_in [file_in ...]\n"
+	        "   -B, --batch             Do not redraw a status line\n"
+	        "   -b, --pll-bw <bw>       PLL bandwidth (default: 1)\n"
+	        "   -d, --freq-delta <hz>   Max carrier deviation in Hz (default: +-3.5 kHz at 72 ksym/s)\n"
+	        "   -f, --fir-order <ord>   RRC filter order (default: 32)\n"
+	        "   -m, --mode <mode>       qpsk (default) or oqpsk\n"
+	        "   -o, --output <file>     Output file (single input only; default LRPT_<date>.s)\n"
+	        "   -O, --oversamp <mult>   Interpolation factor (default: 5)\n"
+	        "   -q, --quiet             No status output\n"
+	        "   -r, --symrate <rate>    Symbol rate (default: 72000)\n"
+	        "   -s, --samplerate <rate> Sample rate of raw input\n"
+	        "       --bps <bits>        Bits per sample of raw input (8, 16, 32)\n"
+	        "       --stdout            Write soft symbols to stdout (implies -B -q)\n"
+	        "       --device <n>        HIP device ordinal (default 0)\n"
+	        "   -h, --help   -v, --version\n", prog);
+}
+
+/* wavfile.c:16-48: canonical 44-byte header, two channels */
+static int
+parse_wav(FILE *f, int *samplerate, int *bps)
+{
+	unsigned char h[44];
+	if (fread(h, sizeof(h), 1, f) != 1) return 1;
+	if (memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) return 1;
+	const unsigned channels = h[22] | (h[23] << 8);
+	const unsigned bits = h[34] | (h[35] << 8);
+	if (channels != 2 || !bits) return 1;
+	*bps = (int)bits;
+	*samplerate = (int)(h[24] | (h[25] << 8) | (h[26] << 16) | ((unsigned)h[27] << 24));
+	return 0;
+}
+
+/* main.c:305-315: ring of 512 symbols, a chunk is written when it completes iff the PLL has
+ * locked at least once by then, i.e. first_lock <= index of the chunk's last symbol. */
+static void
+write_gated(struct stream_io *io, const int8_t *soft, uint32_t n, int64_t first_lock)
+{
+	for (uint32_t k = 0; k < n; k++) {
+		io->ring[io->ring_idx++] = soft[2 * k];
+		io->ring[io->ring_idx++] = soft[2 * k + 1];
+		io->symbols++;
+		if (io->ring_idx >= 2 * RINGSIZE) {
+			io->ring_idx = 0;
+			if (first_lock >= 0 && (uint64_t)first_lock <= io->symbols - 1) {
+				fwrite(io->ring, RINGSIZE, 2, io->out);
+				io->bytes_out += 2 * RINGSIZE;
+			}
+		}
+	}
+}
+
+int
+main(int argc, char **argv)
+{
+	float pll_bw = MDEMOD_DEFAULT_PLL_BW, symrate = MDEMOD_DEFAULT_SYM_RATE, freq_max_delta = -1;
+	int rrc_order = MDEMOD_DEFAULT_RRC_ORDER, interp = MDEMOD_DEFAULT_INTERP;
+	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0;
+	const char *output_fname = NULL;
+	int c;
+
+	while ((c = getopt_long(argc, argv, "a:Bb:d:f:hm:o:O:qR:r:s:S:v", longopts, NULL)) != -1) {
+		switch (c) {
+		case 0x00: stdout_mode = 1; break;
+		case 0x01: device = atoi(optarg); break;
+		case 'b': pll_bw = human_number(optarg); break;
+		case 'B': batch = 1; break;
+		case 'd': freq_max_delta = human_number(optarg); break;
+		case 'f': rrc_order = atoi(optarg); break;
+		case 'h': usage(argv[0]); return 0;
+		case 'm': if (!strcmp(optarg, "oqpsk")) oqpsk = 1; break;     /* unknown modes stay QPSK, main.c:104 */
+		case 'o': output_fname = optarg; break;
+		case 'O': interp = atoi(optarg); break;
+		case 'q': quiet = 1; break;
+		case 'R': break;                                              /* refresh rate: no live status here */
+		case 'r': symrate = human_number(optarg); break;
+		case 's': samplerate = (int)human_number(optarg); break;
+		case 'S': bps = atoi(optarg); break;
+		case 'v': printf("meteor_demod_amd (MI355X) ABI %u\n", mdemod_abi_version()); return 0;
+		default: usage(argv[0]); return 1;
+		}
+	}
+	freq_max_delta = (float)(freq_max_delta * (2 * M_PI) / symrate);       /* main.c:136 */
+	if (argc - optind < 1) { usage(argv[0]); return 1; }
+	if (stdout_mode) { batch = 1; quiet = 1; }
+	(void)batch;
+
+	const int n_files = argc - optind;
+	if (n_files > 1 && (output_fname || stdout_mode)) {
+		fprintf(stderr, "-o/--stdout need a single input file\n");
+		return 1;
+	}
+	struct stream_io *io = calloc((size_t)n_files, sizeof(*io));
+	if (!io) return 1;
+
+	for (int i = 0; i < n_files; i++) {
+		io[i].in_name = argv[optind + i];
+		io[i].in = !strcmp(io[i].in_name, "-") ? stdin : fopen(io[i].in_name, "rb");
+		if (!io[i].in) { fprintf(stderr, "Could not open input file\n"); return 1; }
+		int sr = samplerate, b = bps;
+		if (parse_wav(io[i].in, &sr, &b)) fseek(io[i].in, 0, SEEK_SET);    /* raw: main.c:164-166 */
+		if (i == 0) { samplerate = sr; bps = b; }
+		else if (sr != samplerate || b != bps) { fprintf(stderr, "all inputs of a batch must share rate and format\n"); return 1; }
+	}
+	if (samplerate < 0) {
+		fprintf(stderr, "Could not auto-detect sample rate. Please specify it with -s <samplerate>\n");
+		return 1;
+	}
+	if (!bps) { fprintf(stderr, "Could not auto-detect bits per sample, assuming 16\n"); bps = 16; }
+	if (bps != 8 && bps != 16 && bps != 32) { fprintf(stderr, "unsupported bits per sample\n"); return 1; }
+
+	for (int i = 0; i < n_files; i++) {
+		if (stdout_mode) { io[i].out = stdout; continue; }
+		if (n_files == 1 && output_fname) io[i].out_name = strdup(output_fname);
+		else if (n_files == 1) {                                           /* utils.c:8: LRPT_%Y_%m_%d-%H_%M.s */
+			char buf[64]; time_t t = time(NULL);
+			strftime(buf, sizeof(buf), "LRPT_%Y_%m_%d-%H_%M.s", localtime(&t));
+			io[i].out_name = strdup(buf);
+		} else {
+			io[i].out_name = malloc(strlen(io[i].in_name) + 3);
+			sprintf(io[i].out_name, "%s.s", io[i].in_name);
+		}
+		io[i].out = fopen(io[i].out_name, "wb");
+		if (!io[i].out) { fprintf(stderr, "Could not open output file\n"); return 1; }
+	}
+
+	/* demod_init(pll_bw, SYM_BW, samplerate, symrate, interp, order, oqpsk, freq_max): main.c:187 */
+	mdemod_params p;
+	memset(&p, 0, sizeof(p));
+	p.pll_bw = pll_bw; p.sym_bw = MDEMOD_DEFAULT_SYM_BW; p.samplerate = samplerate; p.symrate = (int)symrate;
+	p.interp_factor = interp; p.rrc_order = rrc_order; p.oqpsk = oqpsk; p.freq_max = freq_max_delta;
+	p.bps = bps; p.device = device; p.n_streams = (uint32_t)n_files;
+	mdemod_ctx *ctx = NULL;
+	int rc = mdemod_create(&p, &ctx);
+	if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_create: %s\n", mdemod_strerror(rc)); return 2; }
+	if (!quiet) fprintf(stderr, "Demodulator initialized (%d stream%s on HIP device %d)\n", n_files, n_files > 1 ? "s" : "", device);
+
+	const size_t block_bytes = (size_t)BLOCK_BUFFERS * FILE_BUFFER_SIZE;
+	const uint32_t block_samples = (uint32_t)(block_bytes / (2 * (size_t)bps / 8));
+	const uint32_t cap = (uint32_t)mdemod_max_symbols(ctx, block_samples);
+	unsigned char *in_buf = malloc(block_bytes * (size_t)n_files);
+	int8_t *soft = malloc((size_t)cap * 2 * (size_t)n_files);
+	const void **iq = malloc(sizeof(*iq) * (size_t)n_files);
+	int8_t **outp = malloc(sizeof(*outp) * (size_t)n_files);
+	uint32_t *n_in = malloc(sizeof(uint32_t) * (size_t)n_files), *caps = malloc(sizeof(uint32_t) * (size_t)n_files);
+	uint32_t *n_out = malloc(sizeof(uint32_t) * (size_t)n_files);
+	mdemod_status *st = malloc(sizeof(*st) * (size_t)n_files);
+	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) return 1;
+
+	for (;;) {
+		int active = 0;
+		for (int i = 0; i < n_files; i++) {
+			iq[i] = in_buf + block_bytes * (size_t)i;
+			outp[i] = soft + (size_t)cap * 2 * (size_t)i;
+			caps[i] = cap;
+			n_in[i] = 0;
+			if (io[i].eof) continue;
+			/* whole 32768-byte buffers only: a short trailing read ends the stream (wavfile.c:55) */
+			const size_t got = fread(in_buf + block_bytes * (size_t)i, FILE_BUFFER_SIZE, BLOCK_BUFFERS, io[i].in);
+			if (got < BLOCK_BUFFERS) io[i].eof = 1;
+			n_in[i] = (uint32_t)(got * FILE_BUFFER_SIZE / (2 * (size_t)bps / 8));
+			if (got) active = 1;
+		}
+		if (!active) break;
+		rc = mdemod_process_host(ctx, iq, n_in, outp, caps, n_out);          /* demod(&sample) x n: main.c:304 */
+		if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_process_host: %s\n", mdemod_strerror(rc)); return 2; }
+		rc = mdemod_get_status(ctx, 0, (uint32_t)n_files, st, NULL);
+		if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_get_status: %s\n", mdemod_strerror(rc)); return 2; }
+		for (int i = 0; i < n_files; i++)
+			write_gated(&io[i], outp[i], n_out[i], st[i].first_lock_symbol);
+		if (!quiet) {
+			/* main.c:250-259 status formulas, once per block instead of on a timer */
+			const double freq_hz = st[0].pll_freq * symrate / (2 * M_PI) * (oqpsk ? 2 : 1);
+			const double rate_hz = st[0].omega * ((double)samplerate * interp) / (2 * M_PI);
+			fprintf(stderr, "\rCarrier: %+7.1f Hz, Symbol rate: %.1f Hz, Locked: %s   ", freq_hz, rate_hz, st[0].locked ? "Yes" : "No");
+		}
+	}
+	if (!quiet) fprintf(stderr, "\n");
+
+	for (int i = 0; i < n_files; i++) {
+		/* main.c:321: fwrite(ring, ring_idx, 2, f) */
+		size_t tail = 2 * (size_t)io[i].ring_idx;
+		if (tail > sizeof(io[i].ring)) tail = sizeof(io[i].ring);
+		fwrite(io[i].ring, 1, tail, io[i].out);
+		io[i].bytes_out += io[i].ring_idx;
+		if (io[i].out != stdout) fclose(io[i].out);
+		if (io[i].in != stdin) fclose(io[i].in);
+	}
+	mdemod_destroy(ctx);                                                          /* demod_deinit: main.c:273 */
+	return 0;
+}

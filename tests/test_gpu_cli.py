@@ -1,0 +1,61 @@
+"""GPU tests of the C host CLI (host/meteor_demod_amd.c): file in -> .s out must equal what the
+reference's own binary produced (tests/golden/file_*.npz, recorded by make_golden.py)."""
+from __future__ import annotations
+
+import hashlib
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_npz
+from golden_cases import file_case_bytes
+
+pytestmark = pytest.mark.gpu
+
+CLI = ROOT / "meteor_demod_amd" / "lib" / "meteor_demod_amd"
+FILE_CASES = ["file_wav_s16", "file_raw_u8", "file_wav_f32", "file_wav_oqpsk", "file_never_locks"]
+
+
+@pytest.mark.parametrize("name", FILE_CASES)
+def test_cli_output_equals_reference_binary(name, manifest, tmp_path, gpu_device):
+    """Same command line as the reference (`-q -B -o out [flags] input`), byte-identical .s file:
+    32 KiB-truncated input, lock-gated 1024-byte chunks, double-length final flush."""
+    meta = manifest["file_cases"][name]
+    data = file_case_bytes(meta)
+    assert hashlib.sha256(data).hexdigest() == meta["file_sha256"]
+    inp = tmp_path / ("in." + meta["container"])
+    out = tmp_path / "out.s"
+    inp.write_bytes(data)
+    r = subprocess.run([str(CLI), "-q", "-B", "-o", str(out), *meta["cli_args"], str(inp)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = out.read_bytes()
+    assert len(got) == meta["out_bytes"]
+    assert got == load_npz(name)["out"].tobytes()
+
+
+def test_cli_batch_of_files_equals_one_by_one(manifest, tmp_path, gpu_device):
+    """Extension: several recordings in one invocation = one stream per file, same bytes as separate runs."""
+    names = ["file_wav_s16", "file_never_locks"]
+    paths = []
+    for n in names:
+        p = tmp_path / f"{n}.wav"
+        p.write_bytes(file_case_bytes(manifest["file_cases"][n]))
+        paths.append(p)
+    r = subprocess.run([str(CLI), "-q", *map(str, paths)], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    for n, p in zip(names, paths):
+        assert Path(str(p) + ".s").read_bytes() == load_npz(n)["out"].tobytes()
+
+
+def test_cli_stdout_mode_and_errors(manifest, tmp_path, gpu_device):
+    meta = manifest["file_cases"]["file_wav_s16"]
+    inp = tmp_path / "in.wav"
+    inp.write_bytes(file_case_bytes(meta))
+    r = subprocess.run([str(CLI), "--stdout", str(inp)], capture_output=True)
+    assert r.returncode == 0 and r.stdout == load_npz("file_wav_s16")["out"].tobytes()
+    raw = tmp_path / "in.raw"
+    raw.write_bytes(b"\0" * 70000)
+    r = subprocess.run([str(CLI), "-q", str(raw)], capture_output=True, text=True)      # raw without -s
+    assert r.returncode == 1 and "sample rate" in r.stderr
