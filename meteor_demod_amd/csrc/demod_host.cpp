@@ -108,12 +108,13 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 	{
 		const double f_hi = (static_cast<double>(c.t_center) + static_cast<double>(c.t_maxdev)) * (1.0 + 1e-6);
 		c.step_fmax = nextafterf(static_cast<float>(f_hi), 1e30f);
+		/* Blind steps: a lane whose phase is below thr - k*f_hi cannot fire within k steps.  After a
+		 * symbol the phase restarts in [-alpha*e, f - alpha*e), so k is sized for a start below
+		 * f_hi + 0.05; the kernel checks the bound per lane and falls back to its generic loop. */
 		const double thr_min = p.oqpsk ? kPi : 2 * kPi;          /* first threshold a fresh symbol meets */
-		int ks = static_cast<int>(floor((thr_min - 0.6 - 1e-3) / f_hi)) - 1;
+		int ks = static_cast<int>(floor((thr_min - f_hi - 0.05 - 1e-3) / f_hi));
 		c.step_safe = ks < 0 ? 0 : ks;
-		const double f_lo = static_cast<double>(c.t_center) - static_cast<double>(c.t_maxdev);
-		int kc = static_cast<int>(ceil(1.1 / f_lo)) + 3;
-		c.step_check = kc > 24 ? 24 : kc;
+		c.step_check = 4;                                         /* fixed in the kernel */
 		c.interp_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(c.interp)) + 1u;
 	}
 

@@ -287,7 +287,7 @@ demod_kernel_rw(const DemodLaunch L)
 	bool done = !valid || n == 0;
 	uint32_t sym_call = 0;
 	uint32_t ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0;           /* 8 buffered soft symbols          */
-	const int k_safe = C.step_safe, k_check = C.step_check;
+	const int k_safe = C.step_safe;
 	const float f_hi = C.step_fmax;
 	const uint32_t magic = C.interp_magic;
 
@@ -296,28 +296,26 @@ demod_kernel_rw(const DemodLaunch L)
 		if (!fired && !done) {
 			const float thr = OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F;
 			const int steps_left = (v_end - 1 - v_cur) * interp + (isub ? interp - isub : 0);
-			const bool fast = (t_phase < thr - (float)k_safe * f_hi - 1e-3f) && (steps_left >= k_safe + k_check);
+			const bool fast = (t_phase < thr - (float)k_safe * f_hi - 1e-3f) && (steps_left >= k_safe + 4);
 			if (fast) {
 				float p = t_phase;
 				for (int k = 0; k < k_safe; k++) p = p + t_freq;       /* cannot reach thr: no compare needed */
-				int m = k_safe;
-				bool hit = false;
-				for (int j = 0; j < k_check; j++) {
-					const float q = p + t_freq;
-					const bool take = !hit;
-					p = take ? q : p;
-					m += take ? 1 : 0;
-					hit = hit || (q >= thr);
-				}
-				t_phase = p;
+				/* four checked steps.  The increment is positive, so "reached thr" is monotone:
+				 * the first hit is after (number of misses) + 1 steps. */
+				const float p1 = p + t_freq, p2 = p1 + t_freq, p3 = p2 + t_freq, p4 = p3 + t_freq;
+				const bool c1 = p1 >= thr, c2 = p2 >= thr, c3 = p3 >= thr, c4 = p4 >= thr;
+				const int m = k_safe + 1 + (c1 ? 0 : 1) + (c2 ? 0 : 1) + (c3 ? 0 : 1);
+				float ph = c3 ? p3 : p4;
+				ph = c2 ? p2 : ph;
+				ph = c1 ? p1 : ph;
+				t_phase = ph;
 				const uint32_t w = (uint32_t)(isub + m);
-				const uint32_t qd = __umulhi(w + (uint32_t)interp - 1u, magic);        /* ceil(w / interp)  */
-				v_cur += (int)qd - (isub > 0 ? 1 : 0);
-				const uint32_t q1 = __umulhi(w - 1u, magic);
-				fire_sub = (int)(w - 1u - q1 * (uint32_t)interp);
-				const uint32_t q0 = __umulhi(w, magic);
-				isub = (int)(w - q0 * (uint32_t)interp);
-				fired = hit;
+				const uint32_t q = __umulhi(w, magic);                 /* floor(w / interp) */
+				const int isub_new = (int)(w - q * (uint32_t)interp);
+				v_cur += (int)q + (isub_new > 0 ? 1 : 0) - (isub > 0 ? 1 : 0);   /* samples pushed: ceil(w/interp) - (isub>0) */
+				fire_sub = (isub_new == 0) ? interp - 1 : isub_new - 1;
+				isub = isub_new;
+				fired = c4;
 			}
 			while (!fired && !done) {                                   /* generic path */
 				if (isub == 0) {
