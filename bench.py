@@ -103,8 +103,9 @@ def cpu_baseline(cfg) -> dict:
                       f"({procs * n / 1e6:.0f} M samples, {sum(per):.1f} s CPU, {wall:.1f} s wall), strict -ffp-contract=off build"}
 
 
-def spot_check(cfg, d, x, tiles, L, n_check=4) -> str:
-    """Untimed: reset, one pass, compare sampled tiles byte-for-byte with the oracle."""
+def spot_check(cfg, d, x, tiles, L, n_check=12) -> str:
+    """Untimed: reset, one pass, compare sampled tiles (always including the first and the last,
+    i.e. blocks of the first and of the last residency round) byte-for-byte with the oracle."""
     sys.path.insert(0, str(ROOT / "tests"))
     import numpy as np
     import torch
@@ -112,13 +113,14 @@ def spot_check(cfg, d, x, tiles, L, n_check=4) -> str:
     d.reset()
     soft = d.process(x)
     torch.cuda.synchronize()
-    for t in np.random.default_rng(0).choice(tiles, n_check, replace=False):
+    picks = {0, tiles - 1, tiles // 2} | set(int(t) for t in np.random.default_rng(0).choice(tiles, n_check, replace=False))
+    for t in sorted(picks):
         st = d.status(int(t), 1)[0]
         want = O.oracle_demod(cfg, x[int(t)].cpu().numpy())[0]
         got = soft[int(t), : st.symbols_this_call].cpu().numpy()
         if got.shape != want.shape or not np.array_equal(got, want):
             return f"MISMATCH tile {int(t)}"
-    return f"{n_check} sampled tiles byte-identical to oracle"
+    return f"{len(picks)} sampled tiles byte-identical to oracle"
 
 
 def main() -> None:

@@ -10,6 +10,9 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / "lib"
 LIB_PATH = LIB_DIR / "libmeteor_demod_amd.so"
+import os as _os
+if _os.environ.get("MDEMOD_LIB_PATH"):        # experiments only: load an alternative build of the same library
+    LIB_PATH = Path(_os.environ["MDEMOD_LIB_PATH"])
 
 MDEMOD_OK = 0
 MDEMOD_ERR_PARAM = -1

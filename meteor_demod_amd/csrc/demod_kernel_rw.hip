@@ -196,7 +196,7 @@ fir_window(const typename W::elem_t (&win)[NW], const float *row, bool skip_firs
 /* ---- the kernel ------------------------------------------------------------------ */
 
 template <int FMT, int OQPSK, bool PACKED>
-__global__ void __launch_bounds__(256, PACKED ? 3 : 2)
+__global__ void __launch_bounds__(MDEMOD_RW_BLOCK, PACKED ? 3 : 2)
 demod_kernel_rw(const DemodLaunch L)
 {
 	typedef Fmt<FMT> F;
@@ -469,13 +469,13 @@ demod_kernel_rw(const DemodLaunch L)
 		L.st.overflow[stream_e] = overflow;
 
 		/* history := last 64 samples of (old history ++ block), as floats; ascending k is in-place safe */
-		float2 *hist = reinterpret_cast<float2 *>(L.st.hist);
+		float2 *hist = reinterpret_cast<float2 *>(L.st.hist) + (size_t)stream_e * kBack;   /* [stream][64] */
 		for (int k = 0; k < kBack; k++) {
 			const int idx = n + k;
 			float2 h;
-			if (idx < kBack) h = hist[(size_t)idx * L.n_streams + stream_e];
+			if (idx < kBack) h = hist[idx];
 			else { const cf32 s = F::decode(src[idx - kBack]); h = make_float2(s.re, s.im); }
-			hist[(size_t)k * L.n_streams + stream_e] = h;
+			hist[k] = h;
 		}
 	}
 }
