@@ -91,7 +91,7 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	L.ctab_floats = static_cast<uint32_t>(ctx->tab.ctab.size());
 	L.tanh_lut = ctx->d_lut;
 	if (ctx->tab.use_rw)
-		HIP_TRY(mdemod_launch_demod_rw(L, ctx->params.bps, env_int("MDEMOD_RW_PACKED", 1), ctx->lds_bytes, stream));
+		HIP_TRY(mdemod_launch_demod_rw(L, ctx->params.bps, env_int("MDEMOD_RW_PACKED", 0), ctx->lds_bytes, stream));
 	else
 		HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->lds_bytes, stream));
 	return MDEMOD_OK;

@@ -24,8 +24,8 @@ def _torch():
 
 
 KERNEL_VARIANTS = {
-    "v2-packed": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "1"},    # default: register window, raw samples
-    "v2-float": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0"},     # register window, converted floats
+    "v2-float": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0"},     # default: register window, converted floats
+    "v2-packed": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "1"},    # register window, raw samples (3 waves/SIMD)
     "v1-ring": {"MDEMOD_KERNEL": "v1", "MDEMOD_RW_PACKED": "1"},    # LDS ring (generic fallback, > 65 taps)
 }
 
