@@ -377,3 +377,49 @@ def test_full_size_batch_properties(gpu_device, kernel_variant):
             want = O.oracle_demod(C1, iq)[0]
             assert st[i].symbols_this_call == want.shape[0]
             assert np.array_equal(soft[i, : want.shape[0]].cpu().numpy(), want), i
+
+
+# ---- the multi-GPU layer on the real backend (RCCL); only one GPU is available here ------------------
+
+def _rccl_worker(port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from meteor_demod_amd.sharding import fanin_soft, shard_range
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    n_streams = 70
+    lo, hi = shard_range(n_streams, 0, 1)
+    streams = [synth.make_stream(40 + i, 230000, 72000, f0_hz=50.0 * i, esn0_db=20.0) for i in range(n_streams)]
+    x = synth.generate_device(streams, 6000)
+    with Demodulator(C1, hi - lo) as d:
+        soft = d.process(x[lo:hi])
+        torch.cuda.synchronize()
+        counts = torch.tensor([s.symbols_this_call for s in d.status()], dtype=torch.int32, device="cuda")
+        all_soft, all_cnt = fanin_soft(soft, counts, n_streams, dst=0)
+        torch.cuda.synchronize()
+        ok = torch.equal(all_cnt, counts) and torch.equal(all_soft[:, : soft.shape[1]], soft)
+        want = O.oracle_demod(C1, synth.generate_host(streams[69], 6000))[0]
+        ok = ok and np.array_equal(all_soft[69, : int(all_cnt[69])].cpu().numpy(), want)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(bool(ok))
+
+
+@pytest.mark.timeout(300)
+def test_rccl_fanin_path_world_size_one(gpu_device):
+    """sharding.fanin_soft over the nccl (= RCCL) backend with device tensors.  One rank is all this box
+    has; the world_size-2 logic is covered by the gloo test in test_dist_cpu.py."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    ok = q.get(timeout=240)
+    p.join(timeout=60)
+    assert ok and p.exitcode == 0
