@@ -12,7 +12,9 @@ soft symbols on rank 0 over RCCL (outside the timed region by default).
 
 One JSON line on rank 0, with `roofline` (HBM, algorithmic bytes / measured
 kernel time) and `cpu_baseline` (the reference's own code from oracle/_ref, or
-the oracle port, timed on the host cores).
+the oracle port, timed on the host cores).  The same CPU leg also verifies sampled
+tiles of the GPU output byte-for-byte against the oracle ("check"); with
+--no-cpu-baseline nothing under oracle/ is touched.
 """
 from __future__ import annotations
 
@@ -225,10 +227,12 @@ def main() -> None:
     }
     if fanin_ms is not None:
         out["fanin_ms"] = round(fanin_ms, 2)
-    if not args.no_check:
-        out["check"] = spot_check(cfg, d, x, T, L)
     if world == 1 and not args.no_cpu_baseline:
+        # The CPU leg: the only place in this file that touches oracle/ — it times the reference's own
+        # code on the host cores and (unless --no-check) uses the oracle as CHECKER on sampled tiles.
         out["cpu_baseline"] = cpu_baseline(cfg)
+        if not args.no_check:
+            out["check"] = spot_check(cfg, d, x, T, L)
     print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
