@@ -167,7 +167,7 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 		if (c.ring_granules < c.hpad / 4 + 4) c.ring_granules = c.hpad / 4 + 4;
 	}
 	const int waves = env_int("MDEMOD_WAVES_PER_BLOCK", 3);
-	ctx->block_threads = 64 * (waves < 1 ? 1 : (waves > 16 ? 16 : waves));
+	ctx->block_threads = 64 * (waves < 1 ? 1 : (waves > 4 ? 4 : waves));      /* v1 kernel: __launch_bounds__(256) */
 
 	auto lds_need = [&](int threads) {
 		return (ctx->tab.ctab.size() + 32) * sizeof(float) +

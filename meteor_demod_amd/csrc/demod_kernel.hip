@@ -99,8 +99,12 @@ load_granule(const typename Format<FMT>::sample_t *p)
  * NGW  > 0: compile-time number of window granules (fully unrolled FIR)
  * NGW == 0: taken from DemodConsts at run time (generic configurations)
  */
+/* Blocks are at most 256 threads and the 24 KB-per-wave LDS ring already limits this kernel to <= 2
+ * waves per SIMD, so the register allocator may use up to 256 VGPRs.  Without the bound hipcc must
+ * assume 1024-thread blocks (4 waves/SIMD), caps at 128 VGPRs and spills 300-800 bytes per lane to
+ * scratch (= HBM): measured 2x slower. */
 template <int FMT, int OQPSK, int NGW, int CHUNK>
-__global__ void
+__global__ void __launch_bounds__(256, 2)
 demod_kernel(const DemodLaunch L)
 {
 	typedef Format<FMT> F;
@@ -265,6 +269,9 @@ demod_kernel(const DemodLaunch L)
 			const int ngw = NGW ? NGW : C.win_granules;
 #pragma unroll
 			for (int q = 0; q < ngw; q++) {
+				/* every 4th granule: make the next addresses depend on the running sums, or hipcc hoists
+				 * all 2*NGW LDS reads of the unrolled loop to the top and spills (264 VGPRs at 129 taps) */
+				if ((q & 3) == 3) asm volatile("" : "+v"(gq) : "v"(acc_re), "v"(acc_im));
 				const Granule<FMT> g = *reinterpret_cast<const Granule<FMT> *>(col + gq * 64 * GB);
 				const float4 h = *reinterpret_cast<const float4 *>(row + 4 * q);
 				gq = (gq + 1 == G) ? 0 : gq + 1;
