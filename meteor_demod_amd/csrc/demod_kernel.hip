@@ -213,9 +213,37 @@ demod_kernel(const DemodLaunch L)
 			staged = false;
 		}
 
-		/* (2) step the symbol clock to the next firing (timing.c:32-57) */
+		/* (2) step the symbol clock to the next firing (timing.c:32-57).  Fast path as in the v2
+		 * kernel: k_safe blind adds that provably cannot fire (checked per lane), then four checked
+		 * steps (the increment is positive, so "reached thr" is monotone); generic loop otherwise. */
 		if (!fired && !done) {
-			while (true) {
+			const float thr = OQPSK ? (float)dual_state * MD_PI_F : thr_q;
+			const int k_safe = C.step_safe;
+			const int steps_left = (v_end - 1 - v_cur) * C.interp + (isub ? C.interp - isub : 0);
+			if ((t_phase < thr - (float)k_safe * C.step_fmax - 1e-3f) && (steps_left >= k_safe + 4)) {
+				float p = t_phase;
+				int k = 0;
+				for (; k + 8 <= k_safe; k += 8) {
+					p = p + t_freq; p = p + t_freq; p = p + t_freq; p = p + t_freq;
+					p = p + t_freq; p = p + t_freq; p = p + t_freq; p = p + t_freq;
+				}
+				for (; k < k_safe; k++) p = p + t_freq;
+				const float p1 = p + t_freq, p2 = p1 + t_freq, p3 = p2 + t_freq, p4 = p3 + t_freq;
+				const bool c1 = p1 >= thr, c2 = p2 >= thr, c3 = p3 >= thr, c4 = p4 >= thr;
+				const int m = k_safe + 1 + (c1 ? 0 : 1) + (c2 ? 0 : 1) + (c3 ? 0 : 1);
+				float ph = c3 ? p3 : p4;
+				ph = c2 ? p2 : ph;
+				ph = c1 ? p1 : ph;
+				t_phase = ph;
+				const uint32_t w = (uint32_t)(isub + m);
+				const uint32_t qd = __umulhi(w, C.interp_magic);          /* floor(w / interp) */
+				const int isub_new = (int)(w - qd * (uint32_t)C.interp);
+				v_cur += (int)qd + (isub_new > 0 ? 1 : 0) - (isub > 0 ? 1 : 0);
+				fire_sub = (isub_new == 0) ? C.interp - 1 : isub_new - 1;
+				isub = isub_new;
+				fired = c4;
+			}
+			while (!fired && !done) {
 				if (isub == 0) {
 					if (v_cur + 1 >= v_end) { done = true; break; }
 					v_cur++;                                  /* filter_fwd_sample, filter.c:39-43 */
@@ -223,8 +251,7 @@ demod_kernel(const DemodLaunch L)
 				t_phase = t_phase + t_freq;
 				fire_sub = isub;
 				isub = (isub + 1 == C.interp) ? 0 : isub + 1;
-				const float thr = OQPSK ? (float)dual_state * MD_PI_F : thr_q;
-				if (t_phase >= thr) { fired = true; break; }
+				if (t_phase >= thr) fired = true;
 			}
 		}
 		if (__all(done)) break;
