@@ -171,7 +171,7 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 
 	auto lds_need = [&](int threads) {
 		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
-		       (ctx->tab.use_rw ? static_cast<size_t>(MDEMOD_RW_BLOCK / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
+		       (ctx->tab.use_rw ? static_cast<size_t>((ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
 		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes);
 	};
 	while (ctx->block_threads > 64 && lds_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;

@@ -120,9 +120,13 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 
 	/* ---- kernel selection + geometry ---- */
 	const double per_firing = static_cast<double>(out.osf) / (p.oqpsk ? 2.0 : 1.0);   /* samples consumed per firing */
-	out.use_rw = allow_rw && c.taps <= 65 && per_firing <= 3.6;
+	const bool std_ok = c.taps <= 65 && per_firing <= 3.6;
+	/* wide: packed window only (s16 / u8), up to 129 taps, up to 15 samples per firing */
+	const bool wide_ok = !std_ok && c.taps <= 129 && per_firing <= 15.0 && p.bps != 32;
+	out.use_rw = allow_rw && (std_ok || wide_ok);
+	out.rw_wide = out.use_rw && !std_ok;
 	c.chunk_granules = 2;
-	if (out.use_rw) {
+	if (out.use_rw && !out.rw_wide) {
 		/* v2: 80-slot register window, filter embedded as 65 taps (leading zeros), 16 alignments */
 		const int kTaps = 65, NW = 80, AL = NW - kTaps + 1;
 		c.hpad = kTaps - 1;
@@ -137,6 +141,29 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 				float *row = &out.ctab[(static_cast<size_t>(a) * banks + b) * c.ctab_row_stride];
 				for (int k = 0; k < c.taps; k++) row[a + lead + k] = out.rrc[b * taps + k];
 			}
+		return MDEMOD_OK;
+	}
+	if (out.rw_wide) {
+		/* v2 wide: 152-slot packed window, filter embedded as 129 taps, 24 alignments.  Compact
+		 * table: per bank the padded sequence P = 23 zeros ++ taps ++ 23 zeros, stored twice:
+		 * array (bank, 0)[i] = P[i], array (bank, 1)[i] = P[i + 1].  A lane at alignment a reads
+		 * P[(23 - a) + s] for slot s, i.e. array (bank, o & 1) at the even index (o & ~1) + s. */
+		const int kTaps = 129, NW = 152, AMAX = NW - kTaps;
+		const int LP = kTaps + 2 * AMAX;                  /* 175 */
+		c.hpad = kTaps - 1;
+		c.win_granules = NW / 4;
+		c.ring_granules = 0;
+		c.ctab_row_floats = LP;
+		c.ctab_row_stride = LP + 3;                       /* 178 floats = 89 x 8 B (odd) */
+		out.ctab.assign(static_cast<size_t>(2) * banks * c.ctab_row_stride, 0.0f);
+		const int lead = kTaps - c.taps;
+		for (unsigned b = 0; b < banks; b++) {
+			std::vector<float> P(static_cast<size_t>(LP) + 1, 0.0f);
+			for (int k = 0; k < c.taps; k++) P[AMAX + lead + k] = out.rrc[b * taps + k];
+			float *even = &out.ctab[(static_cast<size_t>(b) * 2 + 0) * c.ctab_row_stride];
+			float *odd = &out.ctab[(static_cast<size_t>(b) * 2 + 1) * c.ctab_row_stride];
+			for (int i = 0; i < LP; i++) { even[i] = P[i]; odd[i] = P[i + 1]; }
+		}
 		return MDEMOD_OK;
 	}
 

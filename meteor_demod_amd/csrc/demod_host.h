@@ -16,6 +16,7 @@ struct HostTables {
 	std::vector<float> rrc;       /* interp*taps, bank-major (filter.c:20)     */
 	std::vector<float> ctab;      /* [4 alignments][interp banks][row stride]  */
 	float              tanh_lut[32];
+	bool               rw_wide;   /* v2 wide geometry (129-tap packed window, compact table, 512-thread blocks) */
 	bool               use_rw;    /* v2 register-window kernel eligible (taps <= 65, <= 3.6 samples per firing) */
 };
 

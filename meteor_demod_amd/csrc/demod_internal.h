@@ -11,6 +11,7 @@
 #define MDEMOD_WAVE            64
 #define MDEMOD_GRANULE_SAMPLES 4      /* ring granule = 4 consecutive IQ samples */
 #define MDEMOD_RW_STATE_SLOTS   11     /* per-lane LDS state words of the v2 kernel */
+#define MDEMOD_RW_WIDE_BLOCK    512    /* threads per block of the wide v2 geometry */
 #ifndef MDEMOD_RW_BLOCK
 #define MDEMOD_RW_BLOCK         256    /* threads per block of the v2 kernel        */
 #endif

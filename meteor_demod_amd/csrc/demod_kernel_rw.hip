@@ -47,8 +47,24 @@
 
 namespace {
 
-constexpr int kTaps = 65;                 /* embedded filter length          */
-constexpr int kBack = kTaps - 1;          /* 64 = history length             */
+/* Window geometry.  Std: filters up to 65 taps, <= 3.6 samples per firing (the LRPT rates at
+ * ~230 kS/s).  Wide: up to 129 taps and 15 samples per firing (1 MS/s recordings): the window
+ * only fits as packed raw samples, the lanes of a wave are spread over a whole symbol period
+ * (up to 15 samples) so 24 alignments are needed, and the per-alignment coefficient rows
+ * (24 x interp x 154 floats) no longer fit in LDS: the table is stored once per bank, zero
+ * padded on both sides, in two copies shifted by one float so that every (alignment, slot
+ * pair) is an aligned 8-byte read ("compact"). */
+template <int KT_, int NW_, int MAXSL_, bool COMPACT_, int BLOCK_>
+struct Geo {
+	static constexpr int KT = KT_;            /* embedded filter length                  */
+	static constexpr int KB = KT_ - 1;        /* history length                          */
+	static constexpr int NW = NW_;            /* window slots                            */
+	static constexpr int MAXSL = MAXSL_;      /* slides of 8 slots per loop iteration    */
+	static constexpr bool COMPACT = COMPACT_;
+	static constexpr int BLOCK = BLOCK_;
+};
+typedef Geo<65, 80, 1, false, MDEMOD_RW_BLOCK> GeoStd;
+typedef Geo<129, 152, 2, true, MDEMOD_RW_WIDE_BLOCK> GeoWide;
 
 template <int FMT> struct Fmt;
 template <> struct Fmt<16> {
@@ -206,16 +222,18 @@ blind_steps(float p, float f)
 
 /* ---- the kernel ------------------------------------------------------------------ */
 
-template <int FMT, int OQPSK, bool PACKED>
-__global__ void __launch_bounds__(MDEMOD_RW_BLOCK, PACKED ? 3 : 2)
+template <int FMT, int OQPSK, bool PACKED, typename G>
+__global__ void __launch_bounds__(G::BLOCK, (PACKED && G::KT <= 65) ? 3 : 2)
 demod_kernel_rw(const DemodLaunch L)
 {
 	typedef Fmt<FMT> F;
 	typedef Win<FMT, PACKED> W;
 	typedef typename F::sample_t sample_t;
-	constexpr int NW = 80;                       /* window slots                       */
+	constexpr int kTaps = G::KT, kBack = G::KB;
+	constexpr int NW = G::NW;                    /* window slots                       */
 	constexpr int SLIDE = 8;                     /* slots per slide (two granules)     */
-	constexpr int AMAX = NW - kTaps;             /* alignments 0..15                   */
+	constexpr int AMAX = NW - kTaps;             /* alignments 0..AMAX                 */
+	constexpr int NST = 2 * G::MAXSL;            /* granules staged ahead of the window */
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	float *ctab = reinterpret_cast<float *>(lds);
@@ -285,9 +303,10 @@ demod_kernel_rw(const DemodLaunch L)
 	}
 	/* the two granules that enter at the next slide are fetched right after the previous one */
 	int g_load = (NW - kBack) / 4;                         /* next block granule to fetch (wave-uniform) */
-	Gran<FMT> st0 = fetch_granule<FMT>(src, 4 * g_load, n);
-	Gran<FMT> st1 = fetch_granule<FMT>(src, 4 * g_load + 4, n);
-	g_load += 2;
+	Gran<FMT> stg[NST];
+#pragma unroll
+	for (int i = 0; i < NST; i++) stg[i] = fetch_granule<FMT>(src, 4 * (g_load + i), n);
+	g_load += NST;
 
 	__syncthreads();                                       /* coefficient rows + LUT visible */
 
@@ -348,19 +367,22 @@ demod_kernel_rw(const DemodLaunch L)
 		if (__all(done)) break;
 
 		/* ---- (2) slide the window by 8 slots when nobody needs slots 0..7 any more ---- */
-		{
+#pragma unroll
+		for (int r = 0; r < G::MAXSL; r++) {
 			const int a_now = v_cur - kBack - base;
 			if (__all(done || a_now >= SLIDE)) {
 #pragma unroll
 				for (int k = 0; k < NW - SLIDE; k++) win[k] = win[k + SLIDE];
 #pragma unroll
 				for (int u = 0; u < 4; u++) {
-					win[NW - 8 + u] = W::pack(st0.s[u]);
-					win[NW - 4 + u] = W::pack(st1.s[u]);
+					win[NW - 8 + u] = W::pack(stg[0].s[u]);
+					win[NW - 4 + u] = W::pack(stg[1].s[u]);
 				}
 				base += SLIDE;
-				st0 = fetch_granule<FMT>(src, 4 * g_load, n);
-				st1 = fetch_granule<FMT>(src, 4 * g_load + 4, n);
+#pragma unroll
+				for (int i = 0; i + 2 < NST; i++) stg[i] = stg[i + 2];
+				stg[NST - 2] = fetch_granule<FMT>(src, 4 * g_load, n);
+				stg[NST - 1] = fetch_granule<FMT>(src, 4 * g_load + 4, n);
 				g_load += 2;
 			}
 		}
@@ -370,12 +392,18 @@ demod_kernel_rw(const DemodLaunch L)
 		if (fired && a <= AMAX) {
 			fired = false;
 			const int bank = interp - 1 - fire_sub;                     /* filter.c:52 */
-			const float *row = ctab + (a * interp + bank) * C.ctab_row_stride;
+			const float *row;
+			if (G::COMPACT) {
+				const int o = AMAX - a;                                 /* offset into the padded bank */
+				row = ctab + (bank * 2 + (o & 1)) * C.ctab_row_stride + (o & ~1);
+			} else {
+				row = ctab + (a * interp + bank) * C.ctab_row_stride;
+			}
 			cf32 y;
-			/* slots 0..7 carry only zeros for a lane with a >= 8, slots 72..79 only zeros for a < 8:
-			 * when the whole wave agrees the chunk is dropped (exact: acc + 0*x == acc). */
+			/* slots 0..7 carry only zeros for a lane with a >= 8, the last 8 slots only zeros for
+			 * a <= AMAX - 8: when the whole wave agrees the chunk is dropped (exact: acc + 0*x == acc). */
 			const bool skip_first = __all(a >= 8);              /* over the lanes active in this branch */
-			const bool skip_last = __all(a < 8);
+			const bool skip_last = __all(a <= AMAX - 8);
 			fir_window<NW, W>(win, row, skip_first, skip_last, y.re, y.im);
 
 			/* ---- scalar part: state comes from / goes back to the LDS slots ---- */
@@ -497,13 +525,13 @@ demod_kernel_rw(const DemodLaunch L)
 	}
 }
 
-template <int FMT, int OQPSK, bool PACKED>
+template <int FMT, int OQPSK, bool PACKED, typename G>
 hipError_t
 launch_rw(const DemodLaunch &L, size_t lds_bytes, hipStream_t stream)
 {
-	const int block = MDEMOD_RW_BLOCK;
+	const int block = G::BLOCK;
 	const uint32_t blocks = (L.n_streams + block - 1) / block;
-	auto kfn = demod_kernel_rw<FMT, OQPSK, PACKED>;
+	auto kfn = demod_kernel_rw<FMT, OQPSK, PACKED, G>;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if (e != hipSuccess) return e;
@@ -516,8 +544,15 @@ hipError_t
 launch_rw_mode(const DemodLaunch &L, bool packed, size_t lds_bytes, hipStream_t stream)
 {
 	if (FMT != 32 && packed)
-		return L.c.oqpsk ? launch_rw<FMT, 1, true>(L, lds_bytes, stream) : launch_rw<FMT, 0, true>(L, lds_bytes, stream);
-	return L.c.oqpsk ? launch_rw<FMT, 1, false>(L, lds_bytes, stream) : launch_rw<FMT, 0, false>(L, lds_bytes, stream);
+		return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoStd>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoStd>(L, lds_bytes, stream);
+	return L.c.oqpsk ? launch_rw<FMT, 1, false, GeoStd>(L, lds_bytes, stream) : launch_rw<FMT, 0, false, GeoStd>(L, lds_bytes, stream);
+}
+
+template <int FMT>
+hipError_t
+launch_rw_wide(const DemodLaunch &L, size_t lds_bytes, hipStream_t stream)
+{
+	return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoWide>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoWide>(L, lds_bytes, stream);
 }
 
 } /* namespace */
@@ -525,6 +560,13 @@ launch_rw_mode(const DemodLaunch &L, bool packed, size_t lds_bytes, hipStream_t 
 hipError_t
 mdemod_launch_demod_rw(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream)
 {
+	if (L.c.hpad == GeoWide::KB) {                 /* wide geometry: packed window only */
+		switch (fmt) {
+		case 16: return launch_rw_wide<16>(L, lds_bytes, stream);
+		case 8:  return launch_rw_wide<8>(L, lds_bytes, stream);
+		default: return hipErrorInvalidValue;
+		}
+	}
 	switch (fmt) {
 	case 16: return launch_rw_mode<16>(L, packed != 0, lds_bytes, stream);
 	case 8:  return launch_rw_mode<8>(L, packed != 0, lds_bytes, stream);
