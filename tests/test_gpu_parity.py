@@ -202,6 +202,78 @@ def test_batch_chained_over_several_calls(gpu_device, kernel_variant):
             assert np.array_equal(np.concatenate(parts[i]), O.oracle_demod(C1, iqs[i])[0]), i
 
 
+WIDE_CFGS = {
+    "c4_s16": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8),
+    "c4_u8": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=8),
+    "oqpsk80k_1M": DemodConfig(samplerate=1000000, symrate=80000, oqpsk=True, rrc_order=64, interp_factor=8),
+    "taps97_os6": DemodConfig(samplerate=500000, rrc_order=48, interp_factor=6),
+    "edge_15_per_symbol": DemodConfig(samplerate=1075000, rrc_order=40, interp_factor=4),   # 14.93 samples per symbol (1080000 would put an RRC singularity 0/0 on a tap: NaN, UB in the reference)
+    "taps65_slow_clock": DemodConfig(samplerate=460000, rrc_order=32, interp_factor=5),   # 65 taps but 6.4 samples/firing: ring kernel
+}
+
+
+@pytest.mark.parametrize("name", list(WIDE_CFGS))
+def test_wide_window_batch_chained(name, gpu_device):
+    """The 129-tap / 15-samples-per-firing geometry of the register-window kernel (packed window,
+    compact coefficient table, two slides per iteration): 70 distinct streams (more than one wave,
+    every symbol phase) x chained blocks, byte-identical to the oracle, loop state included."""
+    torch = _torch()
+    cfg = WIDE_CFGS[name]
+    rms = {8: 50.0, 16: 5000.0}[cfg.bps]
+    ns, blocks = 70, [5000, 3, 9000, 1, 2047]
+    streams = [synth.make_stream(8100 + i, cfg.samplerate, cfg.symrate, f0_hz=(i % 9 - 4) * 350.0, clock_ppm=(i % 7 - 3) * 15.0,
+                                 esn0_db=15.0, rms=rms, oqpsk=cfg.oqpsk, fmt=cfg.bps) for i in range(ns)]
+    iqs = [synth.generate_host(s, sum(blocks)) for s in streams]
+    with Demodulator(cfg, ns) as d:
+        parts = [[] for _ in range(ns)]
+        pos = 0
+        for b in blocks:
+            soft = d.process(torch.from_numpy(np.stack([a[pos:pos + b] for a in iqs])).cuda())
+            torch.cuda.synchronize()
+            st = d.status()
+            for i in range(ns):
+                parts[i].append(soft[i, : st[i].symbols_this_call].cpu().numpy())
+            pos += b
+        for i in range(ns):
+            ost = O.OracleStream(cfg)
+            want = ost.run(iqs[i])[0]
+            assert np.array_equal(np.concatenate(parts[i]), want), (name, i)
+            assert np.float32(st[i].pll_freq) == np.float32(ost.state.pll_freq) and st[i].locked == ost.state.locked
+            assert st[i].n_samples == sum(blocks)
+
+
+def test_wide_window_multi_round_and_ragged(gpu_device):
+    """Wide geometry with more tiles than are resident (131072 lanes) and ragged lengths."""
+    torch = _torch()
+    cfg = WIDE_CFGS["c4_s16"]
+    T, L = 131072 + 3000, 1500
+    one = synth.generate_device([synth.make_stream(77, cfg.samplerate, cfg.symrate, f0_hz=-600.0)], L)
+    want = O.oracle_demod(cfg, one[0].cpu().numpy())[0]
+    with Demodulator(cfg, T) as d:
+        cap = d.max_symbols(L)
+        soft = torch.zeros((T, cap, 2), dtype=torch.int8, device="cuda")
+        d.process(one.expand(T, L, 2), soft=soft)
+        torch.cuda.synchronize()
+        assert bool((soft == soft[:1]).all())
+        assert np.array_equal(soft[T - 1, : want.shape[0]].cpu().numpy(), want)
+    lens = [0, 1, 127, 128, 129, 151, 152, 153, 700, 1499, 1500]
+    buf = one[0].cpu().numpy()
+    offsets = [1 + sum(lens[:i]) + i for i in range(len(lens))]          # odd, unaligned starts
+    flat = np.zeros((offsets[-1] + lens[-1] + 8, 2), dtype=np.int16)
+    for o, n in zip(offsets, lens):
+        flat[o:o + n] = buf[:n]
+    with Demodulator(cfg, len(lens)) as d:
+        soft = torch.zeros((len(lens), d.max_symbols(max(lens)), 2), dtype=torch.int8, device="cuda")
+        d.process_ragged(torch.from_numpy(flat).cuda(), torch.tensor(offsets, dtype=torch.int64).cuda(),
+                         torch.tensor(lens, dtype=torch.int32).cuda(), soft)
+        torch.cuda.synchronize()
+        st = d.status()
+        for i, n in enumerate(lens):
+            w = O.oracle_demod(cfg, buf[:n])[0] if n else np.zeros((0, 2), np.int8)
+            assert st[i].symbols_this_call == w.shape[0], (i, n)
+            assert np.array_equal(soft[i, : w.shape[0]].cpu().numpy(), w), (i, n)
+
+
 def test_multi_round_launch_is_deterministic_and_exact(gpu_device, kernel_variant):
     """More tiles than the GPU can hold at once (blocks that start after others have finished, on CUs
     that are still busy): every tile of an all-identical batch must give the same bytes, twice in a row,
