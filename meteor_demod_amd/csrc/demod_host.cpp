@@ -144,17 +144,18 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 		return MDEMOD_OK;
 	}
 	if (out.rw_wide) {
-		/* v2 wide: 152-slot packed window, filter embedded as 129 taps, 24 alignments.  Compact
-		 * table: per bank the padded sequence P = 23 zeros ++ taps ++ 23 zeros, stored twice:
+		/* v2 wide: NW-slot packed window, filter embedded as 129 taps, AMAX + 1 = NW - 128 alignments.
+		 * Compact table: per bank the padded sequence P = AMAX zeros ++ taps ++ AMAX zeros, stored twice:
 		 * array (bank, 0)[i] = P[i], array (bank, 1)[i] = P[i + 1].  A lane at alignment a reads
-		 * P[(23 - a) + s] for slot s, i.e. array (bank, o & 1) at the even index (o & ~1) + s. */
-		const int kTaps = 129, NW = 152, AMAX = NW - kTaps;
-		const int LP = kTaps + 2 * AMAX;                  /* 175 */
+		 * P[(AMAX - a) + s] for slot s, i.e. array (bank, o & 1) at the even index (o & ~1) + s. */
+		const int kTaps = 129, NW = MDEMOD_RW_WIDE_NW, AMAX = NW - kTaps;
+		const int LP = kTaps + 2 * AMAX;
 		c.hpad = kTaps - 1;
 		c.win_granules = NW / 4;
 		c.ring_granules = 0;
 		c.ctab_row_floats = LP;
-		c.ctab_row_stride = LP + 3;                       /* 178 floats = 89 x 8 B (odd) */
+		c.ctab_row_stride = (LP + 2) / 2 * 2;             /* even number of floats ...                */
+		if ((c.ctab_row_stride / 2) % 2 == 0) c.ctab_row_stride += 2;   /* ... and an odd number of 8-byte words */
 		out.ctab.assign(static_cast<size_t>(2) * banks * c.ctab_row_stride, 0.0f);
 		const int lead = kTaps - c.taps;
 		for (unsigned b = 0; b < banks; b++) {

@@ -54,8 +54,9 @@ namespace {
  * (24 x interp x 154 floats) no longer fit in LDS: the table is stored once per bank, zero
  * padded on both sides, in two copies shifted by one float so that every (alignment, slot
  * pair) is an aligned 8-byte read ("compact"). */
-template <int KT_, int NW_, int MAXSL_, bool COMPACT_, int BLOCK_>
+template <int KT_, int NW_, int SLIDE_, int MAXSL_, bool COMPACT_, int BLOCK_>
 struct Geo {
+	static constexpr int SLIDE = SLIDE_;      /* slots per slide (whole granules)        */
 	static constexpr int KT = KT_;            /* embedded filter length                  */
 	static constexpr int KB = KT_ - 1;        /* history length                          */
 	static constexpr int NW = NW_;            /* window slots                            */
@@ -63,8 +64,8 @@ struct Geo {
 	static constexpr bool COMPACT = COMPACT_;
 	static constexpr int BLOCK = BLOCK_;
 };
-typedef Geo<65, 80, 1, false, MDEMOD_RW_BLOCK> GeoStd;
-typedef Geo<129, 152, 2, true, MDEMOD_RW_WIDE_BLOCK> GeoWide;
+typedef Geo<65, 80, 8, 1, false, MDEMOD_RW_BLOCK> GeoStd;
+typedef Geo<129, MDEMOD_RW_WIDE_NW, MDEMOD_RW_WIDE_SLIDE, MDEMOD_RW_WIDE_MAXSL, true, MDEMOD_RW_WIDE_BLOCK> GeoWide;
 
 template <int FMT> struct Fmt;
 template <> struct Fmt<16> {
@@ -231,9 +232,10 @@ demod_kernel_rw(const DemodLaunch L)
 	typedef typename F::sample_t sample_t;
 	constexpr int kTaps = G::KT, kBack = G::KB;
 	constexpr int NW = G::NW;                    /* window slots                       */
-	constexpr int SLIDE = 8;                     /* slots per slide (two granules)     */
+	constexpr int SLIDE = G::SLIDE;              /* slots per slide (whole granules)   */
+	constexpr int SG = SLIDE / 4;                /* granules per slide                 */
 	constexpr int AMAX = NW - kTaps;             /* alignments 0..AMAX                 */
-	constexpr int NST = 2 * G::MAXSL;            /* granules staged ahead of the window */
+	constexpr int NST = SG * G::MAXSL;           /* granules staged ahead of the window */
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	float *ctab = reinterpret_cast<float *>(lds);
@@ -334,7 +336,15 @@ demod_kernel_rw(const DemodLaunch L)
 				case 13: p = blind_steps<13>(p, t_freq); break;
 				case 6:  p = blind_steps<6>(p, t_freq); break;         /* OQPSK 80k @ 230 kS/s */
 				case 5:  p = blind_steps<5>(p, t_freq); break;
-				default: for (int k = 0; k < k_safe; k++) p = p + t_freq; break;
+				default: {                                             /* e.g. 109 steps at 1 MS/s, -O 8 */
+					int k = k_safe;
+					for (; k >= 16; k -= 16) p = blind_steps<16>(p, t_freq);
+					if (k & 8) p = blind_steps<8>(p, t_freq);
+					if (k & 4) p = blind_steps<4>(p, t_freq);
+					if (k & 2) p = blind_steps<2>(p, t_freq);
+					if (k & 1) p = p + t_freq;
+					break;
+				}
 				}
 				/* four checked steps.  The increment is positive, so "reached thr" is monotone:
 				 * the first hit is after (number of misses) + 1 steps. */
@@ -374,16 +384,15 @@ demod_kernel_rw(const DemodLaunch L)
 #pragma unroll
 				for (int k = 0; k < NW - SLIDE; k++) win[k] = win[k + SLIDE];
 #pragma unroll
-				for (int u = 0; u < 4; u++) {
-					win[NW - 8 + u] = W::pack(stg[0].s[u]);
-					win[NW - 4 + u] = W::pack(stg[1].s[u]);
-				}
+				for (int g = 0; g < SG; g++)
+#pragma unroll
+					for (int u = 0; u < 4; u++) win[NW - SLIDE + 4 * g + u] = W::pack(stg[g].s[u]);
 				base += SLIDE;
 #pragma unroll
-				for (int i = 0; i + 2 < NST; i++) stg[i] = stg[i + 2];
-				stg[NST - 2] = fetch_granule<FMT>(src, 4 * g_load, n);
-				stg[NST - 1] = fetch_granule<FMT>(src, 4 * g_load + 4, n);
-				g_load += 2;
+				for (int i = 0; i + SG < NST; i++) stg[i] = stg[i + SG];
+#pragma unroll
+				for (int g = 0; g < SG; g++) stg[NST - SG + g] = fetch_granule<FMT>(src, 4 * (g_load + g), n);
+				g_load += SG;
 			}
 		}
 
