@@ -220,8 +220,7 @@ def main() -> None:
                    "input_bytes_per_gpu": T * L * 4},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": ("demod_kernel (v1 LDS ring)" if args.config == "c4" or os.environ.get("MDEMOD_KERNEL") == "v1"
-                                else "demod_kernel_rw (v2 register window)"),
+                     "kernel": d.kernel_name,
                      "kernel_ms": round(kernel_ms, 3),
                      "algorithmic_bytes_per_sample": round(bytes_per_sample, 4)},
     }

@@ -196,6 +196,23 @@ uint32_t mdemod_history_len(const mdemod_ctx *ctx);
 int  mdemod_get_history(mdemod_ctx *ctx, uint32_t stream, float *iq_pairs, void *hip_stream);
 int  mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs, void *hip_stream);
 
+/* ---- overlapped tiles of ONE recording ------------------------------------
+ * The reference demodulates a recording as one serial recurrence (main.c:303).
+ * To run tiles of it in parallel each tile is an independent stream that starts
+ * `pre` samples early from a converged seed state; these two calls are what the
+ * host-side stitcher (meteor_demod_amd/recording.py) needs besides the ragged
+ * process call. */
+
+/* Every stream := *seed (loop state and counters); filter history zeroed. */
+int  mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void *hip_stream);
+/* pll phase of stream s += quarter_turns_dev[s] * pi/2 (device array, n_streams
+ * entries; wrapped like pll.c:113): moves a stream that locked k*90 degrees away
+ * from its predecessor onto the predecessor's constellation rotation. */
+int  mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, void *hip_stream);
+
+/* Name of the kernel variant this context launches (for logs and bench output). */
+const char *mdemod_kernel_name(const mdemod_ctx *ctx);
+
 /* ---- init-time tables, exposed for known-answer tests -------------------- */
 
 /* Host-only: derive the init-time tables for `params` without touching a device

@@ -80,6 +80,9 @@ SIGNATURES = {
                                          _P(C.c_uint32), C.c_void_p]),
     "mdemod_get_state": (C.c_int, [C.c_void_p, C.c_uint32, _P(MdemodStreamState), C.c_void_p]),
     "mdemod_set_state": (C.c_int, [C.c_void_p, C.c_uint32, _P(MdemodStreamState), C.c_void_p]),
+    "mdemod_set_state_all": (C.c_int, [C.c_void_p, _P(MdemodStreamState), C.c_void_p]),
+    "mdemod_rotate_carrier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdemod_kernel_name": (C.c_char_p, [C.c_void_p]),
     "mdemod_history_len": (C.c_uint32, [C.c_void_p]),
     "mdemod_get_history": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_float), C.c_void_p]),
     "mdemod_set_history": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_float), C.c_void_p]),

@@ -469,6 +469,40 @@ mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in
 }
 #undef ONE
 
+int
+mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void *hip_stream)
+{
+	if (!ctx || !seed) return MDEMOD_ERR_PARAM;
+	if (seed->t_dual_state != 1 && seed->t_dual_state != 2) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	const int32_t flags = (seed->pll_locked ? MDEMOD_FLAG_LOCKED : 0) | (seed->pll_locked_once ? MDEMOD_FLAG_LOCKED_ONCE : 0) |
+	                      (seed->pll_updown > 0 ? MDEMOD_FLAG_UPDOWN_POS : 0) | (seed->t_dual_state << MDEMOD_FLAG_DUAL_SHIFT);
+	HIP_TRY(mdemod_launch_seed(ctx->st, ctx->tab.c, *seed, flags, ctx->params.bps, ctx->tab.use_rw ? 1 : 0,
+	                           ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
+	return MDEMOD_OK;
+}
+
+int
+mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, void *hip_stream)
+{
+	if (!ctx || !quarter_turns_dev) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	HIP_TRY(mdemod_launch_rotate(ctx->st, quarter_turns_dev, ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
+	return MDEMOD_OK;
+}
+
+const char *
+mdemod_kernel_name(const mdemod_ctx *ctx)
+{
+	if (!ctx) return "";
+	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
+	if (ctx->tab.rw_wide) return "demod_kernel_rw (v2 register window, wide: 129 taps, packed)";
+	return (ctx->params.bps != 32 && env_int("MDEMOD_RW_PACKED", 0))
+	       ? "demod_kernel_rw (v2 register window, packed)" : "demod_kernel_rw (v2 register window, float)";
+}
+
 uint32_t
 mdemod_history_len(const mdemod_ctx *ctx)
 {

@@ -33,6 +33,36 @@ reset_kernel(DemodStateSoA st, float t_center, int hpad, uint32_t n_streams, sam
 	for (int k = 0; k < hpad; k++) hist[stream_major ? (size_t)s * hpad + k : (size_t)k * n_streams + s] = zero;
 }
 
+/* Broadcast one loop state to every stream (seed of overlapped tiles); history := zeros. */
+template <typename sample_t>
+__global__ void
+seed_kernel(DemodStateSoA st, mdemod_stream_state v, int32_t flags, int hpad, uint32_t n_streams, sample_t zero, int stream_major)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_streams) return;
+	st.agc_gain[s] = v.agc_gain; st.agc_bias_re[s] = v.agc_bias_re; st.agc_bias_im[s] = v.agc_bias_im;
+	st.pll_phase[s] = v.pll_phase; st.pll_freq[s] = v.pll_freq; st.pll_err[s] = v.pll_err;
+	st.t_phase[s] = v.t_phase; st.t_freq[s] = v.t_freq; st.t_prev[s] = v.t_prev;
+	st.inphase[s] = v.oqpsk_inphase;
+	st.flags[s] = flags;
+	st.n_samples[s] = v.n_samples; st.n_symbols[s] = v.n_symbols; st.first_lock[s] = v.first_lock_symbol;
+	st.sym_this_call[s] = 0; st.ev_this_call[s] = 0; st.overflow[s] = 0;
+	sample_t *hist = reinterpret_cast<sample_t *>(st.hist);
+	for (int k = 0; k < hpad; k++) hist[stream_major ? (size_t)s * hpad + k : (size_t)k * n_streams + s] = zero;
+}
+
+/* phase += k * pi/2, wrapped with the dividend's sign like pll.c:113 */
+__global__ void
+rotate_kernel(DemodStateSoA st, const int32_t *quarter_turns, uint32_t n_streams)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_streams) return;
+	const int32_t k = quarter_turns[s] & 3;
+	if (!k) return;
+	const double p = (double)st.pll_phase[s] + (double)k * MD_HALF_PI_D;
+	st.pll_phase[s] = (float)fmod(p, MD_TWO_PI_D);
+}
+
 __global__ void
 selftest_sincos_kernel(const float *x, uint32_t n, float *s, float *c)
 {
@@ -92,6 +122,37 @@ mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int 
 	default:
 		return hipErrorInvalidValue;
 	}
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_seed(const DemodStateSoA &st, const DemodConsts &c, const mdemod_stream_state &v, int32_t flags, int fmt,
+                   int float_history, uint32_t n_streams, hipStream_t stream)
+{
+	if (n_streams == 0) return hipSuccess;
+	const dim3 block(256), grid((n_streams + 255) / 256);
+	if (float_history) fmt = 32;
+	switch (fmt) {
+	case 16:
+		hipLaunchKernelGGL(seed_kernel<uint32_t>, grid, block, 0, stream, st, v, flags, c.hpad, n_streams, (uint32_t)0, float_history);
+		break;
+	case 8:
+		hipLaunchKernelGGL(seed_kernel<uint16_t>, grid, block, 0, stream, st, v, flags, c.hpad, n_streams, (uint16_t)0x8080, float_history);
+		break;
+	case 32:
+		hipLaunchKernelGGL(seed_kernel<float2>, grid, block, 0, stream, st, v, flags, c.hpad, n_streams, make_float2(0.0f, 0.0f), float_history);
+		break;
+	default:
+		return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_turns_dev, uint32_t n_streams, hipStream_t stream)
+{
+	if (n_streams == 0) return hipSuccess;
+	hipLaunchKernelGGL(rotate_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, quarter_turns_dev, n_streams);
 	return hipGetLastError();
 }
 

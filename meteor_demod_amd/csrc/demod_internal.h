@@ -86,6 +86,9 @@ struct DemodLaunch {
 hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_rw(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int float_history, uint32_t n_streams, hipStream_t stream);
+hipError_t mdemod_launch_seed(const DemodStateSoA &st, const DemodConsts &c, const mdemod_stream_state &v, int32_t flags, int fmt,
+                              int float_history, uint32_t n_streams, hipStream_t stream);
+hipError_t mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_turns_dev, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_selftest_sincos(const float *x, uint32_t n, float *s, float *c, hipStream_t stream);
 hipError_t mdemod_launch_selftest_turncode(unsigned long long *mismatch_dev, hipStream_t stream);
 hipError_t mdemod_launch_selftest_hypot(const float *xy, uint32_t n, float *out, hipStream_t stream);

@@ -178,6 +178,18 @@ class Demodulator:
         check(self._lib.mdemod_get_status(self._ctx, first, count, arr, self._stream()), "mdemod_get_status")
         return list(arr)
 
+    def status_array(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """Same snapshot as :meth:`status` as one numpy structured array (cheap for 10^5 streams)."""
+        count = self.n_streams - first if count is None else count
+        arr = (MdemodStatus * max(count, 1))()
+        check(self._lib.mdemod_get_status(self._ctx, first, count, arr, self._stream()), "mdemod_get_status")
+        return np.ctypeslib.as_array(arr)[:count].copy()
+
+    def symbol_counts(self):
+        """Symbols each stream produced in the last call: int64 CPU tensor [n_streams] (synchronises)."""
+        import torch
+        return torch.from_numpy(self.status_array()["symbols_this_call"].astype(np.int64))
+
     def lock_events(self, stream: int) -> list[tuple[int, int]]:
         arr = (MdemodLockEvent * _capi.MDEMOD_MAX_LOCK_EVENTS)()
         n = C.c_uint32()
@@ -192,6 +204,20 @@ class Demodulator:
 
     def set_state(self, stream: int, st: MdemodStreamState) -> None:
         check(self._lib.mdemod_set_state(self._ctx, stream, C.byref(st), self._stream()), "mdemod_set_state")
+
+    def set_state_all(self, st: MdemodStreamState) -> None:
+        """Every stream := ``st`` (loop state + counters), filter history zeroed: the seed of overlapped tiles."""
+        check(self._lib.mdemod_set_state_all(self._ctx, C.byref(st), self._stream()), "mdemod_set_state_all")
+
+    def rotate_carrier(self, quarter_turns) -> None:
+        """pll phase of stream s += quarter_turns[s] * pi/2 (int32 device tensor of n_streams entries)."""
+        assert quarter_turns.numel() == self.n_streams and quarter_turns.element_size() == 4
+        check(self._lib.mdemod_rotate_carrier(self._ctx, C.c_void_p(quarter_turns.data_ptr()), self._stream()),
+              "mdemod_rotate_carrier")
+
+    @property
+    def kernel_name(self) -> str:
+        return self._lib.mdemod_kernel_name(self._ctx).decode()
 
     def history_len(self) -> int:
         return int(self._lib.mdemod_history_len(self._ctx))

@@ -1,0 +1,346 @@
+"""One long recording as overlapped tiles (BASELINE north star: "the IQ stream tiled
+into overlapping blocks so each block runs the serial PLL/Gardner recurrences").
+
+The reference demodulates a recording as ONE serial recurrence (main.c:303-316):
+tiles of it cannot be made bit-identical to that run.  What can be
+made exact is every piece of the following scheme, because each piece is an
+ordinary stream with a defined initial state, and streams are bit-exact:
+
+  pilot    The head of the recording runs as one stream from the reference's
+           power-on state until the PLL has locked AND converged (the carrier
+           loop of pll.c needs ~1.5e5 symbols after lock before its frequency
+           estimate stops moving; a seed taken earlier leaves every tile with the
+           same static phase lag, 3-4 LSB against the serial run).  Its symbols
+           ARE the reference's symbols (first-lock index included, so the lock
+           gate of main.c:312 opens on the same chunk).  One lane runs ~1.3 MS/s,
+           so the pilot is the latency of a single recording (~0.5 s); in a batch
+           of recordings the pilots are just more lanes.
+  pass 1   Every tile starts ``pre`` samples early from the pilot's end state
+           (converged AGC / carrier frequency / symbol clock), warm-up symbols
+           are dropped, the body's symbols are kept.
+  rotation A QPSK Costas loop locks on any of four constellation rotations.  Each
+           tile's rotation relative to its predecessor is measured on the samples
+           both demodulated (the predecessor's tail = the tile's warm-up), prefix
+           summed, and undone.  The same comparison detects the one-symbol
+           duplicate / gap that appears when two tiles place the symbol that
+           straddles their seam on different sides of it.
+  pass 2   (``refine=True``) Tile i+1 is demodulated again, this time as the exact
+           continuation of tile i's pass-1 end state (history included), turned
+           into the pilot's rotation.  No warm-up is needed and all tiles now run
+           in the rotation the serial reference runs in, which matters because the
+           timing detector reads only the Q rail (timing.c:65-66).
+
+All arithmetic on samples happens in the HIP kernels; this module only plans
+offsets, compares int8 tails and concatenates.  It is written against a small
+"bank" interface so that the CPU tests can drive exactly the same code with the
+oracle as the tile engine (tests/test_recording_cpu.py).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+# ---- planning (pure host logic) ------------------------------------------------------------
+
+@dataclass
+class TilePlan:
+    n_samples: int
+    pilot_end: int                 # samples [0, pilot_end) belong to the pilot
+    starts: np.ndarray             # int64 [T]  first body sample of each tile
+    lens: np.ndarray               # int64 [T]  body samples of each tile
+    pres: np.ndarray               # int64 [T]  warm-up samples actually available (<= pre)
+
+    @property
+    def n_tiles(self) -> int:
+        return int(self.starts.shape[0])
+
+
+def plan_tiles(n_samples: int, pilot_end: int, tile_samples: int, pre_samples: int) -> TilePlan:
+    """Tiles of ``tile_samples`` cover [pilot_end, n_samples); the last one may be short."""
+    assert tile_samples > 0 and pre_samples >= 0 and 0 <= pilot_end <= n_samples
+    starts = np.arange(pilot_end, n_samples, tile_samples, dtype=np.int64)
+    lens = np.minimum(tile_samples, n_samples - starts).astype(np.int64)
+    pres = np.minimum(pre_samples, starts).astype(np.int64)
+    return TilePlan(n_samples, pilot_end, starts, lens, pres)
+
+
+# ---- int8 symbol helpers (torch tensors, any device) -------------------------------------------
+
+def rotate_symbols(sym, quarter_turns):
+    """(I + jQ) * j**k for int8 pairs [..., 2]; ``quarter_turns`` broadcasts over the leading dims.
+    Exact: soft symbols are clamped to +-127 (main.c:305), so negation never overflows."""
+    import torch
+    k = torch.as_tensor(quarter_turns, device=sym.device) & 3
+    while k.dim() < sym.dim() - 1:
+        k = k.unsqueeze(-1)
+    i, q = sym[..., 0], sym[..., 1]
+    ri = torch.where(k == 0, i, torch.where(k == 1, -q, torch.where(k == 2, -i, q)))
+    rq = torch.where(k == 0, q, torch.where(k == 1, i, torch.where(k == 2, -q, -i)))
+    return torch.stack((ri, rq), dim=-1)
+
+
+def gather_tails(soft, counts, k):
+    """Last ``k`` symbols of each row of ``soft`` [T, cap, 2] given per-row ``counts`` -> [T, k, 2] (int32),
+    plus a validity mask [T, k] (False where the row has fewer than k symbols)."""
+    import torch
+    T = soft.shape[0]
+    idx = counts.view(T, 1).to(torch.int64) - k + torch.arange(k, device=soft.device).view(1, k)
+    ok = idx >= 0
+    g = torch.gather(soft, 1, idx.clamp(min=0).unsqueeze(-1).expand(T, k, 2)).to(torch.int32)
+    return g * ok.unsqueeze(-1), ok
+
+
+def match_tails(a_tail, b_tail):
+    """Best (shift, rotation) aligning tail B onto tail A.
+
+    ``a_tail``, ``b_tail``: [T, K+1, 2] int32, the last K+1 symbols that two demodulations produced
+    for the same stretch of samples.  Returns (shift [T], rot [T], score [T], energy [T]) where
+    ``b * j**rot`` matches ``a`` and shift is
+       0  both end on the same symbol,
+      +1  A ends one symbol later than B (A holds a symbol B does not have yet),
+      -1  B ends one symbol later than A.
+    """
+    import torch
+    K = a_tail.shape[1] - 1
+    best = None
+    for shift, (asl, bsl) in ((0, (slice(1, K + 1), slice(1, K + 1))),
+                              (1, (slice(0, K), slice(1, K + 1))),
+                              (-1, (slice(1, K + 1), slice(0, K)))):
+        a, b = a_tail[:, asl], b_tail[:, bsl]
+        ai, aq, bi, bq = a[..., 0], a[..., 1], b[..., 0], b[..., 1]
+        re = (ai * bi + aq * bq).sum(1)            # Re sum a * conj(b)
+        im = (aq * bi - ai * bq).sum(1)            # Im sum a * conj(b)
+        # a ~ b * j**r  <=>  sum a conj(b) ~ |b|^2 j**r
+        scores = torch.stack((re, im, -re, -im), dim=1)          # r = 0, 1, 2, 3
+        sc, r = scores.max(dim=1)
+        cand = (sc, torch.full_like(r, shift), r)
+        if best is None:
+            best = cand
+        else:
+            take = cand[0] > best[0]
+            best = tuple(torch.where(take, c, b0) for c, b0 in zip(cand, best))
+    energy = (a_tail[:, 1:].to(torch.int64) ** 2).sum((1, 2))
+    return best[1], best[2], best[0], energy
+
+
+# ---- result ---------------------------------------------------------------------------------
+
+@dataclass
+class StitchReport:
+    n_tiles: int = 0
+    pilot_samples: int = 0
+    pilot_symbols: int = 0
+    pilot_locked: bool = False
+    first_lock_symbol: int = -1
+    rotations: list = field(default_factory=list)          # absolute quarter turns per tile (pass 1)
+    seam_shifts: list = field(default_factory=list)        # per seam: -1 / 0 / +1
+    weak_seams: int = 0                                    # seams whose correlation was too weak to trust
+    refine_rotations: list = field(default_factory=list)   # pass 2: residual rotation per tile (0 expected)
+    samples_demodulated: int = 0                           # total kernel work incl. warm-up and pass 2
+
+
+@dataclass
+class StitchedRecording:
+    soft: object                   # int8 [m, 2] tensor: pilot symbols ++ tile symbols
+    tile_first_symbol: np.ndarray  # index into soft of each tile's first symbol
+    plan: TilePlan
+    report: StitchReport
+
+
+# ---- the stitcher -------------------------------------------------------------------------------
+
+class RecordingDemodulator:
+    """Demodulate ONE recording with many lanes.
+
+    ``bank_factory(cfg, n_streams)`` must return an object with the :class:`Demodulator` methods used here
+    (``reset, process, process_ragged, max_symbols, symbol_counts, get_state, set_state, get_history,
+    set_history, set_state_all, rotate_carrier, close``).  The default is the HIP :class:`Demodulator`.
+    """
+
+    def __init__(self, cfg, tile_samples: int = 65536, pre_samples: int = 16384, refine: bool = True,
+                 pilot_block: int = 65536, pilot_margin_symbols: int = 160000, max_pilot_samples: int = 1 << 22,
+                 match_symbols: int = 192, device: int = 0, bank_factory=None):
+        if cfg.oqpsk:
+            # the I and Q rails of OQPSK come from different firings (demod.c:66-76): a 90 degree lock offset is
+            # entangled with the half-symbol state of the symbol clock, which rotate_symbols() cannot undo.
+            raise NotImplementedError("overlapped tiles of one recording are implemented for QPSK only; "
+                                      "demodulate OQPSK recordings as whole streams (one per lane)")
+        self.cfg = cfg
+        self.tile_samples = int(tile_samples)
+        self.pre_samples = int(pre_samples)
+        self.refine = bool(refine)
+        self.pilot_block = int(pilot_block)
+        self.pilot_margin_symbols = int(pilot_margin_symbols)
+        self.max_pilot_samples = int(max_pilot_samples)
+        self.match_symbols = int(match_symbols)
+        self.device = device
+        if bank_factory is None:
+            from .demod import Demodulator
+            bank_factory = lambda c, n: Demodulator(c, n, device=device)
+        self._factory = bank_factory
+
+    # -- pilot ---------------------------------------------------------------------------------
+    def _run_pilot(self, iq, rep: StitchReport):
+        """Serial head: blocks of ``pilot_block`` until locked for ``pilot_margin_symbols`` (or the cap)."""
+        import torch
+        n = iq.shape[0]
+        pilot = self._factory(self.cfg, 1)
+        parts, pos, locked_at = [], 0, None
+        while pos < n:
+            b = min(self.pilot_block, n - pos)
+            soft = pilot.process(iq[pos:pos + b].unsqueeze(0))
+            m = int(pilot.symbol_counts()[0])
+            parts.append(soft[0, :m].clone())
+            pos += b
+            st = pilot.get_state(0)
+            if st.pll_locked and locked_at is None:
+                locked_at = st.n_symbols
+            if not st.pll_locked:
+                locked_at = None
+            if locked_at is not None and st.n_symbols - locked_at >= self.pilot_margin_symbols:
+                break
+            if pos >= self.max_pilot_samples:
+                break
+        st = pilot.get_state(0)
+        rep.pilot_samples, rep.pilot_symbols = pos, int(st.n_symbols)
+        rep.pilot_locked, rep.first_lock_symbol = bool(st.pll_locked), int(st.first_lock_symbol)
+        rep.samples_demodulated += pos
+        soft = torch.cat(parts) if parts else torch.empty((0, 2), dtype=torch.int8, device=iq.device)
+        return pilot, soft, pos
+
+    # -- main entry ------------------------------------------------------------------------------
+    def demodulate(self, iq) -> StitchedRecording:
+        """``iq``: [n, 2] tensor of the recording (device tensor for the HIP bank)."""
+        import torch
+        assert iq.dim() == 2 and iq.shape[1] == 2
+        rep = StitchReport()
+        pilot, pilot_soft, pilot_end = self._run_pilot(iq, rep)
+        plan = plan_tiles(int(iq.shape[0]), pilot_end, self.tile_samples, self.pre_samples)
+        T = plan.n_tiles
+        rep.n_tiles = T
+        if T == 0:
+            pilot.close()
+            return StitchedRecording(pilot_soft, np.zeros(0, np.int64), plan, rep)
+
+        dev = iq.device
+        K = self.match_symbols
+        seed = pilot.get_state(0)
+        seed_hist = pilot.get_history(0)
+        bank = self._factory(self.cfg, T)
+        i64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64), device=dev)
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=dev)
+
+        # ---- pass 1: warm-up (dropped) then body, from the pilot's end state -----------------
+        bank.set_state_all(seed)
+        cap_pre = max(1, bank.max_symbols(int(plan.pres.max())))
+        cap = bank.max_symbols(int(plan.lens.max()))
+        soft_pre = torch.zeros((T, cap_pre, 2), dtype=torch.int8, device=dev)
+        soft1 = torch.zeros((T, cap, 2), dtype=torch.int8, device=dev)
+        bank.process_ragged(iq, i64(plan.starts - plan.pres), i32(plan.pres), soft_pre)
+        cnt_pre = bank.symbol_counts().to(dev)
+        bank.process_ragged(iq, i64(plan.starts), i32(plan.lens), soft1)
+        cnt1 = bank.symbol_counts().to(dev)
+        rep.samples_demodulated += int(plan.pres.sum() + plan.lens.sum())
+
+        # ---- rotation + seam of every tile against its predecessor (tile 0: against the pilot) ----
+        prev_tail, _ = gather_tails(soft1[:-1], cnt1[:-1], K + 1) if T > 1 else (torch.zeros((0, K + 1, 2), dtype=torch.int32, device=dev), None)
+        ptail, _ = gather_tails(pilot_soft.unsqueeze(0), torch.tensor([pilot_soft.shape[0]], device=dev), K + 1)
+        a_tail = torch.cat((ptail, prev_tail))
+        b_tail, _ = gather_tails(soft_pre, cnt_pre, K + 1)
+        shift, rot, score, energy = match_tails(a_tail, b_tail)
+        weak = score * 2 < energy                                  # less than half of a perfect match
+        weak |= torch.as_tensor(plan.pres == 0, device=dev)        # no overlap at all
+        shift = torch.where(weak, torch.zeros_like(shift), shift)
+        rot = torch.where(weak, torch.zeros_like(rot), rot)
+        R = torch.cumsum(rot, 0) & 3                               # absolute rotation of each tile
+        rep.rotations = R.cpu().tolist()
+        rep.seam_shifts = shift.cpu().tolist()
+        rep.weak_seams = int(weak.sum())
+
+        if not self.refine:
+            body = rotate_symbols(soft1, R)
+            pre_last, _ = gather_tails(soft_pre, cnt_pre, 1)
+            head_sym = rotate_symbols(pre_last.to(torch.int8), R)[:, 0]           # used where shift == -1
+            out = self._assemble(pilot_soft, body, cnt1, shift, head_sym)
+            pilot.close(); bank.close()
+            return StitchedRecording(out[0], out[1], plan, rep)
+
+        # ---- pass 2: tile i+1 := exact continuation of tile i's pass-1 end state, in rotation 0 ----
+        bank.rotate_carrier(((4 - R) & 3).to(torch.int32))
+        # stream T-1 is free in pass 2: it takes over from the pilot and runs tile 0 (exact continuation)
+        bank.set_state(T - 1, seed)
+        bank.set_history(T - 1, seed_hist)
+        starts2 = np.concatenate((plan.starts[1:], plan.starts[:1]))
+        lens2 = np.concatenate((plan.lens[1:], plan.lens[:1]))
+        soft2 = torch.zeros((T, cap, 2), dtype=torch.int8, device=dev)
+        bank.process_ragged(iq, i64(starts2), i32(lens2), soft2)
+        cnt2s = bank.symbol_counts().to(dev)
+        rep.samples_demodulated += int(plan.lens.sum())
+        # back to tile order: tile 0 came from stream T-1, tile i from stream i-1
+        order = torch.cat((torch.tensor([T - 1], device=dev), torch.arange(T - 1, device=dev)))
+        soft2, cnt2 = soft2[order], cnt2s[order]
+
+        # seam i|i+1: tile i+1 continued from tile i's PASS-1 trajectory; what is emitted for tile i is its
+        # PASS-2 body.  Compare the two tails of tile i (same samples) for a one-symbol disagreement.
+        a2, _ = gather_tails(soft2, cnt2, K + 1)
+        b1, _ = gather_tails(rotate_symbols(soft1, R), cnt1, K + 1)
+        shift2, rot2, score2, energy2 = match_tails(a2, b1)
+        weak2 = score2 * 2 < energy2
+        shift2 = torch.where(weak2, torch.zeros_like(shift2), shift2)
+        rep.refine_rotations = torch.where(weak2, torch.zeros_like(rot2), rot2).cpu().tolist()
+        rep.weak_seams += int(weak2[:-1].sum())
+        # express as "shift of tile i+1 against its predecessor" like pass 1: +1 => predecessor (A = pass-2
+        # tile i) holds an extra symbol, -1 => the reference tail (B = pass-1 tile i) holds one more.
+        seam = torch.cat((torch.zeros(1, dtype=shift2.dtype, device=dev), shift2[:-1]))
+        b1_last = rotate_symbols(gather_tails(soft1, cnt1, 1)[0].to(torch.int8), R)[:, 0]
+        head_sym = torch.cat((torch.zeros((1, 2), dtype=torch.int8, device=dev), b1_last[:-1]))
+        rep.seam_shifts = seam.cpu().tolist()
+        out = self._assemble(pilot_soft, soft2, cnt2, seam, head_sym)
+        pilot.close(); bank.close()
+        return StitchedRecording(out[0], out[1], plan, rep)
+
+    # -- concatenation with seam fixes -------------------------------------------------------------
+    @staticmethod
+    def _assemble(pilot_soft, body, cnt, shift, head_sym):
+        """pilot ++ tiles.  shift[i] = +1: the predecessor of tile i ends with a symbol tile i also emits
+        (drop it from the predecessor); -1: the symbol before tile i's first one is missing (insert
+        ``head_sym[i]``)."""
+        import torch
+        T, cap = body.shape[0], body.shape[1]
+        dev = body.device
+        cnt = cnt.to(torch.int64)
+        drop_prev = (shift == 1).to(torch.int64)
+        add_head = (shift == -1).to(torch.int64)
+        n_pilot = pilot_soft.shape[0] - int(drop_prev[0])
+        keep = cnt - torch.cat((drop_prev[1:], torch.zeros(1, dtype=torch.int64, device=dev)))
+        keep = keep.clamp(min=0)
+        per_tile = keep + add_head
+        first = n_pilot + torch.cumsum(per_tile, 0) - per_tile
+        total = int(n_pilot + per_tile.sum())
+        out = torch.empty((total, 2), dtype=torch.int8, device=dev)
+        out[:n_pilot] = pilot_soft[:n_pilot]
+        hs = torch.nonzero(add_head).flatten()
+        if hs.numel():
+            out[first[hs]] = head_sym[hs]
+        col = torch.arange(cap, device=dev).view(1, cap)
+        mask = col < keep.view(T, 1)
+        dst = (first + add_head).view(T, 1) + col
+        out[dst[mask]] = body[mask]
+        return out, first.cpu().numpy()
+
+
+# ---- evaluation helper (tests / bench) --------------------------------------------------------
+
+def agreement(stitched: np.ndarray, serial: np.ndarray, window: int = 4096) -> dict:
+    """Fraction of symbols within +-1 LSB of the serial demodulation, overall and per window.  Both are
+    int8 [m, 2]; a length difference is reported, the common prefix is compared."""
+    m = min(len(stitched), len(serial))
+    d = np.abs(stitched[:m].astype(np.int16) - serial[:m].astype(np.int16)).max(axis=1)
+    ok = d <= 1
+    sign_ok = ((stitched[:m] >= 0) == (serial[:m] >= 0)).all(axis=1)
+    wins = [float(ok[i:i + window].mean()) for i in range(0, m, window)]
+    return {"len_stitched": int(len(stitched)), "len_serial": int(len(serial)), "within_1lsb": float(ok.mean()) if m else 1.0,
+            "hard_decisions_equal": float(sign_ok.mean()) if m else 1.0, "worst_window": min(wins) if wins else 1.0,
+            "windows": wins}
