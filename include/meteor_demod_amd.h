@@ -210,6 +210,42 @@ int  mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void
  * from its predecessor onto the predecessor's constellation rotation. */
 int  mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, void *hip_stream);
 
+/* The whole scheme in one call (native counterpart of meteor_demod_amd/recording.py):
+ * the head of the recording is demodulated serially from the reference's power-on state until the
+ * carrier loop has locked and converged (those symbols are the reference's symbols), the rest as
+ * overlapped tiles seeded from that state, rotation- and seam-resolved, optionally refined by an exact
+ * continuation pass.  QPSK only.  iq_dev: n_samples IQ samples in the format of params->bps, in device
+ * memory; soft_dev: device buffer for soft_cap_symbols int8 pairs (mdemod_max_symbols-sized is enough).
+ * params->n_streams is ignored.  Synchronous on hip_stream. */
+typedef struct {
+	uint32_t tile_samples;          /* body samples per tile                      (65536)  */
+	uint32_t pre_samples;           /* warm-up samples in front of each tile      (16384)  */
+	uint32_t pilot_block;           /* pilot granularity in samples               (65536)  */
+	uint32_t pilot_margin_symbols;  /* symbols the pilot stays locked before tiles start (160000) */
+	uint64_t max_pilot_samples;     /* give up waiting for lock after this many   (1 << 22) */
+	uint32_t match_symbols;         /* symbols compared across a seam             (192)    */
+	int32_t  refine;                /* 1: exact-continuation second pass          (1)      */
+	uint64_t reserved;
+} mdemod_recording_opts;
+
+typedef struct {
+	uint64_t n_symbols;             /* symbols written to soft_dev                           */
+	uint64_t pilot_samples;         /* samples [0, pilot_samples) were demodulated serially  */
+	uint64_t pilot_symbols;         /* ... and produced this many symbols (bit-exact)        */
+	int64_t  first_lock_symbol;     /* as mdemod_status, from the pilot                      */
+	uint64_t samples_demodulated;   /* kernel work including warm-up and second pass         */
+	uint32_t n_tiles;
+	uint32_t weak_seams;            /* seams whose correlation was too weak to trust         */
+	uint32_t seam_fixes;            /* one-symbol duplicates / gaps repaired                 */
+	int32_t  pilot_locked;
+} mdemod_recording_report;
+
+void mdemod_recording_default_opts(mdemod_recording_opts *opts);
+int  mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_opts *opts,
+                                 const void *iq_dev, uint64_t n_samples,
+                                 int8_t *soft_dev, uint64_t soft_cap_symbols,
+                                 mdemod_recording_report *report, void *hip_stream);
+
 /* Name of the kernel variant this context launches (for logs and bench output). */
 const char *mdemod_kernel_name(const mdemod_ctx *ctx);
 

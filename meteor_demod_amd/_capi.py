@@ -60,6 +60,19 @@ class MdemodStreamState(C.Structure):
     ]
 
 
+class MdemodRecordingOpts(C.Structure):
+    _fields_ = [("tile_samples", C.c_uint32), ("pre_samples", C.c_uint32), ("pilot_block", C.c_uint32),
+                ("pilot_margin_symbols", C.c_uint32), ("max_pilot_samples", C.c_uint64),
+                ("match_symbols", C.c_uint32), ("refine", C.c_int32), ("reserved", C.c_uint64)]
+
+
+class MdemodRecordingReport(C.Structure):
+    _fields_ = [("n_symbols", C.c_uint64), ("pilot_samples", C.c_uint64), ("pilot_symbols", C.c_uint64),
+                ("first_lock_symbol", C.c_int64), ("samples_demodulated", C.c_uint64),
+                ("n_tiles", C.c_uint32), ("weak_seams", C.c_uint32), ("seam_fixes", C.c_uint32),
+                ("pilot_locked", C.c_int32)]
+
+
 # name -> (restype, argtypes); this table is also what the symbol-export test walks.
 _P = C.POINTER
 SIGNATURES = {
@@ -83,6 +96,9 @@ SIGNATURES = {
     "mdemod_set_state_all": (C.c_int, [C.c_void_p, _P(MdemodStreamState), C.c_void_p]),
     "mdemod_rotate_carrier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "mdemod_recording_default_opts": (None, [_P(MdemodRecordingOpts)]),
+    "mdemod_demodulate_recording": (C.c_int, [_P(MdemodParams), _P(MdemodRecordingOpts), C.c_void_p, C.c_uint64,
+                                              C.c_void_p, C.c_uint64, _P(MdemodRecordingReport), C.c_void_p]),
     "mdemod_history_len": (C.c_uint32, [C.c_void_p]),
     "mdemod_get_history": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_float), C.c_void_p]),
     "mdemod_set_history": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_float), C.c_void_p]),

@@ -55,7 +55,8 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
     out: dict[str, Path] = {}
 
     # --- product library ---------------------------------------------------
-    srcs = [CSRC / "demod_kernel.hip", CSRC / "demod_kernel_rw.hip", CSRC / "demod_aux.hip", CSRC / "demod_api.cpp", CSRC / "demod_host.cpp"]
+    srcs = [CSRC / "demod_kernel.hip", CSRC / "demod_kernel_rw.hip", CSRC / "demod_aux.hip", CSRC / "recording.hip",
+            CSRC / "demod_api.cpp", CSRC / "demod_host.cpp"]
     objs = []
     for src in srcs:
         obj = LIB / (src.stem + ".o")

@@ -1,0 +1,355 @@
+/*
+ * recording.hip — ONE recording demodulated on many lanes as overlapped tiles.
+ *
+ * Native counterpart of meteor_demod_amd/recording.py (same scheme, same
+ * decisions, byte-identical result: tests/test_gpu_recording.py).  The reference
+ * runs a recording as one serial recurrence (main.c:303-316); see DESIGN.md §3.1
+ * for why tiles cannot equal it bit for bit and what is exact instead:
+ *
+ *   pilot   head of the recording as one stream from power-on state until the
+ *           carrier loop has locked and converged  -> the reference's own bytes
+ *   pass 1  every tile starts `pre` samples early from the pilot's end state
+ *   match   rotation (Costas lock is 4-fold ambiguous) and one-symbol seam
+ *           disagreement of each tile against its predecessor, measured on the
+ *           samples both demodulated
+ *   pass 2  stream i continues exactly from its pass-1 end state, turned into
+ *           the pilot's rotation, with tile i+1
+ *
+ * All sample arithmetic is done by the demodulator kernels through the public
+ * C-ABI of this library; the kernels here only compare and move int8 symbols.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "meteor_demod_amd.h"
+
+namespace {
+
+struct TailPair {            /* what match_kernel compares for one tile */
+	const int8_t *a; uint32_t a_cnt;          /* A: reference demodulation (predecessor / pass 2) */
+	const int8_t *b; uint32_t b_cnt;          /* B: this tile's demodulation of the same samples  */
+	int32_t b_rot;                            /* quarter turns applied to B before comparing      */
+	int32_t force_weak;                       /* no overlap at all                                */
+};
+
+struct TileCopy {            /* what assemble_kernel moves for one tile */
+	const int8_t *src; uint32_t keep; int32_t rot;
+	const int8_t *head; int32_t head_rot;     /* optional symbol inserted in front (seam gap)     */
+	uint64_t dst;                             /* symbol index in the output                       */
+};
+
+__device__ __forceinline__ void
+rot_pair(int i, int q, int k, int &ri, int &rq)    /* (i + jq) * j^k */
+{
+	switch (k & 3) {
+	case 0: ri = i; rq = q; break;
+	case 1: ri = -q; rq = i; break;
+	case 2: ri = -i; rq = -q; break;
+	default: ri = q; rq = -i; break;
+	}
+}
+
+/* One block per tile.  Tails are the last K+1 symbols of A and of B; three alignments:
+ *   shift  0: a[1..K] vs b[1..K]     +1: a[0..K-1] vs b[1..K]     -1: a[1..K] vs b[0..K-1]
+ * score(r) = Re( sum a * conj(b) * j^-r ): r=0 re, 1 im, 2 -re, 3 -im.  First maximum wins. */
+__global__ void
+match_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *rot_out, int32_t *weak_out)
+{
+	const TailPair p = pairs[blockIdx.x];
+	__shared__ long long acc[7][64];
+	long long s[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	auto load = [&](const int8_t *base, uint32_t cnt, int x, int rot, int &i, int &q) {
+		const long long idx = (long long)cnt - (K + 1) + x;
+		if (idx < 0) { i = 0; q = 0; return; }
+		const int ri = base[2 * idx], rq = base[2 * idx + 1];
+		rot_pair(ri, rq, rot, i, q);
+	};
+	for (int j = threadIdx.x; j < K; j += blockDim.x) {
+		int a0i, a0q, a1i, a1q, b0i, b0q, b1i, b1q;
+		load(p.a, p.a_cnt, j, 0, a0i, a0q);      load(p.a, p.a_cnt, j + 1, 0, a1i, a1q);
+		load(p.b, p.b_cnt, j, p.b_rot, b0i, b0q); load(p.b, p.b_cnt, j + 1, p.b_rot, b1i, b1q);
+		s[0] += a1i * b1i + a1q * b1q;  s[1] += a1q * b1i - a1i * b1q;      /* shift 0  */
+		s[2] += a0i * b1i + a0q * b1q;  s[3] += a0q * b1i - a0i * b1q;      /* shift +1 */
+		s[4] += a1i * b0i + a1q * b0q;  s[5] += a1q * b0i - a1i * b0q;      /* shift -1 */
+		s[6] += a1i * a1i + a1q * a1q;                                      /* energy of a[1..K] */
+	}
+	for (int k = 0; k < 7; k++) acc[k][threadIdx.x] = s[k];
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		long long t[7];
+		for (int k = 0; k < 7; k++) { t[k] = 0; for (unsigned l = 0; l < blockDim.x; l++) t[k] += acc[k][l]; }
+		const int shifts[3] = { 0, 1, -1 };
+		long long best = 0; int bs = 0, br = 0; bool have = false;
+		for (int c = 0; c < 3; c++) {
+			const long long re = t[2 * c], im = t[2 * c + 1];
+			const long long sc4[4] = { re, im, -re, -im };
+			int r = 0;
+			for (int k = 1; k < 4; k++) if (sc4[k] > sc4[r]) r = k;
+			if (!have || sc4[r] > best) { best = sc4[r]; bs = shifts[c]; br = r; have = true; }
+		}
+		const bool weak = (best * 2 < t[6]) || p.force_weak;
+		shift_out[blockIdx.x] = weak ? 0 : bs;
+		rot_out[blockIdx.x] = weak ? 0 : br;
+		weak_out[blockIdx.x] = weak ? 1 : 0;
+	}
+}
+
+__global__ void
+assemble_kernel(const TileCopy *tiles, int8_t *out)
+{
+	const TileCopy t = tiles[blockIdx.x];
+	int8_t *dst = out + 2 * t.dst;
+	if (t.head && threadIdx.x == 0) {
+		int i, q; rot_pair(t.head[0], t.head[1], t.head_rot, i, q);
+		dst[0] = (int8_t)i; dst[1] = (int8_t)q;
+	}
+	if (t.head) dst += 2;
+	for (uint32_t k = threadIdx.x; k < t.keep; k += blockDim.x) {
+		int i, q; rot_pair(t.src[2 * k], t.src[2 * k + 1], t.rot, i, q);
+		dst[2 * k] = (int8_t)i; dst[2 * k + 1] = (int8_t)q;
+	}
+}
+
+/* ---- host side ----------------------------------------------------------------------------- */
+
+struct DevMem {                      /* frees everything on scope exit */
+	std::vector<void *> p;
+	~DevMem() { for (void *q : p) (void)hipFree(q); }
+	template <typename T> int alloc(T **out, size_t n) {
+		void *q = nullptr;
+		if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return MDEMOD_ERR_NOMEM;
+		p.push_back(q); *out = static_cast<T *>(q); return MDEMOD_OK;
+	}
+};
+
+struct Ctx {                         /* owns a demodulator context */
+	mdemod_ctx *c = nullptr;
+	~Ctx() { if (c) mdemod_destroy(c); }
+};
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
+#define HTRY(expr) do { if ((expr) != hipSuccess) { fprintf(stderr, "meteor_demod_amd: %s failed (%s:%d)\n", #expr, __FILE__, __LINE__); return MDEMOD_ERR_HIP; } } while (0)
+
+template <typename T>
+int
+upload(DevMem &m, const std::vector<T> &h, T **dev, hipStream_t st)
+{
+	TRY(m.alloc(dev, h.size()));
+	if (!h.empty()) HTRY(hipMemcpyAsync(*dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+	return MDEMOD_OK;
+}
+
+int
+counts_of(mdemod_ctx *c, uint32_t n, std::vector<uint32_t> &out, hipStream_t st)
+{
+	std::vector<mdemod_status> s(n);
+	TRY(mdemod_get_status(c, 0, n, s.data(), st));
+	out.resize(n);
+	for (uint32_t i = 0; i < n; i++) {
+		if (s[i].overflow) return MDEMOD_ERR_OVERFLOW;
+		out[i] = s[i].symbols_this_call;
+	}
+	return MDEMOD_OK;
+}
+
+int
+run_match(DevMem &m, const std::vector<TailPair> &pairs, int K, std::vector<int32_t> &shift, std::vector<int32_t> &rot,
+          std::vector<int32_t> &weak, hipStream_t st)
+{
+	const size_t T = pairs.size();
+	TailPair *d_pairs; int32_t *d_out;
+	TRY(upload(m, pairs, &d_pairs, st));
+	TRY(m.alloc(&d_out, 3 * T));
+	hipLaunchKernelGGL(match_kernel, dim3((unsigned)T), dim3(64), 0, st, d_pairs, K, d_out, d_out + T, d_out + 2 * T);
+	HTRY(hipGetLastError());
+	std::vector<int32_t> h(3 * T);
+	HTRY(hipMemcpyAsync(h.data(), d_out, 3 * T * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	HTRY(hipStreamSynchronize(st));
+	shift.assign(h.begin(), h.begin() + T); rot.assign(h.begin() + T, h.begin() + 2 * T); weak.assign(h.begin() + 2 * T, h.end());
+	return MDEMOD_OK;
+}
+
+} /* namespace */
+
+extern "C" void
+mdemod_recording_default_opts(mdemod_recording_opts *o)
+{
+	if (!o) return;
+	o->tile_samples = 65536; o->pre_samples = 16384; o->pilot_block = 65536; o->pilot_margin_symbols = 160000;
+	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->refine = 1; o->reserved = 0;
+}
+
+extern "C" int
+mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_opts *opts_in,
+                            const void *iq_dev, uint64_t n_samples,
+                            int8_t *soft_dev, uint64_t soft_cap_symbols,
+                            mdemod_recording_report *rep, void *hip_stream)
+{
+	if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
+	if (params->oqpsk) return MDEMOD_ERR_PARAM;     /* QPSK only: see DESIGN.md §3.1 */
+	mdemod_recording_opts o;
+	if (opts_in) o = *opts_in; else mdemod_recording_default_opts(&o);
+	if (!o.tile_samples || !o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	memset(rep, 0, sizeof(*rep));
+	rep->first_lock_symbol = -1;
+	const size_t sb = 2 * static_cast<size_t>(params->bps) / 8;
+	const unsigned char *iq = static_cast<const unsigned char *>(iq_dev);
+	const int K = static_cast<int>(o.match_symbols);
+
+	/* ---- pilot: the reference's own serial run of the head -------------------------------- */
+	mdemod_params pp = *params; pp.n_streams = 1;
+	Ctx pilot;
+	TRY(mdemod_create(&pp, &pilot.c));
+	uint64_t pos = 0, nsym = 0; bool have_lock = false; uint64_t locked_at = 0;
+	mdemod_stream_state seed;
+	memset(&seed, 0, sizeof(seed));
+	TRY(mdemod_get_state(pilot.c, 0, &seed, st));
+	while (pos < n_samples) {
+		const uint32_t b = static_cast<uint32_t>(std::min<uint64_t>(o.pilot_block, n_samples - pos));
+		const uint64_t cap = mdemod_max_symbols(pilot.c, b);
+		if (nsym + cap > soft_cap_symbols) return MDEMOD_ERR_OVERFLOW;
+		TRY(mdemod_process_device_uniform(pilot.c, iq + pos * sb, 0, b, soft_dev + 2 * nsym, cap, static_cast<uint32_t>(cap), st));
+		mdemod_status s1;
+		TRY(mdemod_get_status(pilot.c, 0, 1, &s1, st));
+		nsym += s1.symbols_this_call;
+		pos += b;
+		TRY(mdemod_get_state(pilot.c, 0, &seed, st));
+		if (seed.pll_locked && !have_lock) { have_lock = true; locked_at = seed.n_symbols; }
+		if (!seed.pll_locked) have_lock = false;
+		if (have_lock && seed.n_symbols - locked_at >= o.pilot_margin_symbols) break;
+		if (pos >= o.max_pilot_samples) break;
+	}
+	rep->pilot_samples = pos; rep->pilot_symbols = seed.n_symbols;
+	rep->pilot_locked = seed.pll_locked; rep->first_lock_symbol = seed.first_lock_symbol;
+	rep->samples_demodulated = pos;
+	const uint64_t n_pilot_sym = nsym;
+
+	/* ---- plan ------------------------------------------------------------------------------ */
+	std::vector<uint64_t> starts, lens, pres;
+	for (uint64_t s0 = pos; s0 < n_samples; s0 += o.tile_samples) {
+		starts.push_back(s0);
+		lens.push_back(std::min<uint64_t>(o.tile_samples, n_samples - s0));
+		pres.push_back(std::min<uint64_t>(o.pre_samples, s0));
+	}
+	const size_t T = starts.size();
+	rep->n_tiles = static_cast<uint32_t>(T);
+	if (T == 0) { rep->n_symbols = n_pilot_sym; return MDEMOD_OK; }
+
+	std::vector<float> seed_hist(2 * static_cast<size_t>(mdemod_history_len(pilot.c)));
+	TRY(mdemod_get_history(pilot.c, 0, seed_hist.data(), st));
+
+	mdemod_params bp = *params; bp.n_streams = static_cast<uint32_t>(T);
+	Ctx bank;
+	TRY(mdemod_create(&bp, &bank.c));
+	DevMem mem;
+	const uint64_t cap_pre = std::max<uint64_t>(1, mdemod_max_symbols(bank.c, *std::max_element(pres.begin(), pres.end())));
+	const uint64_t cap = mdemod_max_symbols(bank.c, *std::max_element(lens.begin(), lens.end()));
+	int8_t *soft_pre, *soft1, *soft2 = nullptr;
+	TRY(mem.alloc(&soft_pre, T * cap_pre * 2));
+	TRY(mem.alloc(&soft1, T * cap * 2));
+
+	auto launch = [&](const std::vector<uint64_t> &off, const std::vector<uint64_t> &cnt, int8_t *soft, uint64_t stride,
+	                  std::vector<uint32_t> &produced) -> int {
+		std::vector<uint32_t> c32(cnt.begin(), cnt.end());
+		uint64_t *d_off; uint32_t *d_cnt;
+		TRY(upload(mem, off, &d_off, st));
+		TRY(upload(mem, c32, &d_cnt, st));
+		TRY(mdemod_process_device(bank.c, iq_dev, d_off, d_cnt, soft, stride, static_cast<uint32_t>(stride), st));
+		TRY(counts_of(bank.c, static_cast<uint32_t>(T), produced, st));
+		for (uint64_t c : cnt) rep->samples_demodulated += c;
+		return MDEMOD_OK;
+	};
+
+	/* ---- pass 1 ---------------------------------------------------------------------------- */
+	TRY(mdemod_set_state_all(bank.c, &seed, st));
+	std::vector<uint64_t> off_pre(T);
+	for (size_t i = 0; i < T; i++) off_pre[i] = starts[i] - pres[i];
+	std::vector<uint32_t> cnt_pre, cnt1, cnt2;
+	TRY(launch(off_pre, pres, soft_pre, cap_pre, cnt_pre));
+	TRY(launch(starts, lens, soft1, cap, cnt1));
+
+	/* ---- rotation + seam of every tile against its predecessor (tile 0: against the pilot) ---- */
+	std::vector<TailPair> pairs(T);
+	for (size_t i = 0; i < T; i++) {
+		TailPair &p = pairs[i];
+		if (i == 0) { p.a = soft_dev; p.a_cnt = static_cast<uint32_t>(std::min<uint64_t>(n_pilot_sym, 0xFFFFFFFFu)); if (n_pilot_sym > 0xFFFFFFFFull) { p.a = soft_dev + 2 * (n_pilot_sym - 0xFFFFFFFFull); } }
+		else { p.a = soft1 + (i - 1) * cap * 2; p.a_cnt = cnt1[i - 1]; }
+		p.b = soft_pre + i * cap_pre * 2; p.b_cnt = cnt_pre[i];
+		p.b_rot = 0; p.force_weak = pres[i] == 0;
+	}
+	std::vector<int32_t> shift, rot, weak;
+	TRY(run_match(mem, pairs, K, shift, rot, weak, st));
+	std::vector<int32_t> R(T);
+	int32_t accr = 0;
+	for (size_t i = 0; i < T; i++) { accr = (accr + rot[i]) & 3; R[i] = accr; rep->weak_seams += weak[i]; }
+
+	std::vector<TileCopy> copies(T);
+	std::vector<int32_t> seam(T, 0);
+	if (!o.refine) {
+		for (size_t i = 0; i < T; i++) {
+			seam[i] = shift[i];
+			copies[i].src = soft1 + i * cap * 2; copies[i].rot = R[i]; copies[i].keep = cnt1[i];
+			copies[i].head = (shift[i] == -1 && cnt_pre[i] > 0) ? soft_pre + (i * cap_pre + cnt_pre[i] - 1) * 2 : nullptr;
+			copies[i].head_rot = R[i];
+		}
+	} else {
+		/* ---- pass 2: stream i := exact continuation of its pass-1 end state, in rotation 0, on tile i+1;
+		 *      stream T-1 takes over from the pilot and runs tile 0 ---- */
+		std::vector<int32_t> q(T);
+		for (size_t i = 0; i < T; i++) q[i] = (4 - R[i]) & 3;
+		int32_t *d_q;
+		TRY(upload(mem, q, &d_q, st));
+		TRY(mdemod_rotate_carrier(bank.c, d_q, st));
+		TRY(mdemod_set_state(bank.c, static_cast<uint32_t>(T - 1), &seed, st));
+		TRY(mdemod_set_history(bank.c, static_cast<uint32_t>(T - 1), seed_hist.data(), st));
+		std::vector<uint64_t> starts2(T), lens2(T);
+		for (size_t i = 0; i < T; i++) { starts2[i] = starts[(i + 1) % T]; lens2[i] = lens[(i + 1) % T]; }
+		TRY(mem.alloc(&soft2, T * cap * 2));
+		std::vector<uint32_t> cnt2s;
+		TRY(launch(starts2, lens2, soft2, cap, cnt2s));
+		auto stream_of = [&](size_t tile) { return (tile + T - 1) % T; };     /* tile i was run by stream i-1 */
+		cnt2.resize(T);
+		for (size_t i = 0; i < T; i++) cnt2[i] = cnt2s[stream_of(i)];
+
+		/* seam i|i+1: tile i+1 continued from tile i's PASS-1 trajectory, tile i's PASS-2 body is what is emitted */
+		for (size_t i = 0; i < T; i++) {
+			TailPair &p = pairs[i];
+			p.a = soft2 + stream_of(i) * cap * 2; p.a_cnt = cnt2[i];
+			p.b = soft1 + i * cap * 2; p.b_cnt = cnt1[i]; p.b_rot = R[i]; p.force_weak = 0;
+		}
+		std::vector<int32_t> shift2, rot2, weak2;
+		TRY(run_match(mem, pairs, K, shift2, rot2, weak2, st));
+		for (size_t i = 0; i + 1 < T; i++) rep->weak_seams += weak2[i];
+		for (size_t i = 0; i < T; i++) {
+			seam[i] = i ? shift2[i - 1] : 0;
+			copies[i].src = soft2 + stream_of(i) * cap * 2; copies[i].rot = 0; copies[i].keep = cnt2[i];
+			copies[i].head = (i && seam[i] == -1 && cnt1[i - 1] > 0) ? soft1 + ((i - 1) * cap + cnt1[i - 1] - 1) * 2 : nullptr;
+			copies[i].head_rot = i ? R[i - 1] : 0;
+		}
+	}
+
+	/* ---- concatenate: pilot ++ tiles, with the seam fixes ---- */
+	uint64_t out_pos = n_pilot_sym - (seam[0] == 1 ? 1 : 0);
+	for (size_t i = 0; i < T; i++) {
+		const uint32_t drop = (i + 1 < T && seam[i + 1] == 1) ? 1 : 0;
+		copies[i].keep = copies[i].keep > drop ? copies[i].keep - drop : 0;
+		if (seam[i] == -1 && !copies[i].head) seam[i] = 0;
+		copies[i].dst = out_pos;
+		out_pos += copies[i].keep + (copies[i].head ? 1 : 0);
+		if (seam[i]) rep->seam_fixes++;
+	}
+	if (out_pos > soft_cap_symbols) return MDEMOD_ERR_OVERFLOW;
+	TileCopy *d_copies;
+	TRY(upload(mem, copies, &d_copies, st));
+	hipLaunchKernelGGL(assemble_kernel, dim3(static_cast<unsigned>(T)), dim3(256), 0, st, d_copies, soft_dev);
+	HTRY(hipGetLastError());
+	HTRY(hipStreamSynchronize(st));
+	rep->n_symbols = out_pos;
+	return MDEMOD_OK;
+}

@@ -331,6 +331,31 @@ class RecordingDemodulator:
         return out, first.cpu().numpy()
 
 
+# ---- the same scheme inside the library (csrc/recording.hip) --------------------------------------
+
+def demodulate_recording_native(cfg, iq, tile_samples: int = 65536, pre_samples: int = 16384, refine: bool = True,
+                                pilot_block: int = 65536, pilot_margin_symbols: int = 160000,
+                                max_pilot_samples: int = 1 << 22, match_symbols: int = 192, device: int = 0):
+    """``mdemod_demodulate_recording`` on a device tensor [n, 2]: returns (soft int8 [m, 2] device tensor, report)."""
+    import ctypes as C
+    import torch
+    from . import _capi
+    lib = _capi.lib()
+    assert iq.is_cuda and iq.dim() == 2 and iq.shape[1] == 2 and iq.is_contiguous()
+    opts = _capi.MdemodRecordingOpts(tile_samples, pre_samples, pilot_block, pilot_margin_symbols, max_pilot_samples,
+                                     match_symbols, int(refine), 0)
+    n = int(iq.shape[0])
+    p = cfg.to_c(1, device)
+    cap = int(n * cfg.symrate / cfg.samplerate * 1.02) + 4096
+    soft = torch.empty((cap, 2), dtype=torch.int8, device=iq.device)
+    rep = _capi.MdemodRecordingReport()
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _capi.check(lib.mdemod_demodulate_recording(C.byref(p), C.byref(opts), C.c_void_p(iq.data_ptr()), n,
+                                                C.c_void_p(soft.data_ptr()), cap, C.byref(rep), stream),
+                "mdemod_demodulate_recording")
+    return soft[: rep.n_symbols], rep
+
+
 # ---- evaluation helper (tests / bench) --------------------------------------------------------
 
 def agreement(stitched: np.ndarray, serial: np.ndarray, window: int = 4096) -> dict:

@@ -81,3 +81,32 @@ def test_state_broadcast_and_carrier_rotation_primitives(gpu_device):
         want_all = O.oracle_demod(C1, iq)[0]
         tail = soft[2, :m].cpu().numpy()
         assert np.array_equal(tail, want_all[len(want_all) - m:])
+
+
+@pytest.mark.parametrize("refine", [True, False])
+def test_native_stitcher_equals_python_stitcher(refine, gpu_device):
+    """mdemod_demodulate_recording (csrc/recording.hip) makes the same decisions as recording.py: same bytes."""
+    import torch
+    from meteor_demod_amd.recording import demodulate_recording_native
+    st = synth.make_stream(77, 230000, 72000, f0_hz=450.0, clock_ppm=-30.0, esn0_db=10.0)
+    iq = synth.generate_device([st], 6_000_000)[0]
+    kw = dict(tile_samples=32768, pre_samples=8192, refine=refine, pilot_block=65536, pilot_margin_symbols=80000)
+    want = RecordingDemodulator(C1, **kw).demodulate(iq)
+    soft, rep = demodulate_recording_native(C1, iq, **kw)
+    assert rep.n_tiles == want.report.n_tiles > 100 and rep.pilot_symbols == want.report.pilot_symbols
+    assert rep.first_lock_symbol == want.report.first_lock_symbol and rep.weak_seams == want.report.weak_seams
+    assert rep.seam_fixes == sum(1 for s in want.report.seam_shifts if s)
+    assert rep.samples_demodulated == want.report.samples_demodulated
+    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy())
+
+
+def test_native_stitcher_short_recording_and_errors(gpu_device):
+    import torch
+    from meteor_demod_amd._capi import MdemodError
+    from meteor_demod_amd.recording import demodulate_recording_native
+    st = synth.make_stream(3, 230000, 72000, f0_hz=0.0)
+    iq = synth.generate_device([st], 150_000)[0]
+    soft, rep = demodulate_recording_native(C1, iq)
+    assert rep.n_tiles == 0 and np.array_equal(soft.cpu().numpy(), O.oracle_demod(C1, iq.cpu().numpy())[0])
+    with pytest.raises(MdemodError):
+        demodulate_recording_native(DemodConfig(samplerate=230000, symrate=80000, oqpsk=True), iq)
