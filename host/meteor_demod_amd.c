@@ -10,8 +10,11 @@
  * 2*ring_idx bytes (main.c:321).
  *
  * All demodulation happens on the GPU through the C-ABI (include/meteor_demod_amd.h);
- * there is no CPU demodulator in this program.  Extension: several input files are
- * demodulated as one batch, one stream per file (outputs <input>.s).
+ * there is no CPU demodulator in this program.  Extensions: several input files are
+ * demodulated as one batch, one stream per file (outputs <input>.s); --tiled demodulates
+ * ONE file on many GPU lanes as overlapped tiles (mdemod_demodulate_recording_host: the head
+ * up to PLL lock + settling is the reference's own serial run, the rest agrees with it
+ * statistically).
  *
  * Not reproduced (out of scope): ncurses TUI, the live status thread.
  * Known deviation: if the final flush would read past the 1024-byte ring (ring_idx >
@@ -49,7 +52,8 @@ static const struct option longopts[] = {
 	{ "output", 1, NULL, 'o' },     { "oversamp", 1, NULL, 'O' }, { "quiet", 0, NULL, 'q' },
 	{ "refresh-rate", 1, NULL, 'R' }, { "symrate", 1, NULL, 'r' }, { "stdout", 0, NULL, 0x00 },
 	{ "samplerate", 1, NULL, 's' }, { "bps", 1, NULL, 'S' },      { "version", 0, NULL, 'v' },
-	{ "device", 1, NULL, 0x01 },    { NULL, 0, NULL, 0 }
+	{ "device", 1, NULL, 0x01 },    { "tiled", 0, NULL, 0x02 },   { "tile-samples", 1, NULL, 0x03 },
+	{ "pilot-margin", 1, NULL, 0x04 }, { NULL, 0, NULL, 0 }
 };
 
 /* utils.c:60-86: number with optional k/M suffix, truncated to int, returned as float */
@@ -84,6 +88,8 @@ usage(const char *prog)
 	        "       --bps <bits>        Bits per sample of raw input (8, 16, 32)\n"
 	        "       --stdout            Write soft symbols to stdout (implies -B -q)\n"
 	        "       --device <n>        HIP device ordinal (default 0)\n"
+	        "       --tiled             One QPSK file on many lanes as overlapped tiles (fast, not bit-exact\n"
+	        "                           after the head); --tile-samples <n>, --pilot-margin <symbols>\n"
 	        "   -h, --help   -v, --version\n", prog);
 }
 
@@ -126,7 +132,8 @@ main(int argc, char **argv)
 {
 	float pll_bw = MDEMOD_DEFAULT_PLL_BW, symrate = MDEMOD_DEFAULT_SYM_RATE, freq_max_delta = -1;
 	int rrc_order = MDEMOD_DEFAULT_RRC_ORDER, interp = MDEMOD_DEFAULT_INTERP;
-	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0;
+	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0, tiled = 0;
+	int tile_samples = 0, pilot_margin = -1;
 	const char *output_fname = NULL;
 	int c;
 
@@ -134,6 +141,9 @@ main(int argc, char **argv)
 		switch (c) {
 		case 0x00: stdout_mode = 1; break;
 		case 0x01: device = atoi(optarg); break;
+		case 0x02: tiled = 1; break;
+		case 0x03: tile_samples = (int)human_number(optarg); break;
+		case 0x04: pilot_margin = (int)human_number(optarg); break;
 		case 'b': pll_bw = human_number(optarg); break;
 		case 'B': batch = 1; break;
 		case 'd': freq_max_delta = human_number(optarg); break;
@@ -201,6 +211,43 @@ main(int argc, char **argv)
 	p.pll_bw = pll_bw; p.sym_bw = MDEMOD_DEFAULT_SYM_BW; p.samplerate = samplerate; p.symrate = (int)symrate;
 	p.interp_factor = interp; p.rrc_order = rrc_order; p.oqpsk = oqpsk; p.freq_max = freq_max_delta;
 	p.bps = bps; p.device = device; p.n_streams = (uint32_t)n_files;
+	if (tiled) {
+		/* ---- one file, many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call ---- */
+		if (n_files != 1 || oqpsk) { fprintf(stderr, "--tiled needs a single QPSK input file\n"); return 1; }
+		size_t cap_bytes = 1u << 26, len = 0;
+		unsigned char *data = malloc(cap_bytes);
+		for (;;) {
+			if (len + FILE_BUFFER_SIZE > cap_bytes) { cap_bytes *= 2; data = realloc(data, cap_bytes); }
+			if (!data) return 1;
+			if (fread(data + len, FILE_BUFFER_SIZE, 1, io[0].in) != 1) break;
+			len += FILE_BUFFER_SIZE;
+		}
+		const uint64_t n_samples = len / (2 * (size_t)bps / 8);
+		const uint64_t cap_sym = (uint64_t)((double)n_samples * symrate / samplerate * 1.02) + 4096;
+		int8_t *soft_all = malloc(cap_sym * 2);
+		if (!soft_all) return 1;
+		mdemod_recording_opts ro;
+		mdemod_recording_default_opts(&ro);
+		if (tile_samples > 0) ro.tile_samples = (uint32_t)tile_samples;
+		if (pilot_margin >= 0) ro.pilot_margin_symbols = (uint32_t)pilot_margin;
+		mdemod_recording_report rr;
+		int rc2 = mdemod_demodulate_recording_host(&p, &ro, data, n_samples, soft_all, cap_sym, &rr);
+		if (rc2 != MDEMOD_OK) { fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2)); return 2; }
+		if (!quiet)
+			fprintf(stderr, "%llu samples: %llu serial (pilot) + %u tiles, %llu symbols, first lock at symbol %lld, %u seam fixes, %u weak seams\n",
+			        (unsigned long long)n_samples, (unsigned long long)rr.pilot_samples, rr.n_tiles, (unsigned long long)rr.n_symbols,
+			        (long long)rr.first_lock_symbol, rr.seam_fixes, rr.weak_seams);
+		for (uint64_t k = 0; k < rr.n_symbols; k += 1u << 20)
+			write_gated(&io[0], soft_all + 2 * k, (uint32_t)((rr.n_symbols - k < (1u << 20)) ? rr.n_symbols - k : (1u << 20)), rr.first_lock_symbol);
+		size_t tail = 2 * (size_t)io[0].ring_idx;                       /* main.c:321 */
+		if (tail > sizeof(io[0].ring)) tail = sizeof(io[0].ring);
+		fwrite(io[0].ring, 1, tail, io[0].out);
+		if (io[0].out != stdout) fclose(io[0].out);
+		if (io[0].in != stdin) fclose(io[0].in);
+		free(data); free(soft_all);
+		return 0;
+	}
+
 	mdemod_ctx *ctx = NULL;
 	int rc = mdemod_create(&p, &ctx);
 	if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_create: %s\n", mdemod_strerror(rc)); return 2; }

@@ -246,6 +246,12 @@ int  mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recor
                                  int8_t *soft_dev, uint64_t soft_cap_symbols,
                                  mdemod_recording_report *report, void *hip_stream);
 
+/* Same with host buffers (PCIe inclusive, synchronous): the C CLI's --tiled mode. */
+int  mdemod_demodulate_recording_host(const mdemod_params *params, const mdemod_recording_opts *opts,
+                                      const void *iq_host, uint64_t n_samples,
+                                      int8_t *soft_host, uint64_t soft_cap_symbols,
+                                      mdemod_recording_report *report);
+
 /* Name of the kernel variant this context launches (for logs and bench output). */
 const char *mdemod_kernel_name(const mdemod_ctx *ctx);
 

@@ -353,3 +353,23 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	rep->n_symbols = out_pos;
 	return MDEMOD_OK;
 }
+
+/* Host-buffer convenience (PCIe inclusive): what the C CLI's --tiled mode calls. */
+extern "C" int
+mdemod_demodulate_recording_host(const mdemod_params *params, const mdemod_recording_opts *opts,
+                                 const void *iq_host, uint64_t n_samples,
+                                 int8_t *soft_host, uint64_t soft_cap_symbols,
+                                 mdemod_recording_report *rep)
+{
+	if (!params || !iq_host || !soft_host || !rep) return MDEMOD_ERR_PARAM;
+	if (hipSetDevice(params->device) != hipSuccess) return MDEMOD_ERR_HIP;
+	const size_t sb = 2 * static_cast<size_t>(params->bps) / 8;
+	DevMem mem;
+	unsigned char *d_iq; int8_t *d_soft;
+	TRY(mem.alloc(&d_iq, static_cast<size_t>(n_samples) * sb));
+	TRY(mem.alloc(&d_soft, static_cast<size_t>(soft_cap_symbols) * 2));
+	if (n_samples) HTRY(hipMemcpy(d_iq, iq_host, static_cast<size_t>(n_samples) * sb, hipMemcpyHostToDevice));
+	TRY(mdemod_demodulate_recording(params, opts, d_iq, n_samples, d_soft, soft_cap_symbols, rep, nullptr));
+	if (rep->n_symbols) HTRY(hipMemcpy(soft_host, d_soft, static_cast<size_t>(rep->n_symbols) * 2, hipMemcpyDeviceToHost));
+	return MDEMOD_OK;
+}

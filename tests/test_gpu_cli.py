@@ -59,3 +59,32 @@ def test_cli_stdout_mode_and_errors(manifest, tmp_path, gpu_device):
     raw.write_bytes(b"\0" * 70000)
     r = subprocess.run([str(CLI), "-q", str(raw)], capture_output=True, text=True)      # raw without -s
     assert r.returncode == 1 and "sample rate" in r.stderr
+
+
+def test_cli_tiled_mode_single_file(tmp_path, gpu_device):
+    """--tiled: one file on many lanes.  The .s file is the lock-gated stream of mdemod_demodulate_recording:
+    its head is the reference's own bytes and the whole file agrees with the serial oracle's file to the loops'
+    noise (hard decisions equal, same length)."""
+    import oracle_py as O
+    from golden_cases import wav_header
+    from meteor_demod_amd import DemodConfig, synth
+    cfg = DemodConfig(samplerate=230000)
+    n = 3_000_000 // 8192 * 8192                                  # whole 32 KiB reads
+    iq = synth.generate_host(synth.make_stream(21, 230000, 72000, f0_hz=300.0, esn0_db=12.0), n)
+    inp, out = tmp_path / "in.wav", tmp_path / "out.s"
+    inp.write_bytes(wav_header(230000, 16, iq.nbytes) + iq.tobytes())
+    r = subprocess.run([str(CLI), "-B", "--tiled", "--tile-samples", "32768", "--pilot-margin", "100k", "-o", str(out), str(inp)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "tiles" in r.stderr and "first lock" in r.stderr
+    got = np.frombuffer(out.read_bytes(), dtype=np.int8).reshape(-1, 2)
+    want = np.frombuffer(O.OracleStream(cfg).file_model(iq.tobytes(), 16), dtype=np.int8).reshape(-1, 2)
+    assert got.shape == want.shape
+    head = 100_000
+    assert np.array_equal(got[:head], want[:head])              # inside the pilot: the reference's bytes, same lock gate
+    body = slice(0, len(got) - 512)                              # the final flush repeats stale ring bytes
+    assert ((got[body] >= 0) == (want[body] >= 0)).all(axis=1).mean() > 0.9999
+    assert (np.abs(got[body].astype(int) - want[body].astype(int)).max(axis=1) <= 1).mean() > 0.93
+    # OQPSK is refused
+    r = subprocess.run([str(CLI), "-q", "--tiled", "-m", "oqpsk", "-o", str(out), str(inp)], capture_output=True, text=True)
+    assert r.returncode != 0
