@@ -236,6 +236,9 @@ demod_kernel_rw(const DemodLaunch L)
 	constexpr int SG = SLIDE / 4;                /* granules per slide                 */
 	constexpr int AMAX = NW - kTaps;             /* alignments 0..AMAX                 */
 	constexpr int NST = SG * G::MAXSL;           /* granules staged ahead of the window */
+	/* The float window of the std geometry leaves ~20 VGPRs: AGC and NCO state stay in registers there
+	 * (5 LDS reads + 5 writes per symbol less, and no exposed LDS latency right after the FIR). */
+	constexpr bool REGSTATE = !PACKED && G::KT <= 65;
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	float *ctab = reinterpret_cast<float *>(lds);
@@ -267,6 +270,7 @@ demod_kernel_rw(const DemodLaunch L)
 	/* ---- state: symbol-clock variables in registers, everything else in the LDS slots ---- */
 	float t_phase = 0.0f, t_freq = C.t_center;
 	int dual_state = 1;
+	float r_gain = 1.0f, r_bias_re = 0.0f, r_bias_im = 0.0f, r_phase = 0.0f, r_freq = 0.0f;   /* REGSTATE only */
 	{
 		float gain = 1.0f, bias_re = 0.0f, bias_im = 0.0f, phase = 0.0f, freq = 0.0f, err = 1000.0f, t_prev = 0.0f, inph = 0.0f;
 		int fl = MDEMOD_FLAG_UPDOWN_POS | (1 << MDEMOD_FLAG_DUAL_SHIFT);
@@ -283,6 +287,7 @@ demod_kernel_rw(const DemodLaunch L)
 		sli[S_FLAGS * 64] = fl & 7;                     /* locked | locked_once | updown>0; bit 3 = overflow */
 		sl[S_TPREV * 64] = t_prev; sl[S_INPHASE * 64] = inph;
 		sli[S_EVCALL * 64] = 0; sli[S_FIRSTLOCK * 64] = -1;
+		if (REGSTATE) { r_gain = gain; r_bias_re = bias_re; r_bias_im = bias_im; r_phase = phase; r_freq = freq; }
 	}
 
 	/* ---- window: slots 0..63 = history, 64..79 = first four granules of the block ---- */
@@ -390,8 +395,24 @@ demod_kernel_rw(const DemodLaunch L)
 				base += SLIDE;
 #pragma unroll
 				for (int i = 0; i + SG < NST; i++) stg[i] = stg[i + SG];
+				/* The refill may only be issued once the old staging registers have been consumed (the empty asm
+				 * ties the fetch index to the freshly packed slots): otherwise the scheduler hoists the loads above
+				 * the packing, has to give them other registers, copies them into the staging registers right away
+				 * and waits a full HBM latency on every slide.  One wave-uniform branch separates the common case
+				 * (all granules inside the block) from the ragged end. */
+				int tie = 0;
 #pragma unroll
-				for (int g = 0; g < SG; g++) stg[NST - SG + g] = fetch_granule<FMT>(src, 4 * (g_load + g), n);
+				for (int k = 0; k < SLIDE; k += 4)
+					asm volatile("" : "+v"(tie) : "v"(win[NW - SLIDE + k]), "v"(win[NW - SLIDE + k + 1]),
+					                              "v"(win[NW - SLIDE + k + 2]), "v"(win[NW - SLIDE + k + 3]));
+				const int m_new = 4 * g_load + tie;
+				if (__all(m_new + 4 * SG - 1 < n)) {
+#pragma unroll
+					for (int g = 0; g < SG; g++) __builtin_memcpy(&stg[NST - SG + g], src + m_new + 4 * g, sizeof(Gran<FMT>));
+				} else {
+#pragma unroll
+					for (int g = 0; g < SG; g++) stg[NST - SG + g] = fetch_granule<FMT>(src, m_new + 4 * g, n);
+				}
 				g_load += SG;
 			}
 		}
@@ -416,14 +437,18 @@ demod_kernel_rw(const DemodLaunch L)
 			fir_window<NW, W>(win, row, skip_first, skip_last, y.re, y.im);
 
 			/* ---- scalar part: state comes from / goes back to the LDS slots ---- */
-			{
+			if (REGSTATE) {
+				y = md_agc(y, r_gain, r_bias_re, r_bias_im);
+			} else {
 				float gain = sl[S_GAIN * 64], bias_re = sl[S_BIAS_RE * 64], bias_im = sl[S_BIAS_IM * 64];
 				y = md_agc(y, gain, bias_re, bias_im);
 				sl[S_GAIN * 64] = gain; sl[S_BIAS_RE * 64] = bias_re; sl[S_BIAS_IM * 64] = bias_im;
 			}
 			int fl = sli[S_FLAGS * 64];
 			PllState pll;
-			pll.phase = sl[S_PHASE * 64]; pll.freq = sl[S_FREQ * 64]; pll.err = sl[S_ERR * 64];
+			if (REGSTATE) { pll.phase = r_phase; pll.freq = r_freq; }
+			else { pll.phase = sl[S_PHASE * 64]; pll.freq = sl[S_FREQ * 64]; }
+			pll.err = sl[S_ERR * 64];
 			pll.locked = fl & 1; pll.locked_once = (fl >> 1) & 1; pll.updown = (fl & 4) ? 1 : -1;
 
 			const float sn = md_fast_sin(-pll.phase);
@@ -479,7 +504,9 @@ demod_kernel_rw(const DemodLaunch L)
 					}
 				}
 			}
-			sl[S_PHASE * 64] = pll.phase; sl[S_FREQ * 64] = pll.freq; sl[S_ERR * 64] = pll.err;
+			if (REGSTATE) { r_phase = pll.phase; r_freq = pll.freq; }
+			else { sl[S_PHASE * 64] = pll.phase; sl[S_FREQ * 64] = pll.freq; }
+			sl[S_ERR * 64] = pll.err;
 			sli[S_FLAGS * 64] = (fl & 8) | (pll.locked ? 1 : 0) | (pll.locked_once ? 2 : 0) | (pll.updown > 0 ? 4 : 0);
 		}
 	}
@@ -506,6 +533,10 @@ demod_kernel_rw(const DemodLaunch L)
 	}
 
 	/* ---- store state ---- */
+	if (REGSTATE) {
+		sl[S_GAIN * 64] = r_gain; sl[S_BIAS_RE * 64] = r_bias_re; sl[S_BIAS_IM * 64] = r_bias_im;
+		sl[S_PHASE * 64] = r_phase; sl[S_FREQ * 64] = r_freq;
+	}
 	if (valid) {
 		const int fl = sli[S_FLAGS * 64];
 		L.st.agc_gain[stream_e] = sl[S_GAIN * 64]; L.st.agc_bias_re[stream_e] = sl[S_BIAS_RE * 64]; L.st.agc_bias_im[stream_e] = sl[S_BIAS_IM * 64];
