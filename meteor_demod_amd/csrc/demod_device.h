@@ -42,13 +42,19 @@ md_turn_code_div(float fx)
 __device__ __forceinline__ int32_t
 md_turn_code(float fx)
 {
-	if (!(fabsf(fx) < 16.0f)) return md_turn_code_div(fx);
 	const double xd = (double)(fx * 65536.0f);
 	const double ax = fabs(xd);
 	int32_t n = __double2int_rz(ax * (1.0 / MD_TWO_PI_D));
 	const double r = fma(-(double)n, MD_TWO_PI_D, ax);
 	n = (r < 0.0) ? n - 1 : ((r >= MD_TWO_PI_D) ? n + 1 : n);
-	return (xd < 0.0) ? -n : n;
+	n = (xd < 0.0) ? -n : n;
+	/* outside the proven range: the real division (one wave-uniform test instead of a divergent branch
+	 * per call; the PLL keeps |fx| < 8.9, so this is never taken in practice) */
+	const bool out_of_range = !(fabsf(fx) < 16.0f);
+	if (__any(out_of_range)) {
+		if (out_of_range) n = md_turn_code_div(fx);
+	}
+	return n;
 }
 
 /* dsp/sincos.c:13-34 — Q14 parabola on a 16-bit turn code. */
@@ -118,18 +124,25 @@ __device__ __forceinline__ double
 md_wrap_2pi(double x)
 {
 	const double ax = fabs(x);
-	if (ax < MD_TWO_PI_D) return x;
-	if (ax < 2.0 * MD_TWO_PI_D) return (x < 0.0) ? x + MD_TWO_PI_D : x - MD_TWO_PI_D;
-	return fmod(x, MD_TWO_PI_D);
+	double r = x;
+	const bool wraps = !(ax < MD_TWO_PI_D);
+	if (__any(wraps)) {
+		if (wraps) {
+			if (ax < 2.0 * MD_TWO_PI_D) r = (x < 0.0) ? x + MD_TWO_PI_D : x - MD_TWO_PI_D;
+			else r = fmod(x, MD_TWO_PI_D);
+		}
+	}
+	return r;
 }
 
 /* pll.c:154-159 */
+/* Branch free: v > 15 reads lut[31] = (float)tanh(15) and v < -16 reads lut[0] = (float)tanh(-16), which ARE
+ * 1.0f and -1.0f (|tanh| differs from 1 by 2e-13, far below half a float ulp); mdemod_create checks it. */
 __device__ __forceinline__ float
 md_tanh_lut(const float *lut, float v)
 {
-	if (v > 15.0f) return 1.0f;
-	if (v < -16.0f) return -1.0f;
-	return lut[(int)v + 16];
+	const float c = __builtin_amdgcn_fmed3f(v, -16.0f, 15.0f);
+	return lut[(int)c + 16];
 }
 
 struct PllState {
@@ -151,22 +164,20 @@ md_pll_update(PllState &p, const float *lut, float alpha, float beta, float fmax
 	const float decayed = p.err * (1.0f - 0.001f);
 	p.err = (float)((double)decayed + fabs((double)e) * (double)0.001f);
 
-	int changed = 0;
-	just_locked_first = 0;
-	if (p.err < 85.0f && !p.locked) {
-		p.locked = 1;
-		if (!p.locked_once) just_locked_first = 1;
-		p.locked_once = 1;
-		changed = 1;
-	} else if (p.err > 105.0f && p.locked) {
-		p.locked = 0;
-		changed = 1;
-	}
+	/* pll.c:117-123 as selects (the two conditions exclude each other) */
+	const bool lock_now = (p.err < 85.0f) && !p.locked;
+	const bool unlock_now = (p.err > 105.0f) && p.locked;
+	just_locked_first = (lock_now && !p.locked_once) ? 1 : 0;
+	p.locked = lock_now ? 1 : (unlock_now ? 0 : p.locked);
+	p.locked_once = lock_now ? 1 : p.locked_once;
+	const int changed = (lock_now || unlock_now) ? 1 : 0;
 
-	if (!p.locked)
-		p.freq = (float)((double)p.freq + 0.000001 * (double)p.updown);
-	if (p.freq >= fmax) p.updown = -1;
-	else if (p.freq <= -fmax) p.updown = 1;
+	/* pll.c:125: freq += 0.000001 * updown while unlocked (double; +-1e-6 exactly) */
+	if (__any(!p.locked)) {
+		const float swept = (float)((double)p.freq + (p.updown > 0 ? 0.000001 : -0.000001));
+		p.freq = p.locked ? p.freq : swept;
+	}
+	p.updown = (p.freq >= fmax) ? -1 : ((p.freq <= -fmax) ? 1 : p.updown);
 	p.freq = (fmax < p.freq) ? fmax : p.freq;        /* MIN(fmax, freq)  */
 	p.freq = (-fmax > p.freq) ? -fmax : p.freq;      /* MAX(-fmax, .)    */
 	return changed;

@@ -89,6 +89,8 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 	c.pll_fmax = p.oqpsk ? fmax / 2.0f : fmax;
 	loop_gains(0.7071067811865475f, pll_bw, c.pll_alpha, c.pll_beta);
 	for (int i = 0; i < 32; i++) out.tanh_lut[i] = static_cast<float>(tanh(static_cast<double>(i - 16)));
+	/* the kernels clamp the LUT argument instead of branching on v > 15 / v < -16 (pll.c:156-157) */
+	if (out.tanh_lut[31] != 1.0f || out.tanh_lut[0] != -1.0f) return MDEMOD_ERR_PARAM;
 
 	/* timing.c:19-27 */
 	c.t_center = sym_freq;

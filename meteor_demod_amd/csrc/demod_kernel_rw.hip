@@ -327,29 +327,27 @@ demod_kernel_rw(const DemodLaunch L)
 	const int k_safe = C.step_safe;
 	const float f_hi = C.step_fmax;
 	const uint32_t magic = C.interp_magic;
+	const int steps_need = (k_safe + 4 + C.interp - 1) / C.interp;      /* samples that hold k_safe + 4 steps */
 
 	while (true) {
 		/* ---- (1) symbol clock: timing.c:32-57 ---- */
 		if (!fired && !done) {
 			const float thr = OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F;
-			const int steps_left = (v_end - 1 - v_cur) * interp + (isub ? interp - isub : 0);
-			const bool fast = (t_phase < thr - (float)k_safe * f_hi - 1e-3f) && (steps_left >= k_safe + 4);
+			/* enough input left for k_safe + 4 steps: (v_end - 1 - v_cur) * interp >= k_safe + 4 (the part of the
+			 * current sample that is still to be stepped is ignored: conservative) */
+			const bool fast = (t_phase < thr - (float)k_safe * f_hi - 1e-3f) && (v_cur + steps_need < v_end);
 			if (fast) {
 				float p = t_phase;
-				switch (k_safe) {                                      /* cannot reach thr: no compare needed */
-				case 14: p = blind_steps<14>(p, t_freq); break;        /* QPSK 72k @ 230 kS/s, -O 5 */
-				case 13: p = blind_steps<13>(p, t_freq); break;
-				case 6:  p = blind_steps<6>(p, t_freq); break;         /* OQPSK 80k @ 230 kS/s */
-				case 5:  p = blind_steps<5>(p, t_freq); break;
-				default: {                                             /* e.g. 109 steps at 1 MS/s, -O 8 */
+				/* cannot reach thr: no compare needed */
+				if (k_safe == 14) p = blind_steps<14>(p, t_freq);             /* QPSK 72k @ 230 kS/s, -O 5 */
+				else if (k_safe == 6) p = blind_steps<6>(p, t_freq);          /* OQPSK 80k @ 230 kS/s */
+				else {                                                         /* e.g. 109 steps at 1 MS/s, -O 8 */
 					int k = k_safe;
 					for (; k >= 16; k -= 16) p = blind_steps<16>(p, t_freq);
 					if (k & 8) p = blind_steps<8>(p, t_freq);
 					if (k & 4) p = blind_steps<4>(p, t_freq);
 					if (k & 2) p = blind_steps<2>(p, t_freq);
 					if (k & 1) p = p + t_freq;
-					break;
-				}
 				}
 				/* four checked steps.  The increment is positive, so "reached thr" is monotone:
 				 * the first hit is after (number of misses) + 1 steps. */
@@ -425,9 +423,9 @@ demod_kernel_rw(const DemodLaunch L)
 			const float *row;
 			if (G::COMPACT) {
 				const int o = AMAX - a;                                 /* offset into the padded bank */
-				row = ctab + (bank * 2 + (o & 1)) * C.ctab_row_stride + (o & ~1);
+				row = ctab + __mul24(bank * 2 + (o & 1), C.ctab_row_stride) + (o & ~1);
 			} else {
-				row = ctab + (a * interp + bank) * C.ctab_row_stride;
+				row = ctab + __mul24(__mul24(a, interp) + bank, C.ctab_row_stride);     /* small numbers: 24-bit multiplies */
 			}
 			cf32 y;
 			/* slots 0..7 carry only zeros for a lane with a >= 8, the last 8 slots only zeros for
