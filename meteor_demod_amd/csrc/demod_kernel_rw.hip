@@ -471,6 +471,7 @@ demod_kernel_rw(const DemodLaunch L)
 				sl[S_TPREV * 64] = t_prev;
 				int first = 0;
 				const int changed = md_pll_update(pll, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
+				if (__any(changed)) {                      /* rare: one wave-uniform test on the hot path */
 				if (first) sli[S_FIRSTLOCK * 64] = (int)sym_call;
 				if (changed) {
 					const int ev_call = sli[S_EVCALL * 64];
@@ -480,6 +481,7 @@ demod_kernel_rw(const DemodLaunch L)
 						L.st.events[(size_t)stream * MDEMOD_MAX_LOCK_EVENTS + ev_call] = ev;
 					}
 					sli[S_EVCALL * 64] = ev_call + 1;
+				}
 				}
 				const uint32_t sym = (uint32_t)(md_quantise(out_re) & 0xFF) | ((uint32_t)(md_quantise(out_im) & 0xFF) << 8);
 				ob0 = __builtin_amdgcn_alignbit(ob1, ob0, 16);
