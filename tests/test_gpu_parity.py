@@ -401,6 +401,20 @@ def test_device_turn_code_shortcut_is_exact_everywhere(gpu_device):
     assert n == 2 * 0x41800000 and bad == 0
 
 
+def test_device_fast_sin_cos_outside_the_shortcut_range(gpu_device):
+    """|x| >= 16 takes the real-division fallback (one wave-uniform test in the kernel): mixed waves of in-range and
+    out-of-range arguments against the oracle, up to where the reference's int conversion is defined (|x| < 2e5)."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-9, 9, 4096), rng.uniform(-300, 300, 4096), rng.uniform(-1e5, 1e5, 4096),
+                        [15.999999, 16.0, -16.0, 16.000002, 100.0, -1e5]]).astype(np.float32)
+    rng.shuffle(x)
+    with Demodulator(C1, 1) as d:
+        s, c = d.selftest_sincos(x)
+    L = O.lib()
+    assert np.array_equal(s, np.array([L.orc_fast_sin(float(v)) for v in x], dtype=np.float32))
+    assert np.array_equal(c, np.array([L.orc_fast_cos(float(v)) for v in x], dtype=np.float32))
+
+
 def test_device_cabsf_is_correctly_rounded(gpu_device):
     rng = np.random.default_rng(3)
     xy = np.concatenate([rng.normal(0, 300, (1 << 20, 2)), rng.normal(0, 1e-4, (1 << 16, 2)),
