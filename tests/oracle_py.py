@@ -17,6 +17,7 @@ ORACLE_DIR = ROOT / "oracle"
 ORACLE_SO = ORACLE_DIR / "liblrpt_oracle.so"
 REF_HARNESS = ORACLE_DIR / "_ref" / "ref_harness"
 REF_BINARY = ORACLE_DIR / "_ref" / "meteor_demod_ref"
+REF_HARNESS_SHIPPED = ORACLE_DIR / "_ref" / "ref_harness_shipped"     # the reference's Release flags: timing only
 
 TRACE_DTYPE = np.dtype([("sample_index", "<u8"), ("re", "<f4"), ("im", "<f4"), ("pll_freq", "<f4"),
                         ("omega", "<f4"), ("gain", "<f4"), ("locked", "<i4")])
