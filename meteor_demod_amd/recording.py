@@ -159,7 +159,7 @@ class RecordingDemodulator:
     set_history, set_state_all, rotate_carrier, close``).  The default is the HIP :class:`Demodulator`.
     """
 
-    def __init__(self, cfg, tile_samples: int = 65536, pre_samples: int = 16384, refine: bool = True,
+    def __init__(self, cfg, tile_samples: int = 65600, pre_samples: int = 16384, refine: bool = True,
                  pilot_block: int = 65536, pilot_margin_symbols: int = 160000, max_pilot_samples: int = 1 << 22,
                  match_symbols: int = 192, device: int = 0, bank_factory=None):
         if cfg.oqpsk:
@@ -333,7 +333,7 @@ class RecordingDemodulator:
 
 # ---- the same scheme inside the library (csrc/recording.hip) --------------------------------------
 
-def demodulate_recording_native(cfg, iq, tile_samples: int = 65536, pre_samples: int = 16384, refine: bool = True,
+def demodulate_recording_native(cfg, iq, tile_samples: int = 65600, pre_samples: int = 16384, refine: bool = True,
                                 pilot_block: int = 65536, pilot_margin_symbols: int = 160000,
                                 max_pilot_samples: int = 1 << 22, match_symbols: int = 192, device: int = 0):
     """``mdemod_demodulate_recording`` on a device tensor [n, 2]: returns (soft int8 [m, 2] device tensor, report)."""
