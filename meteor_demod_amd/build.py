@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
 
     # --- product library ---------------------------------------------------
     srcs = [CSRC / "demod_kernel.hip", CSRC / "demod_kernel_rw.hip", CSRC / "demod_aux.hip", CSRC / "recording.hip",
-            CSRC / "demod_api.cpp", CSRC / "demod_host.cpp"]
+            CSRC / "demod_api.cpp", CSRC / "host_pipe.cpp", CSRC / "demod_host.cpp"]
     objs = []
     for src in srcs:
         obj = LIB / (src.stem + ".o")
@@ -69,7 +69,7 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
         objs.append(obj)
     so = LIB / "libmeteor_demod_amd.so"
     if force or _stale(so, objs):
-        _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(so), *map(str, objs)])
+        _run([hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", str(so), *map(str, objs)])
     out["lib"] = so
 
     # --- synthetic signal generator -----------------------------------------

@@ -33,6 +33,7 @@ struct mdemod_ctx {
 	void   *d_iq;      size_t d_iq_bytes;
 	int8_t *d_soft;    size_t d_soft_bytes;
 	uint64_t *d_off;   uint32_t *d_cnt;
+	void   *pipe;      /* host_pipe.cpp: pinned staging, streams, events of mdemod_process_host */
 };
 
 namespace {
@@ -153,6 +154,7 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	ctx->d_iq = nullptr; ctx->d_iq_bytes = 0;
 	ctx->d_soft = nullptr; ctx->d_soft_bytes = 0;
 	ctx->d_off = nullptr; ctx->d_cnt = nullptr;
+	ctx->pipe = nullptr;
 
 	/* MDEMOD_KERNEL=v1 forces the LDS-ring kernel (tests cover both) */
 	const char *kforce = getenv("MDEMOD_KERNEL");
@@ -232,6 +234,7 @@ mdemod_destroy(mdemod_ctx *ctx)
 	if (ctx->d_soft) (void)hipFree(ctx->d_soft);
 	if (ctx->d_off) (void)hipFree(ctx->d_off);
 	if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
+	mdemod_hostpipe_free(ctx->pipe);
 	delete ctx;
 }
 
@@ -301,62 +304,11 @@ mdemod_process_host(mdemod_ctx *ctx, const void *const *iq_host, const uint32_t 
 	if (!ctx || !iq_host || !n_samples || !soft_host || !soft_cap) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
-	const uint32_t ns = ctx->params.n_streams;
-	const size_t sb = ctx->sample_bytes;
-
-	std::vector<uint64_t> off(ns);
-	uint64_t total = 0;
-	uint32_t cap_max = 1;
-	for (uint32_t s = 0; s < ns; s++) {
-		if (n_samples[s] > 0x3FFFFF00u) return MDEMOD_ERR_PARAM;
-		off[s] = total;
-		total += (static_cast<uint64_t>(n_samples[s]) + 7) & ~7ull;   /* keep streams 16-B aligned */
-		if (soft_cap[s] > cap_max) cap_max = soft_cap[s];
-	}
-	const size_t iq_bytes = static_cast<size_t>(total) * sb + 64;
-	const size_t soft_bytes = static_cast<size_t>(cap_max) * 2 * ns;
-	if (iq_bytes > ctx->d_iq_bytes) {
-		if (ctx->d_iq) (void)hipFree(ctx->d_iq);
-		ctx->d_iq = nullptr; ctx->d_iq_bytes = 0;
-		HIP_TRY(hipMalloc(&ctx->d_iq, iq_bytes));
-		ctx->d_iq_bytes = iq_bytes;
-	}
-	if (soft_bytes > ctx->d_soft_bytes) {
-		if (ctx->d_soft) (void)hipFree(ctx->d_soft);
-		ctx->d_soft = nullptr; ctx->d_soft_bytes = 0;
-		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_soft), soft_bytes));
-		ctx->d_soft_bytes = soft_bytes;
-	}
-	if (!ctx->d_off) {
-		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_off), sizeof(uint64_t) * ns));
-		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_cnt), sizeof(uint32_t) * ns));
-	}
-
-	/* one packed H2D transfer */
-	std::vector<unsigned char> pack(static_cast<size_t>(total) * sb);
-	for (uint32_t s = 0; s < ns; s++)
-		if (n_samples[s]) memcpy(&pack[off[s] * sb], iq_host[s], static_cast<size_t>(n_samples[s]) * sb);
-	if (!pack.empty()) HIP_TRY(hipMemcpy(ctx->d_iq, pack.data(), pack.size(), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(ctx->d_off, off.data(), sizeof(uint64_t) * ns, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(ctx->d_cnt, n_samples, sizeof(uint32_t) * ns, hipMemcpyHostToDevice));
-
-	/* per-stream capacities differ: run with the max and clip on the way back */
-	rc = mdemod_process_device(ctx, ctx->d_iq, ctx->d_off, ctx->d_cnt, ctx->d_soft, cap_max, cap_max, nullptr);
-	if (rc) return rc;
+	/* other work of this context (e.g. an asynchronous reset on the caller's stream) must be through before the
+	 * pipeline's own streams touch the state */
 	HIP_TRY(hipDeviceSynchronize());
-
-	std::vector<int8_t> soft(soft_bytes);
-	std::vector<uint32_t> produced(ns);
-	HIP_TRY(hipMemcpy(soft.data(), ctx->d_soft, soft_bytes, hipMemcpyDeviceToHost));
-	HIP_TRY(hipMemcpy(produced.data(), ctx->st.sym_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost));
-	int result = MDEMOD_OK;
-	for (uint32_t s = 0; s < ns; s++) {
-		uint32_t m = produced[s];
-		if (m > soft_cap[s]) { m = soft_cap[s]; result = MDEMOD_ERR_OVERFLOW; }
-		if (m) memcpy(soft_host[s], &soft[static_cast<size_t>(s) * cap_max * 2], static_cast<size_t>(m) * 2);
-		if (n_symbols) n_symbols[s] = m;
-	}
-	return result;
+	return mdemod_hostpipe_run(ctx, &ctx->pipe, ctx->st, ctx->params.n_streams, ctx->sample_bytes,
+	                           iq_host, n_samples, soft_host, soft_cap, n_symbols);
 }
 
 /* ---- status / state ---------------------------------------------------------- */

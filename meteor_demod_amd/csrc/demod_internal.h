@@ -89,6 +89,11 @@ hipError_t mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, in
 hipError_t mdemod_launch_seed(const DemodStateSoA &st, const DemodConsts &c, const mdemod_stream_state &v, int32_t flags, int fmt,
                               int float_history, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_turns_dev, uint32_t n_streams, hipStream_t stream);
+/* host_pipe.cpp: the pipelined host-buffer path behind mdemod_process_host */
+int  mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, uint32_t n_streams, size_t sample_bytes,
+                         const void *const *iq_host, const uint32_t *n_samples,
+                         int8_t *const *soft_host, const uint32_t *soft_cap, uint32_t *n_symbols);
+void mdemod_hostpipe_free(void *pipe);
 hipError_t mdemod_launch_selftest_sincos(const float *x, uint32_t n, float *s, float *c, hipStream_t stream);
 hipError_t mdemod_launch_selftest_turncode(unsigned long long *mismatch_dev, hipStream_t stream);
 hipError_t mdemod_launch_selftest_hypot(const float *xy, uint32_t n, float *out, hipStream_t stream);

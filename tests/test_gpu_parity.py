@@ -366,6 +366,29 @@ def test_host_buffer_path(gpu_device):
             assert np.array_equal(o, want)
 
 
+def test_host_buffer_path_pipelined_sub_blocks(gpu_device):
+    """Large host batches run as a pipeline of chained sub-blocks (csrc/host_pipe.cpp): bytes, "this call" counters and
+    lock events must be those of ONE call, and a second call must chain exactly."""
+    ns, n = 96, 600_000                                   # 230 MB of input -> 7 sub-blocks
+    streams = [synth.make_stream(9000 + i, 230000, 72000, f0_hz=(i % 5) * 60.0, esn0_db=14.0) for i in range(4)]
+    base = [synth.generate_host(s, 2 * n) for s in streams]
+    lens = [n - 1000 * (i % 7) for i in range(ns)]        # ragged
+    with Demodulator(C1, ns) as d:
+        outs1 = d.process_host([base[i % 4][: lens[i]] for i in range(ns)])
+        st1 = d.status()
+        ev1 = [d.lock_events(i) for i in range(4)]
+        outs2 = d.process_host([base[i % 4][lens[i]: lens[i] + 50_000] for i in range(ns)])
+        for i in range(0, ns, 5):
+            ost = O.OracleStream(C1)
+            w1, _, e1 = ost.run(base[i % 4][: lens[i]])
+            w2 = ost.run(base[i % 4][lens[i]: lens[i] + 50_000])[0]
+            assert np.array_equal(outs1[i], w1) and np.array_equal(outs2[i], w2), i
+            assert st1[i].symbols_this_call == w1.shape[0] and st1[i].n_samples == lens[i]
+            assert st1[i].lock_events_this_call == len(e1)
+            if i < 4:
+                assert ev1[i] == e1[:32] and len(e1) >= 1
+
+
 def test_reset_restores_power_on_state(gpu_device):
     torch = _torch()
     iq = BY_NAME["c1_short"].generate()[:15000]
