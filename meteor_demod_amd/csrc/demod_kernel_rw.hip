@@ -583,8 +583,10 @@ template <int FMT>
 hipError_t
 launch_rw_mode(const DemodLaunch &L, bool packed, size_t lds_bytes, hipStream_t stream)
 {
-	if (FMT != 32 && packed)
-		return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoStd>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoStd>(L, lds_bytes, stream);
+	if constexpr (FMT != 32) {              /* float input has no packed form */
+		if (packed)
+			return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoStd>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoStd>(L, lds_bytes, stream);
+	}
 	return L.c.oqpsk ? launch_rw<FMT, 1, false, GeoStd>(L, lds_bytes, stream) : launch_rw<FMT, 0, false, GeoStd>(L, lds_bytes, stream);
 }
 
