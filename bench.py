@@ -121,6 +121,33 @@ def cpu_baseline(cfg) -> dict:
                       f"({procs * n / 1e6:.0f} M samples, {sum(per):.1f} s CPU, {wall:.1f} s wall); value = the faster of the builds listed"}
 
 
+def single_recording(cfg, buf, n=1 << 26) -> dict:
+    """The north star's overlapped tiling of ONE recording on the first n samples of the buffer:
+    end-to-end latency of mdemod_demodulate_recording and agreement with the untiled serial oracle.  Untimed extra,
+    part of the CPU leg (it needs the oracle)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch
+    import oracle_py as O
+    from meteor_demod_amd.recording import agreement, demodulate_recording_native
+    iq = buf[:n].contiguous()
+    demodulate_recording_native(cfg, iq[: 1 << 21])                 # warm-up (allocations)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    soft, rep = demodulate_recording_native(cfg, iq)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    t0 = time.time()
+    serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
+    t_cpu = time.time() - t0
+    a = agreement(soft.cpu().numpy(), serial)
+    return {"samples": n, "seconds": round(dt, 3), "pilot_seconds": round(rep.pilot_seconds, 3),
+            "tiles_seconds": round(rep.tiles_seconds, 3), "pilot_samples": int(rep.pilot_samples), "tiles": int(rep.n_tiles),
+            "msamples_per_s": round(n / dt / 1e6, 1), "serial_oracle_one_core_seconds": round(t_cpu, 2),
+            "symbols": [a["len_stitched"], a["len_serial"]], "pilot_bytes_exact": bool((soft[: rep.pilot_symbols].cpu().numpy() == serial[: rep.pilot_symbols]).all()),
+            "within_1lsb": round(a["within_1lsb"], 4), "hard_decisions_equal": round(a["hard_decisions_equal"], 6),
+            "seam_fixes": int(rep.seam_fixes), "weak_seams": int(rep.weak_seams)}
+
+
 def spot_check(cfg, d, x, tiles, L, n_check=12) -> str:
     """Untimed: reset, one pass, compare sampled tiles (always including the first and the last,
     i.e. blocks of the first and of the last residency round) byte-for-byte with the oracle."""
@@ -248,6 +275,8 @@ def main() -> None:
         out["cpu_baseline"] = cpu_baseline(cfg)
         if not args.no_check:
             out["check"] = spot_check(cfg, d, x, T, L)
+            if not cfg.oqpsk and buf.shape[0] >= (1 << 26):
+                out["single_recording"] = single_recording(cfg, buf)
     print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

@@ -238,6 +238,8 @@ typedef struct {
 	uint32_t weak_seams;            /* seams whose correlation was too weak to trust         */
 	uint32_t seam_fixes;            /* one-symbol duplicates / gaps repaired                 */
 	int32_t  pilot_locked;
+	double   pilot_seconds;         /* wall time of the serial head                          */
+	double   tiles_seconds;         /* wall time of everything after it                      */
 } mdemod_recording_report;
 
 void mdemod_recording_default_opts(mdemod_recording_opts *opts);

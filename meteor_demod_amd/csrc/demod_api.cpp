@@ -29,11 +29,7 @@ struct mdemod_ctx {
 	float        *d_lut;
 	std::vector<void *> allocs;
 
-	/* host-buffer path staging (grow only) */
-	void   *d_iq;      size_t d_iq_bytes;
-	int8_t *d_soft;    size_t d_soft_bytes;
-	uint64_t *d_off;   uint32_t *d_cnt;
-	void   *pipe;      /* host_pipe.cpp: pinned staging, streams, events of mdemod_process_host */
+	void   *pipe;      /* host_pipe.cpp: pinned staging, streams, events of mdemod_process_host (grow only) */
 };
 
 namespace {
@@ -151,9 +147,6 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	mdemod_ctx *ctx = new (std::nothrow) mdemod_ctx();
 	if (!ctx) return MDEMOD_ERR_NOMEM;
 	ctx->params = *params;
-	ctx->d_iq = nullptr; ctx->d_iq_bytes = 0;
-	ctx->d_soft = nullptr; ctx->d_soft_bytes = 0;
-	ctx->d_off = nullptr; ctx->d_cnt = nullptr;
 	ctx->pipe = nullptr;
 
 	/* MDEMOD_KERNEL=v1 forces the LDS-ring kernel (tests cover both) */
@@ -230,10 +223,6 @@ mdemod_destroy(mdemod_ctx *ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->params.device);
 	for (void *p : ctx->allocs) (void)hipFree(p);
-	if (ctx->d_iq) (void)hipFree(ctx->d_iq);
-	if (ctx->d_soft) (void)hipFree(ctx->d_soft);
-	if (ctx->d_off) (void)hipFree(ctx->d_off);
-	if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
 	mdemod_hostpipe_free(ctx->pipe);
 	delete ctx;
 }

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "meteor_demod_amd.h"
@@ -203,6 +204,10 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	const unsigned char *iq = static_cast<const unsigned char *>(iq_dev);
 	const int K = static_cast<int>(o.match_symbols);
 
+	const auto t_start = std::chrono::steady_clock::now();
+	auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
+		return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	};
 	/* ---- pilot: the reference's own serial run of the head -------------------------------- */
 	mdemod_params pp = *params; pp.n_streams = 1;
 	Ctx pilot;
@@ -230,6 +235,8 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	rep->pilot_locked = seed.pll_locked; rep->first_lock_symbol = seed.first_lock_symbol;
 	rep->samples_demodulated = pos;
 	const uint64_t n_pilot_sym = nsym;
+	rep->pilot_seconds = seconds_since(t_start);
+	const auto t_tiles = std::chrono::steady_clock::now();
 
 	/* ---- plan ------------------------------------------------------------------------------ */
 	std::vector<uint64_t> starts, lens, pres;
@@ -352,6 +359,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	HTRY(hipGetLastError());
 	HTRY(hipStreamSynchronize(st));
 	rep->n_symbols = out_pos;
+	rep->tiles_seconds = seconds_since(t_tiles);
 	return MDEMOD_OK;
 }
 
