@@ -166,6 +166,11 @@ demod_kernel(const DemodLaunch L)
 
 	/* ---- history -> ring granules [0, hpad/4) ---- */
 	unsigned char *col = ring + lane * GB;                  /* this lane's column */
+	/* Every ring slot the FIR can touch must hold a FINITE value: the aligned coefficient rows multiply slots outside
+	 * the lane's window by zero, and for float input stale LDS bits can be NaN/Inf (0 * NaN = NaN; found by
+	 * tools/config_fuzz.py).  Granules not loaded yet are therefore cleared once per launch. */
+	for (int g = hpad >> 2; g < C.ring_granules; g++)
+		__builtin_memset(col + g * 64 * GB, 0, GB);
 	{
 		const sample_t *hist = reinterpret_cast<const sample_t *>(L.st.hist);
 		for (int k = 0; k < hpad; k++) {
@@ -201,7 +206,12 @@ demod_kernel(const DemodLaunch L)
 	int8_t *soft_out = L.soft + (size_t)stream * L.soft_stride * 2;
 	const float thr_q = MD_TWO_PI_F;
 
+	/* Watchdog (see demod_kernel_rw.hip): a wave needs at most a few iterations per interpolated step of its longest
+	 * stream; g_need is the wave-uniform number of granules of that stream. */
+	uint32_t guard = 16u * (uint32_t)(g_need + 2) * (uint32_t)C.interp + 4096u;
+
 	while (true) {
+		if (guard-- == 0) { overflow = 1; break; }
 		/* (1) commit the chunk fetched during the previous iteration */
 		if (staged) {
 #pragma unroll
@@ -236,7 +246,7 @@ demod_kernel(const DemodLaunch L)
 				ph = c1 ? p1 : ph;
 				t_phase = ph;
 				const uint32_t w = (uint32_t)(isub + m);
-				const uint32_t qd = __umulhi(w, C.interp_magic);          /* floor(w / interp) */
+				const uint32_t qd = (C.interp == 1) ? w : __umulhi(w, C.interp_magic);   /* floor(w / interp) */
 				const int isub_new = (int)(w - qd * (uint32_t)C.interp);
 				v_cur += (int)qd + (isub_new > 0 ? 1 : 0) - (isub > 0 ? 1 : 0);
 				fire_sub = (isub_new == 0) ? C.interp - 1 : isub_new - 1;

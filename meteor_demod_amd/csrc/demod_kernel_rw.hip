@@ -329,7 +329,17 @@ demod_kernel_rw(const DemodLaunch L)
 	const uint32_t magic = C.interp_magic;
 	const int steps_need = (k_safe + 4 + C.interp - 1) / C.interp;      /* samples that hold k_safe + 4 steps */
 
+	/* Watchdog: every iteration of a wave emits a firing for some lane, slides, or retires a lane, so a wave needs at
+	 * most a few iterations per interpolated step of its longest stream.  A bug must not be able to hang the GPU. */
+	int n_wave_max = n;
+	for (int o = 32; o > 0; o >>= 1) {
+		const int other = __shfl_xor(n_wave_max, o);
+		n_wave_max = other > n_wave_max ? other : n_wave_max;
+	}
+	n_wave_max = __builtin_amdgcn_readfirstlane(n_wave_max);
+	uint32_t guard = 4u * (uint32_t)(n_wave_max + kBack) * (uint32_t)interp + 4096u;
 	while (true) {
+		if (guard-- == 0) { sli[S_FLAGS * 64] |= 8; break; }     /* reported as overflow */
 		/* ---- (1) symbol clock: timing.c:32-57 ---- */
 		if (!fired && !done) {
 			const float thr = OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F;
@@ -359,7 +369,7 @@ demod_kernel_rw(const DemodLaunch L)
 				ph = c1 ? p1 : ph;
 				t_phase = ph;
 				const uint32_t w = (uint32_t)(isub + m);
-				const uint32_t q = __umulhi(w, magic);                 /* floor(w / interp) */
+				const uint32_t q = (interp == 1) ? w : __umulhi(w, magic);     /* floor(w / interp); the magic of 1 does not fit 32 bits */
 				const int isub_new = (int)(w - q * (uint32_t)interp);
 				v_cur += (int)q + (isub_new > 0 ? 1 : 0) - (isub > 0 ? 1 : 0);   /* samples pushed: ceil(w/interp) - (isub>0) */
 				fire_sub = (isub_new == 0) ? interp - 1 : isub_new - 1;

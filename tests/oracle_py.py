@@ -108,7 +108,10 @@ class OracleStream:
 
     def __del__(self):
         if getattr(self, "_p", None):
-            lib().orc_stream_delete(self._p)
+            try:
+                lib().orc_stream_delete(self._p)
+            except TypeError:          # interpreter shutdown: module globals are already gone
+                pass
             self._p = None
 
     @property

@@ -552,6 +552,65 @@ def _random_cfgs(n, seed=2026):
     return out
 
 
+@pytest.mark.parametrize("cfg", [
+    DemodConfig(samplerate=228838, symrate=80000, interp_factor=1, rrc_order=33, oqpsk=True),     # wide geometry, -O 1 (hung once)
+    DemodConfig(samplerate=230000, interp_factor=1),                                                # std geometry, -O 1
+    DemodConfig(samplerate=230000, interp_factor=1, rrc_order=70),                                  # ring kernel, -O 1
+    DemodConfig(samplerate=144000, interp_factor=1, rrc_order=8, oqpsk=True, bps=8),
+], ids=["wide-O1-oqpsk", "std-O1", "ring-O1", "std-O1-oqpsk-u8"])
+def test_oversampling_factor_one(cfg, gpu_device):
+    """-O 1: floor(x / 1) cannot go through the 32-bit reciprocal the symbol clock uses for x / interp (the reciprocal
+    of 1 is 2^32); found by tools/config_fuzz.py as an endless loop in the kernel."""
+    torch = _torch()
+    rms = {8: 50.0, 16: 5000.0}[cfg.bps]
+    streams = [synth.make_stream(300 + i, cfg.samplerate, cfg.symrate, f0_hz=200.0 * i, esn0_db=15.0, rms=rms, oqpsk=cfg.oqpsk, fmt=cfg.bps)
+               for i in range(5)]
+    iqs = [synth.generate_host(s, 9000) for s in streams]
+    with Demodulator(cfg, 5) as d:
+        soft = d.process(torch.from_numpy(np.stack(iqs)).cuda())
+        torch.cuda.synchronize()
+        cnt = d.symbol_counts()
+        for i in range(5):
+            assert np.array_equal(soft[i, : int(cnt[i])].cpu().numpy(), O.oracle_demod(cfg, iqs[i])[0]), i
+        assert all(s.overflow == 0 for s in d.status())
+
+
+def test_float_input_ring_kernel_ignores_stale_lds(gpu_device):
+    """Float input on the LDS-ring kernel: ring slots outside a lane's window are multiplied by zero coefficients, so they
+    must never hold stale NaN bits (0 * NaN = NaN).  A first context fills the CUs' LDS with NaN samples."""
+    torch = _torch()
+    cfg = DemodConfig(samplerate=1072367, pll_bw=5.0, symrate=72000, interp_factor=4, rrc_order=33, oqpsk=True, bps=32)
+    with Demodulator(cfg, 8192) as poison:
+        poison.process(torch.full((8192, 600, 2), float("nan"), dtype=torch.float32, device="cuda"))
+        torch.cuda.synchronize()
+    streams = [synth.make_stream(40 + i, cfg.samplerate, cfg.symrate, f0_hz=300.0, esn0_db=15.0, rms=0.7, oqpsk=True, fmt=32) for i in range(6)]
+    iqs = [synth.generate_host(s, 9051) for s in streams]
+    with Demodulator(cfg, 29) as d:
+        assert "ring" in d.kernel_name
+        got = [[] for _ in range(29)]
+        for lo, hi in ((0, 1000), (1000, 9051)):
+            soft = d.process(torch.from_numpy(np.stack([iqs[i % 6][lo:hi] for i in range(29)])).cuda())
+            torch.cuda.synchronize()
+            cnt = d.symbol_counts()
+            for i in range(29):
+                got[i].append(soft[i, : int(cnt[i])].cpu().numpy())
+        for i in range(29):
+            assert np.array_equal(np.concatenate(got[i]), O.oracle_demod(cfg, iqs[i % 6])[0]), i
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed", [21, 22])
+def test_option_fuzz(seed, gpu_device):
+    """tools/config_fuzz.py: 150 random option combinations (all three kernel geometries, every input format, ragged and
+    empty chained blocks, up to 69 streams) against the oracle, loop state included."""
+    import subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "config_fuzz.py"), "150", str(seed)], capture_output=True, text=True,
+                       cwd=str(ROOT), timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "failures: 0" in r.stdout, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("idx", range(14))
 def test_random_option_combinations_match_oracle(idx, gpu_device):
     """-f/-O/-r/-s/-b/-d/-m/--bps drawn at random (both kernels get selected: > 65 taps or > 3.6 samples per
