@@ -338,8 +338,7 @@ demod_kernel_rw(const DemodLaunch L)
 	}
 	n_wave_max = __builtin_amdgcn_readfirstlane(n_wave_max);
 	uint32_t guard = 4u * (uint32_t)(n_wave_max + kBack) * (uint32_t)interp + 4096u;
-	while (true) {
-		if (guard-- == 0) { sli[S_FLAGS * 64] |= 8; break; }     /* reported as overflow */
+	do {
 		/* ---- (1) symbol clock: timing.c:32-57 ---- */
 		if (!fired && !done) {
 			const float thr = OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F;
@@ -519,7 +518,9 @@ demod_kernel_rw(const DemodLaunch L)
 			sl[S_ERR * 64] = pll.err;
 			sli[S_FLAGS * 64] = (fl & 8) | (pll.locked ? 1 : 0) | (pll.locked_once ? 2 : 0) | (pll.updown > 0 ? 4 : 0);
 		}
-	}
+	} while (--guard);                                               /* the watchdog is the loop's latch */
+
+	if (guard == 0) sli[S_FLAGS * 64] |= 8;                          /* watchdog fired: reported as overflow */
 
 	/* Epilogue addresses are recomputed from an opaque copy of the stream index: otherwise the
 	 * compiler keeps ~30 VGPRs of prologue addresses alive across the main loop. */
