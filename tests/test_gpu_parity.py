@@ -611,6 +611,18 @@ def test_option_fuzz(seed, gpu_device):
     assert "failures: 0" in r.stdout, r.stdout[-3000:]
 
 
+@pytest.mark.timeout(600)
+def test_entry_point_fuzz(gpu_device):
+    """tools/api_fuzz.py: ragged launches with unaligned offsets, state/history hand-off between contexts and the pipelined
+    host path, 120 random option combinations."""
+    import subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "api_fuzz.py"), "120", "5"], capture_output=True, text=True,
+                       cwd=str(ROOT), timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "failures: 0" in r.stdout, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("idx", range(14))
 def test_random_option_combinations_match_oracle(idx, gpu_device):
     """-f/-O/-r/-s/-b/-d/-m/--bps drawn at random (both kernels get selected: > 65 taps or > 3.6 samples per

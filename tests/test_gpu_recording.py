@@ -110,3 +110,25 @@ def test_native_stitcher_short_recording_and_errors(gpu_device):
     assert rep.n_tiles == 0 and np.array_equal(soft.cpu().numpy(), O.oracle_demod(C1, iq.cpu().numpy())[0])
     with pytest.raises(MdemodError):
         demodulate_recording_native(DemodConfig(samplerate=230000, symrate=80000, oqpsk=True), iq)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_native_and_python_stitchers_agree_on_random_settings(seed, gpu_device):
+    """Random tile / warm-up / margin / match settings, offsets of both signs, noise levels down to 4 dB (weak seams,
+    unlocked pilots): the two implementations must make identical decisions."""
+    import torch
+    from meteor_demod_amd.recording import demodulate_recording_native
+    rng = np.random.default_rng(100 + seed)
+    st = synth.make_stream(500 + seed, 230000, 72000, f0_hz=float(rng.uniform(-600, 900)), clock_ppm=float(rng.uniform(-40, 40)),
+                           esn0_db=float(rng.choice([4.0, 8.0, 12.0, 20.0])))
+    n = int(rng.integers(2_000_000, 5_000_000))
+    iq = synth.generate_device([st], n)[0]
+    kw = dict(tile_samples=int(rng.choice([8200, 16448, 40000, 65600])), pre_samples=int(rng.choice([0, 2048, 8192, 20000])),
+              refine=bool(rng.random() < 0.6), pilot_block=int(rng.choice([16384, 65536])),
+              pilot_margin_symbols=int(rng.choice([0, 5000, 60000])), max_pilot_samples=int(rng.choice([300_000, 1 << 22])),
+              match_symbols=int(rng.choice([32, 192, 400])))
+    want = RecordingDemodulator(C1, **kw).demodulate(iq)
+    soft, rep = demodulate_recording_native(C1, iq, **kw)
+    assert rep.n_tiles == want.report.n_tiles and rep.pilot_symbols == want.report.pilot_symbols, kw
+    assert rep.weak_seams == want.report.weak_seams and rep.seam_fixes == sum(1 for s in want.report.seam_shifts if s), kw
+    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy()), kw
