@@ -208,7 +208,8 @@ demod_kernel(const DemodLaunch L)
 
 	/* Watchdog (see demod_kernel_rw.hip): a wave needs at most a few iterations per interpolated step of its longest
 	 * stream; g_need is the wave-uniform number of granules of that stream. */
-	uint32_t guard = 16u * (uint32_t)(g_need + 2) * (uint32_t)C.interp + 4096u;
+	const uint64_t guard64 = 16ull * (uint64_t)(g_need + 2) * (uint64_t)C.interp + 4096ull;
+	uint32_t guard = guard64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)guard64;
 
 	while (true) {
 		if (guard-- == 0) { overflow = 1; break; }

@@ -337,7 +337,8 @@ demod_kernel_rw(const DemodLaunch L)
 		n_wave_max = other > n_wave_max ? other : n_wave_max;
 	}
 	n_wave_max = __builtin_amdgcn_readfirstlane(n_wave_max);
-	uint32_t guard = 4u * (uint32_t)(n_wave_max + kBack) * (uint32_t)interp + 4096u;
+	const uint64_t guard64 = 4ull * (uint64_t)(n_wave_max + kBack) * (uint64_t)interp + 4096ull;
+	uint32_t guard = guard64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)guard64;
 	do {
 		/* ---- (1) symbol clock: timing.c:32-57 ---- */
 		if (!fired && !done) {
