@@ -88,7 +88,7 @@ usage(const char *prog)
 	        "       --bps <bits>        Bits per sample of raw input (8, 16, 32)\n"
 	        "       --stdout            Write soft symbols to stdout (implies -B -q)\n"
 	        "       --device <n>        HIP device ordinal (default 0)\n"
-	        "       --tiled             One QPSK file on many lanes as overlapped tiles (fast, not bit-exact\n"
+	        "       --tiled             Each QPSK file on many lanes as overlapped tiles (fast, not bit-exact\n"
 	        "                           after the head); --tile-samples <n>, --pilot-margin <symbols>\n"
 	        "   -h, --help   -v, --version\n", prog);
 }
@@ -212,39 +212,42 @@ main(int argc, char **argv)
 	p.interp_factor = interp; p.rrc_order = rrc_order; p.oqpsk = oqpsk; p.freq_max = freq_max_delta;
 	p.bps = bps; p.device = device; p.n_streams = (uint32_t)n_files;
 	if (tiled) {
-		/* ---- one file, many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call ---- */
-		if (n_files != 1 || oqpsk) { fprintf(stderr, "--tiled needs a single QPSK input file\n"); return 1; }
-		size_t cap_bytes = 1u << 26, len = 0;
-		unsigned char *data = malloc(cap_bytes);
-		for (;;) {
-			if (len + FILE_BUFFER_SIZE > cap_bytes) { cap_bytes *= 2; data = realloc(data, cap_bytes); }
-			if (!data) return 1;
-			if (fread(data + len, FILE_BUFFER_SIZE, 1, io[0].in) != 1) break;
-			len += FILE_BUFFER_SIZE;
+		/* ---- each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file ---- */
+		if (oqpsk) { fprintf(stderr, "--tiled is implemented for QPSK only\n"); return 1; }
+		for (int f = 0; f < n_files; f++) {
+			size_t cap_bytes = 1u << 26, len = 0;
+			unsigned char *data = malloc(cap_bytes);
+			for (;;) {
+				if (len + FILE_BUFFER_SIZE > cap_bytes) { cap_bytes *= 2; data = realloc(data, cap_bytes); }
+				if (!data) return 1;
+				if (fread(data + len, FILE_BUFFER_SIZE, 1, io[f].in) != 1) break;
+				len += FILE_BUFFER_SIZE;
+			}
+			const uint64_t n_samples = len / (2 * (size_t)bps / 8);
+			const uint64_t cap_sym = (uint64_t)((double)n_samples * symrate / samplerate * 1.02) + 4096;
+			int8_t *soft_all = malloc(cap_sym * 2);
+			if (!soft_all) return 1;
+			mdemod_recording_opts ro;
+			mdemod_recording_default_opts(&ro);
+			if (tile_samples > 0) ro.tile_samples = (uint32_t)tile_samples;
+			if (pilot_margin >= 0) ro.pilot_margin_symbols = (uint32_t)pilot_margin;
+			mdemod_recording_report rr;
+			int rc2 = mdemod_demodulate_recording_host(&p, &ro, data, n_samples, soft_all, cap_sym, &rr);
+			if (rc2 != MDEMOD_OK) { fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2)); return 2; }
+			if (!quiet)
+				fprintf(stderr, "%s: %llu samples: %llu serial (pilot) + %u tiles, %llu symbols, first lock at symbol %lld, %u seam fixes, "
+				        "%u weak seams, %.2f s\n", io[f].in_name, (unsigned long long)n_samples, (unsigned long long)rr.pilot_samples, rr.n_tiles,
+				        (unsigned long long)rr.n_symbols, (long long)rr.first_lock_symbol, rr.seam_fixes, rr.weak_seams,
+				        rr.pilot_seconds + rr.tiles_seconds);
+			for (uint64_t k = 0; k < rr.n_symbols; k += 1u << 20)
+				write_gated(&io[f], soft_all + 2 * k, (uint32_t)((rr.n_symbols - k < (1u << 20)) ? rr.n_symbols - k : (1u << 20)), rr.first_lock_symbol);
+			size_t tail = 2 * (size_t)io[f].ring_idx;                       /* main.c:321 */
+			if (tail > sizeof(io[f].ring)) tail = sizeof(io[f].ring);
+			fwrite(io[f].ring, 1, tail, io[f].out);
+			if (io[f].out != stdout) fclose(io[f].out);
+			if (io[f].in != stdin) fclose(io[f].in);
+			free(data); free(soft_all);
 		}
-		const uint64_t n_samples = len / (2 * (size_t)bps / 8);
-		const uint64_t cap_sym = (uint64_t)((double)n_samples * symrate / samplerate * 1.02) + 4096;
-		int8_t *soft_all = malloc(cap_sym * 2);
-		if (!soft_all) return 1;
-		mdemod_recording_opts ro;
-		mdemod_recording_default_opts(&ro);
-		if (tile_samples > 0) ro.tile_samples = (uint32_t)tile_samples;
-		if (pilot_margin >= 0) ro.pilot_margin_symbols = (uint32_t)pilot_margin;
-		mdemod_recording_report rr;
-		int rc2 = mdemod_demodulate_recording_host(&p, &ro, data, n_samples, soft_all, cap_sym, &rr);
-		if (rc2 != MDEMOD_OK) { fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2)); return 2; }
-		if (!quiet)
-			fprintf(stderr, "%llu samples: %llu serial (pilot) + %u tiles, %llu symbols, first lock at symbol %lld, %u seam fixes, %u weak seams\n",
-			        (unsigned long long)n_samples, (unsigned long long)rr.pilot_samples, rr.n_tiles, (unsigned long long)rr.n_symbols,
-			        (long long)rr.first_lock_symbol, rr.seam_fixes, rr.weak_seams);
-		for (uint64_t k = 0; k < rr.n_symbols; k += 1u << 20)
-			write_gated(&io[0], soft_all + 2 * k, (uint32_t)((rr.n_symbols - k < (1u << 20)) ? rr.n_symbols - k : (1u << 20)), rr.first_lock_symbol);
-		size_t tail = 2 * (size_t)io[0].ring_idx;                       /* main.c:321 */
-		if (tail > sizeof(io[0].ring)) tail = sizeof(io[0].ring);
-		fwrite(io[0].ring, 1, tail, io[0].out);
-		if (io[0].out != stdout) fclose(io[0].out);
-		if (io[0].in != stdin) fclose(io[0].in);
-		free(data); free(soft_all);
 		return 0;
 	}
 

@@ -85,6 +85,13 @@ def test_cli_tiled_mode_single_file(tmp_path, gpu_device):
     body = slice(0, len(got) - 512)                              # the final flush repeats stale ring bytes
     assert ((got[body] >= 0) == (want[body] >= 0)).all(axis=1).mean() > 0.9999
     assert (np.abs(got[body].astype(int) - want[body].astype(int)).max(axis=1) <= 1).mean() > 0.93
+    # several files: each one tiled, outputs <input>.s, same bytes as the single-file run
+    inp2 = tmp_path / "copy.wav"
+    inp2.write_bytes(inp.read_bytes())
+    r = subprocess.run([str(CLI), "-q", "--tiled", "--tile-samples", "32768", "--pilot-margin", "100k", str(inp), str(inp2)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert Path(str(inp) + ".s").read_bytes() == out.read_bytes() == Path(str(inp2) + ".s").read_bytes()
     # OQPSK is refused
     r = subprocess.run([str(CLI), "-q", "--tiled", "-m", "oqpsk", "-o", str(out), str(inp)], capture_output=True, text=True)
     assert r.returncode != 0
