@@ -135,7 +135,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 		c.win_granules = NW / 4;
 		c.ring_granules = 0;
 		c.ctab_row_floats = NW;
-		c.ctab_row_stride = NW + 2;                       /* 41 x 8 B: odd => consecutive rows hit distinct b64 bank slots */
+		c.ctab_row_stride = NW + 4;                       /* 21 x 16 B: rows 16-byte aligned for ds_read_b128, odd => consecutive rows on distinct 16-byte slots */
 		out.ctab.assign(static_cast<size_t>(AL) * banks * c.ctab_row_stride, 0.0f);
 		const int lead = kTaps - c.taps;
 		for (int a = 0; a < AL; a++)

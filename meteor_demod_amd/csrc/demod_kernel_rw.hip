@@ -140,6 +140,7 @@ fetch_granule(const typename Fmt<FMT>::sample_t *src, int m0, int n)
  * ds_read2_b64: the fused form is serviced in 16-lane groups over 16 bank slots and measured
  * 2.7x bank-conflict cycles on the ~40 distinct rows a wave uses; plain b64 has 32 slots. */
 typedef float coef2_t __attribute__((ext_vector_type(2)));
+typedef float coef4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float2
 ld_coef(const float *row, int s)
 {
@@ -147,6 +148,28 @@ ld_coef(const float *row, int s)
 	typedef const volatile coef2_t __attribute__((address_space(3))) *lds_coef_ptr;
 	const coef2_t v = *(lds_coef_ptr)(row + s);
 	return make_float2(v.x, v.y);
+}
+/* Four coefficients with one ds_read_b128 (rows 16-byte aligned): half the LDS instructions of the b64 form at the
+ * same LDS bandwidth; serviced in 16-lane groups over 16 slots of 16 bytes. */
+__device__ __forceinline__ void
+ld_coef4(const float *row, int s, float2 &lo, float2 &hi)
+{
+	typedef const volatile coef4_t __attribute__((address_space(3))) *lds_coef4_ptr;
+	const coef4_t v = *(lds_coef4_ptr)(row + s);
+	lo = make_float2(v.x, v.y); hi = make_float2(v.z, v.w);
+}
+/* one chunk of 8 coefficients into h[4] */
+template <bool WIDE_LOADS>
+__device__ __forceinline__ void
+ld_chunk(const float *row, int s0, float2 (&h)[4])
+{
+	if (WIDE_LOADS) {
+		ld_coef4(row, s0, h[0], h[1]);
+		ld_coef4(row, s0 + 4, h[2], h[3]);
+	} else {
+#pragma unroll
+		for (int j = 0; j < 4; j++) h[j] = ld_coef(row, s0 + 2 * j);
+	}
 }
 
 /* One chunk of CH taps: filter.c:55-62, sequential, oldest first, unfused. */
@@ -172,7 +195,7 @@ fir_chunk(const typename W::elem_t (&win)[NW], int c, const float2 (&h)[CH / 2],
  * the compiler cannot hoist all 40 reads to the top (80 live VGPRs of coefficients was what
  * capped the kernel at 2 waves/SIMD).
  */
-template <int NW, typename W>
+template <int NW, typename W, bool WIDE_LOADS>
 __device__ __forceinline__ void
 fir_window(const typename W::elem_t (&win)[NW], const float *row, bool skip_first, bool skip_last,
            float &out_re, float &out_im)
@@ -182,28 +205,23 @@ fir_window(const typename W::elem_t (&win)[NW], const float *row, bool skip_firs
 	float ar = 0.0f, ai = 0.0f;
 	float2 h0[CH / 2], h1[CH / 2];
 
+	static_assert(CH == 8, "ld_chunk loads 8 coefficients");
 	if (!skip_first) {                                   /* wave-uniform */
-#pragma unroll
-		for (int j = 0; j < CH / 2; j++) h0[j] = ld_coef(row, 2 * j);
+		ld_chunk<WIDE_LOADS>(row, 0, h0);
 		fir_chunk<NW, W, CH>(win, 0, h0, ar, ai);
 	}
-#pragma unroll
-	for (int j = 0; j < CH / 2; j++) h0[j] = ld_coef(row, CH + 2 * j);
+	ld_chunk<WIDE_LOADS>(row, CH, h0);
 #pragma unroll
 	for (int c = 1; c < NCH - 1; c++) {
 		int tie = 0;                                             /* opaque zero: keeps the LDS address space of `row` */
 		asm volatile("" : "+v"(tie) : "v"(ar), "v"(ai));         /* fetch of chunk c+1 may not pass chunk c-1's sum */
-		if (c + 1 < NCH - 1) {
-#pragma unroll
-			for (int j = 0; j < CH / 2; j++) h1[j] = ld_coef(row + tie, (c + 1) * CH + 2 * j);
-		}
+		if (c + 1 < NCH - 1) ld_chunk<WIDE_LOADS>(row + tie, (c + 1) * CH, h1);
 		fir_chunk<NW, W, CH>(win, c, h0, ar, ai);
 #pragma unroll
 		for (int j = 0; j < CH / 2; j++) h0[j] = h1[j];
 	}
 	if (!skip_last) {
-#pragma unroll
-		for (int j = 0; j < CH / 2; j++) h0[j] = ld_coef(row, (NCH - 1) * CH + 2 * j);
+		ld_chunk<WIDE_LOADS>(row, (NCH - 1) * CH, h0);
 		fir_chunk<NW, W, CH>(win, NCH - 1, h0, ar, ai);
 	}
 	out_re = ar;
@@ -442,7 +460,7 @@ demod_kernel_rw(const DemodLaunch L)
 			 * a <= AMAX - 8: when the whole wave agrees the chunk is dropped (exact: acc + 0*x == acc). */
 			const bool skip_first = __all(a >= 8);              /* over the lanes active in this branch */
 			const bool skip_last = __all(a <= AMAX - 8);
-			fir_window<NW, W>(win, row, skip_first, skip_last, y.re, y.im);
+			fir_window<NW, W, !G::COMPACT>(win, row, skip_first, skip_last, y.re, y.im);
 
 			/* ---- scalar part: state comes from / goes back to the LDS slots ---- */
 			if (REGSTATE) {
