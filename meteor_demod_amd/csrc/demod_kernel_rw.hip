@@ -45,6 +45,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MDEMOD_RW_PREFETCH
+#define MDEMOD_RW_PREFETCH 2          /* FIR coefficient prefetch distance (chunks) of the float std variant */
+#endif
+
 namespace {
 
 /* Window geometry.  Std: filters up to 65 taps, <= 3.6 samples per firing (the LRPT rates at
@@ -195,34 +199,53 @@ fir_chunk(const typename W::elem_t (&win)[NW], int c, const float2 (&h)[CH / 2],
  * the compiler cannot hoist all 40 reads to the top (80 live VGPRs of coefficients was what
  * capped the kernel at 2 waves/SIMD).
  */
-template <int NW, typename W, bool WIDE_LOADS>
+template <int NW, typename W, bool WIDE_LOADS, int PF>
 __device__ __forceinline__ void
 fir_window(const typename W::elem_t (&win)[NW], const float *row, bool skip_first, bool skip_last,
            float &out_re, float &out_im)
 {
 	constexpr int CH = 8, NCH = NW / CH;
 	static_assert(NW % CH == 0, "window is a whole number of chunks");
-	float ar = 0.0f, ai = 0.0f;
-	float2 h0[CH / 2], h1[CH / 2];
-
 	static_assert(CH == 8, "ld_chunk loads 8 coefficients");
-	if (!skip_first) {                                   /* wave-uniform */
-		ld_chunk<WIDE_LOADS>(row, 0, h0);
-		fir_chunk<NW, W, CH>(win, 0, h0, ar, ai);
-	}
-	ld_chunk<WIDE_LOADS>(row, CH, h0);
+	float ar = 0.0f, ai = 0.0f;
+
+	if (PF == 1) {
+		float2 h0[CH / 2], h1[CH / 2];
+		if (!skip_first) {                                   /* wave-uniform */
+			ld_chunk<WIDE_LOADS>(row, 0, h0);
+			fir_chunk<NW, W, CH>(win, 0, h0, ar, ai);
+		}
+		ld_chunk<WIDE_LOADS>(row, CH, h0);
 #pragma unroll
-	for (int c = 1; c < NCH - 1; c++) {
-		int tie = 0;                                             /* opaque zero: keeps the LDS address space of `row` */
-		asm volatile("" : "+v"(tie) : "v"(ar), "v"(ai));         /* fetch of chunk c+1 may not pass chunk c-1's sum */
-		if (c + 1 < NCH - 1) ld_chunk<WIDE_LOADS>(row + tie, (c + 1) * CH, h1);
-		fir_chunk<NW, W, CH>(win, c, h0, ar, ai);
+		for (int c = 1; c < NCH - 1; c++) {
+			int tie = 0;                                             /* opaque zero: keeps the LDS address space of `row` */
+			asm volatile("" : "+v"(tie) : "v"(ar), "v"(ai));         /* fetch of chunk c+1 may not pass chunk c-1's sum */
+			if (c + 1 < NCH - 1) ld_chunk<WIDE_LOADS>(row + tie, (c + 1) * CH, h1);
+			fir_chunk<NW, W, CH>(win, c, h0, ar, ai);
 #pragma unroll
-		for (int j = 0; j < CH / 2; j++) h0[j] = h1[j];
-	}
-	if (!skip_last) {
-		ld_chunk<WIDE_LOADS>(row, (NCH - 1) * CH, h0);
-		fir_chunk<NW, W, CH>(win, NCH - 1, h0, ar, ai);
+			for (int j = 0; j < CH / 2; j++) h0[j] = h1[j];
+		}
+		if (!skip_last) {
+			ld_chunk<WIDE_LOADS>(row, (NCH - 1) * CH, h0);
+			fir_chunk<NW, W, CH>(win, NCH - 1, h0, ar, ai);
+		}
+	} else {
+		/* coefficients two chunks ahead of the arithmetic (three rotating buffers: 8 more VGPRs): the LDS latency
+		 * under load is about one chunk of arithmetic */
+		float2 h[3][CH / 2];
+		if (!skip_first) ld_chunk<WIDE_LOADS>(row, 0, h[0]);
+		ld_chunk<WIDE_LOADS>(row, CH, h[1]);
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			const bool need_c = c == 0 ? !skip_first : (c == NCH - 1 ? !skip_last : true);
+			if (c + 2 < NCH) {
+				int tie = 0;
+				asm volatile("" : "+v"(tie) : "v"(ar), "v"(ai));     /* fetch of chunk c+2 may not pass chunk c-1's sum */
+				const bool need_n = (c + 2 == NCH - 1) ? !skip_last : true;
+				if (need_n) ld_chunk<WIDE_LOADS>(row + tie, (c + 2) * CH, h[(c + 2) % 3]);
+			}
+			if (need_c) fir_chunk<NW, W, CH>(win, c, h[c % 3], ar, ai);
+		}
 	}
 	out_re = ar;
 	out_im = ai;
@@ -460,7 +483,7 @@ demod_kernel_rw(const DemodLaunch L)
 			 * a <= AMAX - 8: when the whole wave agrees the chunk is dropped (exact: acc + 0*x == acc). */
 			const bool skip_first = __all(a >= 8);              /* over the lanes active in this branch */
 			const bool skip_last = __all(a <= AMAX - 8);
-			fir_window<NW, W, !G::COMPACT>(win, row, skip_first, skip_last, y.re, y.im);
+			fir_window<NW, W, !G::COMPACT, (MDEMOD_RW_PREFETCH == 2 && !PACKED && !G::COMPACT && FMT != 32) ? 2 : 1>(win, row, skip_first, skip_last, y.re, y.im);
 
 			/* ---- scalar part: state comes from / goes back to the LDS slots ---- */
 			if (REGSTATE) {
