@@ -207,7 +207,10 @@ int  mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs,
 int  mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void *hip_stream);
 /* pll phase of stream s += quarter_turns_dev[s] * pi/2 (device array, n_streams
  * entries; wrapped like pll.c:113): moves a stream that locked k*90 degrees away
- * from its predecessor onto the predecessor's constellation rotation. */
+ * from its predecessor onto the predecessor's constellation rotation.  In OQPSK
+ * mode an odd number of quarter turns also moves the symbol clock by half a symbol
+ * (t_phase +- pi, dual state toggled: the rails swap and their firings are half a
+ * symbol apart). */
 int  mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, void *hip_stream);
 
 /* The whole scheme in one call (native counterpart of meteor_demod_amd/recording.py):

@@ -430,7 +430,7 @@ mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, void *h
 	if (!ctx || !quarter_turns_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
-	HIP_TRY(mdemod_launch_rotate(ctx->st, quarter_turns_dev, ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
+	HIP_TRY(mdemod_launch_rotate(ctx->st, quarter_turns_dev, ctx->params.n_streams, ctx->params.oqpsk ? 1 : 0, static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
 }
 

@@ -51,9 +51,12 @@ seed_kernel(DemodStateSoA st, mdemod_stream_state v, int32_t flags, int hpad, ui
 	for (int k = 0; k < hpad; k++) hist[stream_major ? (size_t)s * hpad + k : (size_t)k * n_streams + s] = zero;
 }
 
-/* phase += k * pi/2, wrapped with the dividend's sign like pll.c:113 */
+/* phase += k * pi/2, wrapped with the dividend's sign like pll.c:113.  OQPSK: an odd number of quarter turns also
+ * swaps the rails, whose firings are half a symbol apart (demod.c:66-76): the firing the symbol clock is waiting for
+ * changes its role (timing.c:41-57: state 1 fires at pi = in-phase, state 2 at 2*pi = quadrature + retime), i.e. the
+ * clock phase moves by pi and the state toggles. */
 __global__ void
-rotate_kernel(DemodStateSoA st, const int32_t *quarter_turns, uint32_t n_streams)
+rotate_kernel(DemodStateSoA st, const int32_t *quarter_turns, uint32_t n_streams, int oqpsk)
 {
 	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n_streams) return;
@@ -61,6 +64,18 @@ rotate_kernel(DemodStateSoA st, const int32_t *quarter_turns, uint32_t n_streams
 	if (!k) return;
 	const double p = (double)st.pll_phase[s] + (double)k * MD_HALF_PI_D;
 	st.pll_phase[s] = (float)fmod(p, MD_TWO_PI_D);
+	if (oqpsk && (k & 1)) {
+		const int fl = st.flags[s];
+		const int state = (fl >> MDEMOD_FLAG_DUAL_SHIFT) & 3;
+		const float tp = st.t_phase[s];
+		st.t_phase[s] = (state == 1) ? tp + MD_PI_F : tp - MD_PI_F;
+		st.flags[s] = (fl & ~(3 << MDEMOD_FLAG_DUAL_SHIFT)) | ((state == 1 ? 2 : 1) << MDEMOD_FLAG_DUAL_SHIFT);
+		/* the sample held for the next pairing changes rail too: out * j^k has I' = -Q, Q' = I (k = 1) or I' = Q,
+		 * Q' = -I (k = 3); the last quadrature sample is t_prev (timing.c:65), the pending in-phase one is inphase */
+		const float last_q = st.t_prev[s], pend_i = st.inphase[s];
+		if (state == 1) st.inphase[s] = (k == 1) ? -last_q : last_q;      /* now waiting for Q': its I' is the old last Q */
+		else st.t_prev[s] = (k == 1) ? pend_i : -pend_i;                   /* now waiting for I': the last Q' is the old pending I */
+	}
 }
 
 __global__ void
@@ -149,10 +164,10 @@ mdemod_launch_seed(const DemodStateSoA &st, const DemodConsts &c, const mdemod_s
 }
 
 hipError_t
-mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_turns_dev, uint32_t n_streams, hipStream_t stream)
+mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_turns_dev, uint32_t n_streams, int oqpsk, hipStream_t stream)
 {
 	if (n_streams == 0) return hipSuccess;
-	hipLaunchKernelGGL(rotate_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, quarter_turns_dev, n_streams);
+	hipLaunchKernelGGL(rotate_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, quarter_turns_dev, n_streams, oqpsk);
 	return hipGetLastError();
 }
 

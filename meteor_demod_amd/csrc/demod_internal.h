@@ -88,7 +88,7 @@ hipError_t mdemod_launch_demod_rw(const DemodLaunch &L, int fmt, int packed, siz
 hipError_t mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int float_history, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_seed(const DemodStateSoA &st, const DemodConsts &c, const mdemod_stream_state &v, int32_t flags, int fmt,
                               int float_history, uint32_t n_streams, hipStream_t stream);
-hipError_t mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_turns_dev, uint32_t n_streams, hipStream_t stream);
+hipError_t mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_turns_dev, uint32_t n_streams, int oqpsk, hipStream_t stream);
 /* host_pipe.cpp: the pipelined host-buffer path behind mdemod_process_host */
 int  mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, uint32_t n_streams, size_t sample_bytes,
                          const void *const *iq_host, const uint32_t *n_samples,

@@ -125,6 +125,59 @@ def match_tails(a_tail, b_tail):
     return best[1], best[2], best[0], energy
 
 
+def gather_heads(soft, counts, k):
+    """First ``k`` symbols of each row -> [T, k, 2] int32 (zeros where the row is shorter)."""
+    import torch
+    T = soft.shape[0]
+    kk = min(k, soft.shape[1])
+    g = soft[:, :kk].to(torch.int32)
+    if kk < k:
+        g = torch.cat((g, torch.zeros((T, k - kk, 2), dtype=torch.int32, device=soft.device)), dim=1)
+    ok = torch.arange(k, device=soft.device).view(1, k) < counts.view(T, 1)
+    return g * ok.unsqueeze(-1)
+
+
+def match_heads(a_head, b_head):
+    """Like :func:`match_tails` for two demodulations that START on the same sample ([T, K+1, 2] int32 each):
+    shift 0: both start with the same symbol; +1: A starts one symbol earlier (A[1] is B[0]); -1: B starts one earlier."""
+    import torch
+    K = a_head.shape[1] - 1
+    best = None
+    for shift, (asl, bsl) in ((0, (slice(0, K), slice(0, K))), (1, (slice(1, K + 1), slice(0, K))), (-1, (slice(0, K), slice(1, K + 1)))):
+        a, b = a_head[:, asl], b_head[:, bsl]
+        ai, aq, bi, bq = a[..., 0], a[..., 1], b[..., 0], b[..., 1]
+        re = (ai * bi + aq * bq).sum(1)
+        im = (aq * bi - ai * bq).sum(1)
+        sc, r = torch.stack((re, im, -re, -im), dim=1).max(dim=1)
+        cand = (sc, torch.full_like(r, shift), r)
+        best = cand if best is None else tuple(torch.where(cand[0] > best[0], c, b0) for c, b0 in zip(cand, best))
+    energy = (a_head[:, :K].to(torch.int64) ** 2).sum((1, 2))
+    return best[1], best[2], best[0], energy
+
+
+def match_rails(a_tail, b_tail):
+    """OQPSK: rotation of tail B against tail A when the two rails may be paired differently.
+
+    The I and Q rails of an OQPSK symbol come from firings half a symbol apart (demod.c:66-76).  A tile locked 90
+    degrees off has the rails swapped AND paired one symbol apart (at +90 its pair k is (-Q_k, I_k+1) of the reference),
+    so the rails are correlated separately: 4 rotations x 3 shifts per rail, tails [T, K+2, 2] aligned at their ends.
+    Returns (rot [T], score [T], energy [T])."""
+    import torch
+    K = a_tail.shape[1] - 2
+    a = a_tail[:, 1:K + 1]                                      # K symbols, one symbol of margin on both sides
+    bI, bQ = b_tail[..., 0], b_tail[..., 1]
+    maps = ((bI, bQ), (-bQ, bI), (-bI, -bQ), (bQ, -bI))        # rails of b * j**r, the convention of match_tails()
+    best = None
+    for r, (mI, mQ) in enumerate(maps):
+        sI = torch.stack([(a[..., 0] * mI[:, 1 + d:K + 1 + d]).sum(1) for d in (-1, 0, 1)], dim=1).max(dim=1)[0]
+        sQ = torch.stack([(a[..., 1] * mQ[:, 1 + d:K + 1 + d]).sum(1) for d in (-1, 0, 1)], dim=1).max(dim=1)[0]
+        sc = sI + sQ
+        cand = (sc, torch.full_like(sc, r))
+        best = cand if best is None else tuple(torch.where(cand[0] > best[0], c, b0) for c, b0 in zip(cand, best))
+    energy = (a.to(torch.int64) ** 2).sum((1, 2))
+    return best[1], best[0], energy
+
+
 # ---- result ---------------------------------------------------------------------------------
 
 @dataclass
@@ -161,13 +214,14 @@ class RecordingDemodulator:
 
     def __init__(self, cfg, tile_samples: int = 65600, pre_samples: int = 16384, refine: bool = True,
                  pilot_block: int = 65536, pilot_margin_symbols: int = 160000, max_pilot_samples: int = 1 << 22,
-                 match_symbols: int = 192, device: int = 0, bank_factory=None):
-        if cfg.oqpsk:
+                 match_symbols: int = 192, device: int = 0, bank_factory=None, post_samples: int = 4096):
+        if cfg.oqpsk and not refine:
             # the I and Q rails of OQPSK come from different firings (demod.c:66-76): a 90 degree lock offset is
-            # entangled with the half-symbol state of the symbol clock, which rotate_symbols() cannot undo.
-            raise NotImplementedError("overlapped tiles of one recording are implemented for QPSK only; "
-                                      "demodulate OQPSK recordings as whole streams (one per lane)")
+            # entangled with the half-symbol state of the symbol clock, which rotate_symbols() cannot undo on the
+            # output; only the second pass (which turns the STATE, mdemod_rotate_carrier) handles it.
+            raise NotImplementedError("overlapped tiles of an OQPSK recording need refine=True")
         self.cfg = cfg
+        self.post_samples = int(post_samples)
         self.tile_samples = int(tile_samples)
         self.pre_samples = int(pre_samples)
         self.refine = bool(refine)
@@ -244,6 +298,9 @@ class RecordingDemodulator:
         cnt1 = bank.symbol_counts().to(dev)
         rep.samples_demodulated += int(plan.pres.sum() + plan.lens.sum())
 
+        if self.cfg.oqpsk:
+            return self._finish_oqpsk(iq, rep, plan, pilot, bank, pilot_soft, seed, seed_hist, soft_pre, cnt_pre, soft1, cnt1, cap)
+
         # ---- rotation + seam of every tile against its predecessor (tile 0: against the pilot) ----
         prev_tail, _ = gather_tails(soft1[:-1], cnt1[:-1], K + 1) if T > 1 else (torch.zeros((0, K + 1, 2), dtype=torch.int32, device=dev), None)
         ptail, _ = gather_tails(pilot_soft.unsqueeze(0), torch.tensor([pilot_soft.shape[0]], device=dev), K + 1)
@@ -296,6 +353,63 @@ class RecordingDemodulator:
         seam = torch.cat((torch.zeros(1, dtype=shift2.dtype, device=dev), shift2[:-1]))
         b1_last = rotate_symbols(gather_tails(soft1, cnt1, 1)[0].to(torch.int8), R)[:, 0]
         head_sym = torch.cat((torch.zeros((1, 2), dtype=torch.int8, device=dev), b1_last[:-1]))
+        rep.seam_shifts = seam.cpu().tolist()
+        out = self._assemble(pilot_soft, soft2, cnt2, seam, head_sym)
+        pilot.close(); bank.close()
+        return StitchedRecording(out[0], out[1], plan, rep)
+
+    # -- OQPSK: rotation from per-rail correlation, second pass with a look-ahead into the next tile ---------------
+    def _finish_oqpsk(self, iq, rep, plan, pilot, bank, pilot_soft, seed, seed_hist, soft_pre, cnt_pre, soft1, cnt1, cap):
+        import torch
+        dev, T, K = iq.device, plan.n_tiles, self.match_symbols
+        i64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64), device=dev)
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=dev)
+        prev_tail, _ = gather_tails(soft1[:-1], cnt1[:-1], K + 2) if T > 1 else (torch.zeros((0, K + 2, 2), dtype=torch.int32, device=dev), None)
+        ptail, _ = gather_tails(pilot_soft.unsqueeze(0), torch.tensor([pilot_soft.shape[0]], device=dev), K + 2)
+        b_tail, _ = gather_tails(soft_pre, cnt_pre, K + 2)
+        rot, score, energy = match_rails(torch.cat((ptail, prev_tail)), b_tail)
+        weak = (score * 2 < energy) | torch.as_tensor(plan.pres == 0, device=dev)
+        rot = torch.where(weak, torch.zeros_like(rot), rot)
+        R = torch.cumsum(rot, 0) & 3
+        rep.rotations = R.cpu().tolist()
+        rep.weak_seams = int(weak.sum())
+
+        # pass 2: stream i continues from its pass-1 end state, turned into the pilot's rotation (carrier AND
+        # half-symbol pairing), with tile i+1 and then `post` samples of tile i+2 for the seam check
+        bank.rotate_carrier(((4 - R) & 3).to(torch.int32))
+        bank.set_state(T - 1, seed)
+        bank.set_history(T - 1, seed_hist)
+        starts2 = np.concatenate((plan.starts[1:], plan.starts[:1]))
+        lens2 = np.concatenate((plan.lens[1:], plan.lens[:1]))
+        ends2 = starts2 + lens2
+        post2 = np.minimum(self.post_samples, plan.n_samples - ends2)
+        soft2 = torch.zeros((T, cap, 2), dtype=torch.int8, device=dev)
+        bank.process_ragged(iq, i64(starts2), i32(lens2), soft2)
+        cnt2s = bank.symbol_counts().to(dev)
+        cap_post = max(1, bank.max_symbols(int(post2.max())))
+        soft_post = torch.zeros((T, cap_post, 2), dtype=torch.int8, device=dev)
+        bank.process_ragged(iq, i64(ends2), i32(post2), soft_post)
+        cnt_posts = bank.symbol_counts().to(dev)
+        rep.samples_demodulated += int(lens2.sum() + post2.sum())
+        order = torch.cat((torch.tensor([T - 1], device=dev), torch.arange(T - 1, device=dev)))
+        soft2, cnt2, soft_post, cnt_post = soft2[order], cnt2s[order], soft_post[order], cnt_posts[order]
+
+        # seam i | i+1: tile i's look-ahead and tile i+1's body start on the same sample
+        seam = torch.zeros(T, dtype=torch.int64, device=dev)
+        head_sym = torch.zeros((T, 2), dtype=torch.int8, device=dev)
+        if T > 1:
+            a = gather_heads(soft_post[:-1], cnt_post[:-1], K + 1)
+            b = gather_heads(soft2[1:], cnt2[1:], K + 1)
+            sh, r2, sc2, en2 = match_heads(a, b)
+            weak2 = sc2 * 2 < en2
+            sh = torch.where(weak2, torch.zeros_like(sh), sh)
+            rep.refine_rotations = [0] + torch.where(weak2, torch.zeros_like(r2), r2).cpu().tolist()
+            rep.weak_seams += int(weak2.sum())
+            # +1: tile i fired a symbol right after the boundary that tile i+1 does not have: insert it in front of tile
+            # i+1; -1: tile i+1 starts with a symbol tile i already emitted before the boundary: drop tile i's last one
+            # (the same repair _assemble() applies, with the signs of its tail convention)
+            seam[1:] = -sh
+            head_sym[1:] = soft_post[:-1, 0]
         rep.seam_shifts = seam.cpu().tolist()
         out = self._assemble(pilot_soft, soft2, cnt2, seam, head_sym)
         pilot.close(); bank.close()

@@ -111,3 +111,12 @@ class OracleBank:
             if k:
                 s = st._p.contents.s
                 s.pll_phase = float(np.float32(math.fmod(float(s.pll_phase) + k * (math.pi / 2), 2 * math.pi)))
+                if self.cfg.oqpsk and (k & 1):             # rails swap: the symbol clock moves by half a symbol
+                    pi_f = np.float32(math.pi)
+                    last_q, pend_i = float(s.t_prev), float(s.inphase)
+                    if s.dual_state == 1:
+                        s.t_phase = float(np.float32(s.t_phase) + pi_f); s.dual_state = 2
+                        s.inphase = -last_q if k == 1 else last_q
+                    else:
+                        s.t_phase = float(np.float32(s.t_phase) - pi_f); s.dual_state = 1
+                        s.t_prev = pend_i if k == 1 else -pend_i

@@ -33,6 +33,23 @@ def test_hip_stitched_recording_equals_oracle_stitched_recording(refine, gpu_dev
     assert np.array_equal(got.tile_first_symbol, want.tile_first_symbol)
 
 
+def test_hip_stitched_oqpsk_recording_equals_oracle_stitched_recording(gpu_device):
+    """OQPSK: per-rail rotation matching, state rotation with the half-symbol clock move (mdemod_rotate_carrier in OQPSK
+    mode), look-ahead seams: the HIP bank reproduces the oracle bank byte for byte and agrees with the serial run."""
+    import torch
+    cfg = DemodConfig(samplerate=230000, symrate=80000, oqpsk=True)
+    st = synth.make_stream(4242, 230000, 80000, f0_hz=300.0, clock_ppm=11.0, esn0_db=14.0, oqpsk=True)
+    iq = synth.generate_host(st, 2_000_000)
+    kw = dict(tile_samples=32768, pre_samples=8192, pilot_block=65536, pilot_margin_symbols=80000)
+    want = RecordingDemodulator(cfg, bank_factory=lambda c, k: OracleBank(c, k), **kw).demodulate(torch.from_numpy(iq))
+    got = RecordingDemodulator(cfg, **kw).demodulate(torch.from_numpy(iq).cuda())
+    assert got.report.n_tiles == want.report.n_tiles > 30 and got.report.rotations == want.report.rotations
+    assert len(set(got.report.rotations)) == 4 and got.report.seam_shifts == want.report.seam_shifts
+    assert np.array_equal(got.soft.cpu().numpy(), want.soft.numpy())
+    a = agreement(got.soft.cpu().numpy(), O.oracle_demod(cfg, iq)[0])
+    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999
+
+
 def test_long_recording_on_many_lanes_agrees_with_the_serial_reference(gpu_device):
     """16 M samples (70 s of signal) as 237 tiles of 65536: pilot bytes are the reference's, tiles within the
     loops' noise of the serial run, symbol count preserved."""

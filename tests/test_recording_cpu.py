@@ -114,6 +114,40 @@ def test_recording_shorter_than_the_pilot_is_exact():
     assert res.report.n_tiles == 0 and np.array_equal(res.soft.numpy(), serial)
 
 
-def test_oqpsk_is_refused_loudly():
+def test_oqpsk_recording_needs_the_state_rotation_pass():
     with pytest.raises(NotImplementedError):
-        RecordingDemodulator(DemodConfig(samplerate=230000, symrate=80000, oqpsk=True))
+        RecordingDemodulator(DemodConfig(samplerate=230000, symrate=80000, oqpsk=True), refine=False)
+
+
+def test_match_rails_sees_through_the_oqpsk_pairing():
+    """A tile locked +90 degrees pairs (-Q_k, I_k+1): per-rail correlation must still find the quarter turn."""
+    from meteor_demod_amd.recording import match_rails
+    rng = np.random.default_rng(3)
+    K = 64
+    a_i = rng.choice([-60, 60], K + 8) + rng.integers(-5, 6, K + 8)
+    a_q = rng.choice([-60, 60], K + 8) + rng.integers(-5, 6, K + 8)
+    ref = np.stack([a_i, a_q], axis=1)                                   # reference pairs (a_k, b_k)
+    plus90 = np.stack([-a_q[:-1], a_i[1:]], axis=1)                      # what a +90 degree lock emits
+    a = torch.from_numpy(ref[-(K + 3):-1].astype(np.int32)).unsqueeze(0)
+    for b_np, want in ((ref[-(K + 3):-1], 0), (-ref[-(K + 3):-1], 2), (plus90[-(K + 2):], 3), (-plus90[-(K + 2):], 1)):
+        rot, score, energy = match_rails(a, torch.from_numpy(b_np.astype(np.int32)).unsqueeze(0))
+        assert int(rot) == want and int(score) * 2 > int(energy), (want, int(rot))
+
+
+def test_stitched_oqpsk_recording_against_the_serial_reference():
+    """OQPSK 80k: tiles lock on all four rotations, odd ones with the rails paired one symbol apart; the second pass turns
+    carrier AND symbol clock of every stream into the pilot's convention."""
+    cfg = DemodConfig(samplerate=230000, symrate=80000, oqpsk=True)
+    st = synth.make_stream(4242, cfg.samplerate, cfg.symrate, f0_hz=300.0, clock_ppm=11.0, esn0_db=14.0, oqpsk=True)
+    iq = synth.generate_host(st, 3_000_000)
+    serial = O.oracle_demod(cfg, iq)[0]
+    rd = RecordingDemodulator(cfg, tile_samples=32768, pre_samples=8192, pilot_block=65536, pilot_margin_symbols=160000,
+                              bank_factory=lambda c, k: OracleBank(c, k))
+    res = rd.demodulate(torch.from_numpy(iq))
+    r, out = res.report, res.soft.numpy()
+    assert r.pilot_locked and r.n_tiles == 74 and r.weak_seams == 0 and len(set(r.rotations)) == 4
+    assert np.array_equal(out[: r.pilot_symbols], serial[: r.pilot_symbols])
+    assert all(x == 0 for x in r.refine_rotations)
+    a = agreement(out, serial)
+    assert a["len_stitched"] == a["len_serial"]
+    assert a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.94
