@@ -88,7 +88,7 @@ usage(const char *prog)
 	        "       --bps <bits>        Bits per sample of raw input (8, 16, 32)\n"
 	        "       --stdout            Write soft symbols to stdout (implies -B -q)\n"
 	        "       --device <n>        HIP device ordinal (default 0)\n"
-	        "       --tiled             Each QPSK file on many lanes as overlapped tiles (fast, not bit-exact\n"
+	        "       --tiled             Each file on many lanes as overlapped tiles (fast, not bit-exact\n"
 	        "                           after the head); --tile-samples <n>, --pilot-margin <symbols>\n"
 	        "   -h, --help   -v, --version\n", prog);
 }
@@ -213,7 +213,6 @@ main(int argc, char **argv)
 	p.bps = bps; p.device = device; p.n_streams = (uint32_t)n_files;
 	if (tiled) {
 		/* ---- each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file ---- */
-		if (oqpsk) { fprintf(stderr, "--tiled is implemented for QPSK only\n"); return 1; }
 		for (int f = 0; f < n_files; f++) {
 			size_t cap_bytes = 1u << 26, len = 0;
 			unsigned char *data = malloc(cap_bytes);

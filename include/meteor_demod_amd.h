@@ -217,7 +217,7 @@ int  mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, vo
  * the head of the recording is demodulated serially from the reference's power-on state until the
  * carrier loop has locked and converged (those symbols are the reference's symbols), the rest as
  * overlapped tiles seeded from that state, rotation- and seam-resolved, optionally refined by an exact
- * continuation pass.  QPSK only.  iq_dev: n_samples IQ samples in the format of params->bps, in device
+ * continuation pass (mandatory for OQPSK).  iq_dev: n_samples IQ samples in the format of params->bps, in device
  * memory; soft_dev: device buffer for soft_cap_symbols int8 pairs (mdemod_max_symbols-sized is enough).
  * params->n_streams is ignored.  Synchronous on hip_stream. */
 typedef struct {

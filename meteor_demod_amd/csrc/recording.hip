@@ -100,6 +100,88 @@ match_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *rot_out,
 	}
 }
 
+/* OQPSK (see recording.py:match_rails): the rails are correlated separately because a tile locked +-90 degrees pairs
+ * them one symbol apart.  Tails of K+2 symbols aligned at their ends; a = A[1..K]; for every quarter turn r the rails of
+ * B * j^r are tried at shifts -1, 0, +1 each.  mode 1 = this; mode 2 = heads (both start on the same sample, complex
+ * symbols, shifts 0 / +1 / -1 like match_kernel). */
+__global__ void
+match_rails_kernel(const TailPair *pairs, int K, int32_t *rot_out, int32_t *weak_out)
+{
+	const TailPair p = pairs[blockIdx.x];
+	__shared__ long long acc[25][64];                      /* [r][rail][d] = 24 sums + energy */
+	long long s[25];
+	for (int k = 0; k < 25; k++) s[k] = 0;
+	auto load = [&](const int8_t *base, uint32_t cnt, int x, int &i, int &q) {     /* x in 0..K+1 from the tail start */
+		const long long idx = (long long)cnt - (K + 2) + x;
+		if (idx < 0) { i = 0; q = 0; return; }
+		i = base[2 * idx]; q = base[2 * idx + 1];
+	};
+	for (int j = threadIdx.x; j < K; j += blockDim.x) {
+		int ai, aq; load(p.a, p.a_cnt, j + 1, ai, aq);
+		for (int d = 0; d < 3; d++) {                       /* shift d-1 */
+			int bi, bq; load(p.b, p.b_cnt, j + d, bi, bq);  /* b index 1 + (d-1) + j */
+			const int mI[4] = { bi, -bq, -bi, bq }, mQ[4] = { bq, bi, -bq, -bi };
+			for (int r = 0; r < 4; r++) { s[r * 6 + d] += ai * mI[r]; s[r * 6 + 3 + d] += aq * mQ[r]; }
+		}
+		s[24] += ai * ai + aq * aq;
+	}
+	for (int k = 0; k < 25; k++) acc[k][threadIdx.x] = s[k];
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		long long t[25];
+		for (int k = 0; k < 25; k++) { t[k] = 0; for (unsigned l = 0; l < blockDim.x; l++) t[k] += acc[k][l]; }
+		long long best = 0; int br = 0;
+		for (int r = 0; r < 4; r++) {
+			long long sI = t[r * 6], sQ = t[r * 6 + 3];
+			for (int d = 1; d < 3; d++) { if (t[r * 6 + d] > sI) sI = t[r * 6 + d]; if (t[r * 6 + 3 + d] > sQ) sQ = t[r * 6 + 3 + d]; }
+			if (r == 0 || sI + sQ > best) { best = sI + sQ; br = r; }
+		}
+		const bool weak = (best * 2 < t[24]) || p.force_weak;
+		rot_out[blockIdx.x] = weak ? 0 : br;
+		weak_out[blockIdx.x] = weak ? 1 : 0;
+	}
+}
+
+__global__ void
+match_heads_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *rot_out, int32_t *weak_out)
+{
+	const TailPair p = pairs[blockIdx.x];
+	__shared__ long long acc[7][64];
+	long long s[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	auto load = [&](const int8_t *base, uint32_t cnt, int x, int &i, int &q) {
+		if ((uint32_t)x >= cnt) { i = 0; q = 0; return; }
+		i = base[2 * x]; q = base[2 * x + 1];
+	};
+	for (int j = threadIdx.x; j < K; j += blockDim.x) {
+		int a0i, a0q, a1i, a1q, b0i, b0q, b1i, b1q;
+		load(p.a, p.a_cnt, j, a0i, a0q); load(p.a, p.a_cnt, j + 1, a1i, a1q);
+		load(p.b, p.b_cnt, j, b0i, b0q); load(p.b, p.b_cnt, j + 1, b1i, b1q);
+		s[0] += a0i * b0i + a0q * b0q;  s[1] += a0q * b0i - a0i * b0q;      /* shift 0:  a[0..K-1] vs b[0..K-1] */
+		s[2] += a1i * b0i + a1q * b0q;  s[3] += a1q * b0i - a1i * b0q;      /* shift +1: a[1..K]   vs b[0..K-1] */
+		s[4] += a0i * b1i + a0q * b1q;  s[5] += a0q * b1i - a0i * b1q;      /* shift -1: a[0..K-1] vs b[1..K]   */
+		s[6] += a0i * a0i + a0q * a0q;
+	}
+	for (int k = 0; k < 7; k++) acc[k][threadIdx.x] = s[k];
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		long long t[7];
+		for (int k = 0; k < 7; k++) { t[k] = 0; for (unsigned l = 0; l < blockDim.x; l++) t[k] += acc[k][l]; }
+		const int shifts[3] = { 0, 1, -1 };
+		long long best = 0; int bs = 0, br = 0; bool have = false;
+		for (int c = 0; c < 3; c++) {
+			const long long re = t[2 * c], im = t[2 * c + 1];
+			const long long sc4[4] = { re, im, -re, -im };
+			int r = 0;
+			for (int k = 1; k < 4; k++) if (sc4[k] > sc4[r]) r = k;
+			if (!have || sc4[r] > best) { best = sc4[r]; bs = shifts[c]; br = r; have = true; }
+		}
+		const bool weak = best * 2 < t[6];
+		shift_out[blockIdx.x] = weak ? 0 : bs;
+		rot_out[blockIdx.x] = weak ? 0 : br;
+		weak_out[blockIdx.x] = weak ? 1 : 0;
+	}
+}
+
 __global__ void
 assemble_kernel(const TileCopy *tiles, int8_t *out)
 {
@@ -160,13 +242,17 @@ counts_of(mdemod_ctx *c, uint32_t n, std::vector<uint32_t> &out, hipStream_t st)
 
 int
 run_match(DevMem &m, const std::vector<TailPair> &pairs, int K, std::vector<int32_t> &shift, std::vector<int32_t> &rot,
-          std::vector<int32_t> &weak, hipStream_t st)
+          std::vector<int32_t> &weak, hipStream_t st, int mode = 0)
 {
 	const size_t T = pairs.size();
+	if (T == 0) { shift.clear(); rot.clear(); weak.clear(); return MDEMOD_OK; }
 	TailPair *d_pairs; int32_t *d_out;
 	TRY(upload(m, pairs, &d_pairs, st));
 	TRY(m.alloc(&d_out, 3 * T));
-	hipLaunchKernelGGL(match_kernel, dim3((unsigned)T), dim3(64), 0, st, d_pairs, K, d_out, d_out + T, d_out + 2 * T);
+	HTRY(hipMemsetAsync(d_out, 0, 3 * T * sizeof(int32_t), st));
+	if (mode == 1) hipLaunchKernelGGL(match_rails_kernel, dim3((unsigned)T), dim3(64), 0, st, d_pairs, K, d_out + T, d_out + 2 * T);
+	else if (mode == 2) hipLaunchKernelGGL(match_heads_kernel, dim3((unsigned)T), dim3(64), 0, st, d_pairs, K, d_out, d_out + T, d_out + 2 * T);
+	else hipLaunchKernelGGL(match_kernel, dim3((unsigned)T), dim3(64), 0, st, d_pairs, K, d_out, d_out + T, d_out + 2 * T);
 	HTRY(hipGetLastError());
 	std::vector<int32_t> h(3 * T);
 	HTRY(hipMemcpyAsync(h.data(), d_out, 3 * T * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -193,9 +279,9 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
                             mdemod_recording_report *rep, void *hip_stream)
 {
 	if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
-	if (params->oqpsk) return MDEMOD_ERR_PARAM;     /* QPSK only: see DESIGN.md §3.1 */
 	mdemod_recording_opts o;
 	if (opts_in) o = *opts_in; else mdemod_recording_default_opts(&o);
+	if (params->oqpsk && !o.refine) return MDEMOD_ERR_PARAM;     /* OQPSK needs the state rotation pass: DESIGN.md 3.1 */
 	if (!o.tile_samples || !o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
 	memset(rep, 0, sizeof(*rep));
@@ -292,14 +378,52 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		p.b_rot = 0; p.force_weak = pres[i] == 0;
 	}
 	std::vector<int32_t> shift, rot, weak;
-	TRY(run_match(mem, pairs, K, shift, rot, weak, st));
+	TRY(run_match(mem, pairs, K, shift, rot, weak, st, params->oqpsk ? 1 : 0));
 	std::vector<int32_t> R(T);
 	int32_t accr = 0;
 	for (size_t i = 0; i < T; i++) { accr = (accr + rot[i]) & 3; R[i] = accr; rep->weak_seams += weak[i]; }
 
 	std::vector<TileCopy> copies(T);
 	std::vector<int32_t> seam(T, 0);
-	if (!o.refine) {
+	if (params->oqpsk) {
+		/* ---- OQPSK pass 2: state rotation (carrier + half-symbol clock), body, then a look-ahead into the next tile ---- */
+		std::vector<int32_t> q(T);
+		for (size_t i = 0; i < T; i++) q[i] = (4 - R[i]) & 3;
+		int32_t *d_q;
+		TRY(upload(mem, q, &d_q, st));
+		TRY(mdemod_rotate_carrier(bank.c, d_q, st));
+		TRY(mdemod_set_state(bank.c, static_cast<uint32_t>(T - 1), &seed, st));
+		TRY(mdemod_set_history(bank.c, static_cast<uint32_t>(T - 1), seed_hist.data(), st));
+		const uint64_t post = 4096;
+		std::vector<uint64_t> starts2(T), lens2(T), ends2(T), post2(T);
+		for (size_t i = 0; i < T; i++) {
+			starts2[i] = starts[(i + 1) % T]; lens2[i] = lens[(i + 1) % T];
+			ends2[i] = starts2[i] + lens2[i]; post2[i] = std::min<uint64_t>(post, n_samples - ends2[i]);
+		}
+		TRY(mem.alloc(&soft2, T * cap * 2));
+		std::vector<uint32_t> cnt2s, cnt_posts;
+		TRY(launch(starts2, lens2, soft2, cap, cnt2s));
+		const uint64_t cap_post = std::max<uint64_t>(1, mdemod_max_symbols(bank.c, *std::max_element(post2.begin(), post2.end())));
+		int8_t *soft_post;
+		TRY(mem.alloc(&soft_post, T * cap_post * 2));
+		TRY(launch(ends2, post2, soft_post, cap_post, cnt_posts));
+		auto stream_of = [&](size_t tile) { return (tile + T - 1) % T; };
+		std::vector<TailPair> heads(T > 1 ? T - 1 : 0);
+		for (size_t i = 0; i + 1 < T; i++) {                       /* seam i | i+1 */
+			heads[i].a = soft_post + stream_of(i) * cap_post * 2; heads[i].a_cnt = cnt_posts[stream_of(i)];
+			heads[i].b = soft2 + stream_of(i + 1) * cap * 2;      heads[i].b_cnt = cnt2s[stream_of(i + 1)];
+			heads[i].b_rot = 0; heads[i].force_weak = 0;
+		}
+		std::vector<int32_t> sh, r2, w2;
+		TRY(run_match(mem, heads, K, sh, r2, w2, st, 2));
+		for (size_t i = 0; i < T; i++) {
+			seam[i] = i ? -sh[i - 1] : 0;
+			if (i) rep->weak_seams += w2[i - 1];
+			copies[i].src = soft2 + stream_of(i) * cap * 2; copies[i].rot = 0; copies[i].keep = cnt2s[stream_of(i)];
+			copies[i].head = (i && seam[i] == -1) ? soft_post + stream_of(i - 1) * cap_post * 2 : nullptr;
+			copies[i].head_rot = 0;
+		}
+	} else if (!o.refine) {
 		for (size_t i = 0; i < T; i++) {
 			seam[i] = shift[i];
 			copies[i].src = soft1 + i * cap * 2; copies[i].rot = R[i]; copies[i].keep = cnt1[i];

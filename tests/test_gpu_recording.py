@@ -117,6 +117,21 @@ def test_native_stitcher_equals_python_stitcher(refine, gpu_device):
     assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy())
 
 
+def test_native_stitcher_equals_python_stitcher_oqpsk(gpu_device):
+    import torch
+    from meteor_demod_amd.recording import demodulate_recording_native
+    cfg = DemodConfig(samplerate=230000, symrate=80000, oqpsk=True)
+    st = synth.make_stream(78, 230000, 80000, f0_hz=-350.0, clock_ppm=25.0, esn0_db=12.0, oqpsk=True)
+    iq = synth.generate_device([st], 5_000_000)[0]
+    kw = dict(tile_samples=32768, pre_samples=8192, refine=True, pilot_block=65536, pilot_margin_symbols=80000)
+    want = RecordingDemodulator(cfg, **kw).demodulate(iq)
+    soft, rep = demodulate_recording_native(cfg, iq, **kw)
+    assert rep.n_tiles == want.report.n_tiles > 50 and rep.weak_seams == want.report.weak_seams
+    assert rep.seam_fixes == sum(1 for s in want.report.seam_shifts if s)
+    assert rep.samples_demodulated == want.report.samples_demodulated
+    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy())
+
+
 def test_native_stitcher_short_recording_and_errors(gpu_device):
     import torch
     from meteor_demod_amd._capi import MdemodError
@@ -125,8 +140,8 @@ def test_native_stitcher_short_recording_and_errors(gpu_device):
     iq = synth.generate_device([st], 150_000)[0]
     soft, rep = demodulate_recording_native(C1, iq)
     assert rep.n_tiles == 0 and np.array_equal(soft.cpu().numpy(), O.oracle_demod(C1, iq.cpu().numpy())[0])
-    with pytest.raises(MdemodError):
-        demodulate_recording_native(DemodConfig(samplerate=230000, symrate=80000, oqpsk=True), iq)
+    with pytest.raises(MdemodError):      # OQPSK needs the state rotation pass
+        demodulate_recording_native(DemodConfig(samplerate=230000, symrate=80000, oqpsk=True), iq, refine=False)
 
 
 @pytest.mark.parametrize("seed", range(6))
