@@ -90,7 +90,9 @@ def test_product_constants_equal_oracle_constants():
 
 def test_bad_parameters_are_rejected():
     lib = _capi.lib()
-    for bad in (dict(interp_factor=0), dict(rrc_order=0), dict(samplerate=0), dict(symrate=-1), dict(bps=12)):
+    # samplerate 72000 at 72k symbols/s: < 1 sample per symbol, where the reference returns only the last symbol of a sample
+    for bad in (dict(interp_factor=0), dict(rrc_order=0), dict(samplerate=0), dict(symrate=-1), dict(bps=12), dict(samplerate=72000),
+                dict(samplerate=60000)):
         cfg = DemodConfig(samplerate=230000)
         for k, v in bad.items():
             setattr(cfg, k, v)
