@@ -10,7 +10,7 @@
 
 #define MDEMOD_WAVE            64
 #define MDEMOD_GRANULE_SAMPLES 4      /* ring granule = 4 consecutive IQ samples */
-#define MDEMOD_RW_STATE_SLOTS   11     /* per-lane LDS state words of the v2 kernel */
+#define MDEMOD_RW_STATE_SLOTS   12     /* per-lane LDS state words of the v2 kernel */
 #define MDEMOD_RW_WIDE_BLOCK    512    /* threads per block of the wide v2 geometry */
 #ifndef MDEMOD_RW_WIDE_NW
 #define MDEMOD_RW_WIDE_NW       160    /* window slots of the wide geometry (129 taps + 32 alignments) */

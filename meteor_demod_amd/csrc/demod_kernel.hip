@@ -191,6 +191,7 @@ demod_kernel(const DemodLaunch L)
 	bool fired = false;                                      /* a firing is waiting for its data                    */
 	bool done = !valid || n == 0;
 	uint32_t sym_call = 0, ev_call = 0;
+	int v_last_emit = -1;                                    /* sample of the last emitted symbol            */
 	int overflow = 0;
 
 	/* wave-uniform end of data: max over lanes of needed granules */
@@ -344,6 +345,9 @@ demod_kernel(const DemodLaunch L)
 			md_nco_advance(pll.phase, pll.freq);
 
 			if (emit) {
+				/* only the LAST symbol fired inside one input sample is kept (demod.c:33-47, 62-90; see demod_kernel_rw.hip) */
+				if (v_cur == v_last_emit) { sym_call--; n_symbols--; }
+				v_last_emit = v_cur;
 				md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);
 				int first = 0;
 				const int changed = md_pll_update(pll, lut, C.pll_alpha, C.pll_beta, C.pll_fmax,

@@ -285,7 +285,7 @@ demod_kernel_rw(const DemodLaunch L)
 	float *ctab = reinterpret_cast<float *>(lds);
 	float *lut = ctab + L.ctab_floats;
 	/* per-lane state slots: field f of this lane is sl[f * 64] */
-	enum { S_GAIN, S_BIAS_RE, S_BIAS_IM, S_PHASE, S_FREQ, S_ERR, S_FLAGS, S_TPREV, S_INPHASE, S_EVCALL, S_FIRSTLOCK, S_COUNT };
+	enum { S_GAIN, S_BIAS_RE, S_BIAS_IM, S_PHASE, S_FREQ, S_ERR, S_FLAGS, S_TPREV, S_INPHASE, S_EVCALL, S_FIRSTLOCK, S_LASTV, S_COUNT };
 	static_assert(S_COUNT == MDEMOD_RW_STATE_SLOTS, "host LDS sizing");
 	float *sl = lut + 32 + (threadIdx.x >> 6) * (S_COUNT * 64) + (threadIdx.x & 63);
 	int *sli = reinterpret_cast<int *>(sl);
@@ -327,7 +327,7 @@ demod_kernel_rw(const DemodLaunch L)
 		sl[S_PHASE * 64] = phase; sl[S_FREQ * 64] = freq; sl[S_ERR * 64] = err;
 		sli[S_FLAGS * 64] = fl & 7;                     /* locked | locked_once | updown>0; bit 3 = overflow */
 		sl[S_TPREV * 64] = t_prev; sl[S_INPHASE * 64] = inph;
-		sli[S_EVCALL * 64] = 0; sli[S_FIRSTLOCK * 64] = -1;
+		sli[S_EVCALL * 64] = 0; sli[S_FIRSTLOCK * 64] = -1; sli[S_LASTV * 64] = -1;
 		if (REGSTATE) { r_gain = gain; r_bias_re = bias_re; r_bias_im = bias_im; r_phase = phase; r_freq = freq; }
 	}
 
@@ -517,6 +517,15 @@ demod_kernel_rw(const DemodLaunch L)
 			md_nco_advance(pll.phase, pll.freq);
 
 			if (emit) {
+				/* The reference's per-sample loop keeps only the LAST symbol fired inside one input sample (demod.c:33-47,
+				 * 62-90: `*sample` and `ret` are overwritten).  It happens when a huge timing error term pulls the clock
+				 * back over the threshold at once (full-scale input before the AGC has settled): the symbol emitted for this
+				 * sample a moment ago is then replaced, index and all.  The sample index of the last emitted symbol lives in
+				 * an LDS state word (deriving "no sample consumed since" from the symbol clock instead measured 2 % slower). */
+				const bool again = (v_cur == sli[S_LASTV * 64]);
+				sli[S_LASTV * 64] = v_cur;
+				const bool any_again = __any(again);
+				if (any_again) { if (again) sym_call--; }
 				float t_prev = sl[S_TPREV * 64];
 				md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);
 				sl[S_TPREV * 64] = t_prev;
@@ -535,10 +544,14 @@ demod_kernel_rw(const DemodLaunch L)
 				}
 				}
 				const uint32_t sym = (uint32_t)(md_quantise(out_re) & 0xFF) | ((uint32_t)(md_quantise(out_im) & 0xFF) << 8);
-				ob0 = __builtin_amdgcn_alignbit(ob1, ob0, 16);
-				ob1 = __builtin_amdgcn_alignbit(ob2, ob1, 16);
-				ob2 = __builtin_amdgcn_alignbit(ob3, ob2, 16);
-				ob3 = (ob3 >> 16) | (sym << 16);
+				if (any_again && again) {
+					ob3 = (ob3 & 0xFFFFu) | (sym << 16);                    /* replace the newest buffered symbol */
+				} else {
+					ob0 = __builtin_amdgcn_alignbit(ob1, ob0, 16);
+					ob1 = __builtin_amdgcn_alignbit(ob2, ob1, 16);
+					ob2 = __builtin_amdgcn_alignbit(ob3, ob2, 16);
+					ob3 = (ob3 >> 16) | (sym << 16);
+				}
 				sym_call++;
 				if ((sym_call & 7u) == 0) {
 					const uint32_t sb = sym_call - 8;

@@ -598,6 +598,35 @@ def test_float_input_ring_kernel_ignores_stale_lds(gpu_device):
             assert np.array_equal(np.concatenate(got[i]), O.oracle_demod(cfg, iqs[i % 6])[0]), i
 
 
+@pytest.mark.parametrize("cfg", [
+    DemodConfig(samplerate=324459, symrate=36000, interp_factor=2, rrc_order=33, pll_bw=100.0, freq_max=1.5),   # wide window
+    DemodConfig(samplerate=230000, pll_bw=100.0, freq_max=1.5),                                                 # std window
+    DemodConfig(samplerate=230000, symrate=80000, oqpsk=True, pll_bw=100.0),
+    DemodConfig(samplerate=230000),
+], ids=["wide", "std", "std-oqpsk", "defaults"])
+def test_full_scale_input_only_last_symbol_of_a_sample_is_kept(cfg, gpu_device, kernel_variant):
+    """A full-scale burst after silence (AGC gain high): the timing error term (alpha * e, e ~ 1e5) pulls the symbol clock
+    back over its threshold at once and several symbols fire inside one input sample; the reference keeps only the last
+    one (demod.c:33-47).  Happens with the default options too.  Found by tools/config_fuzz.py with pathological inputs."""
+    torch = _torch()
+    iqs = []
+    for sd in range(4):                    # silence lets the AGC gain climb, then a full-scale burst arrives
+        rng = np.random.default_rng(sd)
+        iqs.append(np.concatenate([np.zeros((3000, 2), np.int16), rng.choice(np.array([-32767, 32767], dtype=np.int16), size=(6000, 2))]))
+    iqs.append(np.random.default_rng(9).choice(np.array([-32767, 32767], dtype=np.int16), size=(9000, 2)))
+    iqs.append(np.zeros((9000, 2), np.int16))                      # silence only: the gain ramps up, nothing else happens
+    with Demodulator(cfg, len(iqs)) as d:
+        soft = d.process(torch.from_numpy(np.stack(iqs)).cuda())
+        torch.cuda.synchronize()
+        cnt = d.symbol_counts()
+        st = d.status()
+        for i, a in enumerate(iqs):
+            ost = O.OracleStream(cfg)
+            want = ost.run(a)[0]
+            assert int(cnt[i]) == len(want) and np.array_equal(soft[i, : len(want)].cpu().numpy(), want), i
+            assert np.float32(st[i].gain) == np.float32(ost.state.gain) and st[i].n_symbols == len(want)
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("seed", [21, 22])
 def test_option_fuzz(seed, gpu_device):

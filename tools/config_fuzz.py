@@ -21,8 +21,8 @@ for ci in range(n_cfg):
     cfg = DemodConfig(samplerate=samplerate, symrate=symrate, oqpsk=oqpsk,
                       rrc_order=int(rng.choice([4, 8, 16, 17, 24, 32, 33, 40, 48, 63, 64, 65, 80])),
                       interp_factor=int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10])),
-                      pll_bw=float(rng.choice([0.5, 1.0, 2.0, 5.0])),
-                      freq_max=float(rng.choice([-1.0, 0.05, 0.3, 1.5])),
+                      pll_bw=float(rng.choice([0.01, 0.5, 1.0, 2.0, 5.0, 100.0, 3000.0])),
+                      freq_max=float(rng.choice([-1.0, 0.0, 0.001, 0.05, 0.3, 1.5])),
                       bps=int(rng.choice([8, 16, 16, 16, 32])))
     # the reference divides 0/0 when an RRC tap falls on t = 1/(4*alpha): undefined there, skip
     if cfg.samplerate < cfg.symrate * 1.001:
@@ -42,6 +42,23 @@ for ci in range(n_cfg):
                                  clock_ppm=float(rng.uniform(-40, 40)), esn0_db=float(rng.uniform(5, 25)), rms=rms,
                                  dc=(rms / 150, -rms / 250), oqpsk=cfg.oqpsk, fmt=cfg.bps) for _ in range(min(ns, 6))]
     iqs = [synth.generate_host(s, total) for s in streams]
+    # pathological inputs on some streams: silence, full-scale noise, a pure tone, a DC level
+    DTs = {8: np.uint8, 16: np.int16, 32: np.float32}
+    full = {8: 127, 16: 32767, 32: 1.0}[cfg.bps]
+    zero = 128 if cfg.bps == 8 else 0
+    for i in range(len(iqs)):
+        kind = int(rng.integers(0, 8))
+        if kind == 0:
+            iqs[i] = np.full((total, 2), zero, dtype=DTs[cfg.bps])
+        elif kind == 1:
+            v = rng.choice([-full, full], size=(total, 2))
+            iqs[i] = (v + zero).astype(DTs[cfg.bps]) if cfg.bps != 32 else v.astype(np.float32)
+        elif kind == 2:
+            ph = 2 * np.pi * float(rng.uniform(-0.2, 0.2)) * np.arange(total)
+            v = np.stack([np.cos(ph), np.sin(ph)], axis=1) * full * 0.9
+            iqs[i] = (np.round(v) + zero).astype(DTs[cfg.bps]) if cfg.bps != 32 else v.astype(np.float32)
+        elif kind == 3:
+            iqs[i] = np.full((total, 2), zero + (full // 2 if cfg.bps != 32 else 0.5), dtype=DTs[cfg.bps])
     if len(sys.argv) > 3 and ci != int(sys.argv[3]):
         continue
     print(f"cfg {ci}: {cfg} ns={ns} blocks={blocks}", flush=True)
