@@ -141,7 +141,9 @@ void mdemod_destroy(mdemod_ctx *ctx);
 /* Put every stream back into the reference's power-on state. */
 int  mdemod_reset(mdemod_ctx *ctx, void *hip_stream);
 
-/* Soft-symbol capacity (in SYMBOLS) that is always enough for n input samples. */
+/* Soft-symbol capacity (in SYMBOLS) that is always enough for n input samples: one symbol per
+ * sample is the hard bound of the reference's per-sample loop (demod.c:33-47); the nominal
+ * n*symrate/samplerate is exceeded while the symbol clock drains a large phase excursion. */
 uint64_t mdemod_max_symbols(const mdemod_ctx *ctx, uint64_t n_samples);
 
 /* ---- the hot path (replaces the main.c:303-306 loop body) ---------------- */

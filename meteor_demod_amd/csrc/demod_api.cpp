@@ -96,6 +96,15 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 
 } /* namespace */
 
+uint64_t
+mdemod_nominal_symbols(const mdemod_ctx *ctx, uint64_t n_samples)
+{
+	if (!ctx) return 0;
+	const double steps = static_cast<double>(n_samples) * ctx->tab.c.interp;
+	const double per_step = static_cast<double>(ctx->tab.c.t_center) * (1.0 + 1.0 / 4096.0) / 6.283185307179586;
+	return ((static_cast<uint64_t>(steps * per_step * 1.01) + 16 + 7) / 8) * 8;
+}
+
 extern "C" {
 
 uint32_t
@@ -244,13 +253,10 @@ uint64_t
 mdemod_max_symbols(const mdemod_ctx *ctx, uint64_t n_samples)
 {
 	if (!ctx) return 0;
-	/* The symbol clock can run at most center*(1+2^-12) rad per interpolated
-	 * step and fires every 2*pi (pi for the OQPSK half symbols, but only every
-	 * second firing emits): a generous closed-form bound plus slack for the
-	 * phase the stream starts with. */
-	const double steps = static_cast<double>(n_samples) * ctx->tab.c.interp;
-	const double per_step = static_cast<double>(ctx->tab.c.t_center) * (1.0 + 1.0 / 4096.0) / 6.283185307179586;
-	return static_cast<uint64_t>(steps * per_step * 1.01) + 16;
+	/* The reference emits at most one symbol per input sample (demod.c:33-47: its per-sample loop keeps the last firing),
+	 * and so do the kernels.  A bound from the nominal symbol rate (samples * symrate / samplerate) is NOT safe: while the
+	 * symbol clock drains a large phase excursion (a full-scale burst after silence) it fires on every sample. */
+	return n_samples + 8;
 }
 
 int

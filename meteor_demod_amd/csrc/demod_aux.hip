@@ -78,6 +78,21 @@ rotate_kernel(DemodStateSoA st, const int32_t *quarter_turns, uint32_t n_streams
 	}
 }
 
+/* Host path: the demodulator writes its soft symbols with the hard-bound row pitch (one symbol per input sample);
+ * what goes over PCIe is a copy with the nominal pitch.  One block per stream, 16-byte moves (pitches are multiples of
+ * 8 symbols). */
+__global__ void
+compact_rows_kernel(const int8_t *src, uint64_t src_pitch, int8_t *dst, uint64_t dst_pitch, const uint32_t *counts, uint32_t n_streams)
+{
+	const uint32_t s = blockIdx.x;
+	if (s >= n_streams) return;
+	uint32_t m = counts[s];
+	if (m > dst_pitch) m = (uint32_t)dst_pitch;
+	const uint4 *a = reinterpret_cast<const uint4 *>(src + 2 * src_pitch * s);
+	uint4 *b = reinterpret_cast<uint4 *>(dst + 2 * dst_pitch * s);
+	for (uint32_t k = threadIdx.x; k < (m + 7) / 8; k += blockDim.x) b[k] = a[k];
+}
+
 __global__ void
 selftest_sincos_kernel(const float *x, uint32_t n, float *s, float *c)
 {
@@ -168,6 +183,15 @@ mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_turns_dev, 
 {
 	if (n_streams == 0) return hipSuccess;
 	hipLaunchKernelGGL(rotate_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, quarter_turns_dev, n_streams, oqpsk);
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_compact_rows(const int8_t *src, uint64_t src_pitch_sym, int8_t *dst, uint64_t dst_pitch_sym, const uint32_t *counts_dev,
+                           uint32_t n_streams, hipStream_t stream)
+{
+	if (n_streams == 0) return hipSuccess;
+	hipLaunchKernelGGL(compact_rows_kernel, dim3(n_streams), dim3(128), 0, stream, src, src_pitch_sym, dst, dst_pitch_sym, counts_dev, n_streams);
 	return hipGetLastError();
 }
 

@@ -40,12 +40,17 @@ namespace {
 
 struct Slot {                    /* one of the two staging sets */
 	unsigned char *h_iq = nullptr, *d_iq = nullptr;   size_t iq_bytes = 0;
-	int8_t *h_soft = nullptr, *d_soft = nullptr;      size_t soft_bytes = 0;
+	int8_t *h_soft = nullptr;  size_t h_soft_bytes = 0;
+	int8_t *d_soft = nullptr;  size_t d_soft_bytes = 0;          /* kernel output, hard-bound pitch              */
+	int8_t *d_pack = nullptr;  size_t d_pack_bytes = 0;          /* the same rows at the nominal pitch: what is copied out */
+	uint32_t pitch = 0;          /* nominal pitch (symbols) of d_pack / h_soft for the sub-block in flight */
 	uint64_t *h_off = nullptr, *d_off = nullptr;
 	uint32_t *h_cnt = nullptr, *d_cnt = nullptr, *h_prod = nullptr, *h_ev = nullptr;
 	hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
 	bool used_in = false, used_k = false, used_out = false;
-	uint32_t cap = 0;            /* symbol stride of this slot's soft buffers for the sub-block in flight */
+	uint32_t cap = 0;            /* symbol stride of the DEVICE soft buffer for the sub-block in flight: one symbol per input
+	                              * sample is the hard bound (a full-scale transient can exceed mdemod_max_symbols) */
+	uint32_t width = 0;          /* symbols per stream actually copied out = the largest count of the sub-block */
 };
 
 struct HostPipe {
@@ -65,6 +70,30 @@ grow_pair(T **host, T **dev, size_t *have, size_t need)
 	*host = nullptr; *dev = nullptr; *have = 0;
 	need += need / 8;                                        /* a little headroom: fewer re-allocations */
 	PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(host), need, hipHostMallocDefault));
+	PIPE_TRY(hipMalloc(reinterpret_cast<void **>(dev), need));
+	*have = need;
+	return MDEMOD_OK;
+}
+
+int
+grow_host(int8_t **host, size_t *have, size_t need)
+{
+	if (need <= *have) return MDEMOD_OK;
+	if (*host) (void)hipHostFree(*host);
+	*host = nullptr; *have = 0;
+	need += need / 8;
+	PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(host), need, hipHostMallocDefault));
+	*have = need;
+	return MDEMOD_OK;
+}
+
+int
+grow_dev(int8_t **dev, size_t *have, size_t need)
+{
+	if (need <= *have) return MDEMOD_OK;
+	if (*dev) (void)hipFree(*dev);
+	*dev = nullptr; *have = 0;
+	need += need / 8;
 	PIPE_TRY(hipMalloc(reinterpret_cast<void **>(dev), need));
 	*have = need;
 	return MDEMOD_OK;
@@ -127,6 +156,7 @@ mdemod_hostpipe_free(void *opaque)
 		if (s.d_iq) (void)hipFree(s.d_iq);
 		if (s.h_soft) (void)hipHostFree(s.h_soft);
 		if (s.d_soft) (void)hipFree(s.d_soft);
+		if (s.d_pack) (void)hipFree(s.d_pack);
 		if (s.h_off) (void)hipHostFree(s.h_off);
 		if (s.h_cnt) (void)hipHostFree(s.h_cnt);
 		if (s.h_prod) (void)hipHostFree(s.h_prod);
@@ -170,6 +200,22 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 
 	auto unpack = [&](Slot &sl) -> int {
 		PIPE_TRY(hipEventSynchronize(sl.ev_out));
+		/* common case: every row fits the nominal pitch and h_soft holds it.  A stream that fired on (almost) every sample
+		 * (full-scale transient) exceeds it: then the rows are fetched again, 2-D, from the hard-pitch buffer. */
+		uint32_t widest = 0;
+		for (uint32_t s = 0; s < ns; s++) {
+			if (sl.h_prod[s] > sl.cap) return MDEMOD_ERR_OVERFLOW;       /* cannot happen: <= 1 symbol per input sample */
+			widest = std::max(widest, sl.h_prod[s]);
+		}
+		sl.width = sl.pitch;
+		if (widest > sl.pitch) {
+			int rcg = grow_host(&sl.h_soft, &sl.h_soft_bytes, static_cast<size_t>(widest) * 2 * ns + 16);
+			if (rcg) return rcg;
+			PIPE_TRY(hipMemcpy2DAsync(sl.h_soft, static_cast<size_t>(widest) * 2, sl.d_soft, static_cast<size_t>(sl.cap) * 2,
+			                          static_cast<size_t>(widest) * 2, ns, hipMemcpyDeviceToHost, p->s_out));
+			PIPE_TRY(hipStreamSynchronize(p->s_out));
+			sl.width = widest;
+		}
 		std::vector<uint64_t> w(ns);
 		uint64_t acc = 0;
 		for (uint32_t s = 0; s < ns; s++) { acc += sl.h_prod[s]; w[s] = acc; }
@@ -178,7 +224,7 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 				uint32_t m = sl.h_prod[s];
 				const uint32_t room = soft_cap[s] > produced[s] ? soft_cap[s] - produced[s] : 0;
 				if (m > room) m = room;                           /* overflow is reported below */
-				if (m) memcpy(soft_host[s] + 2 * static_cast<size_t>(produced[s]), sl.h_soft + static_cast<size_t>(s) * sl.cap * 2, static_cast<size_t>(m) * 2);
+				if (m) memcpy(soft_host[s] + 2 * static_cast<size_t>(produced[s]), sl.h_soft + static_cast<size_t>(s) * sl.width * 2, static_cast<size_t>(m) * 2);
 			}
 		});
 		for (uint32_t s = 0; s < ns; s++) {
@@ -220,14 +266,19 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 			sub_max = std::max(sub_max, hi - lo);
 		}
 		const size_t iq_bytes = static_cast<size_t>(pos) * sb + 64;
-		const uint32_t cap = static_cast<uint32_t>(mdemod_max_symbols(ctx, sub_max));
-		const size_t soft_bytes = static_cast<size_t>(cap) * 2 * ns;
-		if (iq_bytes > sl.iq_bytes || soft_bytes > sl.soft_bytes) {
+		const uint32_t cap = ((sub_max + 8 + 7) / 8) * 8;                   /* hard bound: one symbol per input sample */
+		const uint32_t pitch = static_cast<uint32_t>(std::min<uint64_t>(cap, mdemod_nominal_symbols(ctx, sub_max)));
+		const size_t soft_bytes = static_cast<size_t>(cap) * 2 * ns, pack_bytes = static_cast<size_t>(pitch) * 2 * ns;
+		if (iq_bytes > sl.iq_bytes || soft_bytes > sl.d_soft_bytes || pack_bytes > sl.d_pack_bytes || pack_bytes > sl.h_soft_bytes) {
 			/* the slot's previous sub-block must be completely through before its buffers are replaced */
 			if (sl.used_out) PIPE_TRY(hipEventSynchronize(sl.ev_out));
 			rc = grow_pair(&sl.h_iq, &sl.d_iq, &sl.iq_bytes, iq_bytes);
 			if (rc) return rc;
-			rc = grow_pair(&sl.h_soft, &sl.d_soft, &sl.soft_bytes, soft_bytes);
+			rc = grow_dev(&sl.d_soft, &sl.d_soft_bytes, soft_bytes);
+			if (rc) return rc;
+			rc = grow_dev(&sl.d_pack, &sl.d_pack_bytes, pack_bytes);
+			if (rc) return rc;
+			rc = grow_host(&sl.h_soft, &sl.h_soft_bytes, pack_bytes);
 			if (rc) return rc;
 		}
 		/* ---- pack (CPU) ---- */
@@ -248,15 +299,16 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		if (sl.used_out) PIPE_TRY(hipStreamWaitEvent(p->s_cmp, sl.ev_out, 0));
 		/* the previous sub-block's unpack reads lock events through s_cmp before this launch overwrites them */
 		if (k >= 1) { rc = unpack(p->slot[(k - 1) & 1]); if (rc) return rc; }
-		sl.cap = cap;
+		sl.cap = cap; sl.pitch = pitch;
 		rc = mdemod_process_device(ctx, sl.d_iq, sl.d_off, sl.d_cnt, sl.d_soft, cap, cap, p->s_cmp);
 		if (rc) return rc;
+		PIPE_TRY(mdemod_launch_compact_rows(sl.d_soft, cap, sl.d_pack, pitch, st.sym_this_call, ns, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_prod, st.sym_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_ev, st.ev_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
 		PIPE_TRY(hipEventRecord(sl.ev_k, p->s_cmp)); sl.used_k = true;
-		/* ---- D2H ---- */
+		/* ---- D2H of the nominal-pitch copy ---- */
 		PIPE_TRY(hipStreamWaitEvent(p->s_out, sl.ev_k, 0));
-		PIPE_TRY(hipMemcpyAsync(sl.h_soft, sl.d_soft, soft_bytes, hipMemcpyDeviceToHost, p->s_out));
+		PIPE_TRY(hipMemcpyAsync(sl.h_soft, sl.d_pack, pack_bytes, hipMemcpyDeviceToHost, p->s_out));
 		PIPE_TRY(hipEventRecord(sl.ev_out, p->s_out)); sl.used_out = true;
 	}
 	rc = unpack(p->slot[(K - 1) & 1]);

@@ -460,7 +460,7 @@ def demodulate_recording_native(cfg, iq, tile_samples: int = 65600, pre_samples:
                                      match_symbols, int(refine), 0)
     n = int(iq.shape[0])
     p = cfg.to_c(1, device)
-    cap = int(n * cfg.symrate / cfg.samplerate * 1.02) + 4096
+    cap = int(n * cfg.symrate / cfg.samplerate * 1.05) + 65536          # stitched output: nominal rate + slack (checked by the callee)
     soft = torch.empty((cap, 2), dtype=torch.int8, device=iq.device)
     rep = _capi.MdemodRecordingReport()
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

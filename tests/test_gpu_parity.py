@@ -389,6 +389,38 @@ def test_host_buffer_path_pipelined_sub_blocks(gpu_device):
                 assert ev1[i] == e1[:32] and len(e1) >= 1
 
 
+def test_more_symbols_than_the_nominal_rate(gpu_device):
+    """While the symbol clock drains a large phase excursion (full-scale burst after silence, wide loop) it fires on
+    every sample: more symbols than samples * symrate / samplerate.  mdemod_max_symbols is the hard bound (one per
+    sample), the device path must not flag overflow and the host path must hand back every symbol (its copy-out uses the
+    nominal pitch and falls back to a 2-D copy here)."""
+    torch = _torch()
+    cfg = DemodConfig(samplerate=575303, pll_bw=3000.0, symrate=144000, interp_factor=1, rrc_order=48, freq_max=0.3)
+    rng = np.random.default_rng(1)
+    a = rng.choice(np.array([-32767, 32767], dtype=np.int16), size=(9000, 2))
+    a[:5000] = 0
+    ost = O.OracleStream(cfg)
+    w1 = ost.run(a[:5000])[0]
+    w2 = ost.run(a[5000:5500])[0]
+    nominal = int(500 * 144000 / 575303 * 1.01) + 16
+    assert len(w2) > nominal                                          # the second block really exceeds the nominal bound
+    quiet = synth.generate_host(synth.make_stream(8, cfg.samplerate, cfg.symrate, f0_hz=100.0), 5500)
+    with Demodulator(cfg, 3) as d:                                    # stream 1 is the burst, 0 and 2 are ordinary signals
+        assert d.max_symbols(500) >= 500
+        d.process(torch.from_numpy(np.stack([quiet[:5000], a[:5000], quiet[:5000]])).cuda())
+        soft = d.process(torch.from_numpy(np.stack([quiet[5000:], a[5000:5500], quiet[5000:]])).cuda())
+        torch.cuda.synchronize()
+        st = d.status()
+        assert st[1].overflow == 0 and st[1].symbols_this_call == len(w2)
+        assert np.array_equal(soft[1, : len(w2)].cpu().numpy(), w2)
+    with Demodulator(cfg, 3) as d:
+        o1 = d.process_host([quiet[:5000], a[:5000], quiet[:5000]])
+        o2 = d.process_host([quiet[5000:], a[5000:5500], quiet[5000:]])
+        assert np.array_equal(o1[1], w1) and np.array_equal(o2[1], w2)
+        wq = O.oracle_demod(cfg, quiet)[0]
+        assert np.array_equal(np.concatenate([o1[0], o2[0]]), wq) and np.array_equal(np.concatenate([o1[2], o2[2]]), wq)
+
+
 def test_reset_restores_power_on_state(gpu_device):
     torch = _torch()
     iq = BY_NAME["c1_short"].generate()[:15000]

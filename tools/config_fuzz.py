@@ -59,6 +59,11 @@ for ci in range(n_cfg):
             iqs[i] = (np.round(v) + zero).astype(DTs[cfg.bps]) if cfg.bps != 32 else v.astype(np.float32)
         elif kind == 3:
             iqs[i] = np.full((total, 2), zero + (full // 2 if cfg.bps != 32 else 0.5), dtype=DTs[cfg.bps])
+        elif kind == 4:                                   # silence, then a full-scale burst (AGC gain high when it arrives)
+            v = rng.choice([-full, full], size=(total, 2)); v[: int(rng.integers(100, max(101, total // 2)))] = 0
+            iqs[i] = (v + zero).astype(DTs[cfg.bps]) if cfg.bps != 32 else v.astype(np.float32)
+        elif kind == 5 and cfg.bps == 32:                 # float input far outside [-1, 1]
+            iqs[i] = (iqs[i] * float(rng.choice([1e3, 1e6, 1e-6]))).astype(np.float32)
     if len(sys.argv) > 3 and ci != int(sys.argv[3]):
         continue
     print(f"cfg {ci}: {cfg} ns={ns} blocks={blocks}", flush=True)
@@ -87,13 +92,22 @@ for ci in range(n_cfg):
                 ost = O.OracleStream(cfg)
                 want = ost.run(iqs[i % len(iqs)])[0]
                 g = np.concatenate(got[i])
-                ok = g.shape == want.shape and np.array_equal(g, want) and np.float32(st[i].pll_freq) == np.float32(ost.state.pll_freq) \
+                ok = st[i].overflow == 0 and g.shape == want.shape and np.array_equal(g, want) and np.float32(st[i].pll_freq) == np.float32(ost.state.pll_freq) \
                     and st[i].locked == ost.state.locked and np.float32(st[i].gain) == np.float32(ost.state.gain)
                 if not ok:
                     k = min(len(g), len(want)); diff = np.flatnonzero((g[:k] != want[:k]).any(axis=1))
-                    why = (f"len {g.shape} vs {want.shape}, first diff {diff[:3]}, ndiff {len(diff)}, freq {st[i].pll_freq!r} vs {ost.state.pll_freq!r}, "
+                    why = (f"overflow {st[i].overflow}, len {g.shape} vs {want.shape}, first diff {diff[:3]}, ndiff {len(diff)}, freq {st[i].pll_freq!r} vs {ost.state.pll_freq!r}, "
                            f"locked {st[i].locked} vs {ost.state.locked}, gain {st[i].gain!r} vs {ost.state.gain!r}, ns {ns}")
                     bad.append((ci, i, cfg, d.kernel_name, blocks, why))
+                    if len(sys.argv) > 3:
+                        import os
+                        os.makedirs("gpurun_out", exist_ok=True)
+                        np.savez_compressed("gpurun_out/fuzz_fail.npz", iq=iqs[i % len(iqs)], blocks=np.asarray(blocks))
+                        tr = O.OracleStream(cfg).run(iqs[i % len(iqs)], True)[1]
+                        f = int(diff[0]) if len(diff) else k
+                        print("   per-block gpu counts", [len(p) for p in got[i]], "oracle sample idx near diff", tr["sample_index"][max(0, f - 3): f + 6])
+                        print("   gpu", g[max(0, f - 3): f + 6].tolist()); print("   orc", want[max(0, f - 3): f + 6].tolist())
+                        a = iqs[i % len(iqs)]; print("   input absmax by block", [int(np.abs(a[sum(blocks[:j]): sum(blocks[:j + 1])].astype(np.int64)).max()) if blocks[j] else 0 for j in range(len(blocks))])
                     break
     except Exception as e:
         bad.append((ci, -1, cfg, repr(e), blocks))
