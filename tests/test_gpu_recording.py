@@ -155,6 +155,10 @@ def test_native_and_python_stitchers_agree_on_random_settings(seed, gpu_device):
                            esn0_db=float(rng.choice([4.0, 8.0, 12.0, 20.0])))
     n = int(rng.integers(2_000_000, 5_000_000))
     iq = synth.generate_device([st], n)[0]
+    if seed >= 4:                          # a silent gap and a full-scale burst in the middle: unlocked tiles, weak seams
+        g0 = int(rng.integers(n // 3, n // 2))
+        iq[g0: g0 + 300_000] = 0
+        iq[g0 + 300_000: g0 + 320_000] = 32767
     kw = dict(tile_samples=int(rng.choice([8200, 16448, 40000, 65600])), pre_samples=int(rng.choice([0, 2048, 8192, 20000])),
               refine=bool(rng.random() < 0.6), pilot_block=int(rng.choice([16384, 65536])),
               pilot_margin_symbols=int(rng.choice([0, 5000, 60000])), max_pilot_samples=int(rng.choice([300_000, 1 << 22])),
