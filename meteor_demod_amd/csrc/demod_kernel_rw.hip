@@ -45,6 +45,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MDEMOD_RW_REGSTATE
+#define MDEMOD_RW_REGSTATE 1          /* AGC / NCO state of the float std variant in VGPRs instead of LDS slots */
+#endif
 #ifndef MDEMOD_RW_PREFETCH
 #define MDEMOD_RW_PREFETCH 2          /* FIR coefficient prefetch distance (chunks) of the float std variant */
 #endif
@@ -279,7 +282,7 @@ demod_kernel_rw(const DemodLaunch L)
 	constexpr int NST = SG * G::MAXSL;           /* granules staged ahead of the window */
 	/* The float window of the std geometry leaves ~20 VGPRs: AGC and NCO state stay in registers there
 	 * (5 LDS reads + 5 writes per symbol less, and no exposed LDS latency right after the FIR). */
-	constexpr bool REGSTATE = !PACKED && G::KT <= 65;
+	constexpr bool REGSTATE = MDEMOD_RW_REGSTATE && !PACKED && G::KT <= 65;
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	float *ctab = reinterpret_cast<float *>(lds);
