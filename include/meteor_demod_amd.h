@@ -226,7 +226,7 @@ typedef struct {
 	uint32_t tile_samples;          /* body samples per tile (65600: keep it off powers of two) */
 	uint32_t pre_samples;           /* warm-up samples in front of each tile      (16384)  */
 	uint32_t pilot_block;           /* pilot granularity in samples               (65536)  */
-	uint32_t pilot_margin_symbols;  /* symbols the pilot stays locked before tiles start (160000) */
+	uint32_t pilot_margin_symbols;  /* symbols the pilot stays locked before tiles start (20000) */
 	uint64_t max_pilot_samples;     /* give up waiting for lock after this many   (1 << 22) */
 	uint32_t match_symbols;         /* symbols compared across a seam             (192)    */
 	int32_t  refine;                /* 1: exact-continuation second pass          (1)      */

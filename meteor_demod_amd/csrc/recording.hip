@@ -268,7 +268,7 @@ mdemod_recording_default_opts(mdemod_recording_opts *o)
 {
 	if (!o) return;
 	o->tile_samples = 65600;                 /* not a power of two: the lanes of a wave must not share L2 sets */
-	o->pre_samples = 16384; o->pilot_block = 65536; o->pilot_margin_symbols = 160000;
+	o->pre_samples = 16384; o->pilot_block = 65536; o->pilot_margin_symbols = 20000;
 	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->refine = 1; o->reserved = 0;
 }
 
