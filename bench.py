@@ -148,6 +148,38 @@ def single_recording(cfg, buf, n=1 << 26) -> dict:
             "seam_fixes": int(rep.seam_fixes), "weak_seams": int(rep.weak_seams)}
 
 
+def other_configs(skip: str, T: int, L: int, local: int) -> dict:
+    """Untimed extra (N=1 only): the other single-GPU configurations of BASELINE.json on the same tiling, 3 passes each,
+    so that the round's BENCH file also carries the OQPSK and the 1 MS/s / 129-tap numbers.  Not `value`."""
+    import torch
+    from meteor_demod_amd import Demodulator, synth
+    res = {}
+    for tag in ("c3", "c4"):
+        if tag == skip:
+            continue
+        cfg, workload = demod_config(tag)
+        rec = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0)
+        buf = torch.empty((T * L, 2), dtype=torch.int16, device=f"cuda:{local}")
+        synth.generate_device([rec], T * L, out=buf.view(1, T * L, 2), device=local)
+        x = buf.view(T, L, 2)
+        with Demodulator(cfg, T, device=local) as d:
+            soft = torch.empty((T, d.max_symbols(L), 2), dtype=torch.int8, device=f"cuda:{local}")
+            d.process(x, soft=soft)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                d.process(x, soft=soft)
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / 3
+            bps = cfg.bps / 4 + 2 * cfg.symrate / cfg.samplerate
+            res[workload.split(";")[0]] = {"msamples_per_s": round(T * L / ms / 1e3, 1), "kernel_ms": round(ms, 3),
+                                           "hbm_frac": round(T * L * bps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": d.kernel_name}
+        del buf, x, soft
+        torch.cuda.empty_cache()
+    return res
+
+
 def spot_check(cfg, d, x, tiles, L, n_check=12) -> str:
     """Untimed: reset, one pass, compare sampled tiles (always including the first and the last,
     i.e. blocks of the first and of the last residency round) byte-for-byte with the oracle."""
@@ -277,6 +309,9 @@ def main() -> None:
             out["check"] = spot_check(cfg, d, x, T, L)
             if not cfg.oqpsk and buf.shape[0] >= (1 << 26):
                 out["single_recording"] = single_recording(cfg, buf)
+        del soft
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs(args.config, T, L, local)
     print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
