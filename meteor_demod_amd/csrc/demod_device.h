@@ -113,7 +113,8 @@ __device__ __forceinline__ void
 md_nco_advance(float &phase, float freq)
 {
 	phase = phase + freq;
-	if ((double)phase >= MD_TWO_PI_D)
+	/* (double)phase >= 2*pi  <=>  phase >= 6.2831855f: 2*pi lies strictly between the floats 6.2831850 and 6.2831855 */
+	if (phase >= MD_TWO_PI_F)
 		phase = (float)((double)phase - MD_TWO_PI_D);
 }
 
@@ -121,11 +122,13 @@ md_nco_advance(float &phase, float freq)
  * one period off is an exact double subtraction; anything larger takes libm's
  * exact fmod. */
 __device__ __forceinline__ double
-md_wrap_2pi(double x)
+md_wrap_2pi(float xf)
 {
+	const double x = (double)xf;
 	const double ax = fabs(x);
 	double r = x;
-	const bool wraps = !(ax < MD_TWO_PI_D);
+	/* |x| < 2*pi (double)  <=>  |xf| < 6.2831855f for a float argument (see md_nco_advance) */
+	const bool wraps = !(fabsf(xf) < MD_TWO_PI_F);
 	if (__any(wraps)) {
 		if (wraps) {
 			if (ax < 2.0 * MD_TWO_PI_D) r = (x < 0.0) ? x + MD_TWO_PI_D : x - MD_TWO_PI_D;
@@ -158,7 +161,7 @@ md_pll_update(PllState &p, const float *lut, float alpha, float beta, float fmax
 	const float e = md_tanh_lut(lut, i) * q - md_tanh_lut(lut, q) * i;
 
 	const float ph = p.phase + alpha * e;
-	p.phase = (float)md_wrap_2pi((double)ph);
+	p.phase = (float)md_wrap_2pi(ph);
 	p.freq = p.freq + beta * e;
 
 	const float decayed = p.err * (1.0f - 0.001f);
