@@ -55,16 +55,22 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
     out: dict[str, Path] = {}
 
     # --- product library ---------------------------------------------------
-    srcs = [CSRC / "demod_kernel.hip", CSRC / "demod_kernel_rw.hip", CSRC / "demod_aux.hip", CSRC / "recording.hip",
-            CSRC / "demod_api.cpp", CSRC / "host_pipe.cpp", CSRC / "demod_host.cpp"]
+    # (source, object stem, extra flags).  The register-window kernel file is compiled twice: the std geometry with scalar
+    # f32 ops (packed v_pk_* are slower on gfx950) and the max-ILP machine scheduler (measured +1.7 % on configs[1]); the
+    # wide geometry with the default scheduler (max-ILP makes its u8 variants spill inside the main loop).
+    rw = CSRC / "demod_kernel_rw.hip"
+    units = [(CSRC / "demod_kernel.hip", "demod_kernel", []),
+             (rw, "demod_kernel_rw_std", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+             (rw, "demod_kernel_rw_wide", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=2"]),
+             (CSRC / "demod_aux.hip", "demod_aux", []), (CSRC / "recording.hip", "recording", []),
+             (CSRC / "demod_api.cpp", "demod_api", []), (CSRC / "host_pipe.cpp", "host_pipe", []),
+             (CSRC / "demod_host.cpp", "demod_host", [])]
     objs = []
-    for src in srcs:
-        obj = LIB / (src.stem + ".o")
+    for src, stem, extra in units:
+        obj = LIB / (stem + ".o")
         if force or _stale(obj, [src] + headers):
             if verbose:
-                print("hipcc", src.name, flush=True)
-            # the register-window kernel wants scalar f32 ops: packed v_pk_* are slower on gfx950
-            extra = ["-fno-slp-vectorize"] if src.name == "demod_kernel_rw.hip" else []
+                print("hipcc", src.name, "->", obj.name, flush=True)
             _run([hipcc, *COMMON, *extra, "-x", "hip", "-c", str(src), "-o", str(obj)])
         objs.append(obj)
     so = LIB / "libmeteor_demod_amd.so"

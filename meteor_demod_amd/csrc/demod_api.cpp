@@ -88,7 +88,8 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	L.ctab_floats = static_cast<uint32_t>(ctx->tab.ctab.size());
 	L.tanh_lut = ctx->d_lut;
 	if (ctx->tab.use_rw)
-		HIP_TRY(mdemod_launch_demod_rw(L, ctx->params.bps, env_int("MDEMOD_RW_PACKED", 0), ctx->lds_bytes, stream));
+		HIP_TRY(ctx->tab.rw_wide ? mdemod_launch_demod_rw_wide(L, ctx->params.bps, ctx->lds_bytes, stream)
+		                         : mdemod_launch_demod_rw_std(L, ctx->params.bps, env_int("MDEMOD_RW_PACKED", 0), ctx->lds_bytes, stream));
 	else
 		HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->lds_bytes, stream));
 	return MDEMOD_OK;

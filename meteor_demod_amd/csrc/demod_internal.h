@@ -84,7 +84,8 @@ struct DemodLaunch {
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, size_t lds_bytes, hipStream_t stream);
-hipError_t mdemod_launch_demod_rw(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream);
+hipError_t mdemod_launch_demod_rw_std(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream);
+hipError_t mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int float_history, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_seed(const DemodStateSoA &st, const DemodConsts &c, const mdemod_stream_state &v, int32_t flags, int fmt,
                               int float_history, uint32_t n_streams, hipStream_t stream);

@@ -45,6 +45,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MDEMOD_RW_PART
+#define MDEMOD_RW_PART 0              /* 0 = both geometries in one object, 1 = std only, 2 = wide only */
+#endif
 #ifndef MDEMOD_RW_REGSTATE
 #define MDEMOD_RW_REGSTATE 1          /* AGC / NCO state of the float std variant in VGPRs instead of LDS slots */
 #endif
@@ -648,6 +651,7 @@ launch_rw(const DemodLaunch &L, size_t lds_bytes, hipStream_t stream)
 	return hipGetLastError();
 }
 
+#if MDEMOD_RW_PART != 2
 template <int FMT>
 hipError_t
 launch_rw_mode(const DemodLaunch &L, bool packed, size_t lds_bytes, hipStream_t stream)
@@ -658,26 +662,25 @@ launch_rw_mode(const DemodLaunch &L, bool packed, size_t lds_bytes, hipStream_t 
 	}
 	return L.c.oqpsk ? launch_rw<FMT, 1, false, GeoStd>(L, lds_bytes, stream) : launch_rw<FMT, 0, false, GeoStd>(L, lds_bytes, stream);
 }
+#endif
 
+#if MDEMOD_RW_PART != 1
 template <int FMT>
 hipError_t
 launch_rw_wide(const DemodLaunch &L, size_t lds_bytes, hipStream_t stream)
 {
 	return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoWide>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoWide>(L, lds_bytes, stream);
 }
+#endif
 
 } /* namespace */
 
+/* The file is compiled twice (build.py): part 1 = std geometry with the max-ILP machine scheduler, part 2 = wide geometry
+ * with the default one (max-ILP makes the u8 wide kernels spill inside their main loop). */
+#if MDEMOD_RW_PART != 2
 hipError_t
-mdemod_launch_demod_rw(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream)
+mdemod_launch_demod_rw_std(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream)
 {
-	if (L.c.hpad == GeoWide::KB) {                 /* wide geometry: packed window only */
-		switch (fmt) {
-		case 16: return launch_rw_wide<16>(L, lds_bytes, stream);
-		case 8:  return launch_rw_wide<8>(L, lds_bytes, stream);
-		default: return hipErrorInvalidValue;
-		}
-	}
 	switch (fmt) {
 	case 16: return launch_rw_mode<16>(L, packed != 0, lds_bytes, stream);
 	case 8:  return launch_rw_mode<8>(L, packed != 0, lds_bytes, stream);
@@ -685,3 +688,16 @@ mdemod_launch_demod_rw(const DemodLaunch &L, int fmt, int packed, size_t lds_byt
 	default: return hipErrorInvalidValue;
 	}
 }
+#endif
+
+#if MDEMOD_RW_PART != 1
+hipError_t
+mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, size_t lds_bytes, hipStream_t stream)
+{
+	switch (fmt) {
+	case 16: return launch_rw_wide<16>(L, lds_bytes, stream);
+	case 8:  return launch_rw_wide<8>(L, lds_bytes, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+#endif
