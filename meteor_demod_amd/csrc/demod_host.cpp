@@ -130,10 +130,14 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 	const bool std_ok = c.taps <= 65 && per_firing <= 3.6;
 	/* wide: packed window only (s16 / u8), up to 129 taps, up to 15 samples per firing */
 	const bool wide_ok = !std_ok && c.taps <= 129 && per_firing <= 15.0 && p.bps != 32;
+	/* mid: the short filter at a high sample rate (e.g. the default -f 32 at 1.024 MS/s): same lane spread as wide, but
+	 * a 96-slot window instead of 160 */
+	const bool mid_ok = wide_ok && c.taps <= 65;
 	out.use_rw = allow_rw && (std_ok || wide_ok);
-	out.rw_wide = out.use_rw && !std_ok;
+	out.rw_mid = out.use_rw && !std_ok && mid_ok;
+	out.rw_wide = out.use_rw && !std_ok && !mid_ok;
 	c.chunk_granules = 2;
-	if (out.use_rw && !out.rw_wide) {
+	if (out.use_rw && !out.rw_wide && !out.rw_mid) {
 		/* v2: 80-slot register window, filter embedded as 65 taps (leading zeros), 16 alignments */
 		const int kTaps = 65, NW = 80, AL = NW - kTaps + 1;
 		c.hpad = kTaps - 1;
@@ -150,12 +154,12 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 			}
 		return MDEMOD_OK;
 	}
-	if (out.rw_wide) {
+	if (out.rw_wide || out.rw_mid) {
 		/* v2 wide: NW-slot packed window, filter embedded as 129 taps, AMAX + 1 = NW - 128 alignments.
 		 * Compact table: per bank the padded sequence P = AMAX zeros ++ taps ++ AMAX zeros, stored twice:
 		 * array (bank, 0)[i] = P[i], array (bank, 1)[i] = P[i + 1].  A lane at alignment a reads
 		 * P[(AMAX - a) + s] for slot s, i.e. array (bank, o & 1) at the even index (o & ~1) + s. */
-		const int kTaps = 129, NW = MDEMOD_RW_WIDE_NW, AMAX = NW - kTaps;
+		const int kTaps = out.rw_mid ? 65 : 129, NW = out.rw_mid ? MDEMOD_RW_MID_NW : MDEMOD_RW_WIDE_NW, AMAX = NW - kTaps;
 		const int LP = kTaps + 2 * AMAX;
 		c.hpad = kTaps - 1;
 		c.win_granules = NW / 4;

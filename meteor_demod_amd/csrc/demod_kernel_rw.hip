@@ -76,6 +76,9 @@ struct Geo {
 };
 typedef Geo<65, 80, 8, 1, false, MDEMOD_RW_BLOCK> GeoStd;
 typedef Geo<129, MDEMOD_RW_WIDE_NW, MDEMOD_RW_WIDE_SLIDE, MDEMOD_RW_WIDE_MAXSL, true, MDEMOD_RW_WIDE_BLOCK> GeoWide;
+/* Mid: the short filter at a high sample rate: wide's lane spread (32 alignments, 16-slot slides, compact table) on a
+ * 96-slot packed window */
+typedef Geo<65, MDEMOD_RW_MID_NW, 16, 1, true, MDEMOD_RW_BLOCK> GeoMid;
 
 template <int FMT> struct Fmt;
 template <> struct Fmt<16> {
@@ -271,7 +274,7 @@ blind_steps(float p, float f)
 /* ---- the kernel ------------------------------------------------------------------ */
 
 template <int FMT, int OQPSK, bool PACKED, typename G>
-__global__ void __launch_bounds__(G::BLOCK, (PACKED && G::KT <= 65) ? 3 : 2)
+__global__ void __launch_bounds__(G::BLOCK, (PACKED && G::NW <= 80) ? 3 : 2)
 demod_kernel_rw(const DemodLaunch L)
 {
 	typedef Fmt<FMT> F;
@@ -667,8 +670,9 @@ launch_rw_mode(const DemodLaunch &L, bool packed, size_t lds_bytes, hipStream_t 
 #if MDEMOD_RW_PART != 1
 template <int FMT>
 hipError_t
-launch_rw_wide(const DemodLaunch &L, size_t lds_bytes, hipStream_t stream)
+launch_rw_wide(const DemodLaunch &L, int mid, size_t lds_bytes, hipStream_t stream)
 {
+	if (mid) return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoMid>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoMid>(L, lds_bytes, stream);
 	return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoWide>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoWide>(L, lds_bytes, stream);
 }
 #endif
@@ -692,11 +696,11 @@ mdemod_launch_demod_rw_std(const DemodLaunch &L, int fmt, int packed, size_t lds
 
 #if MDEMOD_RW_PART != 1
 hipError_t
-mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, size_t lds_bytes, hipStream_t stream)
+mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, int mid, size_t lds_bytes, hipStream_t stream)
 {
 	switch (fmt) {
-	case 16: return launch_rw_wide<16>(L, lds_bytes, stream);
-	case 8:  return launch_rw_wide<8>(L, lds_bytes, stream);
+	case 16: return launch_rw_wide<16>(L, mid, lds_bytes, stream);
+	case 8:  return launch_rw_wide<8>(L, mid, lds_bytes, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -208,7 +208,9 @@ WIDE_CFGS = {
     "oqpsk80k_1M": DemodConfig(samplerate=1000000, symrate=80000, oqpsk=True, rrc_order=64, interp_factor=8),
     "taps97_os6": DemodConfig(samplerate=500000, rrc_order=48, interp_factor=6),
     "edge_15_per_symbol": DemodConfig(samplerate=1075000, rrc_order=40, interp_factor=4),   # 14.93 samples per symbol (1080000 would put an RRC singularity 0/0 on a tap: NaN, UB in the reference)
-    "taps65_slow_clock": DemodConfig(samplerate=460000, rrc_order=32, interp_factor=5),   # 65 taps but 6.4 samples/firing: ring kernel
+    "taps65_slow_clock": DemodConfig(samplerate=460000, rrc_order=32, interp_factor=5),   # 65 taps at 6.4 samples/firing: mid geometry
+    "defaults_1024k": DemodConfig(samplerate=1024000),                                    # RTL-SDR rate, default -f 32 -O 5: mid geometry
+    "defaults_1024k_oqpsk_u8": DemodConfig(samplerate=1024000, oqpsk=True, bps=8),
 }
 
 
