@@ -155,11 +155,12 @@ def other_configs(skip: str, T: int, L: int, local: int) -> dict:
     from meteor_demod_amd import Demodulator, synth
     res = {}
     from meteor_demod_amd import DemodConfig
-    extra = (DemodConfig(samplerate=1024000), "not in BASELINE.json: QPSK 72k, 1.024 MS/s s16, default RRC order 32, oversamp 5")
-    for tag in ("c3", "c4", "x"):
+    extra = {"x1": (DemodConfig(samplerate=1024000), "not in BASELINE.json: QPSK 72k, 1.024 MS/s s16, default RRC order 32, oversamp 5"),
+             "x2": (DemodConfig(samplerate=1800000), "not in BASELINE.json: QPSK 72k, 1.8 MS/s s16, default RRC order 32, oversamp 5")}
+    for tag in ("c3", "c4", "x1", "x2"):
         if tag == skip:
             continue
-        cfg, workload = extra if tag == "x" else demod_config(tag)
+        cfg, workload = extra[tag] if tag in extra else demod_config(tag)
         rec = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0)
         buf = torch.empty((T * L, 2), dtype=torch.int16, device=f"cuda:{local}")
         synth.generate_device([rec], T * L, out=buf.view(1, T * L, 2), device=local)

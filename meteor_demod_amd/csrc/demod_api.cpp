@@ -88,7 +88,8 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	L.ctab_floats = static_cast<uint32_t>(ctx->tab.ctab.size());
 	L.tanh_lut = ctx->d_lut;
 	if (ctx->tab.use_rw)
-		HIP_TRY((ctx->tab.rw_wide || ctx->tab.rw_mid) ? mdemod_launch_demod_rw_wide(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : 0, ctx->lds_bytes, stream)
+		HIP_TRY((ctx->tab.rw_wide || ctx->tab.rw_mid || ctx->tab.rw_far)
+		        ? mdemod_launch_demod_rw_wide(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream)
 		                         : mdemod_launch_demod_rw_std(L, ctx->params.bps, env_int("MDEMOD_RW_PACKED", 0), ctx->lds_bytes, stream));
 	else
 		HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->lds_bytes, stream));
@@ -447,6 +448,7 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (!ctx) return "";
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
 	if (ctx->tab.rw_wide) return "demod_kernel_rw (v2 register window, wide: 129 taps, packed)";
+	if (ctx->tab.rw_far) return "demod_kernel_rw (v2 register window, far: 65 taps at up to 30 samples per firing, packed)";
 	if (ctx->tab.rw_mid) return "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, packed)";
 	return (ctx->params.bps != 32 && env_int("MDEMOD_RW_PACKED", 0))
 	       ? "demod_kernel_rw (v2 register window, packed)" : "demod_kernel_rw (v2 register window, float)";

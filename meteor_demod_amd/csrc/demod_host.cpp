@@ -133,11 +133,14 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 	/* mid: the short filter at a high sample rate (e.g. the default -f 32 at 1.024 MS/s): same lane spread as wide, but
 	 * a 96-slot window instead of 160 */
 	const bool mid_ok = wide_ok && c.taps <= 65;
-	out.use_rw = allow_rw && (std_ok || wide_ok);
+	/* far: the short filter at 2 MS/s-class rates: up to 30 samples per firing, two 16-slot slides per iteration */
+	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= 30.0 && p.bps != 32;
+	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok);
 	out.rw_mid = out.use_rw && !std_ok && mid_ok;
-	out.rw_wide = out.use_rw && !std_ok && !mid_ok;
+	out.rw_far = out.use_rw && far_ok;
+	out.rw_wide = out.use_rw && !std_ok && !mid_ok && !far_ok;
 	c.chunk_granules = 2;
-	if (out.use_rw && !out.rw_wide && !out.rw_mid) {
+	if (out.use_rw && !out.rw_wide && !out.rw_mid && !out.rw_far) {
 		/* v2: 80-slot register window, filter embedded as 65 taps (leading zeros), 16 alignments */
 		const int kTaps = 65, NW = 80, AL = NW - kTaps + 1;
 		c.hpad = kTaps - 1;
@@ -154,12 +157,13 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 			}
 		return MDEMOD_OK;
 	}
-	if (out.rw_wide || out.rw_mid) {
+	if (out.rw_wide || out.rw_mid || out.rw_far) {
 		/* v2 wide: NW-slot packed window, filter embedded as 129 taps, AMAX + 1 = NW - 128 alignments.
 		 * Compact table: per bank the padded sequence P = AMAX zeros ++ taps ++ AMAX zeros, stored twice:
 		 * array (bank, 0)[i] = P[i], array (bank, 1)[i] = P[i + 1].  A lane at alignment a reads
 		 * P[(AMAX - a) + s] for slot s, i.e. array (bank, o & 1) at the even index (o & ~1) + s. */
-		const int kTaps = out.rw_mid ? 65 : 129, NW = out.rw_mid ? MDEMOD_RW_MID_NW : MDEMOD_RW_WIDE_NW, AMAX = NW - kTaps;
+		const int kTaps = out.rw_wide ? 129 : 65;
+		const int NW = out.rw_mid ? MDEMOD_RW_MID_NW : (out.rw_far ? MDEMOD_RW_FAR_NW : MDEMOD_RW_WIDE_NW), AMAX = NW - kTaps;
 		const int LP = kTaps + 2 * AMAX;
 		c.hpad = kTaps - 1;
 		c.win_granules = NW / 4;

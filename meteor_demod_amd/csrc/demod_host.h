@@ -17,6 +17,7 @@ struct HostTables {
 	std::vector<float> ctab;      /* [4 alignments][interp banks][row stride]  */
 	float              tanh_lut[32];
 	bool               rw_wide;   /* v2 wide geometry (129-tap packed window, compact table, 512-thread blocks) */
+	bool               rw_far;    /* v2 far geometry: <= 65 taps at 15..30 samples per firing (112-slot packed window, two slides per iteration) */
 	bool               rw_mid;    /* v2 mid geometry: <= 65 taps at 3.6..15 samples per firing (96-slot packed window, compact table) */
 	bool               use_rw;    /* v2 register-window kernel eligible (taps <= 65, <= 3.6 samples per firing) */
 };

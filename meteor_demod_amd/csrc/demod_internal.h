@@ -18,6 +18,7 @@
 #define MDEMOD_RW_WIDE_MAXSL    1      /* slides per loop iteration                 */
 #endif
 #define MDEMOD_RW_MID_NW        96     /* window slots of the mid geometry (65 taps + 32 alignments)      */
+#define MDEMOD_RW_FAR_NW        112    /* window slots of the far geometry (65 taps + 48 alignments)      */
 #ifndef MDEMOD_RW_BLOCK
 #define MDEMOD_RW_BLOCK         256    /* threads per block of the v2 kernel        */
 #endif
@@ -86,7 +87,7 @@ struct DemodLaunch {
 #include <hip/hip_runtime.h>
 hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_rw_std(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream);
-hipError_t mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, int mid, size_t lds_bytes, hipStream_t stream);
+hipError_t mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mid, 2 far */, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int float_history, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_seed(const DemodStateSoA &st, const DemodConsts &c, const mdemod_stream_state &v, int32_t flags, int fmt,
                               int float_history, uint32_t n_streams, hipStream_t stream);

@@ -79,6 +79,8 @@ typedef Geo<129, MDEMOD_RW_WIDE_NW, MDEMOD_RW_WIDE_SLIDE, MDEMOD_RW_WIDE_MAXSL, 
 /* Mid: the short filter at a high sample rate: wide's lane spread (32 alignments, 16-slot slides, compact table) on a
  * 96-slot packed window */
 typedef Geo<65, MDEMOD_RW_MID_NW, 16, 1, true, MDEMOD_RW_BLOCK> GeoMid;
+/* Far: the same at 2 MS/s-class rates (up to 30 samples per firing): 48 alignments, two slides per iteration */
+typedef Geo<65, MDEMOD_RW_FAR_NW, 16, 2, true, MDEMOD_RW_BLOCK> GeoFar;
 
 template <int FMT> struct Fmt;
 template <> struct Fmt<16> {
@@ -672,7 +674,8 @@ template <int FMT>
 hipError_t
 launch_rw_wide(const DemodLaunch &L, int mid, size_t lds_bytes, hipStream_t stream)
 {
-	if (mid) return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoMid>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoMid>(L, lds_bytes, stream);
+	if (mid == 1) return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoMid>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoMid>(L, lds_bytes, stream);
+	if (mid == 2) return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoFar>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoFar>(L, lds_bytes, stream);
 	return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoWide>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoWide>(L, lds_bytes, stream);
 }
 #endif

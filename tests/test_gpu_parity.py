@@ -211,6 +211,8 @@ WIDE_CFGS = {
     "taps65_slow_clock": DemodConfig(samplerate=460000, rrc_order=32, interp_factor=5),   # 65 taps at 6.4 samples/firing: mid geometry
     "defaults_1024k": DemodConfig(samplerate=1024000),                                    # RTL-SDR rate, default -f 32 -O 5: mid geometry
     "defaults_1024k_oqpsk_u8": DemodConfig(samplerate=1024000, oqpsk=True, bps=8),
+    "defaults_2048k": DemodConfig(samplerate=2048000),                                    # 28.4 samples per symbol: far geometry
+    "far_edge_u8": DemodConfig(samplerate=2150000, rrc_order=20, interp_factor=3, bps=8), # 29.9 samples per symbol
 }
 
 
