@@ -45,6 +45,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MDEMOD_RW_3WAVES_NW
+#define MDEMOD_RW_3WAVES_NW 96        /* packed windows up to this many slots are built for 3 waves/SIMD (<= 168 VGPRs): the mid geometry spills ~30 dwords there and is still 7 % faster than at 2 waves */
+#endif
 #ifndef MDEMOD_RW_PART
 #define MDEMOD_RW_PART 0              /* 0 = both geometries in one object, 1 = std only, 2 = wide only */
 #endif
@@ -276,7 +279,7 @@ blind_steps(float p, float f)
 /* ---- the kernel ------------------------------------------------------------------ */
 
 template <int FMT, int OQPSK, bool PACKED, typename G>
-__global__ void __launch_bounds__(G::BLOCK, (PACKED && G::NW <= 80) ? 3 : 2)
+__global__ void __launch_bounds__(G::BLOCK, (PACKED && G::NW <= MDEMOD_RW_3WAVES_NW) ? 3 : 2)
 demod_kernel_rw(const DemodLaunch L)
 {
 	typedef Fmt<FMT> F;
