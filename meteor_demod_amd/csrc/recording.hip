@@ -267,8 +267,9 @@ extern "C" void
 mdemod_recording_default_opts(mdemod_recording_opts *o)
 {
 	if (!o) return;
-	o->tile_samples = 65600;                 /* not a power of two: the lanes of a wave must not share L2 sets */
-	o->pre_samples = 16384; o->pilot_block = 65536; o->pilot_margin_symbols = 20000;
+	o->tile_samples = 0;                     /* 0 = 20 536 symbols worth of samples (65 600 at 72k in 230 kS/s), kept off powers of two */
+	o->pre_samples = 0xFFFFFFFFu;            /* 0xFFFFFFFF = 5 129 symbols worth of samples (16 384 at 72k in 230 kS/s) */
+	o->pilot_block = 65536; o->pilot_margin_symbols = 20000;
 	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->refine = 1; o->reserved = 0;
 }
 
@@ -282,6 +283,14 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	mdemod_recording_opts o;
 	if (opts_in) o = *opts_in; else mdemod_recording_default_opts(&o);
 	if (params->oqpsk && !o.refine) return MDEMOD_ERR_PARAM;     /* OQPSK needs the state rotation pass: DESIGN.md 3.1 */
+	{	/* same rule as recording.py:default_tiling() */
+		const double osf = static_cast<double>(params->samplerate) / static_cast<double>(params->symrate);
+		if (o.tile_samples == 0) {
+			o.tile_samples = std::max<uint32_t>(4096, static_cast<uint32_t>(20536 * osf) / 64 * 64);
+			if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
+		}
+		if (o.pre_samples == 0xFFFFFFFFu) o.pre_samples = static_cast<uint32_t>(5129 * osf);
+	}
 	if (!o.tile_samples || !o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
 	memset(rep, 0, sizeof(*rep));

@@ -68,6 +68,21 @@ def plan_tiles(n_samples: int, pilot_end: int, tile_samples: int, pre_samples: i
     return TilePlan(n_samples, pilot_end, starts, lens, pres)
 
 
+def default_tiling(cfg, tile_samples: int = 0, pre_samples: int = -1):
+    """Tile and warm-up lengths when the caller gives none (0 / -1): 20 536 and 5 129 SYMBOLS worth of samples, i.e. 65 600 and
+    16 384 samples at the reference's 72 k symbols in 230 kS/s, scaled with the samples per symbol so that a 1 MS/s
+    recording gets tiles of the same duration in symbols.  The tile is kept off powers of two (lanes read at base + l * tile:
+    a power-of-two stride puts a wave's lanes on the same L2 sets).  Same rule in csrc/recording.hip."""
+    osf = cfg.samplerate / cfg.symrate
+    if tile_samples <= 0:
+        tile_samples = max(4096, int(20536 * osf) // 64 * 64)
+        if tile_samples & (tile_samples - 1) == 0:
+            tile_samples += 64
+    if pre_samples < 0:
+        pre_samples = int(5129 * osf)
+    return int(tile_samples), int(pre_samples)
+
+
 # ---- int8 symbol helpers (torch tensors, any device) -------------------------------------------
 
 def rotate_symbols(sym, quarter_turns):
@@ -214,7 +229,7 @@ class RecordingDemodulator:
     set_history, set_state_all, rotate_carrier, close``).  The default is the HIP :class:`Demodulator`.
     """
 
-    def __init__(self, cfg, tile_samples: int = 65600, pre_samples: int = 16384, refine: bool = True,
+    def __init__(self, cfg, tile_samples: int = 0, pre_samples: int = -1, refine: bool = True,
                  pilot_block: int = 65536, pilot_margin_symbols: int = 20000, max_pilot_samples: int = 1 << 22,
                  match_symbols: int = 192, device: int = 0, bank_factory=None, post_samples: int = 4096):
         if cfg.oqpsk and not refine:
@@ -224,6 +239,7 @@ class RecordingDemodulator:
             raise NotImplementedError("overlapped tiles of an OQPSK recording need refine=True")
         self.cfg = cfg
         self.post_samples = int(post_samples)
+        tile_samples, pre_samples = default_tiling(cfg, tile_samples, pre_samples)
         self.tile_samples = int(tile_samples)
         self.pre_samples = int(pre_samples)
         self.refine = bool(refine)
@@ -449,7 +465,7 @@ class RecordingDemodulator:
 
 # ---- the same scheme inside the library (csrc/recording.hip) --------------------------------------
 
-def demodulate_recording_native(cfg, iq, tile_samples: int = 65600, pre_samples: int = 16384, refine: bool = True,
+def demodulate_recording_native(cfg, iq, tile_samples: int = 0, pre_samples: int = -1, refine: bool = True,
                                 pilot_block: int = 65536, pilot_margin_symbols: int = 20000,
                                 max_pilot_samples: int = 1 << 22, match_symbols: int = 192, device: int = 0):
     """``mdemod_demodulate_recording`` on a device tensor [n, 2]: returns (soft int8 [m, 2] device tensor, report)."""
@@ -458,6 +474,7 @@ def demodulate_recording_native(cfg, iq, tile_samples: int = 65600, pre_samples:
     from . import _capi
     lib = _capi.lib()
     assert iq.is_cuda and iq.dim() == 2 and iq.shape[1] == 2 and iq.is_contiguous()
+    tile_samples, pre_samples = default_tiling(cfg, tile_samples, pre_samples)
     opts = _capi.MdemodRecordingOpts(tile_samples, pre_samples, pilot_block, pilot_margin_symbols, max_pilot_samples,
                                      match_symbols, int(refine), 0)
     n = int(iq.shape[0])

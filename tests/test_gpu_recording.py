@@ -168,3 +168,24 @@ def test_native_and_python_stitchers_agree_on_random_settings(seed, gpu_device):
     assert rep.n_tiles == want.report.n_tiles and rep.pilot_symbols == want.report.pilot_symbols, kw
     assert rep.weak_seams == want.report.weak_seams and rep.seam_fixes == sum(1 for s in want.report.seam_shifts if s), kw
     assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy()), kw
+
+
+def test_recording_at_one_megasample_uses_scaled_tiles(gpu_device):
+    """A 1.024 MS/s recording (default filter: mid geometry): the default tile and warm-up lengths scale with the samples
+    per symbol (292 k / 73 k samples), native == python, and the result agrees with the serial oracle."""
+    import torch
+    from meteor_demod_amd.recording import default_tiling, demodulate_recording_native
+    cfg = DemodConfig(samplerate=1024000)
+    assert default_tiling(C1) == (65600, 16384) and default_tiling(cfg)[0] > 290_000
+    # rms 1500: with 14 samples per symbol a 6000-LSB signal drives the reference's AGC into its 0 <-> 0.019 limit cycle
+    # (gain += 1e-4 * (190 - |y|) overshoots below zero), in the serial run as much as in the tiles
+    st = synth.make_stream(12, 1024000, 72000, f0_hz=500.0, clock_ppm=-15.0, esn0_db=14.0, rms=1500.0)
+    iq = synth.generate_device([st], 24_000_000)[0]
+    want = RecordingDemodulator(cfg).demodulate(iq)
+    soft, rep = demodulate_recording_native(cfg, iq)
+    assert rep.n_tiles == want.report.n_tiles > 50 and rep.weak_seams == 0
+    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy())
+    serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
+    a = agreement(soft.cpu().numpy(), serial)
+    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.95
+    assert np.array_equal(soft[: rep.pilot_symbols].cpu().numpy(), serial[: rep.pilot_symbols])
