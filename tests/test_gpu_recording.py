@@ -144,6 +144,31 @@ def test_native_stitcher_short_recording_and_errors(gpu_device):
         demodulate_recording_native(DemodConfig(samplerate=230000, symrate=80000, oqpsk=True), iq, refine=False)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_native_and_python_stitchers_agree_on_random_settings_oqpsk(seed, gpu_device):
+    """The same for OQPSK (rail matching, state rotation, look-ahead seams), with gaps and bursts."""
+    import torch
+    from meteor_demod_amd.recording import demodulate_recording_native
+    rng = np.random.default_rng(300 + seed)
+    cfg = DemodConfig(samplerate=int(rng.choice([230000, 250000, 460000])), symrate=80000, oqpsk=True)
+    st = synth.make_stream(700 + seed, cfg.samplerate, 80000, f0_hz=float(rng.uniform(-500, 700)), clock_ppm=float(rng.uniform(-40, 40)),
+                           esn0_db=float(rng.choice([6.0, 10.0, 14.0, 20.0])), oqpsk=True, rms=3000.0)
+    n = int(rng.integers(2_000_000, 4_000_000))
+    iq = synth.generate_device([st], n)[0]
+    if seed >= 2:
+        g0 = int(rng.integers(n // 3, n // 2))
+        iq[g0: g0 + 200_000] = 0
+        iq[g0 + 200_000: g0 + 215_000] = -32768
+    kw = dict(tile_samples=int(rng.choice([0, 16448, 40000])), pre_samples=int(rng.choice([-1, 4096, 20000])), refine=True,
+              pilot_block=int(rng.choice([16384, 65536])), pilot_margin_symbols=int(rng.choice([0, 5000, 60000])),
+              match_symbols=int(rng.choice([64, 192])))
+    want = RecordingDemodulator(cfg, **kw).demodulate(iq)
+    soft, rep = demodulate_recording_native(cfg, iq, **kw)
+    assert rep.n_tiles == want.report.n_tiles and rep.pilot_symbols == want.report.pilot_symbols, kw
+    assert rep.weak_seams == want.report.weak_seams and rep.seam_fixes == sum(1 for s in want.report.seam_shifts if s), kw
+    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy()), kw
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_native_and_python_stitchers_agree_on_random_settings(seed, gpu_device):
     """Random tile / warm-up / margin / match settings, offsets of both signs, noise levels down to 4 dB (weak seams,
