@@ -39,6 +39,18 @@ def test_abi_version_and_struct_layouts():
     assert C.sizeof(_capi.MdemodStatus) == 56
     assert C.sizeof(_capi.MdemodLockEvent) == 16
     assert C.sizeof(_capi.MdemodStreamState) == 80
+    assert C.sizeof(_capi.MdemodRecordingOpts) == 40 and C.sizeof(_capi.MdemodRecordingReport) == 72
+    # the C compiler agrees with the ctypes mirrors
+    import subprocess, tempfile
+    from conftest import ROOT
+    src = ('#include <stdio.h>\n#include "meteor_demod_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mdemod_params), '
+           'sizeof(mdemod_status), sizeof(mdemod_lock_event), sizeof(mdemod_stream_state), sizeof(mdemod_recording_opts), '
+           'sizeof(mdemod_recording_report)); return 0;}')
+    with tempfile.TemporaryDirectory() as td:
+        (Path(td) / "s.c").write_text(src)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), str(Path(td) / "s.c"), "-o", str(Path(td) / "s")], check=True)
+        out = subprocess.run([str(Path(td) / "s")], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(x) for x in out] == [48, 56, 16, 80, 40, 72]
     assert lib.mdemod_strerror(-3).decode().startswith("HIP")
 
 
