@@ -61,6 +61,26 @@ def test_cli_stdout_mode_and_errors(manifest, tmp_path, gpu_device):
     assert r.returncode == 1 and "sample rate" in r.stderr
 
 
+def test_cli_reads_a_pipe_in_short_blocks(manifest, tmp_path, gpu_device):
+    """`-` = stdin (the reference's README: pipe from an SDR), raw samples with -s/--bps, 256 KiB blocks.  Like the
+    reference, the WAV probe consumes 44 bytes and the rewind (main.c:164-166) does nothing on a pipe: the stream starts
+    at byte 44.  Compared with the oracle's file model and, where the reference binary is present, with the binary."""
+    import oracle_py as O
+    from meteor_demod_amd import DemodConfig
+    meta = manifest["file_cases"]["file_raw_u8"]
+    data = file_case_bytes(meta)
+    out = tmp_path / "out.s"
+    r = subprocess.run([str(CLI), "-q", "-B", "-o", str(out), *meta["cli_args"], "-"], input=data, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    got = out.read_bytes()
+    assert got == O.OracleStream(DemodConfig(**meta["cfg"])).file_model(data[44:], 8)
+    if O.REF_BINARY.exists():
+        ref_out = tmp_path / "ref.s"
+        rr = subprocess.run([str(O.REF_BINARY), "-q", "-B", "-o", str(ref_out), *meta["cli_args"], "-"], input=data, capture_output=True)
+        if rr.returncode == 0 and ref_out.exists():
+            assert got == ref_out.read_bytes()
+
+
 def test_cli_tiled_mode_single_file(tmp_path, gpu_device):
     """--tiled: one file on many lanes.  The .s file is the lock-gated stream of mdemod_demodulate_recording:
     its head is the reference's own bytes and the whole file agrees with the serial oracle's file to the loops'
