@@ -215,6 +215,11 @@ int  mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void
  * symbol apart). */
 int  mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, void *hip_stream);
 
+/* Per-stream carrier seeds (device arrays of n_streams entries): pll frequency in rad/symbol and sweep direction
+ * (+1 / -1, pll.c:112) of stream s := freq_dev[s], updown_dev[s]; everything else is left as it is.  Used with
+ * mdemod_set_state_all when the carrier moves along the recording (Doppler) and every tile needs its local estimate. */
+int  mdemod_set_carrier_seeds(mdemod_ctx *ctx, const float *freq_dev, const int32_t *updown_dev, void *hip_stream);
+
 /* The whole scheme in one call (native counterpart of meteor_demod_amd/recording.py):
  * the head of the recording is demodulated serially from the reference's power-on state until the
  * carrier loop has locked and converged (those symbols are the reference's symbols), the rest as

@@ -442,6 +442,16 @@ mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, void *h
 	return MDEMOD_OK;
 }
 
+int
+mdemod_set_carrier_seeds(mdemod_ctx *ctx, const float *freq_dev, const int32_t *updown_dev, void *hip_stream)
+{
+	if (!ctx || !freq_dev || !updown_dev) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	HIP_TRY(mdemod_launch_carrier_seeds(ctx->st, freq_dev, updown_dev, ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
+	return MDEMOD_OK;
+}
+
 const char *
 mdemod_kernel_name(const mdemod_ctx *ctx)
 {

@@ -78,6 +78,16 @@ rotate_kernel(DemodStateSoA st, const int32_t *quarter_turns, uint32_t n_streams
 	}
 }
 
+__global__ void
+carrier_seed_kernel(DemodStateSoA st, const float *freq, const int32_t *updown, uint32_t n_streams)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_streams) return;
+	st.pll_freq[s] = freq[s];
+	const int fl = st.flags[s];
+	st.flags[s] = updown[s] > 0 ? (fl | MDEMOD_FLAG_UPDOWN_POS) : (fl & ~MDEMOD_FLAG_UPDOWN_POS);
+}
+
 /* Host path: the demodulator writes its soft symbols with the hard-bound row pitch (one symbol per input sample);
  * what goes over PCIe is a copy with the nominal pitch.  One block per stream, 16-byte moves (pitches are multiples of
  * 8 symbols). */
@@ -183,6 +193,14 @@ mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_turns_dev, 
 {
 	if (n_streams == 0) return hipSuccess;
 	hipLaunchKernelGGL(rotate_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, quarter_turns_dev, n_streams, oqpsk);
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_carrier_seeds(const DemodStateSoA &st, const float *freq_dev, const int32_t *updown_dev, uint32_t n_streams, hipStream_t stream)
+{
+	if (n_streams == 0) return hipSuccess;
+	hipLaunchKernelGGL(carrier_seed_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, freq_dev, updown_dev, n_streams);
 	return hipGetLastError();
 }
 

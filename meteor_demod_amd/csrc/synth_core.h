@@ -48,6 +48,7 @@ typedef struct {
 	double   dc_i, dc_q;
 	int32_t  oqpsk;         /* Q rail delayed by half a symbol                   */
 	int32_t  fmt;           /* 8, 16, 32 — the reference's --bps values          */
+	int64_t  car_ramp48;    /* Doppler ramp: change of car_step per sample, units of 2^-48 turn per sample^2 */
 } synth_stream;
 
 SYNTH_HD uint64_t
@@ -118,7 +119,10 @@ synth_sample(const synth_tables *tb, const synth_stream *st, uint64_t n, double 
 	const double bi = synth_rail(tb, st->seed, t, 0);
 	const double bq = synth_rail(tb, st->seed, st->oqpsk ? t - 0x80000000ull : t, 1);
 
-	const uint32_t th = st->car_phase0 + (uint32_t)n * st->car_step;
+	/* phase = phase0 + n*step + ramp*n(n-1)/2, all modulo one turn: only bits 16..47 of the 2^-48 product matter, so the
+	 * 64-bit wrap-around of the multiplication is harmless */
+	const uint64_t tri = (n & 1) ? n * ((n - 1) >> 1) : (n >> 1) * (n - 1);
+	const uint32_t th = st->car_phase0 + (uint32_t)n * st->car_step + (uint32_t)((tri * (uint64_t)st->car_ramp48) >> 16);
 	const uint32_t hi = th >> 22, lo = (th >> 12) & 0x3FFu;
 	const double c = tb->cos_hi[hi] * tb->cos_lo[lo] - tb->sin_hi[hi] * tb->sin_lo[lo];
 	const double s = tb->sin_hi[hi] * tb->cos_lo[lo] + tb->cos_hi[hi] * tb->sin_lo[lo];

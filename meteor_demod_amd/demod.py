@@ -215,6 +215,13 @@ class Demodulator:
         check(self._lib.mdemod_rotate_carrier(self._ctx, C.c_void_p(quarter_turns.data_ptr()), self._stream()),
               "mdemod_rotate_carrier")
 
+    def set_carrier_seeds(self, freq, updown) -> None:
+        """pll frequency (rad/symbol, float32 device tensor) and sweep direction (+1/-1, int32 device tensor) per stream."""
+        assert freq.numel() == self.n_streams and updown.numel() == self.n_streams
+        assert freq.element_size() == 4 and updown.element_size() == 4 and freq.is_contiguous() and updown.is_contiguous()
+        check(self._lib.mdemod_set_carrier_seeds(self._ctx, C.c_void_p(freq.data_ptr()), C.c_void_p(updown.data_ptr()),
+                                                 self._stream()), "mdemod_set_carrier_seeds")
+
     @property
     def kernel_name(self) -> str:
         return self._lib.mdemod_kernel_name(self._ctx).decode()

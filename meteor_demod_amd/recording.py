@@ -195,6 +195,42 @@ def match_rails(a_tail, b_tail):
     return best[1], best[0], energy
 
 
+def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33):
+    """Feed-forward carrier estimate of each tile (QPSK): the 4th power of the samples has a spectral line at 4x the carrier
+    offset whatever the data (the reference finds the carrier by sweeping its PLL at 1e-6 rad/symbol per symbol, pll.c:125,
+    which is what a tile that starts far from the pilot's estimate has no time for).  ``nfft`` samples from each start,
+    batched FFT, peak within +-4*fmax with parabolic interpolation.  Returns (freq [T] float32 rad/symbol at the MIDDLE of the
+    window, peak-to-mean ratio [T]).  torch.fft on whatever device ``iq`` lives on; estimation only, never symbols."""
+    import torch
+    T = int(starts.shape[0])
+    dev = iq.device
+    n = iq.shape[0]
+    kmax = int(4 * fmax_rad * symrate / (2 * np.pi) / samplerate * nfft) + 2          # bins of 4 * fmax
+    win = torch.hann_window(nfft, periodic=False, device=dev, dtype=torch.float32)
+    freq = torch.zeros(T, dtype=torch.float32, device=dev)
+    quality = torch.zeros(T, dtype=torch.float32, device=dev)
+    step = max(1, (1 << 28) // (nfft * 8))                                           # <= 256 MiB of complex64 per batch
+    ar = torch.arange(nfft, device=dev)
+    for t0 in range(0, T, step):
+        t1 = min(T, t0 + step)
+        st = torch.as_tensor(np.minimum(np.asarray(starts[t0:t1], dtype=np.int64), max(0, n - nfft)), device=dev)
+        idx = (st.view(-1, 1) + ar.view(1, -1)).clamp(max=n - 1)
+        x = iq[idx]                                                                   # [b, nfft, 2]
+        z = torch.complex(x[..., 0].to(torch.float32), x[..., 1].to(torch.float32))
+        z = z - z.mean(dim=1, keepdim=True)
+        z = z / (z.abs().mean(dim=1, keepdim=True) + 1e-20)
+        z4 = (z * z) * (z * z) * win
+        sp = torch.fft.fft(z4, dim=1).abs()
+        cand = torch.cat((sp[:, -kmax:], sp[:, : kmax + 1]), dim=1)                    # bins -kmax .. +kmax
+        pk = cand[:, 1:-1].argmax(dim=1) + 1
+        a, b, c = (cand.gather(1, (pk + d).view(-1, 1)).squeeze(1) for d in (-1, 0, 1))
+        delta = 0.5 * (a - c) / (a - 2 * b + c - 1e-20)
+        k = (pk - kmax).to(torch.float32) + delta
+        freq[t0:t1] = (k * (samplerate / nfft / 4.0) * (2 * np.pi / symrate)).to(torch.float32)
+        quality[t0:t1] = b / (cand.mean(dim=1) + 1e-20)
+    return freq, quality
+
+
 # ---- result ---------------------------------------------------------------------------------
 
 @dataclass
@@ -209,6 +245,7 @@ class StitchReport:
     weak_seams: int = 0                                    # seams whose correlation was too weak to trust
     refine_rotations: list = field(default_factory=list)   # pass 2: residual rotation per tile (0 expected)
     samples_demodulated: int = 0                           # total kernel work incl. warm-up and pass 2
+    carrier_seeds: list = field(default_factory=list)      # carrier_seed='spectrum': rad/symbol given to every tile
 
 
 @dataclass
@@ -231,12 +268,16 @@ class RecordingDemodulator:
 
     def __init__(self, cfg, tile_samples: int = 0, pre_samples: int = -1, refine: bool = True,
                  pilot_block: int = 65536, pilot_margin_symbols: int = 20000, max_pilot_samples: int = 1 << 22,
-                 match_symbols: int = 192, device: int = 0, bank_factory=None, post_samples: int = 4096):
+                 match_symbols: int = 192, device: int = 0, bank_factory=None, post_samples: int = 4096,
+                 carrier_seed: str = "pilot"):
         if cfg.oqpsk and not refine:
             # the I and Q rails of OQPSK come from different firings (demod.c:66-76): a 90 degree lock offset is
             # entangled with the half-symbol state of the symbol clock, which rotate_symbols() cannot undo on the
             # output; only the second pass (which turns the STATE, mdemod_rotate_carrier) handles it.
             raise NotImplementedError("overlapped tiles of an OQPSK recording need refine=True")
+        if carrier_seed not in ("pilot", "spectrum") or (carrier_seed == "spectrum" and cfg.oqpsk):
+            raise NotImplementedError("carrier_seed is 'pilot' or, for QPSK, 'spectrum'")
+        self.carrier_seed = carrier_seed
         self.cfg = cfg
         self.post_samples = int(post_samples)
         tile_samples, pre_samples = default_tiling(cfg, tile_samples, pre_samples)
@@ -306,6 +347,22 @@ class RecordingDemodulator:
 
         # ---- pass 1: warm-up (dropped) then body, from the pilot's end state -----------------
         bank.set_state_all(seed)
+        if self.carrier_seed == "spectrum":
+            # Doppler: every tile starts from ITS OWN carrier estimate (4th-power spectrum of its warm-up and the samples
+            # after it), moved to the first warm-up sample with the local slope, sweep direction = sign of the slope
+            nfft = 1 << int(np.floor(np.log2(max(4096, min(self.tile_samples + self.pre_samples, 1 << 17)))))
+            w0 = plan.starts - plan.pres
+            fmid, qual = carrier_estimates(iq, w0, nfft, self.cfg.samplerate, self.cfg.symrate)
+            dt_sym = self.tile_samples * self.cfg.symrate / self.cfg.samplerate            # symbols between tile starts
+            slope = torch.zeros_like(fmid)
+            if T > 2:
+                slope[1:-1] = (fmid[2:] - fmid[:-2]) / (2 * dt_sym)
+                slope[0], slope[-1] = slope[1], slope[-2]
+            f0 = fmid - slope * (nfft / 2) * self.cfg.symrate / self.cfg.samplerate
+            fmax = float(bank.carrier_fmax()) if hasattr(bank, "carrier_fmax") else 0.3
+            f0 = f0.clamp(-fmax, fmax)
+            bank.set_carrier_seeds(f0.to(torch.float32).contiguous(), torch.where(slope >= 0, 1, -1).to(torch.int32).contiguous())
+            rep.carrier_seeds = f0.cpu().tolist()
         cap_pre = max(1, bank.max_symbols(int(plan.pres.max())))
         cap = bank.max_symbols(int(plan.lens.max()))
         soft_pre = torch.zeros((T, cap_pre, 2), dtype=torch.int8, device=dev)

@@ -103,6 +103,13 @@ class OracleBank:
                 s.hist[k].re = s.hist[k].im = 0.0
             s.hidx = 0
 
+    def set_carrier_seeds(self, freq, updown) -> None:
+        f, u = freq.cpu().numpy(), updown.cpu().numpy()
+        for i, st in enumerate(self.streams):
+            s = st._p.contents.s
+            s.pll_freq = float(np.float32(f[i]))
+            s.updown = 1 if int(u[i]) > 0 else -1
+
     def rotate_carrier(self, quarter_turns) -> None:
         """phase += k*pi/2 wrapped like pll.c:113, in double then narrowed (mdemod_rotate_carrier)."""
         q = quarter_turns.cpu().numpy()

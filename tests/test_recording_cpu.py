@@ -151,3 +151,23 @@ def test_stitched_oqpsk_recording_against_the_serial_reference():
     a = agreement(out, serial)
     assert a["len_stitched"] == a["len_serial"]
     assert a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.94
+
+
+@pytest.mark.parametrize("rate", [10.0, 40.0])
+def test_doppler_needs_per_tile_carrier_seeds(rate):
+    """A carrier that moves 10 / 40 Hz per second (a satellite pass): tiles seeded with the pilot's frequency fall out of
+    the PLL's reach within seconds, tiles seeded from their own 4th-power spectrum follow it like the serial run does."""
+    st = synth.make_stream(77, 230000, 72000, f0_hz=200.0, clock_ppm=5.0, esn0_db=12.0, doppler_hz_per_s=rate)
+    iq = synth.generate_host(st, 6_000_000)
+    serial, tr, ev = O.oracle_demod(C1, iq, True)
+    assert len(ev) == 1 and tr["locked"].mean() > 0.99                   # the serial reference tracks the ramp
+    mk = lambda seed: RecordingDemodulator(C1, bank_factory=lambda c, k: OracleBank(c, k), carrier_seed=seed).demodulate(torch.from_numpy(iq))
+    good, bad = mk("spectrum"), mk("pilot")
+    a, b = agreement(good.soft.numpy(), serial), agreement(bad.soft.numpy(), serial)
+    assert a["len_stitched"] == a["len_serial"] and good.report.weak_seams == 0
+    assert a["hard_decisions_equal"] > 0.99999 and a["within_1lsb"] > 0.97
+    assert b["hard_decisions_equal"] < 0.99 or b["within_1lsb"] < 0.8     # documents what the option is for
+    # the seeds follow the ramp: rad/symbol per tile = 2*pi*rate/symrate * tile duration
+    d = np.diff(np.asarray(good.report.carrier_seeds))
+    want = 2 * np.pi * rate / 72000 * (65600 / 230000)
+    assert abs(np.median(d) - want) < 0.15 * want
