@@ -54,7 +54,7 @@ static const struct option longopts[] = {
 	{ "refresh-rate", 1, NULL, 'R' }, { "symrate", 1, NULL, 'r' }, { "stdout", 0, NULL, 0x00 },
 	{ "samplerate", 1, NULL, 's' }, { "bps", 1, NULL, 'S' },      { "version", 0, NULL, 'v' },
 	{ "device", 1, NULL, 0x01 },    { "tiled", 0, NULL, 0x02 },   { "tile-samples", 1, NULL, 0x03 },
-	{ "pilot-margin", 1, NULL, 0x04 }, { NULL, 0, NULL, 0 }
+	{ "pilot-margin", 1, NULL, 0x04 }, { "carrier-seed", 1, NULL, 0x05 }, { NULL, 0, NULL, 0 }
 };
 
 /* utils.c:60-86: number with optional k/M suffix, truncated to int, returned as float */
@@ -90,7 +90,8 @@ usage(const char *prog)
 	        "       --stdout            Write soft symbols to stdout (implies -B -q)\n"
 	        "       --device <n>        HIP device ordinal (default 0)\n"
 	        "       --tiled             Each file on many lanes as overlapped tiles (fast, not bit-exact\n"
-	        "                           after the head); --tile-samples <n>, --pilot-margin <symbols>\n"
+	        "                           after the head); --tile-samples <n>, --pilot-margin <symbols>,\n"
+	        "                           --carrier-seed spectrum|pilot (default spectrum: tiles follow Doppler)\n"
 	        "   -h, --help   -v, --version\n", prog);
 }
 
@@ -134,7 +135,7 @@ main(int argc, char **argv)
 	float pll_bw = MDEMOD_DEFAULT_PLL_BW, symrate = MDEMOD_DEFAULT_SYM_RATE, freq_max_delta = -1;
 	int rrc_order = MDEMOD_DEFAULT_RRC_ORDER, interp = MDEMOD_DEFAULT_INTERP;
 	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0, tiled = 0;
-	int tile_samples = 0, pilot_margin = -1;
+	int tile_samples = 0, pilot_margin = -1, carrier_seed = -1;
 	const char *output_fname = NULL;
 	int c;
 
@@ -145,6 +146,11 @@ main(int argc, char **argv)
 		case 0x02: tiled = 1; break;
 		case 0x03: tile_samples = (int)human_number(optarg); break;
 		case 0x04: pilot_margin = (int)human_number(optarg); break;
+		case 0x05:
+			if (!strcmp(optarg, "spectrum")) carrier_seed = 1;
+			else if (!strcmp(optarg, "pilot")) carrier_seed = 0;
+			else { fprintf(stderr, "--carrier-seed: spectrum or pilot\n"); return 1; }
+			break;
 		case 'b': pll_bw = human_number(optarg); break;
 		case 'B': batch = 1; break;
 		case 'd': freq_max_delta = human_number(optarg); break;
@@ -231,6 +237,7 @@ main(int argc, char **argv)
 			mdemod_recording_default_opts(&ro);
 			if (tile_samples > 0) ro.tile_samples = (uint32_t)tile_samples;
 			if (pilot_margin >= 0) ro.pilot_margin_symbols = (uint32_t)pilot_margin;
+			if (carrier_seed >= 0) ro.carrier_seed = (uint32_t)carrier_seed;
 			mdemod_recording_report rr;
 			int rc2 = mdemod_demodulate_recording_host(&p, &ro, data, n_samples, soft_all, cap_sym, &rr);
 			if (rc2 != MDEMOD_OK) { fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2)); return 2; }

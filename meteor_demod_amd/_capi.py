@@ -63,7 +63,7 @@ class MdemodStreamState(C.Structure):
 class MdemodRecordingOpts(C.Structure):
     _fields_ = [("tile_samples", C.c_uint32), ("pre_samples", C.c_uint32), ("pilot_block", C.c_uint32),
                 ("pilot_margin_symbols", C.c_uint32), ("max_pilot_samples", C.c_uint64),
-                ("match_symbols", C.c_uint32), ("refine", C.c_int32), ("reserved", C.c_uint64)]
+                ("match_symbols", C.c_uint32), ("refine", C.c_int32), ("carrier_seed", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MdemodRecordingReport(C.Structure):

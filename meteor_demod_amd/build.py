@@ -75,7 +75,8 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
         objs.append(obj)
     so = LIB / "libmeteor_demod_amd.so"
     if force or _stale(so, objs):
-        _run([hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", str(so), *map(str, objs)])
+        # hipFFT: the per-tile carrier estimator of the recording stitcher (a plain library FFT, csrc/recording.hip)
+        _run([hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", str(so), *map(str, objs), "-lhipfft"])
     out["lib"] = so
 
     # --- synthetic signal generator -----------------------------------------

@@ -19,6 +19,7 @@
  * C-ABI of this library; the kernels here only compare and move int8 symbols.
  */
 #include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -182,6 +183,75 @@ match_heads_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *ro
 	}
 }
 
+/* ---- per-tile carrier estimate (Doppler): z^4 of the samples has a line at 4x the carrier offset -------- */
+
+template <int FMT> struct RawIQ;
+template <> struct RawIQ<16> { typedef int16_t t; __device__ static float2 get(const void *p, uint64_t i) { const int16_t *q = static_cast<const int16_t *>(p) + 2 * i; return make_float2((float)q[0], (float)q[1]); } };
+template <> struct RawIQ<8>  { typedef uint8_t t; __device__ static float2 get(const void *p, uint64_t i) { const uint8_t *q = static_cast<const uint8_t *>(p) + 2 * i; return make_float2((float)((int)q[0] - 128), (float)((int)q[1] - 128)); } };
+template <> struct RawIQ<32> { typedef float t;   __device__ static float2 get(const void *p, uint64_t i) { const float *q = static_cast<const float *>(p) + 2 * i; return make_float2(q[0], q[1]); } };
+
+/* One block per tile: mean removed, fourth power, Hann window -> complex float [tile][nfft]. */
+template <int FMT>
+__global__ void
+fourth_power_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, int nfft, float2 *out)
+{
+	const uint64_t s0 = starts[blockIdx.x];
+	__shared__ float red[2][256];
+	float sr = 0.0f, si = 0.0f;
+	for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
+		const uint64_t i = s0 + k < n_samples ? s0 + k : n_samples - 1;
+		const float2 v = RawIQ<FMT>::get(iq, i);
+		sr += v.x; si += v.y;
+	}
+	red[0][threadIdx.x] = sr; red[1][threadIdx.x] = si;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+		__syncthreads();
+	}
+	const float mr = red[0][0] / nfft, mi = red[1][0] / nfft;
+	float2 *dst = out + (size_t)blockIdx.x * nfft;
+	const float wstep = 6.283185307179586f / (float)(nfft - 1);
+	for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
+		const uint64_t i = s0 + k < n_samples ? s0 + k : n_samples - 1;
+		float2 v = RawIQ<FMT>::get(iq, i);
+		v.x -= mr; v.y -= mi;
+		const float2 z2 = make_float2(v.x * v.x - v.y * v.y, 2.0f * v.x * v.y);
+		const float w = (0.5f - 0.5f * cosf(wstep * (float)k)) * 1e-12f;         /* scale: |z|^4 of full-scale s16 stays far from overflow */
+		dst[k] = make_float2((z2.x * z2.x - z2.y * z2.y) * w, 2.0f * z2.x * z2.y * w);
+	}
+}
+
+/* One block per tile: largest magnitude among bins -kmax+1 .. kmax-1, parabolic interpolation -> rad/symbol. */
+__global__ void
+spectrum_peak_kernel(const float2 *spec, int nfft, int kmax, float hz_per_bin_over4, float rad_per_hz, float *freq_out)
+{
+	const float2 *sp = spec + (size_t)blockIdx.x * nfft;
+	__shared__ float bv[256]; __shared__ int bi[256];
+	float best = -1.0f; int bidx = 0;
+	auto mag = [&](int k) { const float2 v = sp[(k + nfft) % nfft]; return v.x * v.x + v.y * v.y; };
+	for (int k = -kmax + 1 + (int)threadIdx.x; k <= kmax - 1; k += blockDim.x) {
+		const float m = mag(k);
+		if (m > best) { best = m; bidx = k; }
+	}
+	bv[threadIdx.x] = best; bi[threadIdx.x] = bidx;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int)threadIdx.x < o) {
+			const float ov = bv[threadIdx.x + o]; const int oi = bi[threadIdx.x + o];
+			if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = ov; bi[threadIdx.x] = oi; }
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		const int k = bi[0];
+		const float a = sqrtf(mag(k - 1)), b = sqrtf(mag(k)), c = sqrtf(mag(k + 1));
+		const float den = a - 2.0f * b + c;
+		const float delta = den != 0.0f ? 0.5f * (a - c) / den : 0.0f;
+		freq_out[blockIdx.x] = ((float)k + delta) * hz_per_bin_over4 * rad_per_hz;
+	}
+}
+
 __global__ void
 assemble_kernel(const TileCopy *tiles, int8_t *out)
 {
@@ -270,7 +340,7 @@ mdemod_recording_default_opts(mdemod_recording_opts *o)
 	o->tile_samples = 0;                     /* 0 = 20 536 symbols worth of samples (65 600 at 72k in 230 kS/s), kept off powers of two */
 	o->pre_samples = 0xFFFFFFFFu;            /* 0xFFFFFFFF = 5 129 symbols worth of samples (16 384 at 72k in 230 kS/s) */
 	o->pilot_block = 65536; o->pilot_margin_symbols = 20000;
-	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->refine = 1; o->reserved = 0;
+	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->refine = 1; o->carrier_seed = 1; o->reserved = 0;
 }
 
 extern "C" int
@@ -373,6 +443,61 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	TRY(mdemod_set_state_all(bank.c, &seed, st));
 	std::vector<uint64_t> off_pre(T);
 	for (size_t i = 0; i < T; i++) off_pre[i] = starts[i] - pres[i];
+	if (o.carrier_seed == 1 && !params->oqpsk) {
+		/* Doppler: every tile starts from its own carrier estimate (see recording.py:carrier_estimates) */
+		int nfft = 4096;
+		while (nfft * 2 <= static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(o.tile_samples) + o.pre_samples, 1u << 17))) nfft *= 2;
+		float consts[8];
+		TRY(mdemod_get_loop_constants(bank.c, consts));
+		const float fmax = consts[2];
+		const double symrate = params->symrate, fs = params->samplerate;
+		const int kmax = static_cast<int>(4 * 0.33 * symrate / (2 * 3.141592653589793) / fs * nfft) + 2;
+		std::vector<float> fmid(T);
+		uint64_t *d_starts; float *d_freq; float2 *d_spec;
+		TRY(upload(mem, off_pre, &d_starts, st));
+		TRY(mem.alloc(&d_freq, T));
+		const size_t batch_max = std::max<size_t>(1, (size_t(1) << 28) / (static_cast<size_t>(nfft) * sizeof(float2)));
+		const size_t batch = std::min(batch_max, T);
+		TRY(mem.alloc(&d_spec, batch * nfft));
+		for (size_t t0 = 0; t0 < T; t0 += batch) {
+			const size_t b = std::min(batch, T - t0);
+			const dim3 grid(static_cast<unsigned>(b));
+			switch (params->bps) {
+			case 16: hipLaunchKernelGGL(fourth_power_kernel<16>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec); break;
+			case 8:  hipLaunchKernelGGL(fourth_power_kernel<8>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec); break;
+			default: hipLaunchKernelGGL(fourth_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec); break;
+			}
+			HTRY(hipGetLastError());
+			hipfftHandle plan;
+			if (hipfftPlan1d(&plan, nfft, HIPFFT_C2C, static_cast<int>(b)) != HIPFFT_SUCCESS) return MDEMOD_ERR_HIP;
+			hipfftSetStream(plan, st);
+			const hipfftResult fr = hipfftExecC2C(plan, reinterpret_cast<hipfftComplex *>(d_spec), reinterpret_cast<hipfftComplex *>(d_spec), HIPFFT_FORWARD);
+			if (fr != HIPFFT_SUCCESS) { hipfftDestroy(plan); return MDEMOD_ERR_HIP; }
+			hipLaunchKernelGGL(spectrum_peak_kernel, grid, dim3(256), 0, st, d_spec, nfft, kmax, static_cast<float>(fs / nfft / 4.0),
+			                   static_cast<float>(2 * 3.141592653589793 / symrate), d_freq + t0);
+			HTRY(hipGetLastError());
+			HTRY(hipStreamSynchronize(st));
+			hipfftDestroy(plan);
+		}
+		HTRY(hipMemcpyAsync(fmid.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipStreamSynchronize(st));
+		const double dt_sym = static_cast<double>(o.tile_samples) * symrate / fs;
+		std::vector<float> f0(T); std::vector<int32_t> ud(T);
+		for (size_t i = 0; i < T; i++) {
+			double slope = 0.0;
+			if (T > 2) {
+				const size_t j = std::min(std::max<size_t>(i, 1), T - 2);
+				slope = (static_cast<double>(fmid[j + 1]) - fmid[j - 1]) / (2 * dt_sym);
+			}
+			double f = fmid[i] - slope * (nfft / 2) * symrate / fs;
+			f = std::max<double>(-fmax, std::min<double>(fmax, f));
+			f0[i] = static_cast<float>(f); ud[i] = slope >= 0 ? 1 : -1;
+		}
+		float *d_f0; int32_t *d_ud;
+		TRY(upload(mem, f0, &d_f0, st));
+		TRY(upload(mem, ud, &d_ud, st));
+		TRY(mdemod_set_carrier_seeds(bank.c, d_f0, d_ud, st));
+	}
 	std::vector<uint32_t> cnt_pre, cnt1, cnt2;
 	TRY(launch(off_pre, pres, soft_pre, cap_pre, cnt_pre));
 	TRY(launch(starts, lens, soft1, cap, cnt1));

@@ -524,7 +524,8 @@ class RecordingDemodulator:
 
 def demodulate_recording_native(cfg, iq, tile_samples: int = 0, pre_samples: int = -1, refine: bool = True,
                                 pilot_block: int = 65536, pilot_margin_symbols: int = 20000,
-                                max_pilot_samples: int = 1 << 22, match_symbols: int = 192, device: int = 0):
+                                max_pilot_samples: int = 1 << 22, match_symbols: int = 192, device: int = 0,
+                                carrier_seed: str = "pilot"):
     """``mdemod_demodulate_recording`` on a device tensor [n, 2]: returns (soft int8 [m, 2] device tensor, report)."""
     import ctypes as C
     import torch
@@ -533,7 +534,7 @@ def demodulate_recording_native(cfg, iq, tile_samples: int = 0, pre_samples: int
     assert iq.is_cuda and iq.dim() == 2 and iq.shape[1] == 2 and iq.is_contiguous()
     tile_samples, pre_samples = default_tiling(cfg, tile_samples, pre_samples)
     opts = _capi.MdemodRecordingOpts(tile_samples, pre_samples, pilot_block, pilot_margin_symbols, max_pilot_samples,
-                                     match_symbols, int(refine), 0)
+                                     match_symbols, int(refine), 1 if carrier_seed == "spectrum" else 0, 0)
     n = int(iq.shape[0])
     p = cfg.to_c(1, device)
     cap = int(n * cfg.symrate / cfg.samplerate * 1.05) + 65536          # stitched output: nominal rate + slack (checked by the callee)

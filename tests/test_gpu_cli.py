@@ -131,3 +131,36 @@ def test_cli_tiled_mode_single_file(tmp_path, gpu_device):
     assert got.shape == want.shape
     body = slice(0, len(got) - 512)
     assert ((got[body] >= 0) == (want[body] >= 0)).all(axis=1).mean() > 0.9999
+
+
+def test_cli_tiled_follows_doppler(tmp_path, gpu_device):
+    """--tiled on a recording whose carrier drifts 40 Hz/s (a pass's Doppler ramp): the default per-tile spectral carrier
+    seeds keep the stitched file on the serial oracle's decisions; --carrier-seed is parsed and rejects junk."""
+    import oracle_py as O
+    from golden_cases import wav_header
+    from meteor_demod_amd import DemodConfig, synth
+    cfg = DemodConfig(samplerate=230000)
+    n = 9_000_000 // 8192 * 8192
+    st = synth.make_stream(23, 230000, 72000, f0_hz=-250.0, clock_ppm=4.0, esn0_db=12.0, doppler_hz_per_s=40.0)
+    iq = synth.generate_device([st], n)[0].cpu().numpy()
+    for cut in range(0, 64):          # the reference's final flush is only defined for <= 256 symbols left in its ring
+        try:
+            want = O.OracleStream(cfg).file_model(iq[: n - 8192 * cut].tobytes(), 16)
+            iq = iq[: n - 8192 * cut]
+            break
+        except RuntimeError:
+            continue
+    want = np.frombuffer(want, dtype=np.int8).reshape(-1, 2)
+    inp, out = tmp_path / "in.wav", tmp_path / "out.s"
+    inp.write_bytes(wav_header(230000, 16, iq.nbytes) + iq.tobytes())
+    r = subprocess.run([str(CLI), "-q", "--tiled", "-o", str(out), str(inp)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer(out.read_bytes(), dtype=np.int8).reshape(-1, 2)
+    assert got.shape == want.shape
+    body = slice(0, len(got) - 512)
+    assert ((got[body] >= 0) == (want[body] >= 0)).all(axis=1).mean() > 0.9999
+    assert (np.abs(got[body].astype(int) - want[body].astype(int)).max(axis=1) <= 1).mean() > 0.95
+    r = subprocess.run([str(CLI), "-q", "--tiled", "--carrier-seed", "pilot", "-o", str(out), str(inp)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(CLI), "-q", "--tiled", "--carrier-seed", "bogus", "-o", str(out), str(inp)], capture_output=True, text=True)
+    assert r.returncode != 0 and "carrier-seed" in r.stderr

@@ -235,3 +235,24 @@ def test_doppler_recording_with_spectral_carrier_seeds(gpu_device):
         for i in range(5):
             g = d.get_state(i)
             assert np.float32(g.pll_freq) == np.float32(f[i].item()) and g.pll_updown == int(u[i]) and g.agc_gain == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bps", [16, 8])
+def test_native_stitcher_follows_doppler(gpu_device, bps):
+    """mdemod_demodulate_recording with carrier_seed=spectrum (hipFFT estimator in csrc/recording.hip): same bar as the
+    Python stitcher on a 40 Hz/s ramp; with pilot seeds the same recording loses tiles (that is what the option is for)."""
+    import dataclasses
+    from meteor_demod_amd.recording import demodulate_recording_native
+    amp = dict(rms=6000.0) if bps == 16 else dict(rms=40.0, dc=(1.5, -1.0))
+    st = synth.make_stream(79, 230000, 72000, f0_hz=-300.0, clock_ppm=5.0, esn0_db=12.0, doppler_hz_per_s=40.0, fmt=bps, **amp)
+    iq = synth.generate_device([st], 12_000_000)[0]
+    cfg = dataclasses.replace(C1, bps=bps)
+    serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
+    soft, rep = demodulate_recording_native(cfg, iq, carrier_seed="spectrum")
+    a = agreement(soft.cpu().numpy(), serial)
+    assert rep.weak_seams == 0 and a["len_stitched"] == a["len_serial"]
+    assert a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.97
+    soft0, rep0 = demodulate_recording_native(cfg, iq, carrier_seed="pilot")
+    a0 = agreement(soft0.cpu().numpy(), serial)
+    assert a0["hard_decisions_equal"] < a["hard_decisions_equal"] or rep0.weak_seams > 0
