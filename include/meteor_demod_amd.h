@@ -236,7 +236,7 @@ typedef struct {
 	uint32_t match_symbols;         /* symbols compared across a seam             (192)    */
 	int32_t  refine;                /* 1: exact-continuation second pass          (1)      */
 	uint32_t carrier_seed;          /* 0: every tile starts from the pilot's carrier estimate; 1: from its own 4th-power
-	                                   spectrum (follows Doppler; QPSK only, ignored for OQPSK)   (1)      */
+	                                   spectrum (follows Doppler)   (1)      */
 	uint32_t reserved;
 } mdemod_recording_opts;
 

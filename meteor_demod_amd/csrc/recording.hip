@@ -443,7 +443,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	TRY(mdemod_set_state_all(bank.c, &seed, st));
 	std::vector<uint64_t> off_pre(T);
 	for (size_t i = 0; i < T; i++) off_pre[i] = starts[i] - pres[i];
-	if (o.carrier_seed == 1 && !params->oqpsk) {
+	if (o.carrier_seed == 1) {
 		/* Doppler: every tile starts from its own carrier estimate (see recording.py:carrier_estimates) */
 		int nfft = 4096;
 		while (nfft * 2 <= static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(o.tile_samples) + o.pre_samples, 1u << 17))) nfft *= 2;
@@ -474,7 +474,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 			const hipfftResult fr = hipfftExecC2C(plan, reinterpret_cast<hipfftComplex *>(d_spec), reinterpret_cast<hipfftComplex *>(d_spec), HIPFFT_FORWARD);
 			if (fr != HIPFFT_SUCCESS) { hipfftDestroy(plan); return MDEMOD_ERR_HIP; }
 			hipLaunchKernelGGL(spectrum_peak_kernel, grid, dim3(256), 0, st, d_spec, nfft, kmax, static_cast<float>(fs / nfft / 4.0),
-			                   static_cast<float>(2 * 3.141592653589793 / symrate), d_freq + t0);
+			                   static_cast<float>(2 * 3.141592653589793 / (symrate * (params->oqpsk ? 2 : 1))), d_freq + t0);   /* OQPSK: NCO steps twice a symbol */
 			HTRY(hipGetLastError());
 			HTRY(hipStreamSynchronize(st));
 			hipfftDestroy(plan);

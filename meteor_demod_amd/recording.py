@@ -195,9 +195,10 @@ def match_rails(a_tail, b_tail):
     return best[1], best[0], energy
 
 
-def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33):
-    """Feed-forward carrier estimate of each tile (QPSK): the 4th power of the samples has a spectral line at 4x the carrier
-    offset whatever the data (the reference finds the carrier by sweeping its PLL at 1e-6 rad/symbol per symbol, pll.c:125,
+def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33, nco_steps_per_symbol=1):
+    """Feed-forward carrier estimate of each tile: the 4th power of the samples has a spectral line at 4x the carrier
+    offset whatever the data, for QPSK and for RRC-shaped OQPSK alike (``nco_steps_per_symbol`` = 2 for OQPSK, whose NCO
+    advances at both rails' firings, pll.c:77,93, so its frequency word is rad per half symbol) (the reference finds the carrier by sweeping its PLL at 1e-6 rad/symbol per symbol, pll.c:125,
     which is what a tile that starts far from the pilot's estimate has no time for).  ``nfft`` samples from each start,
     batched FFT, peak within +-4*fmax with parabolic interpolation.  Returns (freq [T] float32 rad/symbol at the MIDDLE of the
     window, peak-to-mean ratio [T]).  torch.fft on whatever device ``iq`` lives on; estimation only, never symbols."""
@@ -226,7 +227,7 @@ def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33):
         a, b, c = (cand.gather(1, (pk + d).view(-1, 1)).squeeze(1) for d in (-1, 0, 1))
         delta = 0.5 * (a - c) / (a - 2 * b + c - 1e-20)
         k = (pk - kmax).to(torch.float32) + delta
-        freq[t0:t1] = (k * (samplerate / nfft / 4.0) * (2 * np.pi / symrate)).to(torch.float32)
+        freq[t0:t1] = (k * (samplerate / nfft / 4.0) * (2 * np.pi / (symrate * nco_steps_per_symbol))).to(torch.float32)
         quality[t0:t1] = b / (cand.mean(dim=1) + 1e-20)
     return freq, quality
 
@@ -275,8 +276,8 @@ class RecordingDemodulator:
             # entangled with the half-symbol state of the symbol clock, which rotate_symbols() cannot undo on the
             # output; only the second pass (which turns the STATE, mdemod_rotate_carrier) handles it.
             raise NotImplementedError("overlapped tiles of an OQPSK recording need refine=True")
-        if carrier_seed not in ("pilot", "spectrum") or (carrier_seed == "spectrum" and cfg.oqpsk):
-            raise NotImplementedError("carrier_seed is 'pilot' or, for QPSK, 'spectrum'")
+        if carrier_seed not in ("pilot", "spectrum"):
+            raise NotImplementedError("carrier_seed is 'pilot' or 'spectrum'")
         self.carrier_seed = carrier_seed
         self.cfg = cfg
         self.post_samples = int(post_samples)
@@ -352,7 +353,8 @@ class RecordingDemodulator:
             # after it), moved to the first warm-up sample with the local slope, sweep direction = sign of the slope
             nfft = 1 << int(np.floor(np.log2(max(4096, min(self.tile_samples + self.pre_samples, 1 << 17)))))
             w0 = plan.starts - plan.pres
-            fmid, qual = carrier_estimates(iq, w0, nfft, self.cfg.samplerate, self.cfg.symrate)
+            fmid, qual = carrier_estimates(iq, w0, nfft, self.cfg.samplerate, self.cfg.symrate,
+                                           nco_steps_per_symbol=2 if self.cfg.oqpsk else 1)
             dt_sym = self.tile_samples * self.cfg.symrate / self.cfg.samplerate            # symbols between tile starts
             slope = torch.zeros_like(fmid)
             if T > 2:

@@ -238,16 +238,22 @@ def test_doppler_recording_with_spectral_carrier_seeds(gpu_device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bps", [16, 8])
-def test_native_stitcher_follows_doppler(gpu_device, bps):
+@pytest.mark.parametrize("bps,oqpsk", [(16, False), (8, False), (16, True)])
+def test_native_stitcher_follows_doppler(gpu_device, bps, oqpsk):
     """mdemod_demodulate_recording with carrier_seed=spectrum (hipFFT estimator in csrc/recording.hip): same bar as the
     Python stitcher on a 40 Hz/s ramp; with pilot seeds the same recording loses tiles (that is what the option is for)."""
     import dataclasses
     from meteor_demod_amd.recording import demodulate_recording_native
     amp = dict(rms=6000.0) if bps == 16 else dict(rms=40.0, dc=(1.5, -1.0))
-    st = synth.make_stream(79, 230000, 72000, f0_hz=-300.0, clock_ppm=5.0, esn0_db=12.0, doppler_hz_per_s=40.0, fmt=bps, **amp)
+    symrate = 80000 if oqpsk else 72000
+    # OQPSK: start above the carrier the sweep meets first.  With f0 = -300 Hz the REFERENCE declares lock at +575 Hz while
+    # sweeping up (false lock, 28 k symbols in) and only reaches the carrier 160 k symbols later; tiles seeded from the
+    # spectrum are on the carrier at once, so there is no serial stream to compare them with (DESIGN.md 3.1).
+    f0, ramp = (500.0, -40.0) if oqpsk else (-300.0, 40.0)
+    st = synth.make_stream(80 if oqpsk else 79, 230000, symrate, f0_hz=f0, clock_ppm=5.0, esn0_db=13.0 if oqpsk else 12.0,
+                           doppler_hz_per_s=ramp, fmt=bps, oqpsk=oqpsk, **amp)
     iq = synth.generate_device([st], 12_000_000)[0]
-    cfg = dataclasses.replace(C1, bps=bps)
+    cfg = dataclasses.replace(C1, bps=bps, symrate=symrate, oqpsk=oqpsk)
     serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
     soft, rep = demodulate_recording_native(cfg, iq, carrier_seed="spectrum")
     a = agreement(soft.cpu().numpy(), serial)

@@ -171,3 +171,21 @@ def test_doppler_needs_per_tile_carrier_seeds(rate):
     d = np.diff(np.asarray(good.report.carrier_seeds))
     want = 2 * np.pi * rate / 72000 * (65600 / 230000)
     assert abs(np.median(d) - want) < 0.15 * want
+
+
+def test_doppler_oqpsk_tiles_follow_the_ramp():
+    """OQPSK: the 4th-power line exists for RRC-shaped offset QPSK too; the seed is rad per HALF symbol (the NCO steps at
+    both rails' firings, pll.c:77,93).  40 Hz/s: pilot seeds lose the recording, spectral seeds keep the serial decisions."""
+    cfg = DemodConfig(samplerate=230000, symrate=80000, oqpsk=True)
+    st = synth.make_stream(81, 230000, 80000, f0_hz=200.0, clock_ppm=5.0, esn0_db=13.0, oqpsk=True, doppler_hz_per_s=40.0)
+    iq = synth.generate_host(st, 4_000_000)
+    serial = O.oracle_demod(cfg, iq)[0]
+    mk = lambda seed: RecordingDemodulator(cfg, bank_factory=lambda c, k: OracleBank(c, k), carrier_seed=seed).demodulate(torch.from_numpy(iq))
+    good, bad = mk("spectrum"), mk("pilot")
+    a, b = agreement(good.soft.numpy(), serial), agreement(bad.soft.numpy(), serial)
+    assert a["len_stitched"] == a["len_serial"] and good.report.weak_seams == 0
+    assert a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.97
+    assert b["hard_decisions_equal"] < 0.99
+    d = np.diff(np.asarray(good.report.carrier_seeds))
+    want = 2 * np.pi * 40.0 / (2 * 80000) * (int(good.plan.lens[0]) / 230000)
+    assert abs(np.median(d) - want) < 0.15 * want
