@@ -252,6 +252,8 @@ typedef struct {
 	int32_t  pilot_locked;
 	double   pilot_seconds;         /* wall time of the serial head                          */
 	double   tiles_seconds;         /* wall time of everything after it                      */
+	uint32_t weak_carrier_tiles;    /* carrier_seed=1: tiles without a clear spectral line, seeded from their neighbours */
+	uint32_t reserved;
 } mdemod_recording_report;
 
 void mdemod_recording_default_opts(mdemod_recording_opts *opts);

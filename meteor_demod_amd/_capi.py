@@ -70,7 +70,8 @@ class MdemodRecordingReport(C.Structure):
     _fields_ = [("n_symbols", C.c_uint64), ("pilot_samples", C.c_uint64), ("pilot_symbols", C.c_uint64),
                 ("first_lock_symbol", C.c_int64), ("samples_demodulated", C.c_uint64),
                 ("n_tiles", C.c_uint32), ("weak_seams", C.c_uint32), ("seam_fixes", C.c_uint32),
-                ("pilot_locked", C.c_int32), ("pilot_seconds", C.c_double), ("tiles_seconds", C.c_double)]
+                ("pilot_locked", C.c_int32), ("pilot_seconds", C.c_double), ("tiles_seconds", C.c_double),
+                ("weak_carrier_tiles", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # name -> (restype, argtypes); this table is also what the symbol-export test walks.

@@ -222,24 +222,27 @@ fourth_power_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, 
 	}
 }
 
-/* One block per tile: largest magnitude among bins -kmax+1 .. kmax-1, parabolic interpolation -> rad/symbol. */
+/* One block per tile: largest magnitude among bins -kmax+1 .. kmax-1, parabolic interpolation -> rad per NCO step;
+ * quality = peak / mean magnitude of the searched band (noise alone: 3-4; a 12 dB signal: 40-50). */
 __global__ void
-spectrum_peak_kernel(const float2 *spec, int nfft, int kmax, float hz_per_bin_over4, float rad_per_hz, float *freq_out)
+spectrum_peak_kernel(const float2 *spec, int nfft, int kmax, float hz_per_bin_over4, float rad_per_hz, float *freq_out, float *quality_out)
 {
 	const float2 *sp = spec + (size_t)blockIdx.x * nfft;
-	__shared__ float bv[256]; __shared__ int bi[256];
-	float best = -1.0f; int bidx = 0;
+	__shared__ float bv[256]; __shared__ int bi[256]; __shared__ float bs[256];
+	float best = -1.0f, sum = 0.0f; int bidx = 0;
 	auto mag = [&](int k) { const float2 v = sp[(k + nfft) % nfft]; return v.x * v.x + v.y * v.y; };
-	for (int k = -kmax + 1 + (int)threadIdx.x; k <= kmax - 1; k += blockDim.x) {
+	for (int k = -kmax + (int)threadIdx.x; k <= kmax; k += blockDim.x) {
 		const float m = mag(k);
-		if (m > best) { best = m; bidx = k; }
+		sum += sqrtf(m);
+		if (m > best && k > -kmax && k < kmax) { best = m; bidx = k; }
 	}
-	bv[threadIdx.x] = best; bi[threadIdx.x] = bidx;
+	bv[threadIdx.x] = best; bi[threadIdx.x] = bidx; bs[threadIdx.x] = sum;
 	__syncthreads();
 	for (int o = 128; o > 0; o >>= 1) {
 		if ((int)threadIdx.x < o) {
 			const float ov = bv[threadIdx.x + o]; const int oi = bi[threadIdx.x + o];
 			if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = ov; bi[threadIdx.x] = oi; }
+			bs[threadIdx.x] += bs[threadIdx.x + o];
 		}
 		__syncthreads();
 	}
@@ -249,6 +252,7 @@ spectrum_peak_kernel(const float2 *spec, int nfft, int kmax, float hz_per_bin_ov
 		const float den = a - 2.0f * b + c;
 		const float delta = den != 0.0f ? 0.5f * (a - c) / den : 0.0f;
 		freq_out[blockIdx.x] = ((float)k + delta) * hz_per_bin_over4 * rad_per_hz;
+		quality_out[blockIdx.x] = b / (bs[0] / (float)(2 * kmax + 1) + 1e-30f);
 	}
 }
 
@@ -452,10 +456,11 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		const float fmax = consts[2];
 		const double symrate = params->symrate, fs = params->samplerate;
 		const int kmax = static_cast<int>(4 * 0.33 * symrate / (2 * 3.141592653589793) / fs * nfft) + 2;
-		std::vector<float> fmid(T);
-		uint64_t *d_starts; float *d_freq; float2 *d_spec;
+		std::vector<float> fmid(T), qual(T);
+		uint64_t *d_starts; float *d_freq, *d_qual; float2 *d_spec;
 		TRY(upload(mem, off_pre, &d_starts, st));
 		TRY(mem.alloc(&d_freq, T));
+		TRY(mem.alloc(&d_qual, T));
 		const size_t batch_max = std::max<size_t>(1, (size_t(1) << 28) / (static_cast<size_t>(nfft) * sizeof(float2)));
 		const size_t batch = std::min(batch_max, T);
 		TRY(mem.alloc(&d_spec, batch * nfft));
@@ -468,19 +473,45 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 			default: hipLaunchKernelGGL(fourth_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec); break;
 			}
 			HTRY(hipGetLastError());
-			hipfftHandle plan;
-			if (hipfftPlan1d(&plan, nfft, HIPFFT_C2C, static_cast<int>(b)) != HIPFFT_SUCCESS) return MDEMOD_ERR_HIP;
-			hipfftSetStream(plan, st);
-			const hipfftResult fr = hipfftExecC2C(plan, reinterpret_cast<hipfftComplex *>(d_spec), reinterpret_cast<hipfftComplex *>(d_spec), HIPFFT_FORWARD);
-			if (fr != HIPFFT_SUCCESS) { hipfftDestroy(plan); return MDEMOD_ERR_HIP; }
+			struct Plan {                                   /* destroyed on every exit path of this iteration */
+				hipfftHandle h; bool ok;
+				Plan(int n, int batch) : ok(hipfftPlan1d(&h, n, HIPFFT_C2C, batch) == HIPFFT_SUCCESS) {}
+				~Plan() { if (ok) hipfftDestroy(h); }
+			} plan(nfft, static_cast<int>(b));
+			if (!plan.ok || hipfftSetStream(plan.h, st) != HIPFFT_SUCCESS) return MDEMOD_ERR_HIP;
+			if (hipfftExecC2C(plan.h, reinterpret_cast<hipfftComplex *>(d_spec), reinterpret_cast<hipfftComplex *>(d_spec), HIPFFT_FORWARD) != HIPFFT_SUCCESS)
+				return MDEMOD_ERR_HIP;
 			hipLaunchKernelGGL(spectrum_peak_kernel, grid, dim3(256), 0, st, d_spec, nfft, kmax, static_cast<float>(fs / nfft / 4.0),
-			                   static_cast<float>(2 * 3.141592653589793 / (symrate * (params->oqpsk ? 2 : 1))), d_freq + t0);   /* OQPSK: NCO steps twice a symbol */
+			                   static_cast<float>(2 * 3.141592653589793 / (symrate * (params->oqpsk ? 2 : 1))), d_freq + t0, d_qual + t0);   /* OQPSK: NCO steps twice a symbol */
 			HTRY(hipGetLastError());
 			HTRY(hipStreamSynchronize(st));
-			hipfftDestroy(plan);
 		}
 		HTRY(hipMemcpyAsync(fmid.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipMemcpyAsync(qual.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
 		HTRY(hipStreamSynchronize(st));
+		/* tiles without a clear line (fade, interference) take their good neighbours' estimate, interpolated over the
+		   tile index; with no good tile at all, the pilot's frequency (recording.py:fill_weak_estimates) */
+		{
+			const float min_quality = 8.0f;
+			std::vector<size_t> good;
+			for (size_t i = 0; i < T; i++) if (qual[i] >= min_quality) good.push_back(i);
+			if (good.empty()) {
+				for (size_t i = 0; i < T; i++) fmid[i] = seed.pll_freq;
+			} else if (good.size() < T) {
+				size_t g = 0;
+				for (size_t i = 0; i < T; i++) {
+					if (qual[i] >= min_quality) continue;
+					while (g + 1 < good.size() && good[g + 1] < i) g++;
+					if (i < good.front()) fmid[i] = fmid[good.front()];
+					else if (i > good.back()) fmid[i] = fmid[good.back()];
+					else {
+						const size_t lo = good[g], hi = good[g + 1];
+						fmid[i] = static_cast<float>(fmid[lo] + (static_cast<double>(fmid[hi]) - fmid[lo]) * (i - lo) / static_cast<double>(hi - lo));
+					}
+				}
+				rep->weak_carrier_tiles = static_cast<uint32_t>(T - good.size());
+			}
+		}
 		const double dt_sym = static_cast<double>(o.tile_samples) * symrate / fs;
 		std::vector<float> f0(T); std::vector<int32_t> ud(T);
 		for (size_t i = 0; i < T; i++) {

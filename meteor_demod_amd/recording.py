@@ -232,6 +232,25 @@ def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33, nco_
     return freq, quality
 
 
+SEED_MIN_QUALITY = 8.0      # spectral line / mean of the searched band: noise alone gives 3-4, a 12 dB signal 40-50
+
+
+def fill_weak_estimates(freq, quality, fallback: float, min_quality: float = SEED_MIN_QUALITY):
+    """Tiles whose 4th-power spectrum shows no clear line (fade, interference: the peak is then a noise bin anywhere in
+    +-fmax) take the estimate interpolated between their nearest good neighbours over the tile index; with no good tile
+    at all, ``fallback`` (the pilot's frequency).  Returns a float32 tensor like ``freq``."""
+    import torch
+    f = freq.detach().cpu().numpy().astype(np.float64)
+    good = quality.detach().cpu().numpy() >= min_quality
+    if good.all():
+        return freq
+    if not good.any():
+        return torch.full_like(freq, float(fallback))
+    idx = np.arange(len(f))
+    f = np.interp(idx, idx[good], f[good])
+    return torch.as_tensor(f.astype(np.float32), device=freq.device)
+
+
 # ---- result ---------------------------------------------------------------------------------
 
 @dataclass
@@ -355,6 +374,7 @@ class RecordingDemodulator:
             w0 = plan.starts - plan.pres
             fmid, qual = carrier_estimates(iq, w0, nfft, self.cfg.samplerate, self.cfg.symrate,
                                            nco_steps_per_symbol=2 if self.cfg.oqpsk else 1)
+            fmid = fill_weak_estimates(fmid, qual, float(seed.pll_freq))
             dt_sym = self.tile_samples * self.cfg.symrate / self.cfg.samplerate            # symbols between tile starts
             slope = torch.zeros_like(fmid)
             if T > 2:

@@ -262,3 +262,33 @@ def test_native_stitcher_follows_doppler(gpu_device, bps, oqpsk):
     soft0, rep0 = demodulate_recording_native(cfg, iq, carrier_seed="pilot")
     a0 = agreement(soft0.cpu().numpy(), serial)
     assert a0["hard_decisions_equal"] < a["hard_decisions_equal"] or rep0.weak_seams > 0
+
+
+@pytest.mark.gpu
+def test_native_stitcher_bridges_a_fade_with_neighbouring_carrier_estimates(gpu_device):
+    """Three tiles' worth of the recording replaced by noise while the carrier ramps 40 Hz/s: those tiles have no spectral
+    line and take their neighbours' carrier (mdemod_recording_report.weak_carrier_tiles); before the fade the output is
+    the serial run's, after it the two agree again up to the lock's own quarter-turn ambiguity (the serial run re-locks on
+    its own after the fade, so rotation and the symbol count across the fade are not comparable)."""
+    import torch
+    from meteor_demod_amd.recording import demodulate_recording_native, rotate_symbols
+    st = synth.make_stream(91, 230000, 72000, f0_hz=300.0, clock_ppm=5.0, esn0_db=12.0, doppler_hz_per_s=40.0)
+    iq = synth.generate_device([st], 8_000_000)[0]
+    a, b = 3_000_000, 3_000_000 + 3 * 65600
+    g = torch.Generator(device="cuda").manual_seed(3)
+    iq[a:b] = (torch.randn((b - a, 2), device="cuda", generator=g) * 4200).to(torch.int16)
+    serial, tr, ev = O.oracle_demod(C1, iq.cpu().numpy(), True)
+    soft, rep = demodulate_recording_native(C1, iq, carrier_seed="spectrum")
+    out = soft.cpu().numpy()
+    assert 2 <= rep.weak_carrier_tiles <= 5
+    n_before = int(a * 72000 / 230000) - 2000
+    assert ((out[:n_before] >= 0) == (serial[:n_before] >= 0)).all(axis=1).mean() > 0.9999
+    L = 1_000_000                                                   # the last 3.2 s, long after both have re-locked
+    best = 0.0
+    for r in range(4):
+        rot = rotate_symbols(torch.from_numpy(out[-L - 4:]).unsqueeze(0), torch.tensor([r]))[0].numpy()
+        for s in range(-2, 3):
+            seg = rot[4 + s: 4 + s + L - 8]
+            best = max(best, ((seg >= 0) == (serial[-L: -8] >= 0)).all(axis=1).mean())
+    assert best > 0.9999
+    assert tr["locked"][-L:].all()

@@ -189,3 +189,24 @@ def test_doppler_oqpsk_tiles_follow_the_ramp():
     d = np.diff(np.asarray(good.report.carrier_seeds))
     want = 2 * np.pi * 40.0 / (2 * 80000) * (int(good.plan.lens[0]) / 230000)
     assert abs(np.median(d) - want) < 0.15 * want
+
+
+def test_weak_carrier_estimates_take_their_neighbours():
+    """A tile whose spectrum has no line (fade) must not start from a noise bin: interpolation over the tile index between
+    good neighbours, edges held, and the pilot's frequency when nothing is usable."""
+    from meteor_demod_amd.recording import fill_weak_estimates, carrier_estimates
+    f = torch.tensor([0.01, 0.25, 0.03, -0.2, -0.1, 0.06, 0.3], dtype=torch.float32)
+    q = torch.tensor([40.0, 3.0, 45.0, 2.5, 3.9, 50.0, 1.0])
+    g = fill_weak_estimates(f, q, fallback=0.123)
+    assert np.allclose(g.numpy(), [0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.06], atol=1e-7)
+    assert torch.equal(fill_weak_estimates(f, q + 100, 0.123), f)
+    assert np.allclose(fill_weak_estimates(f, q * 0, 0.123).numpy(), 0.123)
+    # the quality figure separates a signal from noise: 12 dB recording vs the same length of white noise
+    st = synth.make_stream(5, 230000, 72000, f0_hz=400.0, esn0_db=12.0)
+    iq = synth.generate_host(st, 140_000)
+    rng = np.random.default_rng(0)
+    noise = rng.normal(0, 4000, iq.shape).astype(np.int16)
+    both = torch.from_numpy(np.concatenate((iq, noise)))
+    fr, qual = carrier_estimates(both, np.array([0, 140_000]), 65536, 230000, 72000)
+    assert qual[0] > 25 and qual[1] < 6
+    assert abs(float(fr[0]) - 2 * np.pi * 400 / 72000) < 2e-4
