@@ -284,6 +284,11 @@ class RecordingDemodulator:
     ``bank_factory(cfg, n_streams)`` must return an object with the :class:`Demodulator` methods used here
     (``reset, process, process_ragged, max_symbols, symbol_counts, get_state, set_state, get_history,
     set_history, set_state_all, rotate_carrier, close``).  The default is the HIP :class:`Demodulator`.
+
+    ``carrier_seed``: "pilot" (default HERE) starts every tile from the pilot's carrier estimate, which makes the result a
+    pure function of the tile engine: the HIP bank and the oracle bank then give the same bytes, which is what the tests
+    pin.  "spectrum" gives every tile its own estimate (Doppler; the default of the C entry and of the CLI's ``--tiled``):
+    the FFT's rounding depends on the device, so two engines agree only statistically.
     """
 
     def __init__(self, cfg, tile_samples: int = 0, pre_samples: int = -1, refine: bool = True,
