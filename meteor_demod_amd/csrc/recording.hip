@@ -397,7 +397,11 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		TRY(mdemod_get_state(pilot.c, 0, &seed, st));
 		if (seed.pll_locked && !have_lock) { have_lock = true; locked_at = seed.n_symbols; }
 		if (!seed.pll_locked) have_lock = false;
-		if (have_lock && seed.n_symbols - locked_at >= o.pilot_margin_symbols) break;
+		/* ... and not before the reference's AGC has settled: its step is absolute (agc.c:13-25), 6 time constants =
+		   6 * gain / (1e-4 * 190) symbols - nothing for s16-scale input, ~200 k symbols for float input around +-1
+		   (recording.py:agc_settle_symbols) */
+		const double agc_settle = 6.0 * static_cast<double>(seed.agc_gain) / (1e-4 * 190.0);
+		if (have_lock && seed.n_symbols - locked_at >= o.pilot_margin_symbols && static_cast<double>(seed.n_symbols) >= agc_settle) break;
 		if (pos >= o.max_pilot_samples) break;
 	}
 	rep->pilot_samples = pos; rep->pilot_symbols = seed.n_symbols;
@@ -458,7 +462,11 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		const int kmax = static_cast<int>(4 * 0.33 * symrate / (2 * 3.141592653589793) / fs * nfft) + 2;
 		std::vector<float> fmid(T), qual(T);
 		uint64_t *d_starts; float *d_freq, *d_qual; float2 *d_spec;
-		TRY(upload(mem, off_pre, &d_starts, st));
+		/* windows that would run past the end of the recording are moved back (the last tiles) */
+		std::vector<uint64_t> wstart(T);
+		for (size_t i = 0; i < T; i++)
+			wstart[i] = std::min<uint64_t>(off_pre[i], n_samples >= static_cast<uint64_t>(nfft) ? n_samples - nfft : 0);
+		TRY(upload(mem, wstart, &d_starts, st));
 		TRY(mem.alloc(&d_freq, T));
 		TRY(mem.alloc(&d_qual, T));
 		const size_t batch_max = std::max<size_t>(1, (size_t(1) << 28) / (static_cast<size_t>(nfft) * sizeof(float2)));
@@ -520,7 +528,8 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 				const size_t j = std::min(std::max<size_t>(i, 1), T - 2);
 				slope = (static_cast<double>(fmid[j + 1]) - fmid[j - 1]) / (2 * dt_sym);
 			}
-			double f = fmid[i] - slope * (nfft / 2) * symrate / fs;
+			/* the estimate belongs to the middle of the window actually used */
+			double f = fmid[i] - slope * (static_cast<double>(wstart[i]) + nfft / 2 - static_cast<double>(off_pre[i])) * symrate / fs;
 			f = std::max<double>(-fmax, std::min<double>(fmax, f));
 			f0[i] = static_cast<float>(f); ud[i] = slope >= 0 ? 1 : -1;
 		}

@@ -232,6 +232,15 @@ def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33, nco_
     return freq, quality
 
 
+def agc_settle_symbols(gain: float) -> float:
+    """Symbols the reference's AGC needs to settle at this gain: its step is ABSOLUTE, gain += 1e-4 * (190 - |x|)
+    (agc.c:13-25), so the relative speed is 1e-4 * 190 / gain per symbol: instant for s16-scale input (gain ~ 0.03), but
+    ~35 000 symbols per time constant for float input around +-1 (gain ~ 650) - and while the gain is still small the PLL's
+    lock flag is already true (its error scales with the amplitude).  Six time constants; the pilot does not hand over
+    earlier, or every tile would start from a gain the serial run has long left behind."""
+    return 6.0 * float(gain) / (1e-4 * 190.0)
+
+
 SEED_MIN_QUALITY = 8.0      # spectral line / mean of the searched band: noise alone gives 3-4, a 12 dB signal 40-50
 
 
@@ -337,7 +346,8 @@ class RecordingDemodulator:
                 locked_at = st.n_symbols
             if not st.pll_locked:
                 locked_at = None
-            if locked_at is not None and st.n_symbols - locked_at >= self.pilot_margin_symbols:
+            if (locked_at is not None and st.n_symbols - locked_at >= self.pilot_margin_symbols
+                    and st.n_symbols >= agc_settle_symbols(st.agc_gain)):
                 break
             if pos >= self.max_pilot_samples:
                 break
@@ -385,7 +395,10 @@ class RecordingDemodulator:
             if T > 2:
                 slope[1:-1] = (fmid[2:] - fmid[:-2]) / (2 * dt_sym)
                 slope[0], slope[-1] = slope[1], slope[-2]
-            f0 = fmid - slope * (nfft / 2) * self.cfg.symrate / self.cfg.samplerate
+            # the estimate belongs to the middle of the window actually used (clamped at the end of the recording)
+            wstart = np.minimum(w0, max(0, int(iq.shape[0]) - nfft))
+            back = torch.as_tensor((wstart + nfft / 2 - w0).astype(np.float32), device=fmid.device)
+            f0 = fmid - slope * back * (self.cfg.symrate / self.cfg.samplerate)
             fmax = float(bank.carrier_fmax()) if hasattr(bank, "carrier_fmax") else 0.3
             f0 = f0.clamp(-fmax, fmax)
             bank.set_carrier_seeds(f0.to(torch.float32).contiguous(), torch.where(slope >= 0, 1, -1).to(torch.int32).contiguous())

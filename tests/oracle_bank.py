@@ -30,6 +30,10 @@ class Snapshot:
     def pll_locked(self):
         return self.locked
 
+    @property
+    def agc_gain(self):
+        return self.gain
+
     def apply(self, s: O.OrcState) -> None:
         for f in _FIELDS:
             setattr(s, f, getattr(self, f))

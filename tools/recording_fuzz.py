@@ -1,0 +1,75 @@
+"""Soak test of the overlapped-tile stitcher (mdemod_demodulate_recording, csrc/recording.hip): random sample rates,
+QPSK / OQPSK, input formats, carrier offsets, Doppler ramps, clock errors, tile sizes.  Every recording is demodulated
+natively with spectral carrier seeds and compared with the serial oracle.  A case counts only if the serial run's lock
+is genuine (its PLL frequency is on the synthetic carrier when the pilot hands over), otherwise there is
+no serial stream to compare with.  Usage: recording_fuzz.py [n_cases] [seed] [only_case]
+(FUZZ_TILE / FUZZ_SEEDMODE in the environment override a case's tile size / carrier_seed when one case is replayed)"""
+import os
+import dataclasses
+import sys
+import time
+
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np
+import oracle_py as O
+from meteor_demod_amd import DemodConfig, synth
+from meteor_demod_amd.recording import agreement, demodulate_recording_native
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+bad, skipped, t0 = [], 0, time.time()
+for ci in range(n_cases):
+    oqpsk = bool(rng.random() < 0.35)
+    symrate = 80000 if oqpsk else 72000
+    osf = float(rng.choice([2.5, 2.875, 3.1944, 3.6, 4.0, 6.0, 14.2]))
+    samplerate = int(symrate * osf)
+    bps = int(rng.choice([8, 16, 16, 32]))
+    cfg = DemodConfig(samplerate=samplerate, symrate=symrate, oqpsk=oqpsk, bps=bps)
+    ramp = float(rng.choice([0.0, 10.0, -25.0, 40.0, -40.0]))
+    # start on the side the sweep meets first (the reference sweeps up from 0): keeps its lock genuine in most cases
+    f0 = float(rng.uniform(100.0, 900.0)) if ramp <= 0 else float(rng.uniform(-200.0, 600.0))
+    ppm = float(rng.uniform(-30.0, 30.0))
+    n = int(rng.integers(3_000_000, 9_000_000))
+    # s16 amplitude scaled down with the oversampling: at 1 MS/s an RMS of 6000 LSB drives the reference's AGC into a
+    # 0 <-> 0.019 limit cycle (its step is absolute, agc.c:13-25), where no two runs agree on anything
+    amp = {8: dict(rms=40.0, dc=(1.5, -1.0)), 16: dict(rms=float(rng.choice([1500.0, 6000.0])) * min(1.0, 3.2 / osf)),
+           32: dict(rms=0.25, dc=(0.001, -0.002))}[bps]
+    esn0 = float(rng.choice([10.0, 12.0, 15.0]))
+    kw = {}
+    if rng.random() < 0.5:
+        kw["tile_samples"] = int(rng.choice([32768 + 64, 50000 // 64 * 64, 131072 + 64]) * max(1.0, osf / 3.2)) // 64 * 64
+    if only is not None and ci != only:
+        continue
+    mode = "spectrum"
+    if only is not None:
+        if os.environ.get("FUZZ_TILE"):
+            kw["tile_samples"] = int(os.environ["FUZZ_TILE"])
+        mode = os.environ.get("FUZZ_SEEDMODE", mode)
+        print("replay: esn0", esn0, "amp", amp)
+    st = synth.make_stream(1000 + ci, samplerate, symrate, f0_hz=f0, clock_ppm=ppm, esn0_db=esn0,
+                           doppler_hz_per_s=ramp, oqpsk=oqpsk, fmt=bps, **amp)
+    iq = synth.generate_device([st], n)[0]
+    serial, tr, ev = O.oracle_demod(cfg, iq.cpu().numpy(), True)
+    soft, rep = demodulate_recording_native(cfg, iq, carrier_seed=mode, **kw)
+    steps = 2 if oqpsk else 1
+    k = min(int(rep.pilot_symbols), len(tr) - 1)
+    t_k = tr["sample_index"][k] / samplerate
+    f_true = 2 * np.pi * (f0 + ramp * t_k) / (symrate * steps)
+    genuine = rep.pilot_locked and abs(float(tr["pll_freq"][k]) - f_true) < 2 * np.pi * 60.0 / (symrate * steps) and len(ev) == 1
+    tag = f"case {ci}: {'oqpsk' if oqpsk else 'qpsk'} fs={samplerate} bps={bps} f0={f0:.0f} ramp={ramp} ppm={ppm:.1f} n={n} {kw}"
+    if not genuine or rep.n_tiles < 3:
+        skipped += 1
+        print(tag, "-> skipped (serial lock not genuine / too few tiles)", flush=True)
+        continue
+    a = agreement(soft.cpu().numpy(), serial)
+    a.pop("windows", None)
+    ok = a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9995 and rep.weak_seams == 0
+    print(tag, "->", "ok" if ok else "FAIL", {k_: (round(v, 5) if isinstance(v, float) else v) for k_, v in a.items()},
+          "tiles", rep.n_tiles, "weak", rep.weak_seams, "weak_carrier", rep.weak_carrier_tiles, flush=True)
+    if not ok:
+        bad.append(tag)
+print(f"{n_cases} cases in {time.time() - t0:.0f} s, skipped {skipped}, failures {len(bad)}")
+for b in bad:
+    print("  ", b)
+sys.exit(1 if bad else 0)
