@@ -45,3 +45,17 @@ for ci in range(n_cases):
     print("tile first symbols", list(res.tile_first_symbol[:80]))
     cs = np.asarray(r.carrier_seeds)
     print("seed 2nd diff", np.round(np.diff(cs, 2) * 1e5, 1))
+    from meteor_demod_amd.recording import demodulate_recording_native
+    soft, rep = demodulate_recording_native(cfg, iq, carrier_seed="spectrum", **kw)
+    out = soft.cpu().numpy()
+    print("native len", len(out), "serial", len(serial), "python", len(res.soft), "seam_fixes", rep.seam_fixes)
+    # where do native and serial part ways?  compare from the front and from the back
+    m = min(len(out), len(serial))
+    front = ((out[:m] >= 0) == (serial[:m] >= 0)).all(axis=1)
+    back = ((out[-m:] >= 0) == (serial[-m:] >= 0)).all(axis=1)
+    W = 4096
+    fw = [front[i:i + W].mean() for i in range(0, m, W)]
+    bw = [back[i:i + W].mean() for i in range(0, m, W)]
+    print("front-aligned low windows", [(i, round(x, 3)) for i, x in enumerate(fw) if x < 0.99][:10])
+    print("back-aligned low windows", [(i, round(x, 3)) for i, x in enumerate(bw) if x < 0.99][:10])
+    print("tile first symbols (python)", [int(x) for x in res.tile_first_symbol])
