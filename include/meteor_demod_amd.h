@@ -219,6 +219,9 @@ int  mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, vo
  * (+1 / -1, pll.c:112) of stream s := freq_dev[s], updown_dev[s]; everything else is left as it is.  Used with
  * mdemod_set_state_all when the carrier moves along the recording (Doppler) and every tile needs its local estimate. */
 int  mdemod_set_carrier_seeds(mdemod_ctx *ctx, const float *freq_dev, const int32_t *updown_dev, void *hip_stream);
+/* Per-stream AGC gain seeds (agc.c:9, device array of n_streams entries, negative values become 0 like agc.c:23):
+ * for tiles of a recording whose amplitude changes faster than the reference's AGC follows at that gain. */
+int  mdemod_set_gain_seeds(mdemod_ctx *ctx, const float *gain_dev, void *hip_stream);
 
 /* The whole scheme in one call (native counterpart of meteor_demod_amd/recording.py):
  * the head of the recording is demodulated serially from the reference's power-on state until the

@@ -452,6 +452,16 @@ mdemod_set_carrier_seeds(mdemod_ctx *ctx, const float *freq_dev, const int32_t *
 	return MDEMOD_OK;
 }
 
+int
+mdemod_set_gain_seeds(mdemod_ctx *ctx, const float *gain_dev, void *hip_stream)
+{
+	if (!ctx || !gain_dev) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	HIP_TRY(mdemod_launch_gain_seeds(ctx->st, gain_dev, ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
+	return MDEMOD_OK;
+}
+
 const char *
 mdemod_kernel_name(const mdemod_ctx *ctx)
 {

@@ -88,6 +88,15 @@ carrier_seed_kernel(DemodStateSoA st, const float *freq, const int32_t *updown, 
 	st.flags[s] = updown[s] > 0 ? (fl | MDEMOD_FLAG_UPDOWN_POS) : (fl & ~MDEMOD_FLAG_UPDOWN_POS);
 }
 
+__global__ void
+gain_seed_kernel(DemodStateSoA st, const float *gain, uint32_t n_streams)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_streams) return;
+	const float g = gain[s];
+	st.agc_gain[s] = g > 0.0f ? g : 0.0f;                 /* the reference clamps at zero too (agc.c:23) */
+}
+
 /* Host path: the demodulator writes its soft symbols with the hard-bound row pitch (one symbol per input sample);
  * what goes over PCIe is a copy with the nominal pitch.  One block per stream, 16-byte moves (pitches are multiples of
  * 8 symbols). */
@@ -201,6 +210,14 @@ mdemod_launch_carrier_seeds(const DemodStateSoA &st, const float *freq_dev, cons
 {
 	if (n_streams == 0) return hipSuccess;
 	hipLaunchKernelGGL(carrier_seed_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, freq_dev, updown_dev, n_streams);
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_gain_seeds(const DemodStateSoA &st, const float *gain_dev, uint32_t n_streams, hipStream_t stream)
+{
+	if (n_streams == 0) return hipSuccess;
+	hipLaunchKernelGGL(gain_seed_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, gain_dev, n_streams);
 	return hipGetLastError();
 }
 

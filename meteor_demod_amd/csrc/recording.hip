@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <vector>
 
@@ -190,10 +191,11 @@ template <> struct RawIQ<16> { typedef int16_t t; __device__ static float2 get(c
 template <> struct RawIQ<8>  { typedef uint8_t t; __device__ static float2 get(const void *p, uint64_t i) { const uint8_t *q = static_cast<const uint8_t *>(p) + 2 * i; return make_float2((float)((int)q[0] - 128), (float)((int)q[1] - 128)); } };
 template <> struct RawIQ<32> { typedef float t;   __device__ static float2 get(const void *p, uint64_t i) { const float *q = static_cast<const float *>(p) + 2 * i; return make_float2(q[0], q[1]); } };
 
-/* One block per tile: mean removed, fourth power, Hann window -> complex float [tile][nfft]. */
+/* One block per tile: mean removed, fourth power, Hann window -> complex float [tile][nfft]; power_out[tile] = mean
+ * |z - mean|^2 of the window (feeds the AGC seeds). */
 template <int FMT>
 __global__ void
-fourth_power_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, int nfft, float2 *out)
+fourth_power_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, int nfft, float2 *out, float *power_out)
 {
 	const uint64_t s0 = starts[blockIdx.x];
 	__shared__ float red[2][256];
@@ -212,14 +214,57 @@ fourth_power_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, 
 	const float mr = red[0][0] / nfft, mi = red[1][0] / nfft;
 	float2 *dst = out + (size_t)blockIdx.x * nfft;
 	const float wstep = 6.283185307179586f / (float)(nfft - 1);
+	float pw = 0.0f;
+	__syncthreads();
 	for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
 		const uint64_t i = s0 + k < n_samples ? s0 + k : n_samples - 1;
 		float2 v = RawIQ<FMT>::get(iq, i);
 		v.x -= mr; v.y -= mi;
+		pw += v.x * v.x + v.y * v.y;
 		const float2 z2 = make_float2(v.x * v.x - v.y * v.y, 2.0f * v.x * v.y);
 		const float w = (0.5f - 0.5f * cosf(wstep * (float)k)) * 1e-12f;         /* scale: |z|^4 of full-scale s16 stays far from overflow */
 		dst[k] = make_float2((z2.x * z2.x - z2.y * z2.y) * w, 2.0f * z2.x * z2.y * w);
 	}
+	red[0][threadIdx.x] = pw;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int)threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) power_out[blockIdx.x] = red[0][0] / nfft;
+}
+
+/* One block per window: sample power (mean |z - mean|^2) of lens[w] samples from starts[w] (AGC seeds). */
+template <int FMT>
+__global__ void
+window_power_kernel(const void *iq, const uint64_t *starts, const uint32_t *lens, float *power_out)
+{
+	const uint64_t s0 = starts[blockIdx.x];
+	const uint32_t n = lens[blockIdx.x];
+	__shared__ float red[2][256];
+	float sr = 0.0f, si = 0.0f;
+	for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) { const float2 v = RawIQ<FMT>::get(iq, s0 + k); sr += v.x; si += v.y; }
+	red[0][threadIdx.x] = sr; red[1][threadIdx.x] = si;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+		__syncthreads();
+	}
+	const float mr = n ? red[0][0] / n : 0.0f, mi = n ? red[1][0] / n : 0.0f;
+	__syncthreads();
+	float pw = 0.0f;
+	for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+		float2 v = RawIQ<FMT>::get(iq, s0 + k);
+		v.x -= mr; v.y -= mi;
+		pw += v.x * v.x + v.y * v.y;
+	}
+	red[0][threadIdx.x] = pw;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int)threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) power_out[blockIdx.x] = n ? red[0][0] / n : 0.0f;
 }
 
 /* One block per tile: largest magnitude among bins -kmax+1 .. kmax-1, parabolic interpolation -> rad per NCO step;
@@ -335,6 +380,38 @@ run_match(DevMem &m, const std::vector<TailPair> &pairs, int K, std::vector<int3
 	return MDEMOD_OK;
 }
 
+/* One window of the reference's AGC in closed form (recording.py:_agc_step; agc.c:13-25). */
+double
+agc_step(double g, double c, double power, double nsym)
+{
+	const double gstar = c / std::sqrt(std::max(power, 1e-30));
+	return gstar + (g - gstar) * std::exp(-std::min(50.0, 1e-4 * 190.0 / std::max(gstar, 1e-30) * nsym));
+}
+
+/* recording.py:fit_agc_calibration */
+double
+fit_agc_calibration(const std::vector<double> &gains, const std::vector<double> &powers, const std::vector<double> &nsyms)
+{
+	const size_t J = gains.size() - 1;
+	const double c0 = gains[J] * std::sqrt(std::max(powers[J], 1e-30));
+	const size_t j0 = J > 8 ? J - 8 : 0;
+	if (J == j0 || !std::isfinite(c0) || c0 <= 0) return c0;
+	auto model = [&](double c) {
+		double g = gains[j0];
+		for (size_t j = j0 + 1; j <= J; j++) g = agc_step(g, c, powers[j], nsyms[j]);
+		return g;
+	};
+	double lo = c0 / 8, hi = c0 * 8;
+	if (!(model(lo) <= gains[J] && gains[J] <= model(hi))) return c0;
+	for (int it = 0; it < 50; it++) {
+		const double mid = 0.5 * (lo + hi);
+		if (model(mid) < gains[J]) lo = mid; else hi = mid;
+	}
+	return 0.5 * (lo + hi);
+}
+
+struct PilotBlock { uint64_t start; uint32_t len; double gain_after; uint64_t symbols_after; };
+
 } /* namespace */
 
 extern "C" void
@@ -382,6 +459,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	Ctx pilot;
 	TRY(mdemod_create(&pp, &pilot.c));
 	uint64_t pos = 0, nsym = 0; bool have_lock = false; uint64_t locked_at = 0;
+	std::vector<PilotBlock> pilot_blocks;                /* AGC calibration (carrier_seed == 1) */
 	mdemod_stream_state seed;
 	memset(&seed, 0, sizeof(seed));
 	TRY(mdemod_get_state(pilot.c, 0, &seed, st));
@@ -393,8 +471,9 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		mdemod_status s1;
 		TRY(mdemod_get_status(pilot.c, 0, 1, &s1, st));
 		nsym += s1.symbols_this_call;
-		pos += b;
 		TRY(mdemod_get_state(pilot.c, 0, &seed, st));
+		pilot_blocks.push_back(PilotBlock{pos, b, seed.agc_gain, seed.n_symbols});
+		pos += b;
 		if (seed.pll_locked && !have_lock) { have_lock = true; locked_at = seed.n_symbols; }
 		if (!seed.pll_locked) have_lock = false;
 		/* ... and not before the reference's AGC has settled: its step is absolute (agc.c:13-25), 6 time constants =
@@ -460,25 +539,27 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		const float fmax = consts[2];
 		const double symrate = params->symrate, fs = params->samplerate;
 		const int kmax = static_cast<int>(4 * 0.33 * symrate / (2 * 3.141592653589793) / fs * nfft) + 2;
-		std::vector<float> fmid(T), qual(T);
-		uint64_t *d_starts; float *d_freq, *d_qual; float2 *d_spec;
+		const size_t W = T;
+		std::vector<float> fmid(W), qual(W), power(W);
+		uint64_t *d_starts; float *d_freq, *d_qual, *d_pow; float2 *d_spec;
 		/* windows that would run past the end of the recording are moved back (the last tiles) */
-		std::vector<uint64_t> wstart(T);
+		std::vector<uint64_t> wstart(W);
 		for (size_t i = 0; i < T; i++)
 			wstart[i] = std::min<uint64_t>(off_pre[i], n_samples >= static_cast<uint64_t>(nfft) ? n_samples - nfft : 0);
 		TRY(upload(mem, wstart, &d_starts, st));
-		TRY(mem.alloc(&d_freq, T));
-		TRY(mem.alloc(&d_qual, T));
+		TRY(mem.alloc(&d_freq, W));
+		TRY(mem.alloc(&d_qual, W));
+		TRY(mem.alloc(&d_pow, W));
 		const size_t batch_max = std::max<size_t>(1, (size_t(1) << 28) / (static_cast<size_t>(nfft) * sizeof(float2)));
-		const size_t batch = std::min(batch_max, T);
+		const size_t batch = std::min(batch_max, W);
 		TRY(mem.alloc(&d_spec, batch * nfft));
-		for (size_t t0 = 0; t0 < T; t0 += batch) {
-			const size_t b = std::min(batch, T - t0);
+		for (size_t t0 = 0; t0 < W; t0 += batch) {
+			const size_t b = std::min(batch, W - t0);
 			const dim3 grid(static_cast<unsigned>(b));
 			switch (params->bps) {
-			case 16: hipLaunchKernelGGL(fourth_power_kernel<16>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec); break;
-			case 8:  hipLaunchKernelGGL(fourth_power_kernel<8>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec); break;
-			default: hipLaunchKernelGGL(fourth_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec); break;
+			case 16: hipLaunchKernelGGL(fourth_power_kernel<16>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec, d_pow + t0); break;
+			case 8:  hipLaunchKernelGGL(fourth_power_kernel<8>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec, d_pow + t0); break;
+			default: hipLaunchKernelGGL(fourth_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec, d_pow + t0); break;
 			}
 			HTRY(hipGetLastError());
 			struct Plan {                                   /* destroyed on every exit path of this iteration */
@@ -494,9 +575,49 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 			HTRY(hipGetLastError());
 			HTRY(hipStreamSynchronize(st));
 		}
-		HTRY(hipMemcpyAsync(fmid.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
-		HTRY(hipMemcpyAsync(qual.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipMemcpyAsync(fmid.data(), d_freq, W * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipMemcpyAsync(qual.data(), d_qual, W * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipMemcpyAsync(power.data(), d_pow, W * sizeof(float), hipMemcpyDeviceToHost, st));
 		HTRY(hipStreamSynchronize(st));
+		/* AGC gain seeds (recording.py: window_power, fit_agc_calibration, agc_trajectory): g* = c / sqrt(sample power),
+		   c fitted on the pilot's last blocks, then the closed-form recursion over the tiles' bodies */
+		{
+			const size_t nb = std::min<size_t>(10, pilot_blocks.size());
+			const size_t b0 = pilot_blocks.size() - nb;
+			std::vector<uint64_t> ws; std::vector<uint32_t> wl;
+			for (size_t j = b0; j < pilot_blocks.size(); j++) { ws.push_back(pilot_blocks[j].start); wl.push_back(pilot_blocks[j].len); }
+			for (size_t i = 0; i < T; i++) { ws.push_back(starts[i]); wl.push_back(static_cast<uint32_t>(lens[i])); }
+			uint64_t *d_ws; uint32_t *d_wl; float *d_wp;
+			TRY(upload(mem, ws, &d_ws, st));
+			TRY(upload(mem, wl, &d_wl, st));
+			TRY(mem.alloc(&d_wp, ws.size()));
+			const dim3 grid(static_cast<unsigned>(ws.size()));
+			switch (params->bps) {
+			case 16: hipLaunchKernelGGL(window_power_kernel<16>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
+			case 8:  hipLaunchKernelGGL(window_power_kernel<8>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
+			default: hipLaunchKernelGGL(window_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
+			}
+			HTRY(hipGetLastError());
+			std::vector<float> wp(ws.size());
+			HTRY(hipMemcpyAsync(wp.data(), d_wp, wp.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+			HTRY(hipStreamSynchronize(st));
+			std::vector<double> bg(nb), bp(nb), bn(nb);
+			for (size_t j = 0; j < nb; j++) {
+				const PilotBlock &pb = pilot_blocks[b0 + j];
+				const uint64_t before = (b0 + j) ? pilot_blocks[b0 + j - 1].symbols_after : 0;
+				bg[j] = pb.gain_after; bp[j] = wp[j]; bn[j] = static_cast<double>(pb.symbols_after - before);
+			}
+			const double c = fit_agc_calibration(bg, bp, bn);
+			double g = seed.agc_gain;
+			std::vector<float> gains(T);
+			for (size_t i = 0; i < T; i++) {
+				gains[i] = static_cast<float>(g);
+				g = agc_step(g, c, wp[nb + i], static_cast<double>(lens[i]) * symrate / fs);
+			}
+			float *d_gain;
+			TRY(upload(mem, gains, &d_gain, st));
+			TRY(mdemod_set_gain_seeds(bank.c, d_gain, st));
+		}
 		/* tiles without a clear line (fade, interference) take their good neighbours' estimate, interpolated over the
 		   tile index; with no good tile at all, the pilot's frequency (recording.py:fill_weak_estimates) */
 		{

@@ -222,6 +222,11 @@ class Demodulator:
         check(self._lib.mdemod_set_carrier_seeds(self._ctx, C.c_void_p(freq.data_ptr()), C.c_void_p(updown.data_ptr()),
                                                  self._stream()), "mdemod_set_carrier_seeds")
 
+    def set_gain_seeds(self, gain) -> None:
+        """AGC gain per stream (float32 device tensor)."""
+        assert gain.numel() == self.n_streams and gain.element_size() == 4 and gain.is_contiguous()
+        check(self._lib.mdemod_set_gain_seeds(self._ctx, C.c_void_p(gain.data_ptr()), self._stream()), "mdemod_set_gain_seeds")
+
     @property
     def kernel_name(self) -> str:
         return self._lib.mdemod_kernel_name(self._ctx).decode()

@@ -195,7 +195,7 @@ def match_rails(a_tail, b_tail):
     return best[1], best[0], energy
 
 
-def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33, nco_steps_per_symbol=1):
+def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33, nco_steps_per_symbol=1, return_power=False):
     """Feed-forward carrier estimate of each tile: the 4th power of the samples has a spectral line at 4x the carrier
     offset whatever the data, for QPSK and for RRC-shaped OQPSK alike (``nco_steps_per_symbol`` = 2 for OQPSK, whose NCO
     advances at both rails' firings, pll.c:77,93, so its frequency word is rad per half symbol) (the reference finds the carrier by sweeping its PLL at 1e-6 rad/symbol per symbol, pll.c:125,
@@ -210,6 +210,7 @@ def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33, nco_
     win = torch.hann_window(nfft, periodic=False, device=dev, dtype=torch.float32)
     freq = torch.zeros(T, dtype=torch.float32, device=dev)
     quality = torch.zeros(T, dtype=torch.float32, device=dev)
+    power = torch.zeros(T, dtype=torch.float32, device=dev)
     step = max(1, (1 << 28) // (nfft * 8))                                           # <= 256 MiB of complex64 per batch
     ar = torch.arange(nfft, device=dev)
     for t0 in range(0, T, step):
@@ -219,6 +220,7 @@ def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33, nco_
         x = iq[idx]                                                                   # [b, nfft, 2]
         z = torch.complex(x[..., 0].to(torch.float32), x[..., 1].to(torch.float32))
         z = z - z.mean(dim=1, keepdim=True)
+        power[t0:t1] = (z.real * z.real + z.imag * z.imag).mean(dim=1)
         z = z / (z.abs().mean(dim=1, keepdim=True) + 1e-20)
         z4 = (z * z) * (z * z) * win
         sp = torch.fft.fft(z4, dim=1).abs()
@@ -229,7 +231,76 @@ def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33, nco_
         k = (pk - kmax).to(torch.float32) + delta
         freq[t0:t1] = (k * (samplerate / nfft / 4.0) * (2 * np.pi / (symrate * nco_steps_per_symbol))).to(torch.float32)
         quality[t0:t1] = b / (cand.mean(dim=1) + 1e-20)
-    return freq, quality
+    return (freq, quality, power) if return_power else (freq, quality)
+
+
+def window_power(iq, start: int, length: int, count: int, last_length: int = -1):
+    """Sample power (mean |z - mean|^2) of ``count`` consecutive windows of ``length`` samples from ``start`` (the last one
+    ``last_length`` long if given): the pilot's blocks, the tiles' bodies.  float64 numpy array."""
+    import torch
+    out = np.zeros(count, dtype=np.float64)
+    if count == 0:
+        return out
+    full = count if last_length < 0 or last_length == length else count - 1
+    step = max(1, (1 << 26) // max(1, length))
+    for c0 in range(0, full, step):
+        c1 = min(full, c0 + step)
+        x = iq[start + c0 * length: start + c1 * length].reshape(c1 - c0, length, 2).to(torch.float32)
+        x = x - x.mean(dim=1, keepdim=True)
+        out[c0:c1] = (x * x).sum(dim=2).mean(dim=1).double().cpu().numpy()
+    if full < count and last_length > 0:
+        x = iq[start + full * length: start + full * length + last_length].to(torch.float32)
+        x = x - x.mean(dim=0, keepdim=True)
+        out[full] = float((x * x).sum(dim=1).mean())
+    return out
+
+
+def _agc_step(g: float, c: float, power: float, nsym: float) -> float:
+    """One window of the reference's AGC (agc.c:13-25: gain += 1e-4 * (190 - gain * |y|) per symbol) in closed form:
+    towards g* = 190 / E|y| = c / sqrt(power) at the relative rate 1e-4 * 190 / g* per symbol."""
+    gstar = c / float(np.sqrt(max(power, 1e-30)))
+    return gstar + (g - gstar) * float(np.exp(-min(50.0, 1e-4 * 190.0 / max(gstar, 1e-30) * nsym)))
+
+
+def fit_agc_calibration(gains, powers, nsyms) -> float:
+    """The constant c in g* = c / sqrt(sample power), fitted on the pilot: ``gains[j]`` is the pilot's gain after block j,
+    ``powers[j]`` / ``nsyms[j]`` the block's sample power and symbol count.  c is chosen so that the closed-form recursion
+    started from gains[j0] reproduces gains[-1] (bisection; the recursion is monotone in c).  With a fast AGC (s16-scale
+    input) this is simply gain * sqrt(power) of the last block; with a slow one (float input around +-1: time constant of
+    seconds) it removes the lag the pilot's gain has whenever the amplitude is moving at the hand-over."""
+    J = len(gains) - 1
+    c0 = float(gains[J]) * float(np.sqrt(max(powers[J], 1e-30)))
+    j0 = max(0, J - 8)
+    if J == j0 or not np.isfinite(c0) or c0 <= 0:
+        return c0
+
+    def model(c):
+        g = float(gains[j0])
+        for j in range(j0 + 1, J + 1):
+            g = _agc_step(g, c, float(powers[j]), float(nsyms[j]))
+        return g
+    lo, hi = c0 / 8, c0 * 8
+    if not (model(lo) <= gains[J] <= model(hi)):
+        return c0
+    for _ in range(50):
+        mid = 0.5 * (lo + hi)
+        if model(mid) < gains[J]:
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
+def agc_trajectory(gain0: float, c: float, power_tiles, symbols_per_tile):
+    """AGC gain of the serial run at the start of every tile: the closed-form recursion of :func:`_agc_step` from the
+    pilot's last gain over the tiles' sample powers.  With s16-scale input every tile simply gets its own equilibrium
+    (and its warm-up converges anyway); with float input around +-1 the recursion follows the serial run's lag."""
+    g = float(gain0)
+    out = np.empty(len(power_tiles), dtype=np.float32)
+    for i, (p, n) in enumerate(zip(power_tiles, symbols_per_tile)):
+        out[i] = g
+        g = _agc_step(g, c, float(p), float(n))
+    return out
 
 
 def agc_settle_symbols(gain: float) -> float:
@@ -275,6 +346,7 @@ class StitchReport:
     refine_rotations: list = field(default_factory=list)   # pass 2: residual rotation per tile (0 expected)
     samples_demodulated: int = 0                           # total kernel work incl. warm-up and pass 2
     carrier_seeds: list = field(default_factory=list)      # carrier_seed='spectrum': rad/symbol given to every tile
+    gain_seeds: list = field(default_factory=list)         # ... and the AGC gain
 
 
 @dataclass
@@ -335,6 +407,7 @@ class RecordingDemodulator:
         n = iq.shape[0]
         pilot = self._factory(self.cfg, 1)
         parts, pos, locked_at = [], 0, None
+        self._pilot_blocks = []                       # (samples, gain after, symbols after) per block: AGC calibration
         while pos < n:
             b = min(self.pilot_block, n - pos)
             soft = pilot.process(iq[pos:pos + b].unsqueeze(0))
@@ -342,6 +415,7 @@ class RecordingDemodulator:
             parts.append(soft[0, :m].clone())
             pos += b
             st = pilot.get_state(0)
+            self._pilot_blocks.append((b, float(st.agc_gain), int(st.n_symbols)))
             if st.pll_locked and locked_at is None:
                 locked_at = st.n_symbols
             if not st.pll_locked:
@@ -389,6 +463,18 @@ class RecordingDemodulator:
             w0 = plan.starts - plan.pres
             fmid, qual = carrier_estimates(iq, w0, nfft, self.cfg.samplerate, self.cfg.symrate,
                                            nco_steps_per_symbol=2 if self.cfg.oqpsk else 1)
+            # AGC gain seeds: calibrate g* = c / sqrt(power) on the pilot's last blocks, then follow the tiles' powers
+            blocks = self._pilot_blocks[-10:]
+            nb = len(blocks)
+            b_len = blocks[0][0]
+            first = pilot_end - sum(b for b, _, _ in blocks)
+            p_blocks = window_power(iq, first, b_len, nb, blocks[-1][0])
+            sym_after = [s_ for _, _, s_ in blocks]
+            prev = self._pilot_blocks[-nb - 1][2] if len(self._pilot_blocks) > nb else 0
+            n_blocks = np.diff(np.asarray([prev] + sym_after, dtype=np.float64))
+            c_agc = fit_agc_calibration([g_ for _, g_, _ in blocks], p_blocks, n_blocks)
+            p_tiles = window_power(iq, int(plan.starts[0]), int(plan.lens[0]), T, int(plan.lens[-1]))
+            gains = agc_trajectory(float(seed.agc_gain), c_agc, p_tiles, plan.lens * (self.cfg.symrate / self.cfg.samplerate))
             fmid = fill_weak_estimates(fmid, qual, float(seed.pll_freq))
             dt_sym = self.tile_samples * self.cfg.symrate / self.cfg.samplerate            # symbols between tile starts
             slope = torch.zeros_like(fmid)
@@ -403,6 +489,8 @@ class RecordingDemodulator:
             f0 = f0.clamp(-fmax, fmax)
             bank.set_carrier_seeds(f0.to(torch.float32).contiguous(), torch.where(slope >= 0, 1, -1).to(torch.int32).contiguous())
             rep.carrier_seeds = f0.cpu().tolist()
+            bank.set_gain_seeds(torch.as_tensor(gains, dtype=torch.float32, device=dev).contiguous())
+            rep.gain_seeds = gains.tolist()
         cap_pre = max(1, bank.max_symbols(int(plan.pres.max())))
         cap = bank.max_symbols(int(plan.lens.max()))
         soft_pre = torch.zeros((T, cap_pre, 2), dtype=torch.int8, device=dev)

@@ -114,6 +114,11 @@ class OracleBank:
             s.pll_freq = float(np.float32(f[i]))
             s.updown = 1 if int(u[i]) > 0 else -1
 
+    def set_gain_seeds(self, gain) -> None:
+        g = gain.cpu().numpy()
+        for i, st in enumerate(self.streams):
+            st._p.contents.s.gain = max(0.0, float(np.float32(g[i])))
+
     def rotate_carrier(self, quarter_turns) -> None:
         """phase += k*pi/2 wrapped like pll.c:113, in double then narrowed (mdemod_rotate_carrier)."""
         q = quarter_turns.cpu().numpy()

@@ -292,3 +292,30 @@ def test_native_stitcher_bridges_a_fade_with_neighbouring_carrier_estimates(gpu_
             best = max(best, ((seg >= 0) == (serial[-L: -8] >= 0)).all(axis=1).mean())
     assert best > 0.9999
     assert tr["locked"][-L:].all()
+
+
+@pytest.mark.gpu
+def test_native_stitcher_seeds_the_agc_on_float_input(gpu_device):
+    """Float input around +-1 with the amplitude swinging 0.4..1.0 over 12 s: mdemod_demodulate_recording waits for the
+    reference's AGC to settle before handing over, then gives every tile the gain of the closed-form AGC recursion
+    (mdemod_set_gain_seeds).  Without the seeds (carrier_seed=pilot) under a third of the soft symbols are within an LSB."""
+    import dataclasses
+    import torch
+    from meteor_demod_amd import Demodulator
+    from meteor_demod_amd.recording import demodulate_recording_native
+    cfg = dataclasses.replace(C1, bps=32)
+    st = synth.make_stream(7, 230000, 72000, f0_hz=300.0, clock_ppm=5.0, esn0_db=12.0, fmt=32, rms=0.25, dc=(0.001, -0.002))
+    n = 6_000_000
+    iq = synth.generate_device([st], n)[0]
+    t = torch.arange(n, device="cuda", dtype=torch.float32) / 230000
+    iq *= (0.7 - 0.3 * torch.cos(2 * np.pi * t / 12.0))[:, None]
+    serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
+    soft, rep = demodulate_recording_native(cfg, iq, carrier_seed="spectrum")
+    a = agreement(soft.cpu().numpy(), serial)
+    assert rep.pilot_symbols > 150_000 and rep.weak_seams == 0
+    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.99999 and a["within_1lsb"] > 0.98
+    soft0, _ = demodulate_recording_native(cfg, iq, carrier_seed="pilot")
+    assert agreement(soft0.cpu().numpy(), serial)["within_1lsb"] < 0.6
+    with Demodulator(C1, 3) as d:                                        # the seed op against its definition
+        d.set_gain_seeds(torch.tensor([0.5, -2.0, 700.0], dtype=torch.float32, device="cuda"))
+        assert [d.get_state(i).agc_gain for i in range(3)] == [0.5, 0.0, 700.0]

@@ -210,3 +210,33 @@ def test_weak_carrier_estimates_take_their_neighbours():
     fr, qual = carrier_estimates(both, np.array([0, 140_000]), 65536, 230000, 72000)
     assert qual[0] > 25 and qual[1] < 6
     assert abs(float(fr[0]) - 2 * np.pi * 400 / 72000) < 2e-4
+
+
+def test_agc_gain_seeds_follow_a_changing_amplitude():
+    """Float input around +-1: the reference's AGC has a time constant of seconds there (its step is absolute, agc.c:13-25),
+    so a recording whose amplitude swings 0.4..1.0 has every tile on a different gain.  The seeds come from the closed-form
+    AGC recursion over the tiles' sample powers, calibrated on the pilot's own gain history; they must track the serial
+    run's gain to a fraction of a percent, or the soft symbols are off by more than an LSB."""
+    from meteor_demod_amd.recording import agc_trajectory, fit_agc_calibration, _agc_step
+    cfg = DemodConfig(samplerate=230000, bps=32)
+    st = synth.make_stream(7, 230000, 72000, f0_hz=300.0, clock_ppm=5.0, esn0_db=12.0, fmt=32, rms=0.25, dc=(0.001, -0.002))
+    n = 3_200_000
+    iq = synth.generate_host(st, n).copy()
+    t = np.arange(n) / 230000
+    iq *= (0.7 - 0.3 * np.cos(2 * np.pi * t / 12.0)).astype(np.float32)[:, None]
+    serial, tr, ev = O.oracle_demod(cfg, iq, True)
+    mk = lambda seed: RecordingDemodulator(cfg, bank_factory=lambda c, k: OracleBank(c, k), carrier_seed=seed).demodulate(torch.from_numpy(iq))
+    good, bad = mk("spectrum"), mk("pilot")
+    a, b = agreement(good.soft.numpy(), serial), agreement(bad.soft.numpy(), serial)
+    assert good.report.pilot_symbols > 150_000                           # the pilot waited for the AGC (agc_settle_symbols)
+    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.99999
+    assert a["within_1lsb"] > 0.98 and b["within_1lsb"] < 0.6            # measured 0.994 / 0.29
+    want = np.array([float(tr["gain"][k]) for k in good.tile_first_symbol])
+    assert np.abs(np.asarray(good.report.gain_seeds) / want - 1).max() < 0.006   # measured 0.41 %
+    # the calibration is exact on a noiseless model: recursion with c = 100 from gain 50 over blocks of varying power
+    p = np.array([4.0, 3.0, 2.5, 2.0, 1.8, 1.7, 1.9, 2.4, 3.1, 3.9])
+    g, gains = 50.0, []
+    for pj in p:
+        g = _agc_step(g, 100.0, pj, 20000.0); gains.append(g)
+    assert abs(fit_agc_calibration(gains, p, np.full(10, 20000.0)) - 100.0) < 1e-6
+    assert np.allclose(agc_trajectory(gains[-1], 100.0, [2.0, 2.0], [1e9, 1e9]), [gains[-1], 100 / np.sqrt(2.0)], rtol=1e-6)
