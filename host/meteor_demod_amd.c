@@ -243,9 +243,9 @@ main(int argc, char **argv)
 			if (rc2 != MDEMOD_OK) { fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2)); return 2; }
 			if (!quiet)
 				fprintf(stderr, "%s: %llu samples: %llu serial (pilot) + %u tiles, %llu symbols, first lock at symbol %lld, %u seam fixes, "
-				        "%u weak seams, %u tiles without a carrier line, %.2f s\n", io[f].in_name, (unsigned long long)n_samples,
+				        "%u weak seams, %u rotation jumps, %u tiles without a carrier line, %.2f s\n", io[f].in_name, (unsigned long long)n_samples,
 				        (unsigned long long)rr.pilot_samples, rr.n_tiles, (unsigned long long)rr.n_symbols, (long long)rr.first_lock_symbol,
-				        rr.seam_fixes, rr.weak_seams, rr.weak_carrier_tiles, rr.pilot_seconds + rr.tiles_seconds);
+				        rr.seam_fixes, rr.weak_seams, rr.rotation_jumps, rr.weak_carrier_tiles, rr.pilot_seconds + rr.tiles_seconds);
 			for (uint64_t k = 0; k < rr.n_symbols; k += 1u << 20)
 				write_gated(&io[f], soft_all + 2 * k, (uint32_t)((rr.n_symbols - k < (1u << 20)) ? rr.n_symbols - k : (1u << 20)), rr.first_lock_symbol);
 			size_t tail = 2 * (size_t)io[f].ring_idx;                       /* main.c:321 */

@@ -256,7 +256,10 @@ typedef struct {
 	double   pilot_seconds;         /* wall time of the serial head                          */
 	double   tiles_seconds;         /* wall time of everything after it                      */
 	uint32_t weak_carrier_tiles;    /* carrier_seed=1: tiles without a clear spectral line, seeded from their neighbours */
-	uint32_t reserved;
+	uint32_t rotation_jumps;        /* seams where the second pass found the next tile a quarter turn (or more) off the
+	                                   emitted chain: its predecessor's first pass changed rotation inside the tile (a cycle
+	                                   slip or a late lock).  The stream after such a seam is a valid demodulation in another
+	                                   of the four lock rotations, exactly like a serial run after a cycle slip.            */
 } mdemod_recording_report;
 
 void mdemod_recording_default_opts(mdemod_recording_opts *opts);

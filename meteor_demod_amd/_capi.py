@@ -71,7 +71,7 @@ class MdemodRecordingReport(C.Structure):
                 ("first_lock_symbol", C.c_int64), ("samples_demodulated", C.c_uint64),
                 ("n_tiles", C.c_uint32), ("weak_seams", C.c_uint32), ("seam_fixes", C.c_uint32),
                 ("pilot_locked", C.c_int32), ("pilot_seconds", C.c_double), ("tiles_seconds", C.c_double),
-                ("weak_carrier_tiles", C.c_uint32), ("reserved", C.c_uint32)]
+                ("weak_carrier_tiles", C.c_uint32), ("rotation_jumps", C.c_uint32)]
 
 
 # name -> (restype, argtypes); this table is also what the symbol-export test walks.

@@ -347,7 +347,7 @@ upload(DevMem &m, const std::vector<T> &h, T **dev, hipStream_t st)
 }
 
 int
-counts_of(mdemod_ctx *c, uint32_t n, std::vector<uint32_t> &out, hipStream_t st)
+counts_of(mdemod_ctx *c, uint32_t n, std::vector<uint32_t> &out, hipStream_t st, std::vector<mdemod_status> *status_out = nullptr)
 {
 	std::vector<mdemod_status> s(n);
 	TRY(mdemod_get_status(c, 0, n, s.data(), st));
@@ -356,6 +356,7 @@ counts_of(mdemod_ctx *c, uint32_t n, std::vector<uint32_t> &out, hipStream_t st)
 		if (s[i].overflow) return MDEMOD_ERR_OVERFLOW;
 		out[i] = s[i].symbols_this_call;
 	}
+	if (status_out) status_out->swap(s);
 	return MDEMOD_OK;
 }
 
@@ -515,13 +516,13 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	TRY(mem.alloc(&soft1, T * cap * 2));
 
 	auto launch = [&](const std::vector<uint64_t> &off, const std::vector<uint64_t> &cnt, int8_t *soft, uint64_t stride,
-	                  std::vector<uint32_t> &produced) -> int {
+	                  std::vector<uint32_t> &produced, std::vector<mdemod_status> *status_out = nullptr) -> int {
 		std::vector<uint32_t> c32(cnt.begin(), cnt.end());
 		uint64_t *d_off; uint32_t *d_cnt;
 		TRY(upload(mem, off, &d_off, st));
 		TRY(upload(mem, c32, &d_cnt, st));
 		TRY(mdemod_process_device(bank.c, iq_dev, d_off, d_cnt, soft, stride, static_cast<uint32_t>(stride), st));
-		TRY(counts_of(bank.c, static_cast<uint32_t>(T), produced, st));
+		TRY(counts_of(bank.c, static_cast<uint32_t>(T), produced, st, status_out));
 		for (uint64_t c : cnt) rep->samples_demodulated += c;
 		return MDEMOD_OK;
 	};
@@ -661,7 +662,11 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	}
 	std::vector<uint32_t> cnt_pre, cnt1, cnt2;
 	TRY(launch(off_pre, pres, soft_pre, cap_pre, cnt_pre));
-	TRY(launch(starts, lens, soft1, cap, cnt1));
+	std::vector<mdemod_status> status_body;          /* of the launch whose symbols are emitted: first lock when the pilot has none */
+	TRY(launch(starts, lens, soft1, cap, cnt1, &status_body));
+	/* stream count at the start of every tile's EMITTED body, and the stream that ran it (identity without pass 2) */
+	std::vector<uint64_t> n_start(T); std::vector<size_t> body_stream(T);
+	for (size_t i = 0; i < T; i++) { n_start[i] = seed.n_symbols + cnt_pre[i]; body_stream[i] = i; }
 
 	/* ---- rotation + seam of every tile against its predecessor (tile 0: against the pilot) ---- */
 	std::vector<TailPair> pairs(T);
@@ -697,7 +702,11 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		}
 		TRY(mem.alloc(&soft2, T * cap * 2));
 		std::vector<uint32_t> cnt2s, cnt_posts;
-		TRY(launch(starts2, lens2, soft2, cap, cnt2s));
+		TRY(launch(starts2, lens2, soft2, cap, cnt2s, &status_body));
+		for (size_t i = 0; i < T; i++) {
+			body_stream[i] = (i + T - 1) % T;
+			n_start[i] = i ? seed.n_symbols + cnt_pre[i - 1] + cnt1[i - 1] : seed.n_symbols;
+		}
 		const uint64_t cap_post = std::max<uint64_t>(1, mdemod_max_symbols(bank.c, *std::max_element(post2.begin(), post2.end())));
 		int8_t *soft_post;
 		TRY(mem.alloc(&soft_post, T * cap_post * 2));
@@ -714,6 +723,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		for (size_t i = 0; i < T; i++) {
 			seam[i] = i ? -sh[i - 1] : 0;
 			if (i) rep->weak_seams += w2[i - 1];
+			if (i && !w2[i - 1] && (r2[i - 1] & 3)) rep->rotation_jumps++;
 			copies[i].src = soft2 + stream_of(i) * cap * 2; copies[i].rot = 0; copies[i].keep = cnt2s[stream_of(i)];
 			copies[i].head = (i && seam[i] == -1) ? soft_post + stream_of(i - 1) * cap_post * 2 : nullptr;
 			copies[i].head_rot = 0;
@@ -739,7 +749,11 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		for (size_t i = 0; i < T; i++) { starts2[i] = starts[(i + 1) % T]; lens2[i] = lens[(i + 1) % T]; }
 		TRY(mem.alloc(&soft2, T * cap * 2));
 		std::vector<uint32_t> cnt2s;
-		TRY(launch(starts2, lens2, soft2, cap, cnt2s));
+		TRY(launch(starts2, lens2, soft2, cap, cnt2s, &status_body));
+		for (size_t i = 0; i < T; i++) {
+			body_stream[i] = (i + T - 1) % T;
+			n_start[i] = i ? seed.n_symbols + cnt_pre[i - 1] + cnt1[i - 1] : seed.n_symbols;
+		}
 		auto stream_of = [&](size_t tile) { return (tile + T - 1) % T; };     /* tile i was run by stream i-1 */
 		cnt2.resize(T);
 		for (size_t i = 0; i < T; i++) cnt2[i] = cnt2s[stream_of(i)];
@@ -752,7 +766,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		}
 		std::vector<int32_t> shift2, rot2, weak2;
 		TRY(run_match(mem, pairs, K, shift2, rot2, weak2, st));
-		for (size_t i = 0; i + 1 < T; i++) rep->weak_seams += weak2[i];
+		for (size_t i = 0; i + 1 < T; i++) { rep->weak_seams += weak2[i]; if (!weak2[i] && (rot2[i] & 3)) rep->rotation_jumps++; }
 		for (size_t i = 0; i < T; i++) {
 			seam[i] = i ? shift2[i - 1] : 0;
 			copies[i].src = soft2 + stream_of(i) * cap * 2; copies[i].rot = 0; copies[i].keep = cnt2[i];
@@ -772,6 +786,18 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		if (seam[i]) rep->seam_fixes++;
 	}
 	if (out_pos > soft_cap_symbols) return MDEMOD_ERR_OVERFLOW;
+	if (rep->first_lock_symbol < 0) {
+		/* The pilot never locked (a recording that starts before the signal does): the lock gate (main.c:308-315) opens
+		   at the first tile whose stream reports a first lock - inside its emitted body, or before it (then the whole
+		   body counts).  Approximate to the tiles' own acquisition, which is faster than the serial sweep. */
+		for (size_t i = 0; i < T; i++) {
+			const int64_t fl = status_body[body_stream[i]].first_lock_symbol;
+			if (fl < 0) continue;
+			const uint64_t inside = static_cast<uint64_t>(fl) > n_start[i] ? static_cast<uint64_t>(fl) - n_start[i] : 0;
+			rep->first_lock_symbol = static_cast<int64_t>(copies[i].dst + std::min<uint64_t>(inside, copies[i].keep));
+			break;
+		}
+	}
 	TileCopy *d_copies;
 	TRY(upload(mem, copies, &d_copies, st));
 	hipLaunchKernelGGL(assemble_kernel, dim3(static_cast<unsigned>(T)), dim3(256), 0, st, d_copies, soft_dev);

@@ -319,3 +319,38 @@ def test_native_stitcher_seeds_the_agc_on_float_input(gpu_device):
     with Demodulator(C1, 3) as d:                                        # the seed op against its definition
         d.set_gain_seeds(torch.tensor([0.5, -2.0, 700.0], dtype=torch.float32, device="cuda"))
         assert [d.get_state(i).agc_gain for i in range(3)] == [0.5, 0.0, 700.0]
+
+
+@pytest.mark.gpu
+def test_native_stitcher_opens_the_lock_gate_from_the_tiles_when_the_pilot_never_locks(gpu_device):
+    """A recording that starts before the signal does: the serial head gives up after max_pilot_samples without a lock, so
+    the lock gate (main.c:308-315) has to come from the tiles - the first one whose stream reports a first lock.  The
+    symbols after that point are the transmitted ones (checked against the serial run where that one is locked too)."""
+    import torch
+    from meteor_demod_amd.recording import demodulate_recording_native, rotate_symbols
+    st = synth.make_stream(93, 230000, 72000, f0_hz=500.0, clock_ppm=5.0, esn0_db=12.0, rms=1500.0)
+    n_noise, n_sig = 1_500_000, 5_000_000
+    sig = synth.generate_device([st], n_sig)[0]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    noise = (torch.randn((n_noise, 2), device="cuda", generator=g) * 500).to(torch.int16)
+    iq = torch.cat((noise, sig)).contiguous()
+    soft, rep = demodulate_recording_native(C1, iq, carrier_seed="spectrum", max_pilot_samples=600_000)
+    assert not rep.pilot_locked and rep.pilot_samples < 700_000
+    sym_at_signal = int(n_noise * 72000 / 230000)
+    tile_sym = 20536
+    assert sym_at_signal - tile_sym <= rep.first_lock_symbol <= sym_at_signal + 2 * tile_sym, rep.first_lock_symbol
+    assert rep.weak_carrier_tiles >= 10                                  # the noise tiles have no carrier line
+    # the serial run needs its sweep to find the carrier; compare where it is locked too, up to the quarter-turn ambiguity
+    serial, tr, ev = O.oracle_demod(C1, iq.cpu().numpy(), True)
+    out = soft.cpu().numpy()
+    L = 600_000
+    assert tr["locked"][-L:].all()
+    best = 0.0
+    for r in range(4):
+        rot = rotate_symbols(torch.from_numpy(out[-L - 4:]).unsqueeze(0), torch.tensor([r]))[0].numpy()
+        for s in range(-2, 3):
+            best = max(best, ((rot[4 + s: 4 + s + L - 8] >= 0) == (serial[-L: -8] >= 0)).all(axis=1).mean())
+    assert best > 0.9999
+    # the stitched stream is on the data well before the serial run is: right after the gate opens
+    k = rep.first_lock_symbol + 2 * tile_sym
+    assert np.abs(out[k: k + 20000].astype(int)).mean() > 45             # locked constellation (~60), not noise (~30)
