@@ -602,13 +602,13 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 			std::vector<float> wp(ws.size());
 			HTRY(hipMemcpyAsync(wp.data(), d_wp, wp.size() * sizeof(float), hipMemcpyDeviceToHost, st));
 			HTRY(hipStreamSynchronize(st));
-			std::vector<double> bg(nb), bp(nb), bn(nb);
+			std::vector<double> blk_gain(nb), blk_power(nb), blk_syms(nb);
 			for (size_t j = 0; j < nb; j++) {
 				const PilotBlock &pb = pilot_blocks[b0 + j];
 				const uint64_t before = (b0 + j) ? pilot_blocks[b0 + j - 1].symbols_after : 0;
-				bg[j] = pb.gain_after; bp[j] = wp[j]; bn[j] = static_cast<double>(pb.symbols_after - before);
+				blk_gain[j] = pb.gain_after; blk_power[j] = wp[j]; blk_syms[j] = static_cast<double>(pb.symbols_after - before);
 			}
-			const double c = fit_agc_calibration(bg, bp, bn);
+			const double c = fit_agc_calibration(blk_gain, blk_power, blk_syms);
 			double g = seed.agc_gain;
 			std::vector<float> gains(T);
 			for (size_t i = 0; i < T; i++) {
