@@ -524,6 +524,7 @@ class RecordingDemodulator:
             pre_last, _ = gather_tails(soft_pre, cnt_pre, 1)
             head_sym = rotate_symbols(pre_last.to(torch.int8), R)[:, 0]           # used where shift == -1
             out = self._assemble(pilot_soft, body, cnt1, shift, head_sym)
+            self._gate_from_tiles(rep, bank, out[1], int(seed.n_symbols) + cnt_pre.cpu().numpy(), np.arange(T), cnt1.cpu().numpy())
             pilot.close(); bank.close()
             return StitchedRecording(out[0], out[1], plan, rep)
 
@@ -558,6 +559,8 @@ class RecordingDemodulator:
         head_sym = torch.cat((torch.zeros((1, 2), dtype=torch.int8, device=dev), b1_last[:-1]))
         rep.seam_shifts = seam.cpu().tolist()
         out = self._assemble(pilot_soft, soft2, cnt2, seam, head_sym)
+        n_start = np.concatenate(([0], (cnt_pre + cnt1).cpu().numpy()[:-1])) + int(seed.n_symbols)
+        self._gate_from_tiles(rep, bank, out[1], n_start, (np.arange(T) - 1) % T, cnt2.cpu().numpy())
         pilot.close(); bank.close()
         return StitchedRecording(out[0], out[1], plan, rep)
 
@@ -615,8 +618,26 @@ class RecordingDemodulator:
             head_sym[1:] = soft_post[:-1, 0]
         rep.seam_shifts = seam.cpu().tolist()
         out = self._assemble(pilot_soft, soft2, cnt2, seam, head_sym)
+        n_start = np.concatenate(([0], (cnt_pre + cnt1).cpu().numpy()[:-1])) + int(seed.n_symbols)
+        self._gate_from_tiles(rep, bank, out[1], n_start, (np.arange(T) - 1) % T, cnt2.cpu().numpy())
         pilot.close(); bank.close()
         return StitchedRecording(out[0], out[1], plan, rep)
+
+    @staticmethod
+    def _gate_from_tiles(rep, bank, first_out, n_start, body_stream, keep):
+        """The pilot never locked (a recording that starts before the signal does): the lock gate (main.c:308-315) opens at
+        the first tile whose stream reports a first lock - inside its emitted body, or before it (then the whole body
+        counts).  ``n_start[i]``: the stream's symbol count when tile i's emitted body began.  Approximate to the tiles'
+        own acquisition, which is faster than the serial sweep (same rule as csrc/recording.hip)."""
+        if rep.first_lock_symbol >= 0:
+            return
+        for i in range(len(first_out)):
+            fl = int(bank.get_state(int(body_stream[i])).first_lock_symbol)
+            if fl < 0:
+                continue
+            inside = max(0, fl - int(n_start[i]))
+            rep.first_lock_symbol = int(first_out[i]) + min(inside, int(keep[i]))
+            return
 
     # -- concatenation with seam fixes -------------------------------------------------------------
     @staticmethod

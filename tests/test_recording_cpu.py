@@ -240,3 +240,24 @@ def test_agc_gain_seeds_follow_a_changing_amplitude():
         g = _agc_step(g, 100.0, pj, 20000.0); gains.append(g)
     assert abs(fit_agc_calibration(gains, p, np.full(10, 20000.0)) - 100.0) < 1e-6
     assert np.allclose(agc_trajectory(gains[-1], 100.0, [2.0, 2.0], [1e9, 1e9]), [gains[-1], 100 / np.sqrt(2.0)], rtol=1e-6)
+
+
+def test_lock_gate_comes_from_the_tiles_when_the_pilot_never_locks():
+    """Noise in front of the signal and a pilot that gives up before the signal starts: first_lock_symbol is taken from the
+    first tile whose stream locks, within a tile of the signal's first symbol; native entry has the same rule (GPU test)."""
+    st = synth.make_stream(93, 230000, 72000, f0_hz=500.0, clock_ppm=5.0, esn0_db=12.0, rms=1500.0)
+    n_noise, n_sig = 500_000, 900_000
+    rng = np.random.default_rng(5)
+    noise = rng.normal(0, 500, (n_noise, 2)).astype(np.int16)
+    iq = np.concatenate((noise, synth.generate_host(st, n_sig)))
+    for refine in (True, False):
+        rd = RecordingDemodulator(C1, bank_factory=lambda c, k: OracleBank(c, k), carrier_seed="spectrum", refine=refine,
+                                  max_pilot_samples=200_000)
+        res = rd.demodulate(torch.from_numpy(iq))
+        r = res.report
+        assert not r.pilot_locked and r.pilot_samples <= 262_144
+        sym_at_signal = int(n_noise * 72000 / 230000)
+        assert sym_at_signal - 20536 <= r.first_lock_symbol <= sym_at_signal + 2 * 20536, (refine, r.first_lock_symbol)
+        out = res.soft.numpy()
+        k = r.first_lock_symbol + 2 * 20536
+        assert np.abs(out[k: k + 20000].astype(int)).mean() > 45          # on the data (~60), not noise (~30)
