@@ -1,0 +1,54 @@
+"""Robustness soak of mdemod_demodulate_recording's option space: tiny and huge tiles, no warm-up, short seams, no second
+pass, short recordings, pilots that end at the cap - every call must return MDEMOD_OK with a symbol count within a few
+symbols of the serial oracle's and the pilot part byte-exact.  Accuracy is recording_fuzz.py's job; this one looks for
+crashes, overflows and miscounts.  Usage: recording_opts_fuzz.py [n_cases] [seed]"""
+import sys
+import time
+
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np
+import oracle_py as O
+from meteor_demod_amd import DemodConfig, synth
+from meteor_demod_amd.recording import demodulate_recording_native
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad, t0 = [], time.time()
+for ci in range(n_cases):
+    oqpsk = bool(rng.random() < 0.3)
+    symrate = 80000 if oqpsk else 72000
+    osf = float(rng.choice([2.875, 3.1944, 4.0, 6.0]))
+    samplerate = int(symrate * osf)
+    bps = int(rng.choice([8, 16, 16, 32]))
+    cfg = DemodConfig(samplerate=samplerate, symrate=symrate, oqpsk=oqpsk, bps=bps)
+    n = int(rng.choice([1, 100, 5000, 70_000, 300_000, 1_000_000, 2_500_000]))
+    amp = {8: dict(rms=40.0, dc=(1.5, -1.0)), 16: dict(rms=1500.0), 32: dict(rms=0.25, dc=(0.001, -0.002))}[bps]
+    st = synth.make_stream(5000 + ci, samplerate, symrate, f0_hz=float(rng.uniform(0, 600)), clock_ppm=float(rng.uniform(-20, 20)),
+                           esn0_db=12.0, oqpsk=oqpsk, fmt=bps, doppler_hz_per_s=float(rng.choice([0.0, 20.0])), **amp)
+    kw = dict(tile_samples=int(rng.choice([0, 4096, 4160, 8192 + 64, 20000 // 64 * 64, 65600, 300_032])),
+              pre_samples=int(rng.choice([-1, 0, 64, 1000, 16384, 100_000])),
+              refine=bool(oqpsk or rng.random() < 0.7),
+              pilot_block=int(rng.choice([4096, 65536, 100_000])),
+              pilot_margin_symbols=int(rng.choice([0, 2000, 20000])),
+              max_pilot_samples=int(rng.choice([50_000, 400_000, 1 << 22])),
+              match_symbols=int(rng.choice([8, 64, 192, 1000])),
+              carrier_seed=str(rng.choice(["spectrum", "pilot"])))
+    iq = synth.generate_device([st], n)[0]
+    tag = f"case {ci}: {'oqpsk' if oqpsk else 'qpsk'} fs={samplerate} bps={bps} n={n} {kw}"
+    try:
+        soft, rep = demodulate_recording_native(cfg, iq, **kw)
+    except Exception as e:                                    # any MDEMOD_ERR_* is a finding
+        print(tag, "-> ERROR", repr(e), flush=True)
+        bad.append(tag)
+        continue
+    serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
+    out = soft.cpu().numpy()
+    ok = abs(len(out) - len(serial)) <= max(2, rep.weak_seams + rep.n_tiles // 20 + 2) and len(out) == rep.n_symbols   # absurd tilings (no warm-up) may slip a symbol per tile
+    ok = ok and np.array_equal(out[: rep.pilot_symbols], serial[: rep.pilot_symbols])
+    print(tag, "->", "ok" if ok else "FAIL", len(out), len(serial), "tiles", rep.n_tiles, "weak", rep.weak_seams, "pilot", rep.pilot_symbols, flush=True)
+    if not ok:
+        bad.append(tag)
+print(f"{n_cases} cases in {time.time() - t0:.0f} s, failures {len(bad)}")
+for b in bad:
+    print("  ", b)
+sys.exit(1 if bad else 0)
