@@ -466,11 +466,14 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	TRY(mdemod_get_state(pilot.c, 0, &seed, st));
 	while (pos < n_samples) {
 		const uint32_t b = static_cast<uint32_t>(std::min<uint64_t>(o.pilot_block, n_samples - pos));
-		const uint64_t cap = mdemod_max_symbols(pilot.c, b);
-		if (nsym + cap > soft_cap_symbols) return MDEMOD_ERR_OVERFLOW;
+		/* the block may produce up to one symbol per sample (mdemod_max_symbols); the caller's buffer only has to hold what
+		   it does produce: the kernel checks the capacity it is given and reports an overflow */
+		const uint64_t cap = std::min<uint64_t>(mdemod_max_symbols(pilot.c, b), soft_cap_symbols - std::min(nsym, soft_cap_symbols));
+		if (cap == 0) return MDEMOD_ERR_OVERFLOW;
 		TRY(mdemod_process_device_uniform(pilot.c, iq + pos * sb, 0, b, soft_dev + 2 * nsym, cap, static_cast<uint32_t>(cap), st));
 		mdemod_status s1;
 		TRY(mdemod_get_status(pilot.c, 0, 1, &s1, st));
+		if (s1.overflow) return MDEMOD_ERR_OVERFLOW;
 		nsym += s1.symbols_this_call;
 		TRY(mdemod_get_state(pilot.c, 0, &seed, st));
 		pilot_blocks.push_back(PilotBlock{pos, b, seed.agc_gain, seed.n_symbols});
@@ -777,6 +780,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 
 	/* ---- concatenate: pilot ++ tiles, with the seam fixes ---- */
 	uint64_t out_pos = n_pilot_sym - (seam[0] == 1 ? 1 : 0);
+	if (seam[0] == 1 && rep->pilot_symbols) rep->pilot_symbols--;       /* the pilot's last symbol was a duplicate of tile 0's first: the exact prefix is one shorter */
 	for (size_t i = 0; i < T; i++) {
 		const uint32_t drop = (i + 1 < T && seam[i + 1] == 1) ? 1 : 0;
 		copies[i].keep = copies[i].keep > drop ? copies[i].keep - drop : 0;

@@ -524,6 +524,8 @@ class RecordingDemodulator:
             pre_last, _ = gather_tails(soft_pre, cnt_pre, 1)
             head_sym = rotate_symbols(pre_last.to(torch.int8), R)[:, 0]           # used where shift == -1
             out = self._assemble(pilot_soft, body, cnt1, shift, head_sym)
+            if int(shift[0]) == 1 and rep.pilot_symbols:
+                rep.pilot_symbols -= 1             # the pilot's last symbol was a duplicate of tile 0's first one
             self._gate_from_tiles(rep, bank, out[1], int(seed.n_symbols) + cnt_pre.cpu().numpy(), np.arange(T), cnt1.cpu().numpy())
             pilot.close(); bank.close()
             return StitchedRecording(out[0], out[1], plan, rep)
@@ -674,8 +676,9 @@ class RecordingDemodulator:
 def demodulate_recording_native(cfg, iq, tile_samples: int = 0, pre_samples: int = -1, refine: bool = True,
                                 pilot_block: int = 65536, pilot_margin_symbols: int = 20000,
                                 max_pilot_samples: int = 1 << 22, match_symbols: int = 192, device: int = 0,
-                                carrier_seed: str = "pilot"):
-    """``mdemod_demodulate_recording`` on a device tensor [n, 2]: returns (soft int8 [m, 2] device tensor, report)."""
+                                carrier_seed: str = "pilot", soft_capacity: int = 0):
+    """``mdemod_demodulate_recording`` on a device tensor [n, 2]: returns (soft int8 [m, 2] device tensor, report).
+    ``soft_capacity`` (symbols; 0 = nominal rate + 5 % + 65536) is what the callee checks its output against."""
     import ctypes as C
     import torch
     from . import _capi
@@ -686,7 +689,7 @@ def demodulate_recording_native(cfg, iq, tile_samples: int = 0, pre_samples: int
                                      match_symbols, int(refine), 1 if carrier_seed == "spectrum" else 0, 0)
     n = int(iq.shape[0])
     p = cfg.to_c(1, device)
-    cap = int(n * cfg.symrate / cfg.samplerate * 1.05) + 65536          # stitched output: nominal rate + slack (checked by the callee)
+    cap = int(soft_capacity) or int(n * cfg.symrate / cfg.samplerate * 1.05) + 65536   # stitched output: nominal rate + slack (checked by the callee)
     soft = torch.empty((cap, 2), dtype=torch.int8, device=iq.device)
     rep = _capi.MdemodRecordingReport()
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -354,3 +354,31 @@ def test_native_stitcher_opens_the_lock_gate_from_the_tiles_when_the_pilot_never
     # the stitched stream is on the data well before the serial run is: right after the gate opens
     k = rep.first_lock_symbol + 2 * tile_sym
     assert np.abs(out[k: k + 20000].astype(int)).mean() > 45             # locked constellation (~60), not noise (~30)
+
+
+@pytest.mark.gpu
+def test_native_stitcher_needs_no_more_output_room_than_it_writes(gpu_device):
+    """The CLI sizes the output for the nominal symbol rate + 2 % + 4096 (host/meteor_demod_amd.c).  A recording shorter
+    than one pilot block must fit in that (the pilot used to insist on room for one symbol per sample of its block), a
+    buffer that is really too small must be refused, and the byte-exact prefix must be what pilot_symbols says."""
+    from meteor_demod_amd._capi import MdemodError
+    from meteor_demod_amd.recording import demodulate_recording_native
+    st = synth.make_stream(31, 230000, 72000, f0_hz=100.0, esn0_db=12.0)
+    for n in (1, 1000, 100_000, 400_000):
+        iq = synth.generate_device([st], n)[0]
+        serial = O.oracle_demod(C1, iq.cpu().numpy())[0]
+        cap = int(n * 72000 / 230000 * 1.02) + 4096
+        soft, rep = demodulate_recording_native(C1, iq, carrier_seed="spectrum", soft_capacity=cap)
+        out = soft.cpu().numpy()
+        assert abs(len(out) - len(serial)) <= 1 and np.array_equal(out[: rep.pilot_symbols], serial[: rep.pilot_symbols])
+        if rep.n_tiles == 0:
+            assert np.array_equal(out, serial)
+    with pytest.raises(MdemodError):
+        demodulate_recording_native(C1, iq, carrier_seed="spectrum", soft_capacity=1000)
+    # first seam against the pilot may drop the pilot's last symbol (no second pass): the exact prefix shrinks with it
+    iq = synth.generate_device([st], 1_200_000)[0]
+    serial = O.oracle_demod(C1, iq.cpu().numpy())[0]
+    for pre in (0, 1000, 16384):
+        soft, rep = demodulate_recording_native(C1, iq, refine=False, pre_samples=pre, pilot_margin_symbols=2000, tile_samples=20032)
+        out = soft.cpu().numpy()
+        assert np.array_equal(out[: rep.pilot_symbols], serial[: rep.pilot_symbols])
