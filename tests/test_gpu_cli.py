@@ -164,3 +164,19 @@ def test_cli_tiled_follows_doppler(tmp_path, gpu_device):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(CLI), "-q", "--tiled", "--carrier-seed", "bogus", "-o", str(out), str(inp)], capture_output=True, text=True)
     assert r.returncode != 0 and "carrier-seed" in r.stderr
+
+
+def test_cli_tiled_short_file_is_the_serial_file(tmp_path, gpu_device):
+    """A file shorter than the pilot: --tiled must give the bytes of the normal (exact) mode - the whole file is the
+    serial head.  (It used to fail with "soft-symbol capacity too small": the pilot wanted room for one symbol per sample
+    of a 65 536-sample block in a buffer sized for the file.)"""
+    from golden_cases import wav_header
+    from meteor_demod_amd import synth
+    for n in (8192 * 3, 8192 * 12):
+        iq = synth.generate_host(synth.make_stream(77, 230000, 72000, f0_hz=0.0, esn0_db=14.0), n)
+        inp, a, b = tmp_path / "short.wav", tmp_path / "a.s", tmp_path / "b.s"
+        inp.write_bytes(wav_header(230000, 16, iq.nbytes) + iq.tobytes())
+        r1 = subprocess.run([str(CLI), "-q", "-o", str(a), str(inp)], capture_output=True, text=True)
+        r2 = subprocess.run([str(CLI), "-q", "--tiled", "-o", str(b), str(inp)], capture_output=True, text=True)
+        assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+        assert a.read_bytes() == b.read_bytes() and len(a.read_bytes()) > 0
