@@ -54,6 +54,9 @@
 #ifndef MDEMOD_RW_REGSTATE
 #define MDEMOD_RW_REGSTATE 1          /* AGC / NCO state of the float std variant in VGPRs instead of LDS slots */
 #endif
+#ifndef MDEMOD_RW_SETPRIO
+#define MDEMOD_RW_SETPRIO 1           /* the scalar stage of a firing runs at raised wave priority, see the main loop */
+#endif
 #ifndef MDEMOD_RW_PREFETCH
 #define MDEMOD_RW_PREFETCH 2          /* FIR coefficient prefetch distance (chunks) of the float std variant */
 #endif
@@ -294,6 +297,9 @@ demod_kernel_rw(const DemodLaunch L)
 	/* The float window of the std geometry leaves ~20 VGPRs: AGC and NCO state stay in registers there
 	 * (5 LDS reads + 5 writes per symbol less, and no exposed LDS latency right after the FIR). */
 	constexpr bool REGSTATE = MDEMOD_RW_REGSTATE && !PACKED && G::KT <= 65;
+	/* wave priority (see the main loop): 1 = raised for the scalar stage of a firing; 2 = and for the symbol clock's add
+	 * chain that follows it (std QPSK: +2 % more; OQPSK and the compact geometries: -0.3 %, so they stay at 1) */
+	constexpr int PRIO = !MDEMOD_RW_SETPRIO ? 0 : (!OQPSK && !G::COMPACT) ? 2 : 1;
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	float *ctab = reinterpret_cast<float *>(lds);
@@ -443,6 +449,7 @@ demod_kernel_rw(const DemodLaunch L)
 			}
 		}
 		if (__all(done)) break;
+		if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 
 		/* ---- (2) slide the window by 8 slots when nobody needs slots 0..7 any more ---- */
 #pragma unroll
@@ -498,6 +505,15 @@ demod_kernel_rw(const DemodLaunch L)
 			const bool skip_first = __all(a >= 8);              /* over the lanes active in this branch */
 			const bool skip_last = __all(a <= AMAX - 8);
 			fir_window<NW, W, !G::COMPACT, (MDEMOD_RW_PREFETCH == 2 && !PACKED && !G::COMPACT && FMT != 32) ? 2 : 1>(win, row, skip_first, skip_last, y.re, y.im);
+			/* Two waves share a SIMD.  The FIR is ~290 independent VALU instructions, the scalar stage a chain of short
+			 * dependent ones (AGC -> NCO -> mix -> loops): when the arbiter interleaves them evenly, the chain waits behind
+			 * FIR instructions it does not depend on.  Raising the priority of the wave that is in its scalar stage lets the
+			 * chain issue as soon as its operands are ready while the other wave's FIR fills every other slot: +3.2 % on
+			 * configs[1], +4.6 % on OQPSK, +1 % on the wide geometry (measured; the FIR at raised priority instead: +1 %;
+			 * everything but the FIR raised: +1.4 %; level 3 instead of 2: same).  With PRIO == 2 the priority stays up
+			 * through the symbol clock (another dependent chain: 18 float adds) and drops before the slide: 204.5 -> 208.5
+			 * GS/s on configs[1]. */
+			if (PRIO) __builtin_amdgcn_s_setprio(2);
 
 			/* ---- scalar part: state comes from / goes back to the LDS slots ---- */
 			if (REGSTATE) {
@@ -586,6 +602,7 @@ demod_kernel_rw(const DemodLaunch L)
 			else { sl[S_PHASE * 64] = pll.phase; sl[S_FREQ * 64] = pll.freq; }
 			sl[S_ERR * 64] = pll.err;
 			sli[S_FLAGS * 64] = (fl & 8) | (pll.locked ? 1 : 0) | (pll.locked_once ? 2 : 0) | (pll.updown > 0 ? 4 : 0);
+			if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
 		}
 	} while (--guard);                                               /* the watchdog is the loop's latch */
 
