@@ -75,8 +75,7 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
         objs.append(obj)
     so = LIB / "libmeteor_demod_amd.so"
     if force or _stale(so, objs):
-        # hipFFT: the per-tile carrier estimator of the recording stitcher (a plain library FFT, csrc/recording.hip)
-        _run([hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", str(so), *map(str, objs), "-lhipfft"])
+        _run([hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", str(so), *map(str, objs)])
     out["lib"] = so
 
     # --- synthetic signal generator -----------------------------------------

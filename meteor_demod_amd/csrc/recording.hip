@@ -19,7 +19,6 @@
  * C-ABI of this library; the kernels here only compare and move int8 symbols.
  */
 #include <hip/hip_runtime.h>
-#include <hipfft/hipfft.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -191,47 +190,89 @@ template <> struct RawIQ<16> { typedef int16_t t; __device__ static float2 get(c
 template <> struct RawIQ<8>  { typedef uint8_t t; __device__ static float2 get(const void *p, uint64_t i) { const uint8_t *q = static_cast<const uint8_t *>(p) + 2 * i; return make_float2((float)((int)q[0] - 128), (float)((int)q[1] - 128)); } };
 template <> struct RawIQ<32> { typedef float t;   __device__ static float2 get(const void *p, uint64_t i) { const float *q = static_cast<const float *>(p) + 2 * i; return make_float2(q[0], q[1]); } };
 
-/* One block per tile: mean removed, fourth power, Hann window -> complex float [tile][nfft]; power_out[tile] = mean
- * |z - mean|^2 of the window (feeds the AGC seeds). */
+/* One block (1024 threads) per tile, the whole estimate in one kernel and in LDS (no FFT library: hipFFT compiles its
+ * kernels at run time, 1.6 s in every new process - more than a whole recording takes):
+ *   1. mean of the window's nwin = NF * D samples;
+ *   2. z^4 of the mean-free samples, summed in groups of D (boxcar decimation: the line sits within +-4 * fmax, far
+ *      inside the decimated band; the boxcar's droop there is < 1 dB), Hann window, stored bit-reversed;
+ *   3. in-place radix-2 FFT of NF <= 16384 points (128 KB of the CU's 160 KB LDS);
+ *   4. largest magnitude among bins -kmax+1 .. kmax-1, parabolic interpolation -> rad per NCO step; quality = peak / mean
+ *      magnitude of the searched band (noise alone: 3-4; a 12 dB signal: 40-50). */
 template <int FMT>
-__global__ void
-fourth_power_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, int nfft, float2 *out, float *power_out)
+__global__ void __launch_bounds__(1024)
+carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, int log2_nf, int decim, int kmax,
+                    float hz_per_bin_over4, float rad_per_hz, float *freq_out, float *quality_out)
 {
+	extern __shared__ float2 spec[];                      /* NF complex floats */
+	__shared__ float red[3][1024];
+	__shared__ int redi[1024];
+	const int NF = 1 << log2_nf, nwin = NF * decim, tid = threadIdx.x, nth = blockDim.x;
 	const uint64_t s0 = starts[blockIdx.x];
-	__shared__ float red[2][256];
+	auto sample = [&](int k) {
+		const uint64_t i = s0 + (uint64_t)k < n_samples ? s0 + (uint64_t)k : n_samples - 1;
+		return RawIQ<FMT>::get(iq, i);
+	};
 	float sr = 0.0f, si = 0.0f;
-	for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
-		const uint64_t i = s0 + k < n_samples ? s0 + k : n_samples - 1;
-		const float2 v = RawIQ<FMT>::get(iq, i);
-		sr += v.x; si += v.y;
-	}
-	red[0][threadIdx.x] = sr; red[1][threadIdx.x] = si;
+	for (int k = tid; k < nwin; k += nth) { const float2 v = sample(k); sr += v.x; si += v.y; }
+	red[0][tid] = sr; red[1][tid] = si;
 	__syncthreads();
-	for (int o = 128; o > 0; o >>= 1) {
-		if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+	for (int o = nth / 2; o > 0; o >>= 1) {
+		if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
 		__syncthreads();
 	}
-	const float mr = red[0][0] / nfft, mi = red[1][0] / nfft;
-	float2 *dst = out + (size_t)blockIdx.x * nfft;
-	const float wstep = 6.283185307179586f / (float)(nfft - 1);
-	float pw = 0.0f;
+	const float mr = red[0][0] / nwin, mi = red[1][0] / nwin;
 	__syncthreads();
-	for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
-		const uint64_t i = s0 + k < n_samples ? s0 + k : n_samples - 1;
-		float2 v = RawIQ<FMT>::get(iq, i);
-		v.x -= mr; v.y -= mi;
-		pw += v.x * v.x + v.y * v.y;
-		const float2 z2 = make_float2(v.x * v.x - v.y * v.y, 2.0f * v.x * v.y);
-		const float w = (0.5f - 0.5f * cosf(wstep * (float)k)) * 1e-12f;         /* scale: |z|^4 of full-scale s16 stays far from overflow */
-		dst[k] = make_float2((z2.x * z2.x - z2.y * z2.y) * w, 2.0f * z2.x * z2.y * w);
+	const float wstep = 2.0f / (float)(NF - 1);
+	for (int m = tid; m < NF; m += nth) {
+		float ar = 0.0f, ai = 0.0f;
+		for (int d = 0; d < decim; d++) {
+			float2 v = sample(m * decim + d);
+			v.x -= mr; v.y -= mi;
+			const float2 z2 = make_float2(v.x * v.x - v.y * v.y, 2.0f * v.x * v.y);
+			ar += z2.x * z2.x - z2.y * z2.y; ai += 2.0f * z2.x * z2.y;
+		}
+		const float w = (0.5f - 0.5f * cospif(wstep * (float)m)) * 1e-12f;   /* Hann; the scale keeps |z|^4 of full-scale s16 far from overflow */
+		spec[__brev((unsigned)m) >> (32 - log2_nf)] = make_float2(ar * w, ai * w);
 	}
-	red[0][threadIdx.x] = pw;
 	__syncthreads();
-	for (int o = 128; o > 0; o >>= 1) {
-		if ((int)threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o];
+	for (int st = 0; st < log2_nf; st++) {                /* decimation in time, natural-order output */
+		const int half = 1 << st;
+		for (int b = tid; b < NF / 2; b += nth) {
+			const int j = b & (half - 1), i0 = ((b >> st) << (st + 1)) + j, i1 = i0 + half;
+			float sn, cs;
+			sincospif(-(float)j / (float)half, &sn, &cs);
+			const float2 u = spec[i0], v = spec[i1];
+			const float2 t = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+			spec[i0] = make_float2(u.x + t.x, u.y + t.y);
+			spec[i1] = make_float2(u.x - t.x, u.y - t.y);
+		}
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) power_out[blockIdx.x] = red[0][0] / nfft;
+	auto mag = [&](int k) { const float2 v = spec[(k + NF) & (NF - 1)]; return v.x * v.x + v.y * v.y; };
+	float best = -1.0f, sum = 0.0f; int bidx = 0;
+	for (int k = -kmax + tid; k <= kmax; k += nth) {
+		const float m = mag(k);
+		sum += sqrtf(m);
+		if (m > best && k > -kmax && k < kmax) { best = m; bidx = k; }
+	}
+	red[0][tid] = best; redi[tid] = bidx; red[2][tid] = sum;
+	__syncthreads();
+	for (int o = nth / 2; o > 0; o >>= 1) {
+		if (tid < o) {
+			const float ov = red[0][tid + o]; const int oi = redi[tid + o];
+			if (ov > red[0][tid] || (ov == red[0][tid] && oi < redi[tid])) { red[0][tid] = ov; redi[tid] = oi; }
+			red[2][tid] += red[2][tid + o];
+		}
+		__syncthreads();
+	}
+	if (tid == 0) {
+		const int k = redi[0];
+		const float a = sqrtf(mag(k - 1)), b = sqrtf(mag(k)), c = sqrtf(mag(k + 1));
+		const float den = a - 2.0f * b + c;
+		const float delta = den != 0.0f ? 0.5f * (a - c) / den : 0.0f;
+		freq_out[blockIdx.x] = ((float)k + delta) * hz_per_bin_over4 * rad_per_hz;
+		quality_out[blockIdx.x] = b / (red[2][0] / (float)(2 * kmax + 1) + 1e-30f);
+	}
 }
 
 /* One block per window: sample power (mean |z - mean|^2) of lens[w] samples from starts[w] (AGC seeds). */
@@ -265,40 +306,6 @@ window_power_kernel(const void *iq, const uint64_t *starts, const uint32_t *lens
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) power_out[blockIdx.x] = n ? red[0][0] / n : 0.0f;
-}
-
-/* One block per tile: largest magnitude among bins -kmax+1 .. kmax-1, parabolic interpolation -> rad per NCO step;
- * quality = peak / mean magnitude of the searched band (noise alone: 3-4; a 12 dB signal: 40-50). */
-__global__ void
-spectrum_peak_kernel(const float2 *spec, int nfft, int kmax, float hz_per_bin_over4, float rad_per_hz, float *freq_out, float *quality_out)
-{
-	const float2 *sp = spec + (size_t)blockIdx.x * nfft;
-	__shared__ float bv[256]; __shared__ int bi[256]; __shared__ float bs[256];
-	float best = -1.0f, sum = 0.0f; int bidx = 0;
-	auto mag = [&](int k) { const float2 v = sp[(k + nfft) % nfft]; return v.x * v.x + v.y * v.y; };
-	for (int k = -kmax + (int)threadIdx.x; k <= kmax; k += blockDim.x) {
-		const float m = mag(k);
-		sum += sqrtf(m);
-		if (m > best && k > -kmax && k < kmax) { best = m; bidx = k; }
-	}
-	bv[threadIdx.x] = best; bi[threadIdx.x] = bidx; bs[threadIdx.x] = sum;
-	__syncthreads();
-	for (int o = 128; o > 0; o >>= 1) {
-		if ((int)threadIdx.x < o) {
-			const float ov = bv[threadIdx.x + o]; const int oi = bi[threadIdx.x + o];
-			if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = ov; bi[threadIdx.x] = oi; }
-			bs[threadIdx.x] += bs[threadIdx.x + o];
-		}
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) {
-		const int k = bi[0];
-		const float a = sqrtf(mag(k - 1)), b = sqrtf(mag(k)), c = sqrtf(mag(k + 1));
-		const float den = a - 2.0f * b + c;
-		const float delta = den != 0.0f ? 0.5f * (a - c) / den : 0.0f;
-		freq_out[blockIdx.x] = ((float)k + delta) * hz_per_bin_over4 * rad_per_hz;
-		quality_out[blockIdx.x] = b / (bs[0] / (float)(2 * kmax + 1) + 1e-30f);
-	}
 }
 
 __global__ void
@@ -536,52 +543,51 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	for (size_t i = 0; i < T; i++) off_pre[i] = starts[i] - pres[i];
 	if (o.carrier_seed == 1) {
 		/* Doppler: every tile starts from its own carrier estimate (see recording.py:carrier_estimates) */
-		int nfft = 4096;
+		int nfft = 4096;                                     /* window in samples: power of two within tile + warm-up, <= 2^17 */
 		while (nfft * 2 <= static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(o.tile_samples) + o.pre_samples, 1u << 17))) nfft *= 2;
 		float consts[8];
 		TRY(mdemod_get_loop_constants(bank.c, consts));
 		const float fmax = consts[2];
 		const double symrate = params->symrate, fs = params->samplerate;
-		const int kmax = static_cast<int>(4 * 0.33 * symrate / (2 * 3.141592653589793) / fs * nfft) + 2;
-		const size_t W = T;
-		std::vector<float> fmid(W), qual(W), power(W);
-		uint64_t *d_starts; float *d_freq, *d_qual, *d_pow; float2 *d_spec;
+		/* the z^4 line sits within +-4 * 0.33 rad/symbol: decimate by D (boxcar, in the kernel) as far as that band stays
+		   inside 80 % of the decimated one, and keep the transform within the 16384 points that fit in LDS */
+		const double band_hz = 4 * 0.33 * symrate / (2 * 3.141592653589793);
+		int decim = 1;
+		while (decim < 16 && fs / (2.0 * (decim * 2)) >= 1.25 * band_hz) decim *= 2;
+		while (nfft / decim > 16384) nfft /= 2;              /* only when the band forbids more decimation */
+		while (decim > 1 && nfft / decim < 4096) decim /= 2;
+		const int nf = nfft / decim;
+		int log2_nf = 0;
+		while ((1 << log2_nf) < nf) log2_nf++;
+		const int kmax = std::min(nf / 2 - 2, static_cast<int>(band_hz / fs * nfft) + 2);
+		std::vector<float> fmid(T), qual(T);
+		uint64_t *d_starts; float *d_freq, *d_qual;
 		/* windows that would run past the end of the recording are moved back (the last tiles) */
-		std::vector<uint64_t> wstart(W);
+		std::vector<uint64_t> wstart(T);
 		for (size_t i = 0; i < T; i++)
 			wstart[i] = std::min<uint64_t>(off_pre[i], n_samples >= static_cast<uint64_t>(nfft) ? n_samples - nfft : 0);
 		TRY(upload(mem, wstart, &d_starts, st));
-		TRY(mem.alloc(&d_freq, W));
-		TRY(mem.alloc(&d_qual, W));
-		TRY(mem.alloc(&d_pow, W));
-		const size_t batch_max = std::max<size_t>(1, (size_t(1) << 28) / (static_cast<size_t>(nfft) * sizeof(float2)));
-		const size_t batch = std::min(batch_max, W);
-		TRY(mem.alloc(&d_spec, batch * nfft));
-		for (size_t t0 = 0; t0 < W; t0 += batch) {
-			const size_t b = std::min(batch, W - t0);
-			const dim3 grid(static_cast<unsigned>(b));
+		TRY(mem.alloc(&d_freq, T));
+		TRY(mem.alloc(&d_qual, T));
+		{
+			const dim3 grid(static_cast<unsigned>(T));
+			const size_t lds = static_cast<size_t>(nf) * sizeof(float2);
+			const float hz_per_bin_over4 = static_cast<float>(fs / nfft / 4.0);
+			const float rad_per_hz = static_cast<float>(2 * 3.141592653589793 / (symrate * (params->oqpsk ? 2 : 1)));   /* OQPSK: NCO steps twice a symbol */
+#define LAUNCH_LINE(F) do { \
+				HTRY(hipFuncSetAttribute(reinterpret_cast<const void *>(carrier_line_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+				hipLaunchKernelGGL(carrier_line_kernel<F>, grid, dim3(1024), lds, st, iq_dev, n_samples, d_starts, log2_nf, decim, kmax, \
+				                   hz_per_bin_over4, rad_per_hz, d_freq, d_qual); } while (0)
 			switch (params->bps) {
-			case 16: hipLaunchKernelGGL(fourth_power_kernel<16>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec, d_pow + t0); break;
-			case 8:  hipLaunchKernelGGL(fourth_power_kernel<8>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec, d_pow + t0); break;
-			default: hipLaunchKernelGGL(fourth_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, n_samples, d_starts + t0, nfft, d_spec, d_pow + t0); break;
+			case 16: LAUNCH_LINE(16); break;
+			case 8:  LAUNCH_LINE(8); break;
+			default: LAUNCH_LINE(32); break;
 			}
+#undef LAUNCH_LINE
 			HTRY(hipGetLastError());
-			struct Plan {                                   /* destroyed on every exit path of this iteration */
-				hipfftHandle h; bool ok;
-				Plan(int n, int batch) : ok(hipfftPlan1d(&h, n, HIPFFT_C2C, batch) == HIPFFT_SUCCESS) {}
-				~Plan() { if (ok) hipfftDestroy(h); }
-			} plan(nfft, static_cast<int>(b));
-			if (!plan.ok || hipfftSetStream(plan.h, st) != HIPFFT_SUCCESS) return MDEMOD_ERR_HIP;
-			if (hipfftExecC2C(plan.h, reinterpret_cast<hipfftComplex *>(d_spec), reinterpret_cast<hipfftComplex *>(d_spec), HIPFFT_FORWARD) != HIPFFT_SUCCESS)
-				return MDEMOD_ERR_HIP;
-			hipLaunchKernelGGL(spectrum_peak_kernel, grid, dim3(256), 0, st, d_spec, nfft, kmax, static_cast<float>(fs / nfft / 4.0),
-			                   static_cast<float>(2 * 3.141592653589793 / (symrate * (params->oqpsk ? 2 : 1))), d_freq + t0, d_qual + t0);   /* OQPSK: NCO steps twice a symbol */
-			HTRY(hipGetLastError());
-			HTRY(hipStreamSynchronize(st));
 		}
-		HTRY(hipMemcpyAsync(fmid.data(), d_freq, W * sizeof(float), hipMemcpyDeviceToHost, st));
-		HTRY(hipMemcpyAsync(qual.data(), d_qual, W * sizeof(float), hipMemcpyDeviceToHost, st));
-		HTRY(hipMemcpyAsync(power.data(), d_pow, W * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipMemcpyAsync(fmid.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipMemcpyAsync(qual.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
 		HTRY(hipStreamSynchronize(st));
 		/* AGC gain seeds (recording.py: window_power, fit_agc_calibration, agc_trajectory): g* = c / sqrt(sample power),
 		   c fitted on the pilot's last blocks, then the closed-form recursion over the tiles' bodies */

@@ -240,7 +240,7 @@ def test_doppler_recording_with_spectral_carrier_seeds(gpu_device):
 @pytest.mark.gpu
 @pytest.mark.parametrize("bps,oqpsk", [(16, False), (8, False), (16, True)])
 def test_native_stitcher_follows_doppler(gpu_device, bps, oqpsk):
-    """mdemod_demodulate_recording with carrier_seed=spectrum (hipFFT estimator in csrc/recording.hip): same bar as the
+    """mdemod_demodulate_recording with carrier_seed=spectrum (carrier_line_kernel in csrc/recording.hip): same bar as the
     Python stitcher on a 40 Hz/s ramp; with pilot seeds the same recording loses tiles (that is what the option is for)."""
     import dataclasses
     from meteor_demod_amd.recording import demodulate_recording_native
