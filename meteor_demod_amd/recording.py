@@ -201,7 +201,10 @@ def carrier_estimates(iq, starts, nfft, samplerate, symrate, fmax_rad=0.33, nco_
     advances at both rails' firings, pll.c:77,93, so its frequency word is rad per half symbol) (the reference finds the carrier by sweeping its PLL at 1e-6 rad/symbol per symbol, pll.c:125,
     which is what a tile that starts far from the pilot's estimate has no time for).  ``nfft`` samples from each start,
     batched FFT, peak within +-4*fmax with parabolic interpolation.  Returns (freq [T] float32 rad/symbol at the MIDDLE of the
-    window, peak-to-mean ratio [T]).  torch.fft on whatever device ``iq`` lives on; estimation only, never symbols."""
+    window, peak-to-mean ratio [T]).  torch.fft on whatever device ``iq`` lives on; estimation only, never symbols.
+    The native entry computes the same estimate in one kernel (``carrier_line_kernel``, csrc/recording.hip): z^4 summed in
+    groups of 4..16 samples before a 16384-point FFT in LDS - same bin width, same band, no FFT library (its run-time
+    kernel compilation cost 1.6 s per process)."""
     import torch
     T = int(starts.shape[0])
     dev = iq.device
