@@ -223,6 +223,20 @@ int  mdemod_set_carrier_seeds(mdemod_ctx *ctx, const float *freq_dev, const int3
  * for tiles of a recording whose amplitude changes faster than the reference's AGC follows at that gain. */
 int  mdemod_set_gain_seeds(mdemod_ctx *ctx, const float *gain_dev, void *hip_stream);
 
+/* Feed-forward carrier estimate of n_windows windows of one recording (device arrays; what the recording entry below seeds
+ * its tiles with, usable on its own for Doppler curves and signal detection): the 4th power of the samples has a spectral
+ * line at 4x the carrier offset whatever the data (QPSK and RRC-shaped OQPSK).  Window w covers window samples from
+ * starts_dev[w] (reads past the end of the recording repeat its last sample); the window length actually used is
+ * mdemod_carrier_window_samples(): window_samples rounded down to a power of two in [4096, 2^17].  freq_dev[w]: carrier in
+ * rad per NCO step (per symbol; per half symbol for OQPSK: pll.c:77,93) at the MIDDLE of the window, as pll_get_freq()
+ * would report it; quality_dev[w]: line / mean of the searched band (+-0.33 rad/symbol): noise alone gives 3-4, a 12 dB
+ * signal 40-50.  One kernel (z^4, boxcar decimation, FFT in LDS, peak search), asynchronous on hip_stream; only
+ * samplerate, symrate, oqpsk and bps of params are used. */
+uint32_t mdemod_carrier_window_samples(const mdemod_params *params, uint32_t window_samples);
+int  mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
+                             const uint64_t *starts_dev, uint32_t n_windows, uint32_t window_samples,
+                             float *freq_dev, float *quality_dev, void *hip_stream);
+
 /* The whole scheme in one call (native counterpart of meteor_demod_amd/recording.py):
  * the head of the recording is demodulated serially from the reference's power-on state until the
  * carrier loop has locked and converged (those symbols are the reference's symbols), the rest as

@@ -98,6 +98,9 @@ SIGNATURES = {
     "mdemod_rotate_carrier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_set_carrier_seeds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_set_gain_seeds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdemod_carrier_window_samples": (C.c_uint32, [C.c_void_p, C.c_uint32]),
+    "mdemod_estimate_carrier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_kernel_name": (C.c_char_p, [C.c_void_p]),
     "mdemod_demodulate_recording_host": (C.c_int, [_P(MdemodParams), _P(MdemodRecordingOpts), C.c_void_p, C.c_uint64,
                                                    C.c_void_p, C.c_uint64, _P(MdemodRecordingReport)]),

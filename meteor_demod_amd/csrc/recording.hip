@@ -422,6 +422,65 @@ struct PilotBlock { uint64_t start; uint32_t len; double gain_after; uint64_t sy
 
 } /* namespace */
 
+/* Window geometry of the carrier estimator: the z^4 line sits within +-4 * 0.33 rad/symbol; decimate by D (boxcar, in the
+ * kernel) as far as that band stays inside 80 % of the decimated one, keep the transform within the 16384 points that fit
+ * in LDS.  window_samples is rounded down to a power of two in [4096, 2^17] (and further if the band forbids decimation). */
+static void
+carrier_window(const mdemod_params *params, uint32_t window_samples, int *nwin, int *decim, int *log2_nf, int *kmax)
+{
+	const double symrate = params->symrate, fs = params->samplerate;
+	int n = 4096;
+	while (n * 2 <= static_cast<int>(std::min<uint32_t>(window_samples, 1u << 17))) n *= 2;
+	const double band_hz = 4 * 0.33 * symrate / (2 * 3.141592653589793);
+	int d = 1;
+	while (d < 16 && fs / (2.0 * (d * 2)) >= 1.25 * band_hz) d *= 2;
+	while (n / d > 16384) n /= 2;                        /* only when the band forbids more decimation */
+	while (d > 1 && n / d < 4096) d /= 2;
+	int l2 = 0;
+	while ((1 << l2) < n / d) l2++;
+	*nwin = n; *decim = d; *log2_nf = l2;
+	*kmax = std::min(n / d / 2 - 2, static_cast<int>(band_hz / fs * n) + 2);
+}
+
+extern "C" uint32_t
+mdemod_carrier_window_samples(const mdemod_params *params, uint32_t window_samples)
+{
+	if (!params || params->samplerate <= 0 || params->symrate <= 0) return 0;
+	int nwin, decim, l2, kmax;
+	carrier_window(params, window_samples, &nwin, &decim, &l2, &kmax);
+	return static_cast<uint32_t>(nwin);
+}
+
+extern "C" int
+mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
+                        const uint64_t *starts_dev, uint32_t n_windows, uint32_t window_samples,
+                        float *freq_dev, float *quality_dev, void *hip_stream)
+{
+	if (!params || !iq_dev || !starts_dev || !freq_dev || !quality_dev || n_samples == 0) return MDEMOD_ERR_PARAM;
+	if (params->samplerate <= 0 || params->symrate <= 0 || (params->bps != 8 && params->bps != 16 && params->bps != 32)) return MDEMOD_ERR_PARAM;
+	if (n_windows == 0) return MDEMOD_OK;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	int nwin, decim, log2_nf, kmax;
+	carrier_window(params, window_samples, &nwin, &decim, &log2_nf, &kmax);
+	const double symrate = params->symrate, fs = params->samplerate;
+	const dim3 grid(n_windows);
+	const size_t lds = (static_cast<size_t>(nwin) / decim) * sizeof(float2);
+	const float hz_per_bin_over4 = static_cast<float>(fs / nwin / 4.0);
+	const float rad_per_hz = static_cast<float>(2 * 3.141592653589793 / (symrate * (params->oqpsk ? 2 : 1)));   /* OQPSK: NCO steps twice a symbol */
+#define LAUNCH_LINE(F) do { \
+		HTRY(hipFuncSetAttribute(reinterpret_cast<const void *>(carrier_line_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+		hipLaunchKernelGGL(carrier_line_kernel<F>, grid, dim3(1024), lds, st, iq_dev, n_samples, starts_dev, log2_nf, decim, kmax, \
+		                   hz_per_bin_over4, rad_per_hz, freq_dev, quality_dev); } while (0)
+	switch (params->bps) {
+	case 16: LAUNCH_LINE(16); break;
+	case 8:  LAUNCH_LINE(8); break;
+	default: LAUNCH_LINE(32); break;
+	}
+#undef LAUNCH_LINE
+	HTRY(hipGetLastError());
+	return MDEMOD_OK;
+}
+
 extern "C" void
 mdemod_recording_default_opts(mdemod_recording_opts *o)
 {
@@ -543,23 +602,12 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	for (size_t i = 0; i < T; i++) off_pre[i] = starts[i] - pres[i];
 	if (o.carrier_seed == 1) {
 		/* Doppler: every tile starts from its own carrier estimate (see recording.py:carrier_estimates) */
-		int nfft = 4096;                                     /* window in samples: power of two within tile + warm-up, <= 2^17 */
-		while (nfft * 2 <= static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(o.tile_samples) + o.pre_samples, 1u << 17))) nfft *= 2;
+		const int nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(std::min<uint64_t>(
+		                     static_cast<uint64_t>(o.tile_samples) + o.pre_samples, 1u << 17))));   /* window in samples */
 		float consts[8];
 		TRY(mdemod_get_loop_constants(bank.c, consts));
 		const float fmax = consts[2];
 		const double symrate = params->symrate, fs = params->samplerate;
-		/* the z^4 line sits within +-4 * 0.33 rad/symbol: decimate by D (boxcar, in the kernel) as far as that band stays
-		   inside 80 % of the decimated one, and keep the transform within the 16384 points that fit in LDS */
-		const double band_hz = 4 * 0.33 * symrate / (2 * 3.141592653589793);
-		int decim = 1;
-		while (decim < 16 && fs / (2.0 * (decim * 2)) >= 1.25 * band_hz) decim *= 2;
-		while (nfft / decim > 16384) nfft /= 2;              /* only when the band forbids more decimation */
-		while (decim > 1 && nfft / decim < 4096) decim /= 2;
-		const int nf = nfft / decim;
-		int log2_nf = 0;
-		while ((1 << log2_nf) < nf) log2_nf++;
-		const int kmax = std::min(nf / 2 - 2, static_cast<int>(band_hz / fs * nfft) + 2);
 		std::vector<float> fmid(T), qual(T);
 		uint64_t *d_starts; float *d_freq, *d_qual;
 		/* windows that would run past the end of the recording are moved back (the last tiles) */
@@ -569,23 +617,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		TRY(upload(mem, wstart, &d_starts, st));
 		TRY(mem.alloc(&d_freq, T));
 		TRY(mem.alloc(&d_qual, T));
-		{
-			const dim3 grid(static_cast<unsigned>(T));
-			const size_t lds = static_cast<size_t>(nf) * sizeof(float2);
-			const float hz_per_bin_over4 = static_cast<float>(fs / nfft / 4.0);
-			const float rad_per_hz = static_cast<float>(2 * 3.141592653589793 / (symrate * (params->oqpsk ? 2 : 1)));   /* OQPSK: NCO steps twice a symbol */
-#define LAUNCH_LINE(F) do { \
-				HTRY(hipFuncSetAttribute(reinterpret_cast<const void *>(carrier_line_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
-				hipLaunchKernelGGL(carrier_line_kernel<F>, grid, dim3(1024), lds, st, iq_dev, n_samples, d_starts, log2_nf, decim, kmax, \
-				                   hz_per_bin_over4, rad_per_hz, d_freq, d_qual); } while (0)
-			switch (params->bps) {
-			case 16: LAUNCH_LINE(16); break;
-			case 8:  LAUNCH_LINE(8); break;
-			default: LAUNCH_LINE(32); break;
-			}
-#undef LAUNCH_LINE
-			HTRY(hipGetLastError());
-		}
+		TRY(mdemod_estimate_carrier(params, iq_dev, n_samples, d_starts, static_cast<uint32_t>(T), static_cast<uint32_t>(nfft), d_freq, d_qual, st));
 		HTRY(hipMemcpyAsync(fmid.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
 		HTRY(hipMemcpyAsync(qual.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
 		HTRY(hipStreamSynchronize(st));

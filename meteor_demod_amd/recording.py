@@ -676,6 +676,28 @@ class RecordingDemodulator:
 
 # ---- the same scheme inside the library (csrc/recording.hip) --------------------------------------
 
+def estimate_carrier_native(cfg, iq, starts, window_samples: int, device: int = 0):
+    """``mdemod_estimate_carrier`` on a device tensor [n, 2]: (freq [T] float32 rad per NCO step at the middle of each
+    window, quality [T], window length actually used)."""
+    import ctypes as C
+    import torch
+    from . import _capi
+    lib = _capi.lib()
+    assert iq.is_cuda and iq.dim() == 2 and iq.shape[1] == 2 and iq.is_contiguous()
+    p = cfg.to_c(1, device)
+    st = torch.as_tensor(np.ascontiguousarray(starts, dtype=np.int64), device=iq.device)
+    T = int(st.numel())
+    freq = torch.empty(T, dtype=torch.float32, device=iq.device)
+    qual = torch.empty(T, dtype=torch.float32, device=iq.device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _capi.check(lib.mdemod_estimate_carrier(C.byref(p), C.c_void_p(iq.data_ptr()), int(iq.shape[0]), C.c_void_p(st.data_ptr()), T,
+                                            int(window_samples), C.c_void_p(freq.data_ptr()), C.c_void_p(qual.data_ptr()), stream),
+                "mdemod_estimate_carrier")
+    used = int(lib.mdemod_carrier_window_samples(C.byref(p), int(window_samples)))
+    torch.cuda.current_stream(device).synchronize()
+    return freq, qual, used
+
+
 def demodulate_recording_native(cfg, iq, tile_samples: int = 0, pre_samples: int = -1, refine: bool = True,
                                 pilot_block: int = 65536, pilot_margin_symbols: int = 20000,
                                 max_pilot_samples: int = 1 << 22, match_symbols: int = 192, device: int = 0,

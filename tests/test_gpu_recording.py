@@ -382,3 +382,37 @@ def test_native_stitcher_needs_no_more_output_room_than_it_writes(gpu_device):
         soft, rep = demodulate_recording_native(C1, iq, refine=False, pre_samples=pre, pilot_margin_symbols=2000, tile_samples=20032)
         out = soft.cpu().numpy()
         assert np.array_equal(out[: rep.pilot_symbols], serial[: rep.pilot_symbols])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("oqpsk,bps", [(False, 16), (True, 32), (False, 8)])
+def test_estimate_carrier_entry(gpu_device, oqpsk, bps):
+    """mdemod_estimate_carrier (z^4 -> boxcar decimation -> FFT in LDS -> peak, one kernel): the estimate is the synthetic
+    carrier, it agrees with the full-resolution torch.fft estimator of recording.py, the quality figure separates signal
+    from noise, windows past the end of the recording are served, and the window length is rounded as documented."""
+    import dataclasses
+    import torch
+    from meteor_demod_amd.recording import carrier_estimates, estimate_carrier_native
+    symrate = 80000 if oqpsk else 72000
+    cfg = dataclasses.replace(C1, symrate=symrate, oqpsk=oqpsk, bps=bps)
+    amp = {8: dict(rms=40.0, dc=(1.5, -1.0)), 16: dict(rms=3000.0), 32: dict(rms=0.25, dc=(0.001, -0.002))}[bps]
+    f0 = -437.0
+    st = synth.make_stream(61, 230000, symrate, f0_hz=f0, clock_ppm=3.0, esn0_db=12.0, oqpsk=oqpsk, fmt=bps, **amp)
+    n = 600_000
+    iq = synth.generate_device([st], n)[0]
+    noise = (torch.randn((200_000, 2), device="cuda") * (amp["rms"] / 1.4))
+    noise = noise.to(iq.dtype) if bps != 8 else (noise + 128).clamp(0, 255).to(torch.uint8)
+    both = torch.cat((iq, noise)).contiguous()
+    starts = np.array([0, 100_000, 333_333, n - 65536, n + 50_000, n + 190_000])     # signal x4, noise, window past the end
+    freq, qual, used = estimate_carrier_native(cfg, both, starts, 100_000)
+    assert used == 65536
+    steps = 2 if oqpsk else 1
+    want = 2 * np.pi * f0 / (symrate * steps)
+    f, q = freq.cpu().numpy(), qual.cpu().numpy()
+    assert np.abs(f[:4] - want).max() < 2 * np.pi * 1.0 / (symrate * steps)          # within 1 Hz
+    assert q[:4].min() > 20 and q[4] < 7
+    ft, qt = carrier_estimates(both, starts[:4], 65536, 230000, symrate, nco_steps_per_symbol=steps)
+    assert np.abs(ft.cpu().numpy() - f[:4]).max() < 2 * np.pi * 0.5 / (symrate * steps)
+    assert np.isfinite(f).all() and np.isfinite(q).all()
+    f2, q2, used2 = estimate_carrier_native(cfg, both, starts[:2], 5000)              # short windows: 4096 samples
+    assert used2 == 4096 and np.abs(f2.cpu().numpy() - want).max() < 2 * np.pi * 12.0 / (symrate * steps)
