@@ -246,7 +246,7 @@ int  mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, ui
  * params->n_streams is ignored.  Synchronous on hip_stream. */
 typedef struct {
 	uint32_t tile_samples;          /* body samples per tile; 0 = 20 536 symbols worth (65 600 at 72k / 230 kS/s) */
-	uint32_t pre_samples;           /* warm-up samples per tile; 0xFFFFFFFF = 5 129 symbols worth */
+	uint32_t pre_samples;           /* warm-up samples per tile; 0xFFFFFFFF = 5 129 symbols worth (OQPSK: 10 258) */
 	uint32_t pilot_block;           /* pilot granularity in samples               (65536)  */
 	uint32_t pilot_margin_symbols;  /* symbols the pilot stays locked before tiles start (20000) */
 	uint64_t max_pilot_samples;     /* give up waiting for lock after this many   (1 << 22) */

@@ -507,7 +507,9 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 			o.tile_samples = std::max<uint32_t>(4096, static_cast<uint32_t>(20536 * osf) / 64 * 64);
 			if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
 		}
-		if (o.pre_samples == 0xFFFFFFFFu) o.pre_samples = static_cast<uint32_t>(5129 * osf);
+		/* OQPSK: twice the warm-up (its carrier loop has half the bandwidth and may still be re-locking after 5 129 symbols;
+		   recording.py:default_tiling, profiles/r01_rotation_jump_cases.md) */
+		if (o.pre_samples == 0xFFFFFFFFu) o.pre_samples = static_cast<uint32_t>((params->oqpsk ? 10258 : 5129) * osf);
 	}
 	if (!o.tile_samples || !o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);

@@ -69,7 +69,7 @@ def plan_tiles(n_samples: int, pilot_end: int, tile_samples: int, pre_samples: i
 
 
 def default_tiling(cfg, tile_samples: int = 0, pre_samples: int = -1):
-    """Tile and warm-up lengths when the caller gives none (0 / -1): 20 536 and 5 129 SYMBOLS worth of samples, i.e. 65 600 and
+    """Tile and warm-up lengths when the caller gives none (0 / -1): 20 536 and 5 129 (OQPSK: 10 258) SYMBOLS worth of samples, i.e. 65 600 and
     16 384 samples at the reference's 72 k symbols in 230 kS/s, scaled with the samples per symbol so that a 1 MS/s
     recording gets tiles of the same duration in symbols.  The tile is kept off powers of two (lanes read at base + l * tile:
     a power-of-two stride puts a wave's lanes on the same L2 sets).  Same rule in csrc/recording.hip."""
@@ -79,7 +79,10 @@ def default_tiling(cfg, tile_samples: int = 0, pre_samples: int = -1):
         if tile_samples & (tile_samples - 1) == 0:
             tile_samples += 64
     if pre_samples < 0:
-        pre_samples = int(5129 * osf)
+        # OQPSK: twice the warm-up.  Its carrier loop has half the bandwidth (demod.c:8-15) and may still be re-locking when a
+        # 5 129-symbol warm-up ends; a tile that changes rotation after its start was measured throws every later tile a
+        # quarter turn off (profiles/r01_rotation_jump_cases.md: both soak cases vanish with the longer warm-up)
+        pre_samples = int((10258 if cfg.oqpsk else 5129) * osf)
     return int(tile_samples), int(pre_samples)
 
 

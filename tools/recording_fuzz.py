@@ -3,7 +3,7 @@ QPSK / OQPSK, input formats, carrier offsets, Doppler ramps, clock errors, tile 
 natively with spectral carrier seeds and compared with the serial oracle.  A case counts only if the serial run's lock
 is genuine (its PLL frequency is on the synthetic carrier when the pilot hands over), otherwise there is
 no serial stream to compare with.  Usage: recording_fuzz.py [n_cases] [seed] [only_case]
-(FUZZ_TILE / FUZZ_SEEDMODE in the environment override a case's tile size / carrier_seed when one case is replayed)"""
+(FUZZ_TILE / FUZZ_PRE / FUZZ_SEEDMODE in the environment override a case's tile size / carrier_seed when one case is replayed)"""
 import os
 import dataclasses
 import sys
@@ -20,7 +20,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 bad, jumps, skipped, t0 = [], [], 0, time.time()
 for ci in range(n_cases):
-    oqpsk = bool(rng.random() < 0.35)
+    oqpsk = bool(rng.random() < (1.0 if os.environ.get("FUZZ_ONLY_OQPSK") else 0.35))
     symrate = 80000 if oqpsk else 72000
     osf = float(rng.choice([2.5, 2.875, 3.1944, 3.6, 4.0, 6.0, 14.2]))
     samplerate = int(symrate * osf)
@@ -46,6 +46,8 @@ for ci in range(n_cases):
         if os.environ.get("FUZZ_TILE"):
             kw["tile_samples"] = int(os.environ["FUZZ_TILE"])
         mode = os.environ.get("FUZZ_SEEDMODE", mode)
+        if os.environ.get("FUZZ_PRE"):
+            kw["pre_samples"] = int(os.environ["FUZZ_PRE"])
         print("replay: esn0", esn0, "amp", amp)
     st = synth.make_stream(1000 + ci, samplerate, symrate, f0_hz=f0, clock_ppm=ppm, esn0_db=esn0,
                            doppler_hz_per_s=ramp, oqpsk=oqpsk, fmt=bps, **amp)
