@@ -170,3 +170,21 @@ def test_turn_code_shortcut_proof_holds_on_the_host():
         out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "mismatches 0" in out.stdout
+
+
+def test_carrier_window_rounding_is_host_logic():
+    """mdemod_carrier_window_samples needs no GPU: power of two in [4096, 2^17], and no more than 16384 points after the
+    decimation the z^4 band allows (at 2.5 samples per symbol only 4x decimation keeps +-4*0.33 rad/symbol inside 80 % of
+    the band; at one sample per symbol none does, so the window itself shrinks to the 16384 points that fit in LDS)."""
+    import ctypes as C
+    from meteor_demod_amd import DemodConfig, _capi
+    lib = _capi.lib()
+    def used(samplerate, symrate, want):
+        p = DemodConfig(samplerate=samplerate, symrate=symrate).to_c(1, 0)
+        return int(lib.mdemod_carrier_window_samples(C.byref(p), want))
+    assert used(230000, 72000, 100_000) == 65536 and used(230000, 72000, 5000) == 4096 and used(230000, 72000, 100) == 4096
+    assert used(230000, 72000, 1 << 20) == 65536            # 16384 points x 4 (decimation by 8 would fold the band)
+    assert used(1_022_400, 72000, 1 << 20) == 131072        # 16x decimation available, window capped at 2^17
+    assert used(80000, 72000, 100_000) == 32768             # 1.1 samples per symbol: decimation by 2 still keeps the band
+    assert used(73000, 72000, 100_000) == 16384             # barely oversampled: no decimation, 16384 points
+    assert lib.mdemod_carrier_window_samples(None, 4096) == 0
