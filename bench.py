@@ -203,14 +203,36 @@ def spot_check(cfg, d, x, tiles, L, n_check=12) -> str:
     return f"{len(picks)} sampled tiles byte-identical to oracle"
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, RCCL rendezvous on 127.0.0.1) through
+    torch.distributed.run and hand its exit code back.  Runs BEFORE anything touches the GPU in this process
+    (torch.cuda.device_count() does not initialise it)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s); refusing to print an N={have} line "
+                         f"labelled as {args.gpus}\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import torch
     from meteor_demod_amd import Demodulator, synth
     from meteor_demod_amd.sharding import fanin_soft, init_from_env
 
     rank, local, world = init_from_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the demodulator has no CPU path")
@@ -254,15 +276,20 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tt[0]), float(tt[1])
 
-    fanin_ms = None
+    fanin_ms = fanin_bytes = None
     if args.fanin and dist:
-        st = d.status()
-        counts = torch.tensor([s.symbols_this_call for s in st], dtype=torch.int32, device=f"cuda:{local}")
+        # fan-in of the soft symbols to rank 0 over RCCL (outside the timed region): rows compacted on the device to the
+        # nominal symbol pitch first (0.63 B per input sample instead of the hard-bound 2 B), then one gather
+        counts = torch.from_numpy(d.status_array()["symbols_this_call"].astype("int32")).to(f"cuda:{local}")
+        pitch = d.nominal_pitch(L)
         torch.cuda.synchronize(); dist.barrier()
         t1 = time.perf_counter()
-        fanin_soft(soft, counts, T * world, dst=0)
+        packed = d.compact(soft, pitch)
+        got, _ = fanin_soft(packed, counts, T * world, dst=0)
         torch.cuda.synchronize(); dist.barrier()
         fanin_ms = (time.perf_counter() - t1) * 1e3
+        fanin_bytes = int(packed.numel()) * (world - 1)
+        del packed, got
 
     if rank != 0:
         if dist:
@@ -303,7 +330,9 @@ def main() -> None:
                      "algorithmic_bytes_per_sample": round(bytes_per_sample, 4)},
     }
     if fanin_ms is not None:
-        out["fanin_ms"] = round(fanin_ms, 2)
+        out["fanin"] = {"ms": round(fanin_ms, 2), "bytes_over_xgmi": fanin_bytes,
+                        "gbytes_per_s": round(fanin_bytes / (fanin_ms * 1e-3) / 1e9, 1), "row_pitch_symbols": d.nominal_pitch(L),
+                        "note": "compact to nominal pitch + RCCL gather to rank 0, outside the timed region"}
     if world == 1 and not args.no_cpu_baseline:
         # The CPU leg: the only place in this file that touches oracle/ — it times the reference's own
         # code on the host cores and (unless --no-check) uses the oracle as CHECKER on sampled tiles.

@@ -16,7 +16,9 @@
  * up to PLL lock + settling is the reference's own serial run, the rest agrees with it
  * statistically).
  *
- * Not reproduced (out of scope): ncurses TUI, the live status thread.
+ * Status line: the reference's "(%5.1f%%) Carrier: ... Symbol rate: ... Locked: ..." (main.c:249-261) from the status
+ * snapshot of stream 0, at most once per -R milliseconds (default 2000 with -B, 50 without: main.c:144), "\n" separated
+ * with -B and redrawn in place otherwise.  Not reproduced (out of scope): the ncurses TUI.
  * Known deviation: if the final flush would read past the 1024-byte ring (ring_idx >
  * 512, where the reference reads out of bounds) only the bytes inside the ring are
  * written.
@@ -44,6 +46,7 @@ struct stream_io {
 	unsigned    ring_idx;
 	uint64_t    symbols;                 /* symbols emitted so far */
 	unsigned long bytes_out;
+	unsigned long file_len;              /* 0 = unknown (pipe): main.c:192 */
 	int         eof;
 };
 
@@ -104,8 +107,9 @@ parse_wav(FILE *f, int *samplerate, int *bps)
 	if (memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) return 1;
 	const unsigned channels = h[22] | (h[23] << 8);
 	const unsigned bits = h[34] | (h[35] << 8);
-	if (channels != 2 || !bits) return 1;
-	*bps = (int)bits;
+	if (channels != 2) return 1;
+	*bps = (int)bits;                    /* wavfile.c:44: assigned before the zero test, so a 0 here overrides --bps */
+	if (!bits) return 1;
 	*samplerate = (int)(h[24] | (h[25] << 8) | (h[26] << 16) | ((unsigned)h[27] << 24));
 	return 0;
 }
@@ -129,13 +133,32 @@ write_gated(struct stream_io *io, const int8_t *soft, uint32_t n, int64_t first_
 	}
 }
 
+/* error exits: whatever was written so far is flushed and closed */
+static void
+close_all(struct stream_io *io, int n)
+{
+	for (int i = 0; i < n; i++) {
+		if (io[i].out && io[i].out != stdout) fclose(io[i].out);
+		if (io[i].in && io[i].in != stdin) fclose(io[i].in);
+		io[i].out = NULL; io[i].in = NULL;
+	}
+}
+
+static double
+now_ms(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 int
 main(int argc, char **argv)
 {
 	float pll_bw = MDEMOD_DEFAULT_PLL_BW, symrate = MDEMOD_DEFAULT_SYM_RATE, freq_max_delta = -1;
 	int rrc_order = MDEMOD_DEFAULT_RRC_ORDER, interp = MDEMOD_DEFAULT_INTERP;
 	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0, tiled = 0;
-	int tile_samples = 0, pilot_margin = -1, carrier_seed = -1;
+	int tile_samples = 0, pilot_margin = -1, carrier_seed = -1, update_interval = -1;
 	const char *output_fname = NULL;
 	int c;
 
@@ -160,7 +183,7 @@ main(int argc, char **argv)
 		case 'o': output_fname = optarg; break;
 		case 'O': interp = atoi(optarg); break;
 		case 'q': quiet = 1; break;
-		case 'R': break;                                              /* refresh rate: no live status here */
+		case 'R': update_interval = atoi(optarg); break;              /* main.c:116 */
 		case 'r': symrate = human_number(optarg); break;
 		case 's': samplerate = (int)human_number(optarg); break;
 		case 'S': bps = atoi(optarg); break;
@@ -170,8 +193,9 @@ main(int argc, char **argv)
 	}
 	freq_max_delta = (float)(freq_max_delta * (2 * M_PI) / symrate);       /* main.c:136 */
 	if (argc - optind < 1) { usage(argv[0]); return 1; }
+	if (update_interval < 0) update_interval = batch ? 2000 : 50;                 /* main.c:144 (before batch is forced below) */
 	if (stdout_mode) { batch = 1; quiet = 1; }
-	(void)batch;
+	for (int i = optind; i < argc; i++) if (!strcmp(argv[i], "-")) batch = 1;     /* stdin forces batch: main.c:157 */
 
 	const int n_files = argc - optind;
 	if (n_files > 1 && (output_fname || stdout_mode)) {
@@ -195,7 +219,10 @@ main(int argc, char **argv)
 		return 1;
 	}
 	if (!bps) { fprintf(stderr, "Could not auto-detect bits per sample, assuming 16\n"); bps = 16; }
-	if (bps != 8 && bps != 16 && bps != 32) { fprintf(stderr, "unsupported bits per sample\n"); return 1; }
+	/* any other sample size: the reference's reader returns 0 on the first sample (wavfile.c:71-73) and it writes an empty
+	 * output file; same here, without touching the GPU */
+	const int bps_ok = (bps == 8 || bps == 16 || bps == 32);
+	if (!bps_ok) fprintf(stderr, "%d bits per sample: nothing to demodulate (8, 16 or 32 expected)\n", bps);
 
 	for (int i = 0; i < n_files; i++) {
 		if (stdout_mode) { io[i].out = stdout; continue; }
@@ -212,6 +239,19 @@ main(int argc, char **argv)
 		if (!io[i].out) { fprintf(stderr, "Could not open output file\n"); return 1; }
 	}
 
+	if (!bps_ok) {
+		for (int i = 0; i < n_files; i++) { if (io[i].out != stdout) fclose(io[i].out); if (io[i].in != stdin) fclose(io[i].in); }
+		return 0;
+	}
+	/* file lengths for the progress figure of the status line (main.c:189-193) */
+	for (int i = 0; i < n_files; i++) {
+		if (io[i].in == stdin) continue;
+		const long here = ftell(io[i].in);
+		if (here < 0 || fseek(io[i].in, 0, SEEK_END)) continue;
+		const long end = ftell(io[i].in);
+		io[i].file_len = end > 0 ? (unsigned long)end : 0;
+		fseek(io[i].in, here, SEEK_SET);
+	}
 	/* demod_init(pll_bw, SYM_BW, samplerate, symrate, interp, order, oqpsk, freq_max): main.c:187 */
 	mdemod_params p;
 	memset(&p, 0, sizeof(p));
@@ -224,15 +264,20 @@ main(int argc, char **argv)
 			size_t cap_bytes = 1u << 26, len = 0;
 			unsigned char *data = malloc(cap_bytes);
 			for (;;) {
-				if (len + FILE_BUFFER_SIZE > cap_bytes) { cap_bytes *= 2; data = realloc(data, cap_bytes); }
-				if (!data) return 1;
+				if (len + FILE_BUFFER_SIZE > cap_bytes) {
+					unsigned char *grown = realloc(data, cap_bytes * 2);
+					if (!grown) { free(data); data = NULL; break; }
+					data = grown; cap_bytes *= 2;
+				}
+				if (!data) break;
 				if (fread(data + len, FILE_BUFFER_SIZE, 1, io[f].in) != 1) break;
 				len += FILE_BUFFER_SIZE;
 			}
+			if (!data) { fprintf(stderr, "out of memory reading %s\n", io[f].in_name); close_all(io, n_files); return 1; }
 			const uint64_t n_samples = len / (2 * (size_t)bps / 8);
 			const uint64_t cap_sym = (uint64_t)((double)n_samples * symrate / samplerate * 1.02) + 4096;
 			int8_t *soft_all = malloc(cap_sym * 2);
-			if (!soft_all) return 1;
+			if (!soft_all) { free(data); close_all(io, n_files); return 1; }
 			mdemod_recording_opts ro;
 			mdemod_recording_default_opts(&ro);
 			if (tile_samples > 0) ro.tile_samples = (uint32_t)tile_samples;
@@ -240,7 +285,11 @@ main(int argc, char **argv)
 			if (carrier_seed >= 0) ro.carrier_seed = (uint32_t)carrier_seed;
 			mdemod_recording_report rr;
 			int rc2 = mdemod_demodulate_recording_host(&p, &ro, data, n_samples, soft_all, cap_sym, &rr);
-			if (rc2 != MDEMOD_OK) { fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2)); return 2; }
+			if (rc2 != MDEMOD_OK) {
+				fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2));
+				free(data); free(soft_all); close_all(io, n_files);
+				return 2;
+			}
 			if (!quiet)
 				fprintf(stderr, "%s: %llu samples: %llu serial (pilot) + %u tiles, %llu symbols, first lock at symbol %lld, %u seam fixes, "
 				        "%u weak seams, %u rotation jumps, %u tiles without a carrier line, %.2f s\n", io[f].in_name, (unsigned long long)n_samples,
@@ -253,6 +302,7 @@ main(int argc, char **argv)
 			fwrite(io[f].ring, 1, tail, io[f].out);
 			if (io[f].out != stdout) fclose(io[f].out);
 			if (io[f].in != stdin) fclose(io[f].in);
+			io[f].out = NULL; io[f].in = NULL;
 			free(data); free(soft_all);
 		}
 		return 0;
@@ -260,8 +310,8 @@ main(int argc, char **argv)
 
 	mdemod_ctx *ctx = NULL;
 	int rc = mdemod_create(&p, &ctx);
-	if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_create: %s\n", mdemod_strerror(rc)); return 2; }
-	if (!quiet) fprintf(stderr, "Demodulator initialized (%d stream%s on HIP device %d)\n", n_files, n_files > 1 ? "s" : "", device);
+	if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_create: %s\n", mdemod_strerror(rc)); close_all(io, n_files); return 2; }
+	if (!quiet) printf("Demodulator initialized\n");                                 /* main.c:219 */
 
 	size_t block_buffers = BLOCK_BUFFERS;
 	for (int i = 0; i < n_files; i++) if (io[i].in == stdin) block_buffers = PIPE_BUFFERS;     /* live input: short blocks */
@@ -277,6 +327,7 @@ main(int argc, char **argv)
 	mdemod_status *st = malloc(sizeof(*st) * (size_t)n_files);
 	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) return 1;
 
+	double last_status = -1e18;
 	for (;;) {
 		int active = 0;
 		for (int i = 0; i < n_files; i++) {
@@ -293,19 +344,24 @@ main(int argc, char **argv)
 		}
 		if (!active) break;
 		rc = mdemod_process_host(ctx, iq, n_in, outp, caps, n_out);          /* demod(&sample) x n: main.c:304 */
-		if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_process_host: %s\n", mdemod_strerror(rc)); return 2; }
+		if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_process_host: %s\n", mdemod_strerror(rc)); close_all(io, n_files); return 2; }
 		rc = mdemod_get_status(ctx, 0, (uint32_t)n_files, st, NULL);
-		if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_get_status: %s\n", mdemod_strerror(rc)); return 2; }
+		if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_get_status: %s\n", mdemod_strerror(rc)); close_all(io, n_files); return 2; }
 		for (int i = 0; i < n_files; i++)
 			write_gated(&io[i], outp[i], n_out[i], st[i].first_lock_symbol);
-		if (!quiet) {
-			/* main.c:250-259 status formulas, once per block instead of on a timer */
+		if (!quiet && now_ms() - last_status >= update_interval) {
+			/* main.c:249-261: status line from the snapshot of stream 0, at most once per refresh period */
+			last_status = now_ms();
 			const double freq_hz = st[0].pll_freq * symrate / (2 * M_PI) * (oqpsk ? 2 : 1);
 			const double rate_hz = st[0].omega * ((double)samplerate * interp) / (2 * M_PI);
-			fprintf(stderr, "\rCarrier: %+7.1f Hz, Symbol rate: %.1f Hz, Locked: %s   ", freq_hz, rate_hz, st[0].locked ? "Yes" : "No");
+			const long pos = io[0].in != stdin ? ftell(io[0].in) : 0;
+			printf(batch ? "\n" : "\033[1K\r");
+			printf("(%5.1f%%) Carrier: %+7.1f Hz, Symbol rate: %.1f Hz, Locked: %s",
+			       io[0].file_len && pos > 0 ? 100.0 * (double)pos / (double)io[0].file_len : 0.0, freq_hz, rate_hz, st[0].locked ? "Yes" : "No");
+			fflush(stdout);
 		}
 	}
-	if (!quiet) fprintf(stderr, "\n");
+	if (!quiet) printf("\n");
 
 	for (int i = 0; i < n_files; i++) {
 		/* main.c:321: fwrite(ring, ring_idx, 2, f) */

@@ -146,6 +146,17 @@ int  mdemod_reset(mdemod_ctx *ctx, void *hip_stream);
  * n*symrate/samplerate is exceeded while the symbol clock drains a large phase excursion. */
 uint64_t mdemod_max_symbols(const mdemod_ctx *ctx, uint64_t n_samples);
 
+/* Row pitch (in SYMBOLS, a multiple of 8) that holds what n input samples produce at the nominal symbol rate with 1 % slack:
+ * what a consumer of many streams wants to move or keep (0.63 B per input sample at 72k in 230 kS/s) instead of the hard
+ * bound above.  NOT a bound: rows are truncated to it by mdemod_compact_soft (overflow is reported by the process call
+ * against the capacity it was given). */
+uint64_t mdemod_nominal_pitch(const mdemod_ctx *ctx, uint64_t n_samples);
+/* Copy the symbols the LAST process call wrote (per-stream counts kept by the context) from rows of soft_stride_symbols
+ * to rows of out_pitch_symbols (both multiples of 8; 16-byte moves): the compaction in front of a PCIe copy or of the
+ * RCCL fan-in of soft-symbol buffers (main.c:305-315 writes symbols back to back; the hard-bound pitch is a GPU artefact). */
+int  mdemod_compact_soft(mdemod_ctx *ctx, const int8_t *soft_dev, uint64_t soft_stride_symbols,
+                         int8_t *out_dev, uint64_t out_pitch_symbols, void *hip_stream);
+
 /* ---- the hot path (replaces the main.c:303-306 loop body) ---------------- */
 
 /*
@@ -222,6 +233,14 @@ int  mdemod_set_carrier_seeds(mdemod_ctx *ctx, const float *freq_dev, const int3
 /* Per-stream AGC gain seeds (agc.c:9, device array of n_streams entries, negative values become 0 like agc.c:23):
  * for tiles of a recording whose amplitude changes faster than the reference's AGC follows at that gain. */
 int  mdemod_set_gain_seeds(mdemod_ctx *ctx, const float *gain_dev, void *hip_stream);
+
+/* Per-stream symbol-clock frequency seeds (timing.c:14 `freq`, rad per interpolated sample; device array of n_streams entries). */
+int  mdemod_set_clock_seeds(mdemod_ctx *ctx, const float *t_freq_dev, void *hip_stream);
+/* mdemod_get_state for `count` streams from `first` in one round trip (tiles of a recording: thousands of streams). */
+int  mdemod_get_states(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_stream_state *out, void *hip_stream);
+/* dst := src for every stream (loop state, counters, filter history, lock events): a checkpoint of a whole bank.  Both
+ * contexts must have been created from the same parameters (same n_streams, format, device).  Asynchronous on hip_stream. */
+int  mdemod_copy_state(mdemod_ctx *dst, mdemod_ctx *src, void *hip_stream);
 
 /* Feed-forward carrier estimate of n_windows windows of one recording (device arrays; what the recording entry below seeds
  * its tiles with, usable on its own for Doppler curves and signal detection): the 4th power of the samples has a spectral

@@ -98,6 +98,11 @@ SIGNATURES = {
     "mdemod_rotate_carrier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_set_carrier_seeds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_set_gain_seeds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdemod_set_clock_seeds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdemod_get_states": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(MdemodStreamState), C.c_void_p]),
+    "mdemod_copy_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdemod_nominal_pitch": (C.c_uint64, [C.c_void_p, C.c_uint64]),
+    "mdemod_compact_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mdemod_carrier_window_samples": (C.c_uint32, [C.c_void_p, C.c_uint32]),
     "mdemod_estimate_carrier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),

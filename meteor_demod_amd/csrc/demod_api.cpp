@@ -180,6 +180,14 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 		       (ctx->tab.use_rw ? static_cast<size_t>((ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
 		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes);
 	};
+	if (ctx->tab.use_rw && lds_need(ctx->block_threads) > 160 * 1024) {
+		/* The per-alignment coefficient rows of the v2 std geometry grow with -O (16 alignments x interp x 84 floats: past the
+		 * 160 KB of LDS from -O 29 on); the v1 ring kernel keeps 4 alignments and still fits: fall back to it. */
+		rc = mdemod_host_derive(*params, ctx->tab, false);
+		if (rc) { delete ctx; return rc; }
+		c.ring_granules = c.hpad / 4 + env_int("MDEMOD_RING_EXTRA", 8);
+		if (c.ring_granules < c.hpad / 4 + 4) c.ring_granules = c.hpad / 4 + 4;
+	}
 	while (ctx->block_threads > 64 && lds_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
 	ctx->lds_bytes = lds_need(ctx->block_threads);
 	if (ctx->lds_bytes > 160 * 1024) { delete ctx; return MDEMOD_ERR_PARAM; }
@@ -459,6 +467,89 @@ mdemod_set_gain_seeds(mdemod_ctx *ctx, const float *gain_dev, void *hip_stream)
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	HIP_TRY(mdemod_launch_gain_seeds(ctx->st, gain_dev, ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
+	return MDEMOD_OK;
+}
+
+int
+mdemod_set_clock_seeds(mdemod_ctx *ctx, const float *t_freq_dev, void *hip_stream)
+{
+	if (!ctx || !t_freq_dev) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(ctx->st.t_freq, t_freq_dev, sizeof(float) * ctx->params.n_streams, hipMemcpyDeviceToDevice,
+	                       static_cast<hipStream_t>(hip_stream)));
+	return MDEMOD_OK;
+}
+
+int
+mdemod_get_states(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_stream_state *out, void *hip_stream)
+{
+	if (!ctx || !out) return MDEMOD_ERR_PARAM;
+	if (static_cast<uint64_t>(first) + count > ctx->params.n_streams) return MDEMOD_ERR_RANGE;
+	if (!count) return MDEMOD_OK;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	const DemodStateSoA &s = ctx->st;
+	std::vector<float> f[10]; std::vector<int32_t> flags; std::vector<uint64_t> nsamp, nsym; std::vector<int64_t> fl;
+	float *const src[10] = { s.agc_gain, s.agc_bias_re, s.agc_bias_im, s.pll_phase, s.pll_freq, s.pll_err, s.t_phase, s.t_freq, s.t_prev, s.inphase };
+	for (int k = 0; k < 10; k++) if ((rc = fetch(src[k], first, count, f[k], st))) return rc;
+	if ((rc = fetch(s.flags, first, count, flags, st))) return rc;
+	if ((rc = fetch(s.n_samples, first, count, nsamp, st))) return rc;
+	if ((rc = fetch(s.n_symbols, first, count, nsym, st))) return rc;
+	if ((rc = fetch(s.first_lock, first, count, fl, st))) return rc;
+	HIP_TRY(hipStreamSynchronize(st));
+	for (uint32_t i = 0; i < count; i++) {
+		mdemod_stream_state &o = out[i];
+		o.agc_gain = f[0][i]; o.agc_bias_re = f[1][i]; o.agc_bias_im = f[2][i];
+		o.pll_phase = f[3][i]; o.pll_freq = f[4][i]; o.pll_err = f[5][i];
+		o.t_phase = f[6][i]; o.t_freq = f[7][i]; o.t_prev = f[8][i]; o.oqpsk_inphase = f[9][i];
+		o.pll_locked = (flags[i] & MDEMOD_FLAG_LOCKED) ? 1 : 0;
+		o.pll_locked_once = (flags[i] & MDEMOD_FLAG_LOCKED_ONCE) ? 1 : 0;
+		o.pll_updown = (flags[i] & MDEMOD_FLAG_UPDOWN_POS) ? 1 : -1;
+		o.t_dual_state = (flags[i] >> MDEMOD_FLAG_DUAL_SHIFT) & 3;
+		o.n_samples = nsamp[i]; o.n_symbols = nsym[i]; o.first_lock_symbol = fl[i];
+	}
+	return MDEMOD_OK;
+}
+
+int
+mdemod_copy_state(mdemod_ctx *dst, mdemod_ctx *src, void *hip_stream)
+{
+	if (!dst || !src) return MDEMOD_ERR_PARAM;
+	const mdemod_params &a = dst->params, &b = src->params;
+	if (a.n_streams != b.n_streams || a.bps != b.bps || a.device != b.device || dst->tab.use_rw != src->tab.use_rw ||
+	    dst->tab.c.hpad != src->tab.c.hpad) return MDEMOD_ERR_PARAM;
+	int rc = select_device(dst);
+	if (rc) return rc;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	const size_t n = a.n_streams;
+	const DemodStateSoA &d = dst->st, &s = src->st;
+#define CP(field) HIP_TRY(hipMemcpyAsync(d.field, s.field, sizeof(*d.field) * n, hipMemcpyDeviceToDevice, st))
+	CP(agc_gain); CP(agc_bias_re); CP(agc_bias_im); CP(pll_phase); CP(pll_freq); CP(pll_err); CP(t_phase); CP(t_freq); CP(t_prev);
+	CP(inphase); CP(flags); CP(n_samples); CP(n_symbols); CP(first_lock); CP(sym_this_call); CP(ev_this_call); CP(overflow);
+#undef CP
+	HIP_TRY(hipMemcpyAsync(d.hist, s.hist, static_cast<size_t>(dst->tab.c.hpad) * n * (dst->tab.use_rw ? 8 : dst->sample_bytes),
+	                       hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d.events, s.events, sizeof(mdemod_lock_event) * MDEMOD_MAX_LOCK_EVENTS * n, hipMemcpyDeviceToDevice, st));
+	return MDEMOD_OK;
+}
+
+uint64_t
+mdemod_nominal_pitch(const mdemod_ctx *ctx, uint64_t n_samples)
+{
+	return mdemod_nominal_symbols(ctx, n_samples);
+}
+
+int
+mdemod_compact_soft(mdemod_ctx *ctx, const int8_t *soft_dev, uint64_t soft_stride_symbols,
+                    int8_t *out_dev, uint64_t out_pitch_symbols, void *hip_stream)
+{
+	if (!ctx || !soft_dev || !out_dev || (soft_stride_symbols & 7) || (out_pitch_symbols & 7)) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	HIP_TRY(mdemod_launch_compact_rows(soft_dev, soft_stride_symbols, out_dev, out_pitch_symbols, ctx->st.sym_this_call,
+	                                   ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
 }
 

@@ -120,6 +120,37 @@ class Demodulator:
     def max_symbols(self, n_samples: int) -> int:
         return int(self._lib.mdemod_max_symbols(self._ctx, int(n_samples)))
 
+    def _check_iq(self, iq) -> None:
+        """The kernels read raw device memory: a wrong dtype or device is an out-of-bounds read, not an exception."""
+        import torch
+        want = {8: torch.uint8, 16: torch.int16, 32: torch.float32}[self.cfg.bps]
+        if not iq.is_cuda or iq.device.index != self.device:
+            raise ValueError(f"iq lives on {iq.device}, this context on cuda:{self.device}")
+        if iq.dtype != want:
+            raise ValueError(f"iq dtype {iq.dtype} does not match bps={self.cfg.bps} ({want})")
+
+    def _check_soft(self, soft) -> None:
+        import torch
+        if (not soft.is_cuda or soft.device.index != self.device or soft.dtype != torch.int8 or soft.dim() != 3
+                or soft.shape[0] != self.n_streams or soft.shape[2] != 2 or not soft.is_contiguous()):
+            raise ValueError(f"soft must be a contiguous int8 [n_streams={self.n_streams}, cap, 2] tensor on cuda:{self.device}")
+
+    def nominal_pitch(self, n_samples: int) -> int:
+        """Row pitch in symbols for what n_samples produce at the nominal rate (+1 %), a multiple of 8."""
+        return int(self._lib.mdemod_nominal_pitch(self._ctx, int(n_samples)))
+
+    def compact(self, soft, pitch: int, out=None):
+        """Rows of the last call's symbols at ``pitch`` symbols instead of the hard-bound capacity of ``soft``."""
+        import torch
+        self._check_soft(soft)
+        if pitch % 8 or soft.shape[1] % 8:
+            raise ValueError("pitches must be multiples of 8 symbols")
+        if out is None:
+            out = torch.empty((self.n_streams, pitch, 2), dtype=torch.int8, device=soft.device)
+        check(self._lib.mdemod_compact_soft(self._ctx, C.c_void_p(soft.data_ptr()), soft.shape[1], C.c_void_p(out.data_ptr()),
+                                            int(pitch), self._stream()), "mdemod_compact_soft")
+        return out
+
     # -- hot path -------------------------------------------------------------
     def process(self, iq, n_samples: int | None = None, soft=None):
         """Demodulate one block per stream from a device tensor.
@@ -131,13 +162,16 @@ class Demodulator:
         in :meth:`status`.
         """
         import torch
-        assert iq.is_cuda and iq.dim() == 3 and iq.shape[0] == self.n_streams and iq.shape[2] == 2
-        assert iq.stride(2) == 1 and iq.stride(1) == 2
+        self._check_iq(iq)
+        if iq.dim() != 3 or iq.shape[0] != self.n_streams or iq.shape[2] != 2 or iq.stride(2) != 1 or iq.stride(1) != 2:
+            raise ValueError(f"iq must be [n_streams={self.n_streams}, n, 2] with contiguous samples, got {tuple(iq.shape)} strides {iq.stride()}")
         n = int(iq.shape[1] if n_samples is None else n_samples)
+        if n < 0 or n > iq.shape[1]:
+            raise ValueError(f"n_samples={n} outside the block of {iq.shape[1]} samples")
         cap = self.max_symbols(n)
         if soft is None:
             soft = torch.empty((self.n_streams, cap, 2), dtype=torch.int8, device=iq.device)
-        assert soft.is_contiguous() and soft.shape[0] == self.n_streams
+        self._check_soft(soft)
         check(self._lib.mdemod_process_device_uniform(
             self._ctx, C.c_void_p(iq.data_ptr()), iq.stride(0) // 2, n,
             C.c_void_p(soft.data_ptr()), soft.shape[1], min(cap, soft.shape[1]), self._stream()),
@@ -147,6 +181,14 @@ class Demodulator:
     def process_ragged(self, iq_flat, offsets, counts, soft):
         """Ragged batch: ``iq_flat`` [total, 2] device tensor, ``offsets`` (uint64 as int64) and
         ``counts`` (int32/uint32) device tensors of n_streams entries, ``soft`` [n_streams, cap, 2]."""
+        self._check_iq(iq_flat)
+        if iq_flat.dim() != 2 or iq_flat.shape[1] != 2 or not iq_flat.is_contiguous():
+            raise ValueError("iq_flat must be a contiguous [total, 2] tensor")
+        for name, t, size in (("offsets", offsets, 8), ("counts", counts, 4)):
+            if (t.device != iq_flat.device or t.numel() != self.n_streams or t.element_size() != size or not t.is_contiguous()
+                    or t.is_floating_point()):
+                raise ValueError(f"{name} must be a contiguous {size * 8}-bit integer tensor of {self.n_streams} entries on {iq_flat.device}")
+        self._check_soft(soft)
         check(self._lib.mdemod_process_device(
             self._ctx, C.c_void_p(iq_flat.data_ptr()), C.c_void_p(offsets.data_ptr()),
             C.c_void_p(counts.data_ptr()), C.c_void_p(soft.data_ptr()), soft.shape[1], soft.shape[1],
@@ -221,6 +263,20 @@ class Demodulator:
         assert freq.element_size() == 4 and updown.element_size() == 4 and freq.is_contiguous() and updown.is_contiguous()
         check(self._lib.mdemod_set_carrier_seeds(self._ctx, C.c_void_p(freq.data_ptr()), C.c_void_p(updown.data_ptr()),
                                                  self._stream()), "mdemod_set_carrier_seeds")
+
+    def set_clock_seeds(self, t_freq) -> None:
+        """Symbol-clock frequency per stream (rad per interpolated sample, float32 device tensor)."""
+        assert t_freq.numel() == self.n_streams and t_freq.element_size() == 4 and t_freq.is_contiguous()
+        check(self._lib.mdemod_set_clock_seeds(self._ctx, C.c_void_p(t_freq.data_ptr()), self._stream()), "mdemod_set_clock_seeds")
+
+    def get_states(self, first: int = 0, count: int | None = None) -> list[MdemodStreamState]:
+        count = self.n_streams - first if count is None else count
+        arr = (MdemodStreamState * max(count, 1))()
+        check(self._lib.mdemod_get_states(self._ctx, first, count, arr, self._stream()), "mdemod_get_states")
+        return list(arr)[:count]
+
+    def copy_state_from(self, other: "Demodulator") -> None:
+        check(self._lib.mdemod_copy_state(self._ctx, other._ctx, self._stream()), "mdemod_copy_state")
 
     def set_gain_seeds(self, gain) -> None:
         """AGC gain per stream (float32 device tensor)."""

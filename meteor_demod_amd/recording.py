@@ -381,7 +381,8 @@ class RecordingDemodulator:
     def __init__(self, cfg, tile_samples: int = 0, pre_samples: int = -1, refine: bool = True,
                  pilot_block: int = 65536, pilot_margin_symbols: int = 20000, max_pilot_samples: int = 1 << 22,
                  match_symbols: int = 192, device: int = 0, bank_factory=None, post_samples: int = 4096,
-                 carrier_seed: str = "pilot"):
+                 carrier_seed: str = "pilot", acquire_symbols: int = 0):
+        self.acquire_symbols = int(acquire_symbols)
         if cfg.oqpsk and not refine:
             # the I and Q rails of OQPSK come from different firings (demod.c:66-76): a 90 degree lock offset is
             # entangled with the half-symbol state of the symbol clock, which rotate_symbols() cannot undo on the
@@ -501,7 +502,20 @@ class RecordingDemodulator:
         cap = bank.max_symbols(int(plan.lens.max()))
         soft_pre = torch.zeros((T, cap_pre, 2), dtype=torch.int8, device=dev)
         soft1 = torch.zeros((T, cap, 2), dtype=torch.int8, device=dev)
-        bank.process_ragged(iq, i64(plan.starts - plan.pres), i32(plan.pres), soft_pre)
+        acq = np.minimum(int(self.acquire_symbols * self.cfg.samplerate / self.cfg.symrate), plan.pres)
+        if self.acquire_symbols > 0:
+            # two-stage warm-up: acquire carrier phase / symbol clock / gain, then put the two loop INTEGRATORS back on their seeds
+            # (the acquisition transient kicks them and they need 8-16 k symbols to come back: tools/seed_convergence.py)
+            soft_acq = torch.zeros((T, max(1, bank.max_symbols(int(acq.max()))), 2), dtype=torch.int8, device=dev)
+            bank.process_ragged(iq, i64(plan.starts - plan.pres), i32(acq), soft_acq)
+            if self.carrier_seed == "spectrum":
+                bank.set_carrier_seeds(f0.to(torch.float32).contiguous(), torch.where(slope >= 0, 1, -1).to(torch.int32).contiguous())
+            else:
+                bank.set_carrier_seeds(torch.full((T,), float(seed.pll_freq), dtype=torch.float32), torch.full((T,), int(seed.pll_updown if hasattr(seed, "pll_updown") else seed.updown), dtype=torch.int32))
+            bank.set_clock_seeds(torch.full((T,), float(seed.t_freq), dtype=torch.float32))
+            bank.process_ragged(iq, i64(plan.starts - plan.pres + acq), i32(plan.pres - acq), soft_pre)
+        else:
+            bank.process_ragged(iq, i64(plan.starts - plan.pres), i32(plan.pres), soft_pre)
         cnt_pre = bank.symbol_counts().to(dev)
         bank.process_ragged(iq, i64(plan.starts), i32(plan.lens), soft1)
         cnt1 = bank.symbol_counts().to(dev)

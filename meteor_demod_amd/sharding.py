@@ -7,7 +7,7 @@ range of streams from its own HBM.  The only exchange the north star names is th
 optional fan-in of the soft-symbol buffers to one rank, done here with
 `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
 the CPU tests): one all_gather of per-stream symbol counts, then one gather of
-the (padded) int8 buffers.
+the int8 rows at the nominal symbol pitch (compacted on the device first).
 """
 from __future__ import annotations
 
@@ -32,9 +32,14 @@ def owner_of(stream: int, n_streams: int, world: int) -> int:
 def fanin_soft(soft_local, counts_local, n_streams: int, dst: int = 0, group=None):
     """Collect every rank's soft symbols on `dst`.
 
-    soft_local  : int8 tensor [n_local, cap, 2] (device tensor for nccl, CPU for gloo)
+    soft_local  : int8 tensor [n_local, pitch, 2] (device tensor for nccl, CPU for gloo).  Pass rows at the NOMINAL pitch
+                  (Demodulator.compact / mdemod_compact_soft: 0.63 B per input sample at 72k in 230 kS/s), not at the
+                  hard-bound capacity the kernels write with (one symbol per input sample: 3.2x the bytes).
     counts_local: int32 tensor [n_local], symbols valid per local stream
-    Returns on dst: (soft [n_streams, cap_max, 2], counts [n_streams]); elsewhere (None, None).
+    Returns on dst: (soft [n_streams, pitch_max, 2], counts [n_streams]); elsewhere (None, None).
+
+    One all_reduce (common pitch), one all_gather (counts), one gather (symbols).  The gather lands directly in the
+    result buffer when the streams divide evenly over the ranks (no staging copy on the root).
     """
     import torch
     import torch.distributed as dist
@@ -42,25 +47,34 @@ def fanin_soft(soft_local, counts_local, n_streams: int, dst: int = 0, group=Non
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = soft_local.device
+    n_local = soft_local.shape[0]
     n_max = max(shard_range(n_streams, r, world)[1] - shard_range(n_streams, r, world)[0] for r in range(world))
 
-    # 1) capacities differ per rank only through n_local; agree on a common padded shape
+    # 1) agree on a common row pitch (ranks may have been given different block lengths)
     cap = torch.tensor([soft_local.shape[1]], dtype=torch.int64, device=dev)
     dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
     cap = int(cap.item())
 
     cnt_pad = torch.zeros(n_max, dtype=torch.int32, device=dev)
-    cnt_pad[: counts_local.shape[0]] = counts_local.to(torch.int32)
+    cnt_pad[:n_local] = counts_local.to(torch.int32)
     all_cnt = [torch.empty_like(cnt_pad) for _ in range(world)]
     dist.all_gather(all_cnt, cnt_pad, group=group)
 
-    pad = torch.zeros((n_max, cap, 2), dtype=torch.int8, device=dev)
-    pad[: soft_local.shape[0], : soft_local.shape[1]] = soft_local
-    gathered = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, gathered, dst=dst, group=group)
+    # 2) rows: padded only if this rank holds fewer streams or a shorter pitch than the largest shard
+    if n_local == n_max and soft_local.shape[1] == cap and soft_local.is_contiguous():
+        send = soft_local
+    else:
+        send = torch.zeros((n_max, cap, 2), dtype=torch.int8, device=dev)
+        send[:n_local, : soft_local.shape[1]] = soft_local
+    even = n_streams == n_max * world
+    out = torch.empty((n_max * world, cap, 2), dtype=torch.int8, device=dev) if rank == dst else None
+    gathered = [out[r * n_max:(r + 1) * n_max] for r in range(world)] if rank == dst else None
+    dist.gather(send, gathered, dst=dst, group=group)
     if rank != dst:
         return None, None
 
+    if even:
+        return out, torch.cat(all_cnt)
     soft = torch.empty((n_streams, cap, 2), dtype=torch.int8, device=dev)
     counts = torch.empty(n_streams, dtype=torch.int32, device=dev)
     for r in range(world):

@@ -114,6 +114,11 @@ class OracleBank:
             s.pll_freq = float(np.float32(f[i]))
             s.updown = 1 if int(u[i]) > 0 else -1
 
+    def set_clock_seeds(self, t_freq) -> None:
+        f = t_freq.cpu().numpy()
+        for i, st in enumerate(self.streams):
+            st._p.contents.s.t_freq = float(np.float32(f[i]))
+
     def set_gain_seeds(self, gain) -> None:
         g = gain.cpu().numpy()
         for i, st in enumerate(self.streams):

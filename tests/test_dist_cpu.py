@@ -18,7 +18,6 @@ import torch.multiprocessing as mp
 from meteor_demod_amd import DemodConfig, synth
 from meteor_demod_amd.sharding import fanin_soft, owner_of, shard_range
 
-N_STREAMS = 5
 N_SAMPLES = 6000
 
 
@@ -30,7 +29,7 @@ def _stream_soft(idx: int):
     return O.oracle_demod(cfg, iq)[0]
 
 
-def _worker(rank: int, world: int, port: int, q):
+def _worker(rank: int, world: int, port: int, q, N_STREAMS: int):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(N_STREAMS, rank, world)
@@ -70,12 +69,13 @@ def test_shard_ranges_partition_the_streams():
 
 
 @pytest.mark.timeout(180)
-def test_two_rank_fanin_equals_single_process():
+@pytest.mark.parametrize("N_STREAMS", [5, 6], ids=["uneven-shards", "even-shards-zero-copy"])
+def test_two_rank_fanin_equals_single_process(N_STREAMS):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, N_STREAMS)) for r in range(world)]
     for p in procs:
         p.start()
     soft, cnt = q.get(timeout=150)
@@ -86,3 +86,17 @@ def test_two_rank_fanin_equals_single_process():
         want = _stream_soft(i)
         assert cnt[i] == want.shape[0]
         assert np.array_equal(soft[i, : cnt[i]], want)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` starts its own ranks; with fewer than N devices it must fail loudly instead of printing an
+    N=1 line (the driver's scaling run degenerated to one GPU)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    if torch.cuda.device_count() >= 64:
+        pytest.skip("needs a node with fewer than 64 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py"), "--gpus", "64", "--steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()

@@ -524,38 +524,44 @@ def test_full_size_batch_properties(gpu_device, kernel_variant):
             assert np.array_equal(soft[i, : want.shape[0]].cpu().numpy(), want), i
 
 
-# ---- the multi-GPU layer on the real backend (RCCL); only one GPU is available here ------------------
+# ---- the multi-GPU layer on the real backend (RCCL) ------------------------------------------------------
 
-def _rccl_worker(port, q):
+def _rccl_worker(rank, world, port, q):
     import os
     import torch
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     from meteor_demod_amd.sharding import fanin_soft, shard_range
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    n_streams = 70
-    lo, hi = shard_range(n_streams, 0, 1)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    n_streams, n = 70, 6000
+    lo, hi = shard_range(n_streams, rank, world)
     streams = [synth.make_stream(40 + i, 230000, 72000, f0_hz=50.0 * i, esn0_db=20.0) for i in range(n_streams)]
-    x = synth.generate_device(streams, 6000)
-    with Demodulator(C1, hi - lo) as d:
-        soft = d.process(x[lo:hi])
+    x = synth.generate_device(streams[lo:hi], n, device=rank)
+    ok = True
+    with Demodulator(C1, hi - lo, device=rank) as d:
+        soft = d.process(x)
         torch.cuda.synchronize()
-        counts = torch.tensor([s.symbols_this_call for s in d.status()], dtype=torch.int32, device="cuda")
-        all_soft, all_cnt = fanin_soft(soft, counts, n_streams, dst=0)
+        counts = torch.from_numpy(d.status_array()["symbols_this_call"].astype(np.int32)).to(f"cuda:{rank}")
+        pitch = d.nominal_pitch(n)
+        assert pitch < soft.shape[1] and int(counts.max()) <= pitch
+        packed = d.compact(soft, pitch)                     # nominal pitch: what goes over xGMI
+        all_soft, all_cnt = fanin_soft(packed, counts, n_streams, dst=0)
         torch.cuda.synchronize()
-        ok = torch.equal(all_cnt, counts) and torch.equal(all_soft[:, : soft.shape[1]], soft)
-        want = O.oracle_demod(C1, synth.generate_host(streams[69], 6000))[0]
-        ok = ok and np.array_equal(all_soft[69, : int(all_cnt[69])].cpu().numpy(), want)
+        if rank == 0:
+            ok = all_soft.shape == (n_streams, pitch, 2) and torch.equal(all_cnt[lo:hi], counts)
+            for i in (0, 1, 34, 35, 69):                    # both shards when world == 2
+                want = O.oracle_demod(C1, synth.generate_host(streams[i], n))[0]
+                ok = ok and int(all_cnt[i]) == want.shape[0] and np.array_equal(all_soft[i, : want.shape[0]].cpu().numpy(), want)
+        else:
+            ok = all_soft is None
     dist.barrier()
     dist.destroy_process_group()
-    q.put(bool(ok))
+    q.put((rank, bool(ok)))
 
 
-@pytest.mark.timeout(300)
-def test_rccl_fanin_path_world_size_one(gpu_device):
-    """sharding.fanin_soft over the nccl (= RCCL) backend with device tensors.  One rank is all this box
-    has; the world_size-2 logic is covered by the gloo test in test_dist_cpu.py."""
+def _run_rccl(world):
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -563,11 +569,29 @@ def test_rccl_fanin_path_world_size_one(gpu_device):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(port, q))
-    p.start()
-    ok = q.get(timeout=240)
-    p.join(timeout=60)
-    assert ok and p.exitcode == 0
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res.values()), res
+
+
+@pytest.mark.timeout(300)
+def test_rccl_fanin_path_world_size_one(gpu_device):
+    """sharding.fanin_soft over the nccl (= RCCL) backend with device tensors compacted to the nominal pitch."""
+    _run_rccl(1)
+
+
+@pytest.mark.timeout(300)
+def test_rccl_fanin_path_two_ranks(gpu_device):
+    """The same with two ranks on two GPUs (streams sharded, symbols gathered over xGMI); skips itself on a one-GPU box.
+    The world_size-2 logic is also covered by the gloo test in test_dist_cpu.py."""
+    if _torch().cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_rccl(2)
 
 
 # ---- random option combinations ------------------------------------------------------------------------
@@ -595,6 +619,23 @@ def _random_cfgs(n, seed=2026):
     DemodConfig(samplerate=144000, interp_factor=1, rrc_order=8, oqpsk=True, bps=8),
 ], ids=["wide-O1-oqpsk", "std-O1", "ring-O1", "std-O1-oqpsk-u8"])
 def test_oversampling_factor_one(cfg, gpu_device):
+    _check_cfg_against_oracle(cfg)
+
+
+@pytest.mark.parametrize("cfg", [
+    DemodConfig(samplerate=230000, interp_factor=28),                       # largest -O whose std-geometry rows fit in LDS
+    DemodConfig(samplerate=230000, interp_factor=29),                       # first one that does not: falls back to the ring kernel
+    DemodConfig(samplerate=230000, interp_factor=32, rrc_order=16),
+    DemodConfig(samplerate=230000, interp_factor=64),
+    DemodConfig(samplerate=230000, symrate=80000, interp_factor=64, oqpsk=True, bps=8),
+], ids=["O28", "O29", "O32-f16", "O64", "O64-oqpsk-u8"])
+def test_large_oversampling_factors(cfg, gpu_device):
+    """-O 29 and above: the per-alignment coefficient rows of the v2 std geometry exceed the 160 KB of LDS; mdemod_create
+    used to refuse these valid reference configurations instead of using the v1 kernel."""
+    _check_cfg_against_oracle(cfg)
+
+
+def _check_cfg_against_oracle(cfg):
     """-O 1: floor(x / 1) cannot go through the 32-bit reciprocal the symbol clock uses for x / interp (the reciprocal
     of 1 is 2^32); found by tools/config_fuzz.py as an endless loop in the kernel."""
     torch = _torch()

@@ -20,7 +20,7 @@ for ci in range(n_cfg):
     oqpsk = bool(rng.random() < 0.35)
     cfg = DemodConfig(samplerate=samplerate, symrate=symrate, oqpsk=oqpsk,
                       rrc_order=int(rng.choice([4, 8, 16, 17, 24, 32, 33, 40, 48, 63, 64, 65, 80])),
-                      interp_factor=int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10])),
+                      interp_factor=int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 16, 29, 32, 64])),
                       pll_bw=float(rng.choice([0.01, 0.5, 1.0, 2.0, 5.0, 100.0, 3000.0])),
                       freq_max=float(rng.choice([-1.0, 0.0, 0.001, 0.05, 0.3, 1.5])),
                       bps=int(rng.choice([8, 16, 16, 16, 32])))
