@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MDEMOD_ABI_VERSION 1
+#define MDEMOD_ABI_VERSION 2
 
 /* Error codes (the reference surfaces none: demod_init returns void and drops
  * filter_init_rrc's status, demod.c:14). */
@@ -212,8 +212,8 @@ int  mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs,
 /* ---- overlapped tiles of ONE recording ------------------------------------
  * The reference demodulates a recording as one serial recurrence (main.c:303).
  * To run tiles of it in parallel each tile is an independent stream that starts
- * `pre` samples early from a converged seed state; these two calls are what the
- * host-side stitcher (meteor_demod_amd/recording.py) needs besides the ragged
+ * early from a seed state; these calls are what the stitcher
+ * (mdemod_demodulate_recording, csrc/recording.hip) needs besides the ragged
  * process call. */
 
 /* Every stream := *seed (loop state and counters); filter history zeroed. */
@@ -243,10 +243,10 @@ int  mdemod_get_states(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_s
 int  mdemod_copy_state(mdemod_ctx *dst, mdemod_ctx *src, void *hip_stream);
 
 /* Feed-forward carrier estimate of n_windows windows of one recording (device arrays; what the recording entry below seeds
- * its tiles with, usable on its own for Doppler curves and signal detection): the 4th power of the samples has a spectral
+ * its tiles with): the 4th power of the samples has a spectral
  * line at 4x the carrier offset whatever the data (QPSK and RRC-shaped OQPSK).  Window w covers window samples from
  * starts_dev[w] (reads past the end of the recording repeat its last sample); the window length actually used is
- * mdemod_carrier_window_samples(): window_samples rounded down to a power of two in [4096, 2^17].  freq_dev[w]: carrier in
+ * mdemod_carrier_window_samples(): window_samples rounded down to a power of two in [4096, 2^18].  freq_dev[w]: carrier in
  * rad per NCO step (per symbol; per half symbol for OQPSK: pll.c:77,93) at the MIDDLE of the window, as pll_get_freq()
  * would report it; quality_dev[w]: line / mean of the searched band (+-0.33 rad/symbol): noise alone gives 3-4, a 12 dB
  * signal 40-50.  One kernel (z^4, boxcar decimation, FFT in LDS, peak search), asynchronous on hip_stream; only
@@ -255,24 +255,44 @@ uint32_t mdemod_carrier_window_samples(const mdemod_params *params, uint32_t win
 int  mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
                              const uint64_t *starts_dev, uint32_t n_windows, uint32_t window_samples,
                              float *freq_dev, float *quality_dev, void *hip_stream);
+/* The same with a de-chirp: chirp_dev[w] (may be NULL) = carrier slope of window w in rad per NCO step per SAMPLE; the line of a
+ * carrier that moves by more than a bin inside the window (Doppler: up to 40 Hz/s) is smeared without it. */
+int  mdemod_estimate_carrier_chirp(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
+                                   const uint64_t *starts_dev, const float *chirp_dev, uint32_t n_windows, uint32_t window_samples,
+                                   float *freq_dev, float *quality_dev, void *hip_stream);
 
-/* The whole scheme in one call (native counterpart of meteor_demod_amd/recording.py):
- * the head of the recording is demodulated serially from the reference's power-on state until the
- * carrier loop has locked and converged (those symbols are the reference's symbols), the rest as
- * overlapped tiles seeded from that state, rotation- and seam-resolved, optionally refined by an exact
- * continuation pass (mandatory for OQPSK).  iq_dev: n_samples IQ samples in the format of params->bps, in device
- * memory; soft_dev: device buffer for soft_cap_symbols int8 pairs (mdemod_max_symbols-sized is enough).
- * params->n_streams is ignored.  Synchronous on hip_stream. */
+/* ONE recording on many lanes.  The reference runs a recording as one serial recurrence (main.c:303-316);
+ * here only its head runs serially (the "pilot": from the reference's power-on state until the carrier loop has locked and
+ * settled - those symbols ARE the reference's symbols, lock gate included), the rest as tiles, one lane each:
+ *   acquire   every tile starts (acquire + frame + settle) samples early from the pilot's loop state, its own carrier
+ *             estimate (4th-power spectrum, de-chirped) and gain estimate;
+ *   re-seed   after `acquire_samples` the two loop integrators (pll.c:115 freq, timing.c:84 freq) are put back on their
+ *             seeds: the acquisition transient kicks them and they need 8-16 k symbols to come back on their own;
+ *   frame     a Costas loop locks on one of four rotations.  After `frame_samples` more the rotation of every tile relative
+ *             to its predecessor follows from the two NCO phases and the carrier estimate between them (dead reckoning:
+ *             theta_b - theta_a - f * steps, rounded to quarter turns); prefix-summed from the pilot and undone IN THE STATE
+ *             (mdemod_rotate_carrier), so that every tile settles in the rotation the serial run is in (the timing detector
+ *             reads only the Q rail, timing.c:65-66: a tile that settles a quarter turn off tracks the other rail's noise);
+ *   settle    `settle_samples` more (not emitted), then the body (emitted);
+ *   seams     the last symbols before each tile's body were demodulated by its predecessor too: an int8 correlation gives
+ *             the residual rotation (expected 0; otherwise the tile and its successors are repaired: 180 degrees on the
+ *             output, odd quarter turns by one more settle + body pass from the saved post-acquisition state) and the
+ *             one-symbol duplicate / gap at the seam.
+ * Tile 0 is the exact continuation of the pilot.  iq_dev: n_samples IQ samples in the format of params->bps, in device
+ * memory; soft_dev: device buffer for soft_cap_symbols int8 pairs.  params->n_streams is ignored.  Synchronous on hip_stream. */
 typedef struct {
-	uint32_t tile_samples;          /* body samples per tile; 0 = 20 536 symbols worth (65 600 at 72k / 230 kS/s) */
-	uint32_t pre_samples;           /* warm-up samples per tile; 0xFFFFFFFF = 5 129 symbols worth (OQPSK: 10 258) */
+	uint32_t tile_samples;          /* body samples per tile; 0 = automatic: 8 192 ... 41 072 symbols worth, as short as
+	                                   keeps the tiles of this recording within 65 536 lanes                             */
+	uint32_t acquire_samples;       /* 0xFFFFFFFF = 2 000 symbols worth                                                  */
+	uint32_t frame_samples;         /* 0xFFFFFFFF = 1 500 symbols worth                                                  */
+	uint32_t settle_samples;        /* 0xFFFFFFFF = 24 000 symbols worth                                                 */
 	uint32_t pilot_block;           /* pilot granularity in samples               (65536)  */
 	uint32_t pilot_margin_symbols;  /* symbols the pilot stays locked before tiles start (20000) */
 	uint64_t max_pilot_samples;     /* give up waiting for lock after this many   (1 << 22) */
 	uint32_t match_symbols;         /* symbols compared across a seam             (192)    */
-	int32_t  refine;                /* 1: exact-continuation second pass          (1)      */
-	uint32_t carrier_seed;          /* 0: every tile starts from the pilot's carrier estimate; 1: from its own 4th-power
-	                                   spectrum (follows Doppler)   (1)      */
+	int32_t  repair;                /* 1: tiles whose seam shows an odd residual rotation run settle + body again (1)    */
+	uint32_t carrier_seed;          /* 1: every tile from its own 4th-power spectrum (follows Doppler); 0: all tiles from
+	                                   the pilot's carrier estimate (dead reckoning then rarely holds: repair does the work) (1) */
 	uint32_t reserved;
 } mdemod_recording_opts;
 
@@ -280,19 +300,22 @@ typedef struct {
 	uint64_t n_symbols;             /* symbols written to soft_dev                           */
 	uint64_t pilot_samples;         /* samples [0, pilot_samples) were demodulated serially  */
 	uint64_t pilot_symbols;         /* ... and produced this many symbols (bit-exact)        */
+	uint64_t exact_symbols;         /* leading symbols that are the reference's own (pilot + its exact continuation, tile 0) */
 	int64_t  first_lock_symbol;     /* as mdemod_status, from the pilot                      */
-	uint64_t samples_demodulated;   /* kernel work including warm-up and second pass         */
+	uint64_t samples_demodulated;   /* kernel work including acquisition, settling, repairs  */
 	uint32_t n_tiles;
+	uint32_t tile_samples;          /* body samples per tile actually used                   */
 	uint32_t weak_seams;            /* seams whose correlation was too weak to trust         */
 	uint32_t seam_fixes;            /* one-symbol duplicates / gaps repaired                 */
 	int32_t  pilot_locked;
+	uint32_t weak_carrier_tiles;    /* carrier_seed=1: tiles without a clear spectral line, seeded from their neighbours */
 	double   pilot_seconds;         /* wall time of the serial head                          */
 	double   tiles_seconds;         /* wall time of everything after it                      */
-	uint32_t weak_carrier_tiles;    /* carrier_seed=1: tiles without a clear spectral line, seeded from their neighbours */
-	uint32_t rotation_jumps;        /* seams where the second pass found the next tile a quarter turn (or more) off the
-	                                   emitted chain: its predecessor's first pass changed rotation inside the tile (a cycle
-	                                   slip or a late lock).  The stream after such a seam is a valid demodulation in another
-	                                   of the four lock rotations, exactly like a serial run after a cycle slip.            */
+	uint32_t frame_misses;          /* seams where dead reckoning put the tile in another rotation than the correlation found */
+	uint32_t repaired_tiles;        /* tiles that ran settle + body a second time (odd residual rotation)               */
+	uint32_t rotation_jumps;        /* seams that still show a residual rotation after the repair (a cycle slip inside a
+	                                   body): the output is rotated from there on, like a serial run after a cycle slip  */
+	float    frame_residual_rms;    /* rad: dead-reckoned minus measured NCO phase, after removing the quarter turns (0.785 = limit) */
 } mdemod_recording_report;
 
 void mdemod_recording_default_opts(mdemod_recording_opts *opts);

@@ -61,17 +61,20 @@ class MdemodStreamState(C.Structure):
 
 
 class MdemodRecordingOpts(C.Structure):
-    _fields_ = [("tile_samples", C.c_uint32), ("pre_samples", C.c_uint32), ("pilot_block", C.c_uint32),
-                ("pilot_margin_symbols", C.c_uint32), ("max_pilot_samples", C.c_uint64),
-                ("match_symbols", C.c_uint32), ("refine", C.c_int32), ("carrier_seed", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("tile_samples", C.c_uint32), ("acquire_samples", C.c_uint32), ("frame_samples", C.c_uint32),
+                ("settle_samples", C.c_uint32), ("pilot_block", C.c_uint32), ("pilot_margin_symbols", C.c_uint32),
+                ("max_pilot_samples", C.c_uint64), ("match_symbols", C.c_uint32), ("repair", C.c_int32),
+                ("carrier_seed", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MdemodRecordingReport(C.Structure):
     _fields_ = [("n_symbols", C.c_uint64), ("pilot_samples", C.c_uint64), ("pilot_symbols", C.c_uint64),
-                ("first_lock_symbol", C.c_int64), ("samples_demodulated", C.c_uint64),
-                ("n_tiles", C.c_uint32), ("weak_seams", C.c_uint32), ("seam_fixes", C.c_uint32),
-                ("pilot_locked", C.c_int32), ("pilot_seconds", C.c_double), ("tiles_seconds", C.c_double),
-                ("weak_carrier_tiles", C.c_uint32), ("rotation_jumps", C.c_uint32)]
+                ("exact_symbols", C.c_uint64), ("first_lock_symbol", C.c_int64), ("samples_demodulated", C.c_uint64),
+                ("n_tiles", C.c_uint32), ("tile_samples", C.c_uint32), ("weak_seams", C.c_uint32), ("seam_fixes", C.c_uint32),
+                ("pilot_locked", C.c_int32), ("weak_carrier_tiles", C.c_uint32),
+                ("pilot_seconds", C.c_double), ("tiles_seconds", C.c_double),
+                ("frame_misses", C.c_uint32), ("repaired_tiles", C.c_uint32), ("rotation_jumps", C.c_uint32),
+                ("frame_residual_rms", C.c_float)]
 
 
 # name -> (restype, argtypes); this table is also what the symbol-export test walks.
@@ -106,6 +109,8 @@ SIGNATURES = {
     "mdemod_carrier_window_samples": (C.c_uint32, [C.c_void_p, C.c_uint32]),
     "mdemod_estimate_carrier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdemod_estimate_carrier_chirp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_kernel_name": (C.c_char_p, [C.c_void_p]),
     "mdemod_demodulate_recording_host": (C.c_int, [_P(MdemodParams), _P(MdemodRecordingOpts), C.c_void_p, C.c_uint64,
                                                    C.c_void_p, C.c_uint64, _P(MdemodRecordingReport)]),

@@ -1,22 +1,25 @@
 /*
  * recording.hip — ONE recording demodulated on many lanes as overlapped tiles.
  *
- * Native counterpart of meteor_demod_amd/recording.py (same scheme, same
- * decisions, byte-identical result: tests/test_gpu_recording.py).  The reference
- * runs a recording as one serial recurrence (main.c:303-316); see DESIGN.md §3.1
- * for why tiles cannot equal it bit for bit and what is exact instead:
+ * The reference runs a recording as one serial recurrence (main.c:303-316); see
+ * DESIGN.md §3.1 for why tiles cannot equal it bit for bit (a 1-LSB change of one
+ * input sample leaves 0.2 % of the reference's own symbols more than 1 LSB away,
+ * for ever) and what is done instead:
  *
- *   pilot   head of the recording as one stream from power-on state until the
- *           carrier loop has locked and converged  -> the reference's own bytes
- *   pass 1  every tile starts `pre` samples early from the pilot's end state
- *   match   rotation (Costas lock is 4-fold ambiguous) and one-symbol seam
- *           disagreement of each tile against its predecessor, measured on the
- *           samples both demodulated
- *   pass 2  stream i continues exactly from its pass-1 end state, turned into
- *           the pilot's rotation, with tile i+1
+ *   pilot    head of the recording as one stream from power-on state until the
+ *            carrier loop has locked and converged  -> the reference's own bytes
+ *   acquire  every tile starts early from the pilot's loop state and its own
+ *            carrier / gain estimate; after the acquisition the two loop
+ *            integrators are put back on their seeds
+ *   frame    rotation of every tile against its predecessor by dead reckoning of
+ *            the NCO phase (Costas lock is 4-fold ambiguous), undone in the state
+ *   settle   in the serial run's rotation, then the body (emitted)
+ *   seams    residual rotation (repair) and one-symbol disagreement of each tile
+ *            against its predecessor, measured on samples both demodulated
  *
  * All sample arithmetic is done by the demodulator kernels through the public
- * C-ABI of this library; the kernels here only compare and move int8 symbols.
+ * C-ABI of this library; the kernels here estimate carriers and compare and move
+ * int8 symbols.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -200,7 +203,7 @@ template <> struct RawIQ<32> { typedef float t;   __device__ static float2 get(c
  *      magnitude of the searched band (noise alone: 3-4; a 12 dB signal: 40-50). */
 template <int FMT>
 __global__ void __launch_bounds__(1024)
-carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, int log2_nf, int decim, int kmax,
+carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, const float *chirp, float chirp_scale, int log2_nf, int decim, int kmax,
                     float hz_per_bin_over4, float rad_per_hz, float *freq_out, float *quality_out)
 {
 	extern __shared__ float2 spec[];                      /* NF complex floats */
@@ -223,13 +226,23 @@ carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, 
 	const float mr = red[0][0] / nwin, mi = red[1][0] / nwin;
 	__syncthreads();
 	const float wstep = 2.0f / (float)(NF - 1);
+	/* de-chirp: the carrier phase is 0.5 * c * t^2 around the middle of the window (c in turns per sample^2 here), z^4 has four times that */
+	const float c4 = chirp ? chirp[blockIdx.x] * chirp_scale : 0.0f;
 	for (int m = tid; m < NF; m += nth) {
 		float ar = 0.0f, ai = 0.0f;
 		for (int d = 0; d < decim; d++) {
 			float2 v = sample(m * decim + d);
 			v.x -= mr; v.y -= mi;
 			const float2 z2 = make_float2(v.x * v.x - v.y * v.y, 2.0f * v.x * v.y);
-			ar += z2.x * z2.x - z2.y * z2.y; ai += 2.0f * z2.x * z2.y;
+			float2 z4 = make_float2(z2.x * z2.x - z2.y * z2.y, 2.0f * z2.x * z2.y);
+			if (c4 != 0.0f) {
+				const double t = (double)(m * decim + d) - 0.5 * (double)nwin;
+				const double turns = -(double)c4 * t * t;                 /* -4 * 0.5 * c * t^2 in turns */
+				float sn, cs;
+				sincospif(2.0f * (float)(turns - floor(turns)), &sn, &cs);
+				z4 = make_float2(z4.x * cs - z4.y * sn, z4.x * sn + z4.y * cs);
+			}
+			ar += z4.x; ai += z4.y;
 		}
 		const float w = (0.5f - 0.5f * cospif(wstep * (float)m)) * 1e-12f;   /* Hann; the scale keeps |z|^4 of full-scale s16 far from overflow */
 		spec[__brev((unsigned)m) >> (32 - log2_nf)] = make_float2(ar * w, ai * w);
@@ -424,13 +437,13 @@ struct PilotBlock { uint64_t start; uint32_t len; double gain_after; uint64_t sy
 
 /* Window geometry of the carrier estimator: the z^4 line sits within +-4 * 0.33 rad/symbol; decimate by D (boxcar, in the
  * kernel) as far as that band stays inside 80 % of the decimated one, keep the transform within the 16384 points that fit
- * in LDS.  window_samples is rounded down to a power of two in [4096, 2^17] (and further if the band forbids decimation). */
+ * in LDS.  window_samples is rounded down to a power of two in [4096, 2^18] (and further if the band forbids decimation). */
 static void
 carrier_window(const mdemod_params *params, uint32_t window_samples, int *nwin, int *decim, int *log2_nf, int *kmax)
 {
 	const double symrate = params->symrate, fs = params->samplerate;
 	int n = 4096;
-	while (n * 2 <= static_cast<int>(std::min<uint32_t>(window_samples, 1u << 17))) n *= 2;
+	while (n * 2 <= static_cast<int>(std::min<uint32_t>(window_samples, 1u << 18))) n *= 2;
 	const double band_hz = 4 * 0.33 * symrate / (2 * 3.141592653589793);
 	int d = 1;
 	while (d < 16 && fs / (2.0 * (d * 2)) >= 1.25 * band_hz) d *= 2;
@@ -452,9 +465,9 @@ mdemod_carrier_window_samples(const mdemod_params *params, uint32_t window_sampl
 }
 
 extern "C" int
-mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
-                        const uint64_t *starts_dev, uint32_t n_windows, uint32_t window_samples,
-                        float *freq_dev, float *quality_dev, void *hip_stream)
+mdemod_estimate_carrier_chirp(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
+                              const uint64_t *starts_dev, const float *chirp_dev, uint32_t n_windows, uint32_t window_samples,
+                              float *freq_dev, float *quality_dev, void *hip_stream)
 {
 	if (!params || !iq_dev || !starts_dev || !freq_dev || !quality_dev || n_samples == 0) return MDEMOD_ERR_PARAM;
 	if (params->samplerate <= 0 || params->symrate <= 0 || (params->bps != 8 && params->bps != 16 && params->bps != 32)) return MDEMOD_ERR_PARAM;
@@ -463,13 +476,16 @@ mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_
 	int nwin, decim, log2_nf, kmax;
 	carrier_window(params, window_samples, &nwin, &decim, &log2_nf, &kmax);
 	const double symrate = params->symrate, fs = params->samplerate;
+	const int nco = params->oqpsk ? 2 : 1;                       /* OQPSK: the NCO steps twice a symbol (pll.c:77,93) */
 	const dim3 grid(n_windows);
 	const size_t lds = (static_cast<size_t>(nwin) / decim) * sizeof(float2);
 	const float hz_per_bin_over4 = static_cast<float>(fs / nwin / 4.0);
-	const float rad_per_hz = static_cast<float>(2 * 3.141592653589793 / (symrate * (params->oqpsk ? 2 : 1)));   /* OQPSK: NCO steps twice a symbol */
+	const float rad_per_hz = static_cast<float>(2 * 3.141592653589793 / (symrate * nco));
+	/* chirp in rad per NCO step per sample -> carrier rad per sample^2 (x nco * symrate / fs) -> turns of z^4 per sample^2 (/ pi) */
+	const float chirp_scale = static_cast<float>(nco * symrate / fs / 3.141592653589793);
 #define LAUNCH_LINE(F) do { \
 		HTRY(hipFuncSetAttribute(reinterpret_cast<const void *>(carrier_line_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
-		hipLaunchKernelGGL(carrier_line_kernel<F>, grid, dim3(1024), lds, st, iq_dev, n_samples, starts_dev, log2_nf, decim, kmax, \
+		hipLaunchKernelGGL(carrier_line_kernel<F>, grid, dim3(1024), lds, st, iq_dev, n_samples, starts_dev, chirp_dev, chirp_scale, log2_nf, decim, kmax, \
 		                   hz_per_bin_over4, rad_per_hz, freq_dev, quality_dev); } while (0)
 	switch (params->bps) {
 	case 16: LAUNCH_LINE(16); break;
@@ -481,15 +497,66 @@ mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_
 	return MDEMOD_OK;
 }
 
+extern "C" int
+mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
+                        const uint64_t *starts_dev, uint32_t n_windows, uint32_t window_samples,
+                        float *freq_dev, float *quality_dev, void *hip_stream)
+{
+	return mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, starts_dev, nullptr, n_windows, window_samples, freq_dev, quality_dev, hip_stream);
+}
+
 extern "C" void
 mdemod_recording_default_opts(mdemod_recording_opts *o)
 {
 	if (!o) return;
-	o->tile_samples = 0;                     /* 0 = 20 536 symbols worth of samples (65 600 at 72k in 230 kS/s), kept off powers of two */
-	o->pre_samples = 0xFFFFFFFFu;            /* 0xFFFFFFFF = 5 129 symbols worth of samples (16 384 at 72k in 230 kS/s) */
+	o->tile_samples = 0;                     /* automatic, see the header */
+	o->acquire_samples = o->frame_samples = o->settle_samples = 0xFFFFFFFFu;
 	o->pilot_block = 65536; o->pilot_margin_symbols = 20000;
-	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->refine = 1; o->carrier_seed = 1; o->reserved = 0;
+	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->repair = 1; o->carrier_seed = 1; o->reserved = 0;
 }
+
+namespace {
+
+constexpr double kPi = 3.141592653589793;
+
+/* piecewise-linear f(t) through (centre[i], value[i]), extrapolated with the end slopes */
+double
+interp_at(const std::vector<double> &cx, const std::vector<double> &v, double t)
+{
+	const size_t n = cx.size();
+	if (n == 0) return 0.0;
+	if (n == 1) return v[0];
+	size_t j = static_cast<size_t>(std::upper_bound(cx.begin(), cx.end(), t) - cx.begin());
+	j = std::min(std::max<size_t>(j, 1), n - 1);
+	const double w = (t - cx[j - 1]) / (cx[j] - cx[j - 1]);
+	return v[j - 1] + (v[j] - v[j - 1]) * w;
+}
+
+/* time (in interpolated steps from the start of the recording) of the stream's last NCO step, from its symbol clock:
+ * the clock's phase has advanced t_phase since the last symbol (timing.c:32-57; OQPSK: since the last full symbol, and its
+ * I rail fired at pi when the next firing is the Q rail's) */
+double
+last_nco_time(const mdemod_stream_state &s, double pos_samples, int interp, int oqpsk)
+{
+	double ph = s.t_phase;
+	if (oqpsk && s.t_dual_state == 2) ph -= kPi;
+	return pos_samples * interp - ph / static_cast<double>(s.t_freq);
+}
+
+/* quarter turns of stream b against stream a by dead reckoning: theta_b - (theta_a + f * steps) */
+int
+frame_between(double th_a, double t_a, double th_b, double t_b, double f_mean, double steps_per_nco, double *residual)
+{
+	const double n = std::nearbyint((t_b - t_a) / steps_per_nco);
+	double d = std::fmod(th_b - th_a - f_mean * n, 2 * kPi);
+	if (d < 0) d += 2 * kPi;
+	const int r = static_cast<int>(std::nearbyint(d / (kPi / 2))) & 3;
+	double res = d - std::nearbyint(d / (kPi / 2)) * (kPi / 2);
+	*residual = res;
+	return r;
+}
+
+} /* namespace */
 
 extern "C" int
 mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_opts *opts_in,
@@ -498,20 +565,16 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
                             mdemod_recording_report *rep, void *hip_stream)
 {
 	if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
+	if (params->samplerate <= 0 || params->symrate <= 0) return MDEMOD_ERR_PARAM;
 	mdemod_recording_opts o;
 	if (opts_in) o = *opts_in; else mdemod_recording_default_opts(&o);
-	if (params->oqpsk && !o.refine) return MDEMOD_ERR_PARAM;     /* OQPSK needs the state rotation pass: DESIGN.md 3.1 */
-	{	/* same rule as recording.py:default_tiling() */
-		const double osf = static_cast<double>(params->samplerate) / static_cast<double>(params->symrate);
-		if (o.tile_samples == 0) {
-			o.tile_samples = std::max<uint32_t>(4096, static_cast<uint32_t>(20536 * osf) / 64 * 64);
-			if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
-		}
-		/* OQPSK: twice the warm-up (its carrier loop has half the bandwidth and may still be re-locking after 5 129 symbols;
-		   recording.py:default_tiling, profiles/r01_rotation_jump_cases.md) */
-		if (o.pre_samples == 0xFFFFFFFFu) o.pre_samples = static_cast<uint32_t>((params->oqpsk ? 10258 : 5129) * osf);
-	}
-	if (!o.tile_samples || !o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
+	const double osf = static_cast<double>(params->samplerate) / static_cast<double>(params->symrate);
+	const double symrate = params->symrate, fs = params->samplerate;
+	const int nco = params->oqpsk ? 2 : 1;
+	if (o.acquire_samples == 0xFFFFFFFFu) o.acquire_samples = static_cast<uint32_t>(2000 * osf);
+	if (o.frame_samples == 0xFFFFFFFFu) o.frame_samples = static_cast<uint32_t>(1500 * osf);
+	if (o.settle_samples == 0xFFFFFFFFu) o.settle_samples = static_cast<uint32_t>(24000 * osf);
+	if (!o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
 	memset(rep, 0, sizeof(*rep));
 	rep->first_lock_symbol = -1;
@@ -528,7 +591,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	Ctx pilot;
 	TRY(mdemod_create(&pp, &pilot.c));
 	uint64_t pos = 0, nsym = 0; bool have_lock = false; uint64_t locked_at = 0;
-	std::vector<PilotBlock> pilot_blocks;                /* AGC calibration (carrier_seed == 1) */
+	std::vector<PilotBlock> pilot_blocks;                /* AGC calibration */
 	mdemod_stream_state seed;
 	memset(&seed, 0, sizeof(seed));
 	TRY(mdemod_get_state(pilot.c, 0, &seed, st));
@@ -549,285 +612,357 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		if (seed.pll_locked && !have_lock) { have_lock = true; locked_at = seed.n_symbols; }
 		if (!seed.pll_locked) have_lock = false;
 		/* ... and not before the reference's AGC has settled: its step is absolute (agc.c:13-25), 6 time constants =
-		   6 * gain / (1e-4 * 190) symbols - nothing for s16-scale input, ~200 k symbols for float input around +-1
-		   (recording.py:agc_settle_symbols) */
+		   6 * gain / (1e-4 * 190) symbols - nothing for s16-scale input, ~200 k symbols for float input around +-1 */
 		const double agc_settle = 6.0 * static_cast<double>(seed.agc_gain) / (1e-4 * 190.0);
 		if (have_lock && seed.n_symbols - locked_at >= o.pilot_margin_symbols && static_cast<double>(seed.n_symbols) >= agc_settle) break;
 		if (pos >= o.max_pilot_samples) break;
 	}
-	rep->pilot_samples = pos; rep->pilot_symbols = seed.n_symbols;
+	const uint64_t P = pos;
+	rep->pilot_samples = P; rep->pilot_symbols = seed.n_symbols;
 	rep->pilot_locked = seed.pll_locked; rep->first_lock_symbol = seed.first_lock_symbol;
-	rep->samples_demodulated = pos;
+	rep->samples_demodulated = P;
 	const uint64_t n_pilot_sym = nsym;
+	rep->exact_symbols = n_pilot_sym;
 	rep->pilot_seconds = seconds_since(t_start);
 	const auto t_tiles = std::chrono::steady_clock::now();
 
-	/* ---- plan ------------------------------------------------------------------------------ */
-	std::vector<uint64_t> starts, lens, pres;
-	for (uint64_t s0 = pos; s0 < n_samples; s0 += o.tile_samples) {
-		starts.push_back(s0);
-		lens.push_back(std::min<uint64_t>(o.tile_samples, n_samples - s0));
-		pres.push_back(std::min<uint64_t>(o.pre_samples, s0));
+	/* ---- plan: tile i emits [E_i, E_i + len_i); its stream starts `lead` samples early -------------------------- */
+	if (P >= n_samples) { rep->n_symbols = n_pilot_sym; return MDEMOD_OK; }
+	if (o.tile_samples == 0) {
+		/* as short as fills the lanes (latency of a small recording is the samples ONE lane runs: lead + tile), as long as the
+		   lead stays a small part of the work once the GPU is full; kept off powers of two (lanes read at base + l * tile) */
+		const double rest_sym = static_cast<double>(n_samples - P) / osf;
+		const double b_sym = std::min(41072.0, std::max(8192.0, rest_sym / 65536.0));
+		o.tile_samples = std::max<uint32_t>(4096, static_cast<uint32_t>(b_sym * osf) / 64 * 64);
+		if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
 	}
-	const size_t T = starts.size();
+	rep->tile_samples = o.tile_samples;
+	const uint64_t B = o.tile_samples, A = o.acquire_samples, KP = o.frame_samples, WS = o.settle_samples;
+	const size_t T = static_cast<size_t>((n_samples - P + B - 1) / B);
 	rep->n_tiles = static_cast<uint32_t>(T);
-	if (T == 0) { rep->n_symbols = n_pilot_sym; return MDEMOD_OK; }
+	std::vector<uint64_t> E(T), len(T), s0(T), acq(T), frm(T), stl(T), q(T);
+	for (size_t i = 0; i < T; i++) {
+		E[i] = P + i * B; len[i] = std::min<uint64_t>(B, n_samples - E[i]);
+		if (i == 0) { s0[i] = q[i] = E[i]; acq[i] = frm[i] = stl[i] = 0; continue; }     /* tile 0: the pilot's exact continuation */
+		const uint64_t lead = std::min<uint64_t>(A + KP + WS, E[i]);
+		s0[i] = E[i] - lead;
+		acq[i] = std::min<uint64_t>(A, lead); frm[i] = std::min<uint64_t>(KP, lead - acq[i]); stl[i] = lead - acq[i] - frm[i];
+		q[i] = s0[i] + acq[i] + frm[i];
+	}
+
+	mdemod_params bp = *params; bp.n_streams = static_cast<uint32_t>(T);
+	Ctx bank, saved;
+	TRY(mdemod_create(&bp, &bank.c));
+	DevMem mem;
+	float consts[8];
+	TRY(mdemod_get_loop_constants(bank.c, consts));
+	const double pll_alpha = consts[0], pll_beta = consts[1], fmax = consts[2];
+	const double tau_pll = pll_beta > 0 ? pll_alpha / pll_beta : 0.0;     /* slow pole of the (overdamped) carrier loop, in NCO steps: pll.c:133-140 */
+	const int interp = params->interp_factor;
 
 	std::vector<float> seed_hist(2 * static_cast<size_t>(mdemod_history_len(pilot.c)));
 	TRY(mdemod_get_history(pilot.c, 0, seed_hist.data(), st));
 
-	mdemod_params bp = *params; bp.n_streams = static_cast<uint32_t>(T);
-	Ctx bank;
-	TRY(mdemod_create(&bp, &bank.c));
-	DevMem mem;
-	const uint64_t cap_pre = std::max<uint64_t>(1, mdemod_max_symbols(bank.c, *std::max_element(pres.begin(), pres.end())));
-	const uint64_t cap = mdemod_max_symbols(bank.c, *std::max_element(lens.begin(), lens.end()));
-	int8_t *soft_pre, *soft1, *soft2 = nullptr;
-	TRY(mem.alloc(&soft_pre, T * cap_pre * 2));
-	TRY(mem.alloc(&soft1, T * cap * 2));
+	/* ---- carrier of every tile: window i is centred on the span its frame is dead-reckoned over, [q_{i-1}, q_i] ---------------- */
+	std::vector<double> centre(T), fbar(T), slope(T, 0.0);         /* rad per NCO step at centre[i]; slope in rad per NCO step per sample */
+	/* about 20 000 symbols per window (65 536 samples at 72k in 230 kS/s, 262 144 at 1 MS/s): the frames are dead-reckoned over a
+	   tile, the estimate has to be good to a fraction of a radian over that many symbols */
+	const int nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(std::min(262144.0, 20536.0 * osf))));
+	std::vector<uint64_t> wstart(T);
+	for (size_t i = 0; i < T; i++) {
+		const double c = i == 0 ? static_cast<double>(P) : 0.5 * (static_cast<double>(i == 1 ? P : q[i - 1]) + static_cast<double>(q[i]));
+		const double w0 = std::max(0.0, std::min(c - nfft / 2, static_cast<double>(n_samples) - nfft));
+		wstart[i] = static_cast<uint64_t>(w0);
+		centre[i] = static_cast<double>(wstart[i]) + nfft / 2;
+	}
+	if (o.carrier_seed == 1 && T > 1) {
+		uint64_t *d_starts; float *d_freq, *d_qual, *d_chirp;
+		TRY(upload(mem, wstart, &d_starts, st));
+		TRY(mem.alloc(&d_freq, T)); TRY(mem.alloc(&d_qual, T)); TRY(mem.alloc(&d_chirp, T));
+		std::vector<float> fh(T), qh(T), chirp(T, 0.0f);
+		const float min_quality = 8.0f;
+		for (int pass = 0; pass < 3; pass++) {
+			/* pass 0: plain; passes 1, 2: with the local slope taken out of the window (a Doppler ramp smears the line) */
+			if (pass) {
+				for (size_t i = 0; i < T; i++) {      /* robust local slope: median of up to five neighbouring finite differences */
+					double v[5]; int m = 0;
+					for (size_t j = i >= 2 ? i - 2 : 0; j <= std::min(T - 1, i + 2); j++) v[m++] = slope[j];
+					std::sort(v, v + m);
+					chirp[i] = static_cast<float>(v[m / 2]);
+				}
+				bool any = false;
+				for (size_t i = 0; i < T; i++) any = any || std::fabs(chirp[i]) * nfft > 2e-6;      /* less than a tenth of a bin across the window: nothing to take out */
+				if (!any) break;
+				HTRY(hipMemcpyAsync(d_chirp, chirp.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+				HTRY(hipStreamSynchronize(st));
+			}
+			TRY(mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, d_starts, pass ? d_chirp : nullptr, static_cast<uint32_t>(T),
+			                                  static_cast<uint32_t>(nfft), d_freq, d_qual, st));
+			HTRY(hipMemcpyAsync(fh.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
+			HTRY(hipMemcpyAsync(qh.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
+			HTRY(hipStreamSynchronize(st));
+			/* tiles without a clear line (fade, interference) take their good neighbours' estimate, interpolated over time;
+			   with no good tile at all, the pilot's frequency */
+			std::vector<size_t> good;
+			for (size_t i = 0; i < T; i++) if (qh[i] >= min_quality) good.push_back(i);
+			rep->weak_carrier_tiles = static_cast<uint32_t>(T - good.size());
+			if (good.empty()) {
+				for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
+			} else {
+				std::vector<double> gx, gv;
+				for (size_t g : good) { gx.push_back(centre[g]); gv.push_back(fh[g]); }
+				for (size_t i = 0; i < T; i++)
+					fbar[i] = qh[i] >= min_quality ? static_cast<double>(fh[i]) : interp_at(gx, gv, std::min(std::max(centre[i], gx.front()), gx.back()));
+			}
+			for (size_t i = 0; i < T; i++) {
+				const size_t lo = i ? i - 1 : 0, hi = std::min(T - 1, i + 1);
+				slope[i] = centre[hi] > centre[lo] ? (fbar[hi] - fbar[lo]) / (centre[hi] - centre[lo]) : 0.0;
+			}
+		}
+	} else {
+		for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
+	}
+	auto f_at = [&](double t) { return interp_at(centre, fbar, t); };
+	/* The carrier loop is heavily overdamped: its frequency word follows a moving carrier with the lag slope * tau (pll.c:115
+	   integrates beta * e, the phase term alpha * e does the tracking), and right after the pilot's hand-over the serial run is
+	   still converging with the same time constant.  A tile settles for less than tau, so it is seeded with the frequency the
+	   SERIAL loop has at that point, not with the carrier: estimate - lag + what is left of the pilot's own offset. */
+	const double f_pilot_target = f_at(static_cast<double>(P)) - (T > 1 ? slope[0] * osf / nco * tau_pll : 0.0);
+	auto f_seed = [&](size_t i, double t) {
+		const double lag = slope[i] * osf / nco * tau_pll;
+		/* before the hand-over (a lead that starts inside the pilot) the serial run was further away still: same exponential, back to
+		   where the pilot's margin began at most */
+		const double back = -static_cast<double>(o.pilot_margin_symbols) * nco / std::max(tau_pll, 1.0);
+		const double gone = tau_pll > 0 ? std::exp(-std::max(back, (t - static_cast<double>(P)) / osf * nco / tau_pll)) : 0.0;
+		const double f = f_at(t) - lag + (o.carrier_seed == 1 ? (static_cast<double>(seed.pll_freq) - f_pilot_target) * gone : 0.0);
+		return std::max(-fmax, std::min(fmax, f));
+	};
 
+	/* ---- seeds ------------------------------------------------------------------------------------------------ */
+	TRY(mdemod_set_state_all(bank.c, &seed, st));
+	TRY(mdemod_set_state(bank.c, 0, &seed, st));
+	TRY(mdemod_set_history(bank.c, 0, seed_hist.data(), st));
+	std::vector<float> f0(T), tf(T, seed.t_freq), gains(T, seed.agc_gain); std::vector<int32_t> ud(T);
+	float *d_f0, *d_tf, *d_gain; int32_t *d_ud;
+	TRY(mem.alloc(&d_f0, T)); TRY(mem.alloc(&d_tf, T)); TRY(mem.alloc(&d_gain, T)); TRY(mem.alloc(&d_ud, T));
+	auto put_carrier_seeds = [&](bool at_acquired) -> int {
+		for (size_t i = 0; i < T; i++) {
+			f0[i] = i == 0 ? seed.pll_freq : static_cast<float>(f_seed(i, static_cast<double>(s0[i] + (at_acquired ? acq[i] : 0))));
+			ud[i] = i == 0 ? seed.pll_updown : (slope[i] >= 0 ? 1 : -1);
+		}
+		HTRY(hipMemcpyAsync(d_f0, f0.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+		HTRY(hipMemcpyAsync(d_ud, ud.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+		HTRY(hipStreamSynchronize(st));
+		return mdemod_set_carrier_seeds(bank.c, d_f0, d_ud, st);
+	};
+	if (T > 1) {
+		/* AGC gain seeds: g* = c / sqrt(sample power), c fitted on the pilot's last blocks, then the reference's AGC in closed
+		   form over the tiles' powers (agc.c:13-25; for s16-scale input: each tile its own equilibrium) */
+		const size_t nb = std::min<size_t>(10, pilot_blocks.size());
+		const size_t b0 = pilot_blocks.size() - nb;
+		std::vector<uint64_t> ws; std::vector<uint32_t> wl;
+		for (size_t j = b0; j < pilot_blocks.size(); j++) { ws.push_back(pilot_blocks[j].start); wl.push_back(pilot_blocks[j].len); }
+		for (size_t i = 0; i < T; i++) { ws.push_back(E[i]); wl.push_back(static_cast<uint32_t>(len[i])); }
+		uint64_t *d_ws; uint32_t *d_wl; float *d_wp;
+		TRY(upload(mem, ws, &d_ws, st));
+		TRY(upload(mem, wl, &d_wl, st));
+		TRY(mem.alloc(&d_wp, ws.size()));
+		HTRY(hipStreamSynchronize(st));
+		const dim3 grid(static_cast<unsigned>(ws.size()));
+		switch (params->bps) {
+		case 16: hipLaunchKernelGGL(window_power_kernel<16>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
+		case 8:  hipLaunchKernelGGL(window_power_kernel<8>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
+		default: hipLaunchKernelGGL(window_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
+		}
+		HTRY(hipGetLastError());
+		std::vector<float> wp(ws.size());
+		HTRY(hipMemcpyAsync(wp.data(), d_wp, wp.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipStreamSynchronize(st));
+		std::vector<double> blk_gain(nb), blk_power(nb), blk_syms(nb);
+		for (size_t j = 0; j < nb; j++) {
+			const PilotBlock &pb = pilot_blocks[b0 + j];
+			const uint64_t before = (b0 + j) ? pilot_blocks[b0 + j - 1].symbols_after : 0;
+			blk_gain[j] = pb.gain_after; blk_power[j] = wp[j]; blk_syms[j] = static_cast<double>(pb.symbols_after - before);
+		}
+		const double c = nb ? fit_agc_calibration(blk_gain, blk_power, blk_syms) : 0.0;
+		/* gE[k]: the serial run's gain at E_k; stream i starts its lead before E_i and takes the gain of the boundary at or
+		   before its start */
+		std::vector<double> gE(T + 1);
+		gE[0] = seed.agc_gain;
+		for (size_t k = 0; k < T; k++) gE[k + 1] = agc_step(gE[k], c, wp[nb + k], static_cast<double>(len[k]) * symrate / fs);
+		for (size_t i = 1; i < T; i++) {
+			const size_t back = static_cast<size_t>((E[i] - s0[i] + B - 1) / B);
+			gains[i] = static_cast<float>(gE[i > back ? i - back : 0]);
+		}
+		HTRY(hipMemcpyAsync(d_gain, gains.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+		HTRY(hipMemcpyAsync(d_tf, tf.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+		HTRY(hipStreamSynchronize(st));
+		TRY(mdemod_set_gain_seeds(bank.c, d_gain, st));
+		TRY(put_carrier_seeds(false));
+	}
+
+	/* ---- launches ------------------------------------------------------------------------------------------- */
 	auto launch = [&](const std::vector<uint64_t> &off, const std::vector<uint64_t> &cnt, int8_t *soft, uint64_t stride,
 	                  std::vector<uint32_t> &produced, std::vector<mdemod_status> *status_out = nullptr) -> int {
 		std::vector<uint32_t> c32(cnt.begin(), cnt.end());
 		uint64_t *d_off; uint32_t *d_cnt;
 		TRY(upload(mem, off, &d_off, st));
 		TRY(upload(mem, c32, &d_cnt, st));
+		HTRY(hipStreamSynchronize(st));              /* the uploads come from stack vectors */
 		TRY(mdemod_process_device(bank.c, iq_dev, d_off, d_cnt, soft, stride, static_cast<uint32_t>(stride), st));
 		TRY(counts_of(bank.c, static_cast<uint32_t>(T), produced, st, status_out));
 		for (uint64_t c : cnt) rep->samples_demodulated += c;
 		return MDEMOD_OK;
 	};
+	const uint64_t cap_lead = std::max<uint64_t>(8, mdemod_max_symbols(bank.c, std::max<uint64_t>(std::max(A, KP), WS)));
+	const uint64_t cap = mdemod_max_symbols(bank.c, B);
+	int8_t *soft_pre, *soft1;
+	TRY(mem.alloc(&soft_pre, T * cap_lead * 2));
+	TRY(mem.alloc(&soft1, T * cap * 2));
+	std::vector<uint32_t> cnt_tmp, cnt_pre(T, 0), cnt1(T, 0);
+	std::vector<mdemod_status> status_body;
+	std::vector<int32_t> R(T, 0);
+	std::vector<mdemod_stream_state> qs(T);
+	if (T > 1) {
+		/* acquire, then the two integrators back on their seeds (the gain keeps what it found) */
+		TRY(launch(s0, acq, soft_pre, cap_lead, cnt_tmp));
+		TRY(put_carrier_seeds(true));
+		TRY(mdemod_set_clock_seeds(bank.c, d_tf, st));
+		std::vector<uint64_t> off(T);
+		for (size_t i = 0; i < T; i++) off[i] = s0[i] + acq[i];
+		TRY(launch(off, frm, soft_pre, cap_lead, cnt_tmp));
 
-	/* ---- pass 1 ---------------------------------------------------------------------------- */
-	TRY(mdemod_set_state_all(bank.c, &seed, st));
-	std::vector<uint64_t> off_pre(T);
-	for (size_t i = 0; i < T; i++) off_pre[i] = starts[i] - pres[i];
-	if (o.carrier_seed == 1) {
-		/* Doppler: every tile starts from its own carrier estimate (see recording.py:carrier_estimates) */
-		const int nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(std::min<uint64_t>(
-		                     static_cast<uint64_t>(o.tile_samples) + o.pre_samples, 1u << 17))));   /* window in samples */
-		float consts[8];
-		TRY(mdemod_get_loop_constants(bank.c, consts));
-		const float fmax = consts[2];
-		const double symrate = params->symrate, fs = params->samplerate;
-		std::vector<float> fmid(T), qual(T);
-		uint64_t *d_starts; float *d_freq, *d_qual;
-		/* windows that would run past the end of the recording are moved back (the last tiles) */
-		std::vector<uint64_t> wstart(T);
-		for (size_t i = 0; i < T; i++)
-			wstart[i] = std::min<uint64_t>(off_pre[i], n_samples >= static_cast<uint64_t>(nfft) ? n_samples - nfft : 0);
-		TRY(upload(mem, wstart, &d_starts, st));
-		TRY(mem.alloc(&d_freq, T));
-		TRY(mem.alloc(&d_qual, T));
-		TRY(mdemod_estimate_carrier(params, iq_dev, n_samples, d_starts, static_cast<uint32_t>(T), static_cast<uint32_t>(nfft), d_freq, d_qual, st));
-		HTRY(hipMemcpyAsync(fmid.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
-		HTRY(hipMemcpyAsync(qual.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
-		HTRY(hipStreamSynchronize(st));
-		/* AGC gain seeds (recording.py: window_power, fit_agc_calibration, agc_trajectory): g* = c / sqrt(sample power),
-		   c fitted on the pilot's last blocks, then the closed-form recursion over the tiles' bodies */
-		{
-			const size_t nb = std::min<size_t>(10, pilot_blocks.size());
-			const size_t b0 = pilot_blocks.size() - nb;
-			std::vector<uint64_t> ws; std::vector<uint32_t> wl;
-			for (size_t j = b0; j < pilot_blocks.size(); j++) { ws.push_back(pilot_blocks[j].start); wl.push_back(pilot_blocks[j].len); }
-			for (size_t i = 0; i < T; i++) { ws.push_back(starts[i]); wl.push_back(static_cast<uint32_t>(lens[i])); }
-			uint64_t *d_ws; uint32_t *d_wl; float *d_wp;
-			TRY(upload(mem, ws, &d_ws, st));
-			TRY(upload(mem, wl, &d_wl, st));
-			TRY(mem.alloc(&d_wp, ws.size()));
-			const dim3 grid(static_cast<unsigned>(ws.size()));
-			switch (params->bps) {
-			case 16: hipLaunchKernelGGL(window_power_kernel<16>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
-			case 8:  hipLaunchKernelGGL(window_power_kernel<8>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
-			default: hipLaunchKernelGGL(window_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
-			}
-			HTRY(hipGetLastError());
-			std::vector<float> wp(ws.size());
-			HTRY(hipMemcpyAsync(wp.data(), d_wp, wp.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-			HTRY(hipStreamSynchronize(st));
-			std::vector<double> blk_gain(nb), blk_power(nb), blk_syms(nb);
-			for (size_t j = 0; j < nb; j++) {
-				const PilotBlock &pb = pilot_blocks[b0 + j];
-				const uint64_t before = (b0 + j) ? pilot_blocks[b0 + j - 1].symbols_after : 0;
-				blk_gain[j] = pb.gain_after; blk_power[j] = wp[j]; blk_syms[j] = static_cast<double>(pb.symbols_after - before);
-			}
-			const double c = fit_agc_calibration(blk_gain, blk_power, blk_syms);
-			double g = seed.agc_gain;
-			std::vector<float> gains(T);
-			for (size_t i = 0; i < T; i++) {
-				gains[i] = static_cast<float>(g);
-				g = agc_step(g, c, wp[nb + i], static_cast<double>(lens[i]) * symrate / fs);
-			}
-			float *d_gain;
-			TRY(upload(mem, gains, &d_gain, st));
-			TRY(mdemod_set_gain_seeds(bank.c, d_gain, st));
+		/* ---- frames by dead reckoning along the chain pilot -> tile 1 -> tile 2 ... ---------------------------------- */
+		TRY(mdemod_get_states(bank.c, 0, static_cast<uint32_t>(T), qs.data(), st));
+		const double steps_per_nco = 2 * kPi / static_cast<double>(seed.t_freq) / nco;
+		double th_prev = seed.pll_phase, t_prev = last_nco_time(seed, static_cast<double>(P), interp, params->oqpsk);
+		int32_t accr = 0; double res2 = 0.0;
+		for (size_t i = 1; i < T; i++) {
+			const double th = qs[i].pll_phase, tt = last_nco_time(qs[i], static_cast<double>(q[i]), interp, params->oqpsk);
+			const double t_mid = 0.5 * (t_prev + tt) / interp;
+			double res;
+			accr = (accr + frame_between(th_prev, t_prev, th, tt, f_at(t_mid), steps_per_nco, &res)) & 3;
+			R[i] = accr; res2 += res * res;
+			th_prev = th; t_prev = tt;
 		}
-		/* tiles without a clear line (fade, interference) take their good neighbours' estimate, interpolated over the
-		   tile index; with no good tile at all, the pilot's frequency (recording.py:fill_weak_estimates) */
-		{
-			const float min_quality = 8.0f;
-			std::vector<size_t> good;
-			for (size_t i = 0; i < T; i++) if (qual[i] >= min_quality) good.push_back(i);
-			if (good.empty()) {
-				for (size_t i = 0; i < T; i++) fmid[i] = seed.pll_freq;
-			} else if (good.size() < T) {
-				size_t g = 0;
-				for (size_t i = 0; i < T; i++) {
-					if (qual[i] >= min_quality) continue;
-					while (g + 1 < good.size() && good[g + 1] < i) g++;
-					if (i < good.front()) fmid[i] = fmid[good.front()];
-					else if (i > good.back()) fmid[i] = fmid[good.back()];
-					else {
-						const size_t lo = good[g], hi = good[g + 1];
-						fmid[i] = static_cast<float>(fmid[lo] + (static_cast<double>(fmid[hi]) - fmid[lo]) * (i - lo) / static_cast<double>(hi - lo));
-					}
-				}
-				rep->weak_carrier_tiles = static_cast<uint32_t>(T - good.size());
-			}
+		rep->frame_residual_rms = static_cast<float>(std::sqrt(res2 / static_cast<double>(T - 1)));
+		/* checkpoint of the bank before any rotation: what a repair starts from */
+		if (o.repair) {
+			TRY(mdemod_create(&bp, &saved.c));
+			TRY(mdemod_copy_state(saved.c, bank.c, st));
 		}
-		const double dt_sym = static_cast<double>(o.tile_samples) * symrate / fs;
-		std::vector<float> f0(T); std::vector<int32_t> ud(T);
-		for (size_t i = 0; i < T; i++) {
-			double slope = 0.0;
-			if (T > 2) {
-				const size_t j = std::min(std::max<size_t>(i, 1), T - 2);
-				slope = (static_cast<double>(fmid[j + 1]) - fmid[j - 1]) / (2 * dt_sym);
-			}
-			/* the estimate belongs to the middle of the window actually used */
-			double f = fmid[i] - slope * (static_cast<double>(wstart[i]) + nfft / 2 - static_cast<double>(off_pre[i])) * symrate / fs;
-			f = std::max<double>(-fmax, std::min<double>(fmax, f));
-			f0[i] = static_cast<float>(f); ud[i] = slope >= 0 ? 1 : -1;
-		}
-		float *d_f0; int32_t *d_ud;
-		TRY(upload(mem, f0, &d_f0, st));
-		TRY(upload(mem, ud, &d_ud, st));
-		TRY(mdemod_set_carrier_seeds(bank.c, d_f0, d_ud, st));
 	}
-	std::vector<uint32_t> cnt_pre, cnt1, cnt2;
-	TRY(launch(off_pre, pres, soft_pre, cap_pre, cnt_pre));
-	std::vector<mdemod_status> status_body;          /* of the launch whose symbols are emitted: first lock when the pilot has none */
-	TRY(launch(starts, lens, soft1, cap, cnt1, &status_body));
-	/* stream count at the start of every tile's EMITTED body, and the stream that ran it (identity without pass 2) */
-	std::vector<uint64_t> n_start(T); std::vector<size_t> body_stream(T);
-	for (size_t i = 0; i < T; i++) { n_start[i] = seed.n_symbols + cnt_pre[i]; body_stream[i] = i; }
-
-	/* ---- rotation + seam of every tile against its predecessor (tile 0: against the pilot) ---- */
-	std::vector<TailPair> pairs(T);
-	for (size_t i = 0; i < T; i++) {
-		TailPair &p = pairs[i];
-		if (i == 0) { p.a = soft_dev; p.a_cnt = static_cast<uint32_t>(std::min<uint64_t>(n_pilot_sym, 0xFFFFFFFFu)); if (n_pilot_sym > 0xFFFFFFFFull) { p.a = soft_dev + 2 * (n_pilot_sym - 0xFFFFFFFFull); } }
-		else { p.a = soft1 + (i - 1) * cap * 2; p.a_cnt = cnt1[i - 1]; }
-		p.b = soft_pre + i * cap_pre * 2; p.b_cnt = cnt_pre[i];
-		p.b_rot = 0; p.force_weak = pres[i] == 0;
-	}
-	std::vector<int32_t> shift, rot, weak;
-	TRY(run_match(mem, pairs, K, shift, rot, weak, st, params->oqpsk ? 1 : 0));
-	std::vector<int32_t> R(T);
-	int32_t accr = 0;
-	for (size_t i = 0; i < T; i++) { accr = (accr + rot[i]) & 3; R[i] = accr; rep->weak_seams += weak[i]; }
-
-	std::vector<TileCopy> copies(T);
-	std::vector<int32_t> seam(T, 0);
+	int32_t *d_rot;
+	TRY(mem.alloc(&d_rot, T));
+	std::vector<int32_t> shift(T, 0), rot(T, 0), weak(T, 0);
+	std::vector<uint64_t> stl_off(T);
+	for (size_t i = 0; i < T; i++) stl_off[i] = q[i];
+	const uint64_t post = 4096;                               /* OQPSK: look-ahead into the next tile for the seam check */
+	int8_t *soft_post = nullptr; uint64_t cap_post = 0;
+	std::vector<uint32_t> cnt_post(T, 0);
+	std::vector<uint64_t> ends(T), post_len(T);
+	for (size_t i = 0; i < T; i++) { ends[i] = E[i] + len[i]; post_len[i] = std::min<uint64_t>(post, n_samples - ends[i]); }
 	if (params->oqpsk) {
-		/* ---- OQPSK pass 2: state rotation (carrier + half-symbol clock), body, then a look-ahead into the next tile ---- */
-		std::vector<int32_t> q(T);
-		for (size_t i = 0; i < T; i++) q[i] = (4 - R[i]) & 3;
-		int32_t *d_q;
-		TRY(upload(mem, q, &d_q, st));
-		TRY(mdemod_rotate_carrier(bank.c, d_q, st));
-		TRY(mdemod_set_state(bank.c, static_cast<uint32_t>(T - 1), &seed, st));
-		TRY(mdemod_set_history(bank.c, static_cast<uint32_t>(T - 1), seed_hist.data(), st));
-		const uint64_t post = 4096;
-		std::vector<uint64_t> starts2(T), lens2(T), ends2(T), post2(T);
-		for (size_t i = 0; i < T; i++) {
-			starts2[i] = starts[(i + 1) % T]; lens2[i] = lens[(i + 1) % T];
-			ends2[i] = starts2[i] + lens2[i]; post2[i] = std::min<uint64_t>(post, n_samples - ends2[i]);
-		}
-		TRY(mem.alloc(&soft2, T * cap * 2));
-		std::vector<uint32_t> cnt2s, cnt_posts;
-		TRY(launch(starts2, lens2, soft2, cap, cnt2s, &status_body));
-		for (size_t i = 0; i < T; i++) {
-			body_stream[i] = (i + T - 1) % T;
-			n_start[i] = i ? seed.n_symbols + cnt_pre[i - 1] + cnt1[i - 1] : seed.n_symbols;
-		}
-		const uint64_t cap_post = std::max<uint64_t>(1, mdemod_max_symbols(bank.c, *std::max_element(post2.begin(), post2.end())));
-		int8_t *soft_post;
+		cap_post = std::max<uint64_t>(8, mdemod_max_symbols(bank.c, post));
 		TRY(mem.alloc(&soft_post, T * cap_post * 2));
-		TRY(launch(ends2, post2, soft_post, cap_post, cnt_posts));
-		auto stream_of = [&](size_t tile) { return (tile + T - 1) % T; };
-		std::vector<TailPair> heads(T > 1 ? T - 1 : 0);
-		for (size_t i = 0; i + 1 < T; i++) {                       /* seam i | i+1 */
-			heads[i].a = soft_post + stream_of(i) * cap_post * 2; heads[i].a_cnt = cnt_posts[stream_of(i)];
-			heads[i].b = soft2 + stream_of(i + 1) * cap * 2;      heads[i].b_cnt = cnt2s[stream_of(i + 1)];
-			heads[i].b_rot = 0; heads[i].force_weak = 0;
-		}
-		std::vector<int32_t> sh, r2, w2;
-		TRY(run_match(mem, heads, K, sh, r2, w2, st, 2));
-		for (size_t i = 0; i < T; i++) {
-			seam[i] = i ? -sh[i - 1] : 0;
-			if (i) rep->weak_seams += w2[i - 1];
-			if (i && !w2[i - 1] && (r2[i - 1] & 3)) rep->rotation_jumps++;
-			copies[i].src = soft2 + stream_of(i) * cap * 2; copies[i].rot = 0; copies[i].keep = cnt2s[stream_of(i)];
-			copies[i].head = (i && seam[i] == -1) ? soft_post + stream_of(i - 1) * cap_post * 2 : nullptr;
-			copies[i].head_rot = 0;
-		}
-	} else if (!o.refine) {
-		for (size_t i = 0; i < T; i++) {
-			seam[i] = shift[i];
-			copies[i].src = soft1 + i * cap * 2; copies[i].rot = R[i]; copies[i].keep = cnt1[i];
-			copies[i].head = (shift[i] == -1 && cnt_pre[i] > 0) ? soft_pre + (i * cap_pre + cnt_pre[i] - 1) * 2 : nullptr;
-			copies[i].head_rot = R[i];
-		}
-	} else {
-		/* ---- pass 2: stream i := exact continuation of its pass-1 end state, in rotation 0, on tile i+1;
-		 *      stream T-1 takes over from the pilot and runs tile 0 ---- */
-		std::vector<int32_t> q(T);
-		for (size_t i = 0; i < T; i++) q[i] = (4 - R[i]) & 3;
-		int32_t *d_q;
-		TRY(upload(mem, q, &d_q, st));
-		TRY(mdemod_rotate_carrier(bank.c, d_q, st));
-		TRY(mdemod_set_state(bank.c, static_cast<uint32_t>(T - 1), &seed, st));
-		TRY(mdemod_set_history(bank.c, static_cast<uint32_t>(T - 1), seed_hist.data(), st));
-		std::vector<uint64_t> starts2(T), lens2(T);
-		for (size_t i = 0; i < T; i++) { starts2[i] = starts[(i + 1) % T]; lens2[i] = lens[(i + 1) % T]; }
-		TRY(mem.alloc(&soft2, T * cap * 2));
-		std::vector<uint32_t> cnt2s;
-		TRY(launch(starts2, lens2, soft2, cap, cnt2s, &status_body));
-		for (size_t i = 0; i < T; i++) {
-			body_stream[i] = (i + T - 1) % T;
-			n_start[i] = i ? seed.n_symbols + cnt_pre[i - 1] + cnt1[i - 1] : seed.n_symbols;
-		}
-		auto stream_of = [&](size_t tile) { return (tile + T - 1) % T; };     /* tile i was run by stream i-1 */
-		cnt2.resize(T);
-		for (size_t i = 0; i < T; i++) cnt2[i] = cnt2s[stream_of(i)];
-
-		/* seam i|i+1: tile i+1 continued from tile i's PASS-1 trajectory, tile i's PASS-2 body is what is emitted */
-		for (size_t i = 0; i < T; i++) {
-			TailPair &p = pairs[i];
-			p.a = soft2 + stream_of(i) * cap * 2; p.a_cnt = cnt2[i];
-			p.b = soft1 + i * cap * 2; p.b_cnt = cnt1[i]; p.b_rot = R[i]; p.force_weak = 0;
-		}
-		std::vector<int32_t> shift2, rot2, weak2;
-		TRY(run_match(mem, pairs, K, shift2, rot2, weak2, st));
-		for (size_t i = 0; i + 1 < T; i++) { rep->weak_seams += weak2[i]; if (!weak2[i] && (rot2[i] & 3)) rep->rotation_jumps++; }
-		for (size_t i = 0; i < T; i++) {
-			seam[i] = i ? shift2[i - 1] : 0;
-			copies[i].src = soft2 + stream_of(i) * cap * 2; copies[i].rot = 0; copies[i].keep = cnt2[i];
-			copies[i].head = (i && seam[i] == -1 && cnt1[i - 1] > 0) ? soft1 + ((i - 1) * cap + cnt1[i - 1] - 1) * 2 : nullptr;
-			copies[i].head_rot = i ? R[i - 1] : 0;
-		}
 	}
 
-	/* ---- concatenate: pilot ++ tiles, with the seam fixes ---- */
-	uint64_t out_pos = n_pilot_sym - (seam[0] == 1 ? 1 : 0);
-	if (seam[0] == 1 && rep->pilot_symbols) rep->pilot_symbols--;       /* the pilot's last symbol was a duplicate of tile 0's first: the exact prefix is one shorter */
+	/* settle + body (+ OQPSK look-ahead) of the streams in `run` (all of them the first time), then every seam again */
+	std::vector<char> run(T, 1);
+	std::vector<int32_t> state_rot = R;                    /* output rotation taken out of each stream's state before it settles */
+	std::vector<int32_t> out_rot(T, 0), expect(T, 0);     /* rotation left for the output; what the second round should find */
+	for (int round = 0; round < 2; round++) {
+		std::vector<int32_t> qt(T);
+		for (size_t i = 0; i < T; i++) qt[i] = run[i] ? (4 - state_rot[i]) & 3 : 0;
+		HTRY(hipMemcpyAsync(d_rot, qt.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+		HTRY(hipStreamSynchronize(st));
+		TRY(mdemod_rotate_carrier(bank.c, d_rot, st));
+		auto masked = [&](const std::vector<uint64_t> &c) { std::vector<uint64_t> m(T); for (size_t i = 0; i < T; i++) m[i] = run[i] ? c[i] : 0; return m; };
+		std::vector<mdemod_status> stat;
+		TRY(launch(stl_off, masked(stl), soft_pre, cap_lead, cnt_tmp));
+		for (size_t i = 0; i < T; i++) if (run[i]) cnt_pre[i] = cnt_tmp[i];
+		TRY(launch(E, masked(len), soft1, cap, cnt_tmp, &stat));
+		if (status_body.empty()) status_body = stat;
+		for (size_t i = 0; i < T; i++) if (run[i]) { cnt1[i] = cnt_tmp[i]; status_body[i] = stat[i]; }
+		if (params->oqpsk) {
+			TRY(launch(ends, masked(post_len), soft_post, cap_post, cnt_tmp));
+			for (size_t i = 0; i < T; i++) if (run[i]) cnt_post[i] = cnt_tmp[i];
+		}
+
+		/* ---- seams: tile i's settled tail against its predecessor's body tail (tile 1: against tile 0 = the serial run) ---- */
+		std::vector<TailPair> pairs(T > 1 ? T - 1 : 0);
+		for (size_t i = 1; i < T; i++) {
+			TailPair &p = pairs[i - 1];
+			p.a = soft1 + (i - 1) * cap * 2; p.a_cnt = cnt1[i - 1];
+			p.b = soft_pre + i * cap_lead * 2; p.b_cnt = cnt_pre[i];
+			p.b_rot = 0; p.force_weak = stl[i] == 0;
+		}
+		std::vector<int32_t> sh, ro, we;
+		TRY(run_match(mem, pairs, K, sh, ro, we, st, params->oqpsk ? 1 : 0));
+		for (size_t i = 1; i < T; i++) { shift[i] = params->oqpsk ? 0 : sh[i - 1]; rot[i] = we[i - 1] ? 0 : (ro[i - 1] & 3); weak[i] = we[i - 1]; }
+		/* rotation each stream's output still needs to sit in the serial run's frame: b * j^rot matches a, summed along the chain */
+		std::vector<int32_t> C(T, 0);
+		for (size_t i = 1; i < T; i++) C[i] = (C[i - 1] + rot[i]) & 3;
+		bool odd = false;
+		for (size_t i = 1; i < T; i++) odd = odd || (C[i] & 1);
+		if (round == 0) {
+			for (size_t i = 1; i < T; i++) rep->frame_misses += rot[i] ? 1 : 0;
+			out_rot = C;
+			if (!odd) break;
+			if (!o.repair || !saved.c) { for (size_t i = 1; i < T; i++) rep->rotation_jumps += (rot[i] & 1); break; }
+			/* repair: a stream an odd number of quarter turns off has settled on the other rail's noise (timing.c:65-66).  It
+			   starts again from the checkpoint with the measured rotation taken out of its state; streams that are 0 or 180
+			   degrees off keep their run (180 degrees is exact on the output).  The checkpoint restores every stream, the ones
+			   that keep their run are simply not launched again. */
+			TRY(mdemod_copy_state(bank.c, saved.c, st));
+			for (size_t i = 0; i < T; i++) {
+				run[i] = (C[i] & 1) ? 1 : 0;
+				if (run[i]) { state_rot[i] = (R[i] + C[i]) & 3; expect[i] = 0; rep->repaired_tiles++; }
+				else expect[i] = C[i];
+			}
+		} else {
+			out_rot = C;
+			for (size_t i = 1; i < T; i++)
+				rep->rotation_jumps += (((C[i] - C[i - 1]) - (expect[i] - expect[i - 1])) & 3) ? 1 : 0;
+		}
+	}
+	if (params->oqpsk && T > 1) {
+		/* rails come from firings half a symbol apart: the one-symbol disagreement is looked for on heads, tile i-1's
+		   look-ahead past its end against tile i's body (both start on the same sample) */
+		std::vector<TailPair> heads(T - 1);
+		for (size_t i = 1; i < T; i++) {
+			heads[i - 1].a = soft_post + (i - 1) * cap_post * 2; heads[i - 1].a_cnt = cnt_post[i - 1];
+			heads[i - 1].b = soft1 + i * cap * 2;               heads[i - 1].b_cnt = cnt1[i];
+			heads[i - 1].b_rot = 0; heads[i - 1].force_weak = 0;
+		}
+		std::vector<int32_t> sh2, r2, w2;
+		TRY(run_match(mem, heads, K, sh2, r2, w2, st, 2));
+		for (size_t i = 1; i < T; i++) { shift[i] = w2[i - 1] ? 0 : -sh2[i - 1]; if (w2[i - 1]) weak[i] = 1; }
+	}
+	const std::vector<int32_t> &Rtot = out_rot;
+	for (size_t i = 0; i < T; i++) rep->weak_seams += weak[i];
+
+	/* ---- concatenate: pilot ++ tiles, with the seam fixes and what rotation is left on the output ---- */
+	std::vector<TileCopy> copies(T);
 	for (size_t i = 0; i < T; i++) {
-		const uint32_t drop = (i + 1 < T && seam[i + 1] == 1) ? 1 : 0;
+		copies[i].src = soft1 + i * cap * 2; copies[i].rot = Rtot[i]; copies[i].keep = cnt1[i];
+		copies[i].head = nullptr; copies[i].head_rot = 0;
+		if (i && shift[i] == -1) {
+			/* the symbol straddling the seam is missing on both sides: take it from tile i's own settled run (its last symbol
+			   before the body; OQPSK: from the predecessor's look-ahead) */
+			if (params->oqpsk) { if (cnt_post[i - 1] > 0) { copies[i].head = soft_post + (i - 1) * cap_post * 2; copies[i].head_rot = Rtot[i - 1]; } }
+			else if (cnt_pre[i] > 0) { copies[i].head = soft_pre + (i * cap_lead + cnt_pre[i] - 1) * 2; copies[i].head_rot = Rtot[i]; }
+		}
+	}
+	uint64_t out_pos = n_pilot_sym;
+	for (size_t i = 0; i < T; i++) {
+		const uint32_t drop = (i + 1 < T && shift[i + 1] == 1) ? 1 : 0;      /* the successor emits this tile's last symbol too */
 		copies[i].keep = copies[i].keep > drop ? copies[i].keep - drop : 0;
-		if (seam[i] == -1 && !copies[i].head) seam[i] = 0;
+		if (shift[i] == -1 && !copies[i].head) shift[i] = 0;
 		copies[i].dst = out_pos;
 		out_pos += copies[i].keep + (copies[i].head ? 1 : 0);
-		if (seam[i]) rep->seam_fixes++;
+		if (shift[i]) rep->seam_fixes++;
+		if (i == 0) rep->exact_symbols = out_pos;
 	}
 	if (out_pos > soft_cap_symbols) return MDEMOD_ERR_OVERFLOW;
 	if (rep->first_lock_symbol < 0) {
@@ -835,9 +970,10 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		   at the first tile whose stream reports a first lock - inside its emitted body, or before it (then the whole
 		   body counts).  Approximate to the tiles' own acquisition, which is faster than the serial sweep. */
 		for (size_t i = 0; i < T; i++) {
-			const int64_t fl = status_body[body_stream[i]].first_lock_symbol;
+			const int64_t fl = status_body[i].first_lock_symbol;
 			if (fl < 0) continue;
-			const uint64_t inside = static_cast<uint64_t>(fl) > n_start[i] ? static_cast<uint64_t>(fl) - n_start[i] : 0;
+			const uint64_t n_start = status_body[i].n_symbols - cnt1[i];
+			const uint64_t inside = static_cast<uint64_t>(fl) > n_start ? static_cast<uint64_t>(fl) - n_start : 0;
 			rep->first_lock_symbol = static_cast<int64_t>(copies[i].dst + std::min<uint64_t>(inside, copies[i].keep));
 			break;
 		}

@@ -1,71 +1,78 @@
-"""GPU (-m gpu): one recording as overlapped tiles (meteor_demod_amd/recording.py) on the HIP path.
+"""GPU (-m gpu): ONE recording on many lanes (mdemod_demodulate_recording, csrc/recording.hip).
 
-Every piece of the scheme is an ordinary bit-exact stream, so the stitched output of the HIP bank
-must equal, byte for byte, the stitched output of the same scheme driven by the oracle
-(tests/oracle_bank.py); agreement with the UNTILED serial reference is statistical."""
+The head of the result (pilot + tile 0) is the serial reference's own bytes; the rest can only agree with the UNTILED serial
+run statistically: a 1-LSB change of ONE input sample leaves 0.2 % of the reference's own symbols more than 1 LSB away for
+millions of symbols (test_perturbation_floor_of_the_reference below measures it with the oracle).  The bars here sit just
+under that floor: symbol count equal, hard decisions >= 0.9999, no weak seam, +-1 LSB >= 0.996 QPSK / 0.994 OQPSK."""
 from __future__ import annotations
 
 import numpy as np
 import pytest
 
 import oracle_py as O
-from oracle_bank import OracleBank
 from meteor_demod_amd import DemodConfig, synth
-from meteor_demod_amd.recording import RecordingDemodulator, agreement
+from meteor_demod_amd.recording import agreement, demodulate_recording_native
 
 pytestmark = pytest.mark.gpu
 
 C1 = DemodConfig(samplerate=230000)
+C3 = DemodConfig(samplerate=230000, symrate=80000, oqpsk=True)
+C4 = DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8)
 
 
-@pytest.mark.parametrize("refine", [True, False])
-def test_hip_stitched_recording_equals_oracle_stitched_recording(refine, gpu_device):
-    import torch
-    st = synth.make_stream(4242, 230000, 72000, f0_hz=300.0, clock_ppm=11.0, esn0_db=12.0)
-    iq = synth.generate_host(st, 1_500_000)
-    kw = dict(tile_samples=32768, pre_samples=8192, refine=refine, pilot_block=65536, pilot_margin_symbols=60000)
-    want = RecordingDemodulator(C1, bank_factory=lambda c, k: OracleBank(c, k), **kw).demodulate(torch.from_numpy(iq))
-    got = RecordingDemodulator(C1, **kw).demodulate(torch.from_numpy(iq).cuda())
-    assert got.report.n_tiles == want.report.n_tiles > 20
-    assert got.report.rotations == want.report.rotations and got.report.seam_shifts == want.report.seam_shifts
-    assert got.report.first_lock_symbol == want.report.first_lock_symbol == 12775
-    assert np.array_equal(got.soft.cpu().numpy(), want.soft.numpy())
-    assert np.array_equal(got.tile_first_symbol, want.tile_first_symbol)
+def _run(cfg, iq, **kw):
+    serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
+    soft, rep = demodulate_recording_native(cfg, iq, **kw)
+    out = soft.cpu().numpy()
+    a = agreement(out, serial)
+    a.pop("windows")
+    ex = int(rep.exact_symbols)
+    assert rep.pilot_symbols <= ex <= len(out) and np.array_equal(out[:ex], serial[:ex]), "the exact prefix is not the serial run's"
+    return out, serial, rep, a
 
 
-def test_hip_stitched_oqpsk_recording_equals_oracle_stitched_recording(gpu_device):
-    """OQPSK: per-rail rotation matching, state rotation with the half-symbol clock move (mdemod_rotate_carrier in OQPSK
-    mode), look-ahead seams: the HIP bank reproduces the oracle bank byte for byte and agrees with the serial run."""
-    import torch
-    cfg = DemodConfig(samplerate=230000, symrate=80000, oqpsk=True)
-    st = synth.make_stream(4242, 230000, 80000, f0_hz=300.0, clock_ppm=11.0, esn0_db=14.0, oqpsk=True)
-    iq = synth.generate_host(st, 2_000_000)
-    kw = dict(tile_samples=32768, pre_samples=8192, pilot_block=65536, pilot_margin_symbols=80000)
-    want = RecordingDemodulator(cfg, bank_factory=lambda c, k: OracleBank(c, k), **kw).demodulate(torch.from_numpy(iq))
-    got = RecordingDemodulator(cfg, **kw).demodulate(torch.from_numpy(iq).cuda())
-    assert got.report.n_tiles == want.report.n_tiles > 30 and got.report.rotations == want.report.rotations
-    assert len(set(got.report.rotations)) == 4 and got.report.seam_shifts == want.report.seam_shifts
-    assert np.array_equal(got.soft.cpu().numpy(), want.soft.numpy())
-    a = agreement(got.soft.cpu().numpy(), O.oracle_demod(cfg, iq)[0])
-    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999
+# BASELINE.json configs[1], [2], [3] at the bench's +1.2 kHz carrier offset.  configs[3] at an amplitude where the reference's
+# own AGC is stable: at 14 samples per symbol a 6000-LSB signal makes gain += 1e-4 * (190 - |y|) (agc.c:13-25) overshoot through
+# zero every few symbols (|y| * 1e-4 >= 1) and the SERIAL run spends 42 % of its time unlocked.
+@pytest.mark.parametrize("cfg,n,rms,bar", [(C1, 1 << 24, 6000.0, 0.9965), (C3, 1 << 24, 6000.0, 0.994), (C4, 1 << 25, 2000.0, 0.998)],
+                         ids=["configs1-qpsk72k", "configs2-oqpsk80k", "configs3-1MSps-f64-O8"])
+def test_single_recording_parity_on_the_bench_configurations(cfg, n, rms, bar, gpu_device):
+    st = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, rms=rms)
+    iq = synth.generate_device([st], n)[0]
+    out, serial, rep, a = _run(cfg, iq)
+    assert rep.pilot_locked and rep.n_tiles > 100 and rep.weak_seams == 0 and rep.rotation_jumps == 0, (rep.n_tiles, rep.weak_seams)
+    assert a["len_stitched"] == a["len_serial"]
+    assert a["hard_decisions_equal"] >= 0.9999 and a["within_1lsb"] >= bar, a
+    assert rep.frame_misses <= rep.n_tiles // 50 and rep.frame_residual_rms < 0.35, (rep.frame_misses, rep.frame_residual_rms)
+    # the same recording with long tiles (what a recording that fills the GPU gets): same bar, a third of the work
+    osf = cfg.samplerate / cfg.symrate
+    out2, _, rep2, a2 = _run(cfg, iq, tile_samples=int(41072 * osf) // 64 * 64)
+    assert a2["len_stitched"] == a2["len_serial"] and rep2.weak_seams == 0 and rep2.rotation_jumps == 0
+    assert a2["hard_decisions_equal"] >= 0.9999 and a2["within_1lsb"] >= bar - 0.001, a2
+    assert rep2.samples_demodulated < 0.6 * rep.samples_demodulated
+
+
+def test_perturbation_floor_of_the_reference():
+    """Not a GPU test of ours but the yardstick for the bars above (oracle only): ONE input sample changed by 1 LSB and the
+    reference's own output has ~0.2 % of its symbols more than 1 LSB away from then on (SURVEY: 0.12 % on its signal)."""
+    st = synth.make_stream(1000, 230000, 72000, f0_hz=1200.0, clock_ppm=-3.5)
+    iq = synth.generate_host(st, 1 << 23)
+    a = O.oracle_demod(C1, iq)[0]
+    iq[2_000_000, 0] += 1
+    b = O.oracle_demod(C1, iq)[0]
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16)).max(axis=1)
+    first = int(np.argmax(d > 0))
+    frac = float((d[first:] <= 1).mean())
+    assert len(a) == len(b) and 0.995 < frac < 0.9995, frac
 
 
 def test_long_recording_on_many_lanes_agrees_with_the_serial_reference(gpu_device):
-    """16 M samples (70 s of signal) as 237 tiles of 65536: pilot bytes are the reference's, tiles within the
-    loops' noise of the serial run, symbol count preserved."""
-    import torch
+    """16 M samples (70 s of signal) at -700 Hz (the reference sweeps up first: it needs 0.66 M symbols to lock)."""
     st = synth.make_stream(99, 230000, 72000, f0_hz=-700.0, clock_ppm=-20.0, esn0_db=12.0)
     iq = synth.generate_device([st], 16_000_000)[0]
-    serial = O.oracle_demod(C1, iq.cpu().numpy())[0]
-    res = RecordingDemodulator(C1).demodulate(iq)
-    out = res.soft.cpu().numpy()
-    r = res.report
-    assert r.pilot_locked and r.n_tiles > 200 and r.weak_seams == 0
-    assert np.array_equal(out[: r.pilot_symbols], serial[: r.pilot_symbols])
-    a = agreement(out, serial)
-    assert a["len_stitched"] == a["len_serial"]
-    assert a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.93
-    assert all(x == 0 for x in r.refine_rotations)
+    out, serial, rep, a = _run(C1, iq)
+    assert rep.pilot_locked and rep.n_tiles > 200 and rep.weak_seams == 0 and rep.rotation_jumps == 0
+    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.996, a
 
 
 def test_state_broadcast_and_carrier_rotation_primitives(gpu_device):
@@ -100,187 +107,141 @@ def test_state_broadcast_and_carrier_rotation_primitives(gpu_device):
         assert np.array_equal(tail, want_all[len(want_all) - m:])
 
 
-@pytest.mark.parametrize("refine", [True, False])
-def test_native_stitcher_equals_python_stitcher(refine, gpu_device):
-    """mdemod_demodulate_recording (csrc/recording.hip) makes the same decisions as recording.py: same bytes."""
+
+def test_bank_primitives_of_the_stitcher(gpu_device):
+    """mdemod_set_clock_seeds / mdemod_get_states / mdemod_copy_state / mdemod_compact_soft against their definitions."""
     import torch
-    from meteor_demod_amd.recording import demodulate_recording_native
-    st = synth.make_stream(77, 230000, 72000, f0_hz=450.0, clock_ppm=-30.0, esn0_db=10.0)
-    iq = synth.generate_device([st], 6_000_000)[0]
-    kw = dict(tile_samples=32768, pre_samples=8192, refine=refine, pilot_block=65536, pilot_margin_symbols=80000)
-    want = RecordingDemodulator(C1, **kw).demodulate(iq)
-    soft, rep = demodulate_recording_native(C1, iq, **kw)
-    assert rep.n_tiles == want.report.n_tiles > 100 and rep.pilot_symbols == want.report.pilot_symbols
-    assert rep.first_lock_symbol == want.report.first_lock_symbol and rep.weak_seams == want.report.weak_seams
-    assert rep.seam_fixes == sum(1 for s in want.report.seam_shifts if s)
-    assert rep.samples_demodulated == want.report.samples_demodulated
-    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy())
+    from meteor_demod_amd import Demodulator
+    streams = [synth.make_stream(20 + i, 230000, 72000, f0_hz=40.0 * i) for i in range(5)]
+    x = synth.generate_device(streams, 9000)
+    with Demodulator(C1, 5) as a, Demodulator(C1, 5) as b:
+        soft = a.process(x[:, :6000].contiguous())
+        torch.cuda.synchronize()
+        cnt = a.symbol_counts()
+        sts = a.get_states()
+        for i in range(5):
+            one = a.get_state(i)
+            for f, _ in one._fields_:
+                assert getattr(sts[i], f) == getattr(one, f), (i, f)
+        # checkpoint: b := a, then both continue identically; and a restored checkpoint replays the same bytes
+        b.copy_state_from(a)
+        sa = a.process(x[:, 6000:].contiguous()).clone()
+        sb = b.process(x[:, 6000:].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(a.symbol_counts(), b.symbol_counts())
+        assert all(torch.equal(sa[i, : int(c)], sb[i, : int(c)]) for i, c in enumerate(a.symbol_counts()))
+        for i in range(5):
+            want = O.oracle_demod(C1, x[i].cpu().numpy())[0]
+            m0, m1 = int(cnt[i]), int(a.symbol_counts()[i])
+            assert np.array_equal(np.concatenate((soft[i, :m0].cpu().numpy(), sa[i, :m1].cpu().numpy())), want)
+        # compaction to the nominal pitch keeps every symbol
+        pitch = a.nominal_pitch(3000)
+        assert pitch % 8 == 0 and int(a.symbol_counts().max()) <= pitch < sa.shape[1]
+        packed = a.compact(sa, pitch)
+        for i in range(5):
+            m1 = int(a.symbol_counts()[i])
+            assert torch.equal(packed[i, :m1], sa[i, :m1])
+        tf = torch.tensor([0.39, 0.3934, 0.3933, 0.4, 0.393], dtype=torch.float32, device="cuda")
+        a.set_clock_seeds(tf)
+        assert [np.float32(s.t_freq) for s in a.get_states()] == [np.float32(v) for v in tf.cpu().tolist()]
+        with pytest.raises(ValueError):
+            a.process(x.to(torch.float32))                   # wrong dtype for bps=16: refused before any pointer is used
+        with pytest.raises(ValueError):
+            a.process(x, n_samples=x.shape[1] + 1)
 
 
-def test_native_stitcher_equals_python_stitcher_oqpsk(gpu_device):
-    import torch
-    from meteor_demod_amd.recording import demodulate_recording_native
-    cfg = DemodConfig(samplerate=230000, symrate=80000, oqpsk=True)
-    st = synth.make_stream(78, 230000, 80000, f0_hz=-350.0, clock_ppm=25.0, esn0_db=12.0, oqpsk=True)
-    iq = synth.generate_device([st], 5_000_000)[0]
-    kw = dict(tile_samples=32768, pre_samples=8192, refine=True, pilot_block=65536, pilot_margin_symbols=80000)
-    want = RecordingDemodulator(cfg, **kw).demodulate(iq)
-    soft, rep = demodulate_recording_native(cfg, iq, **kw)
-    assert rep.n_tiles == want.report.n_tiles > 50 and rep.weak_seams == want.report.weak_seams
-    assert rep.seam_fixes == sum(1 for s in want.report.seam_shifts if s)
-    assert rep.samples_demodulated == want.report.samples_demodulated
-    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy())
-
-
-def test_native_stitcher_short_recording_and_errors(gpu_device):
-    import torch
+def test_short_recordings_and_bad_options(gpu_device):
     from meteor_demod_amd._capi import MdemodError
-    from meteor_demod_amd.recording import demodulate_recording_native
     st = synth.make_stream(3, 230000, 72000, f0_hz=0.0)
     iq = synth.generate_device([st], 150_000)[0]
     soft, rep = demodulate_recording_native(C1, iq, pilot_margin_symbols=160000)      # the pilot never gets that far: all serial
     assert rep.n_tiles == 0 and np.array_equal(soft.cpu().numpy(), O.oracle_demod(C1, iq.cpu().numpy())[0])
-    with pytest.raises(MdemodError):      # OQPSK needs the state rotation pass
-        demodulate_recording_native(DemodConfig(samplerate=230000, symrate=80000, oqpsk=True), iq, refine=False)
+    # one tile = the pilot's exact continuation: still the serial run, byte for byte
+    iq = synth.generate_device([st], 700_000)[0]
+    soft, rep = demodulate_recording_native(C1, iq, pilot_margin_symbols=2000, tile_samples=1 << 20)
+    assert rep.n_tiles == 1 and rep.exact_symbols == rep.n_symbols
+    assert np.array_equal(soft.cpu().numpy(), O.oracle_demod(C1, iq.cpu().numpy())[0])
+    with pytest.raises(MdemodError):
+        demodulate_recording_native(C1, iq, match_symbols=0)
+    with pytest.raises(ValueError):
+        demodulate_recording_native(C1, iq.to("cpu"))
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_native_and_python_stitchers_agree_on_random_settings_oqpsk(seed, gpu_device):
-    """The same for OQPSK (rail matching, state rotation, look-ahead seams), with gaps and bursts."""
-    import torch
-    from meteor_demod_amd.recording import demodulate_recording_native
-    rng = np.random.default_rng(300 + seed)
-    cfg = DemodConfig(samplerate=int(rng.choice([230000, 250000, 460000])), symrate=80000, oqpsk=True)
-    st = synth.make_stream(700 + seed, cfg.samplerate, 80000, f0_hz=float(rng.uniform(-500, 700)), clock_ppm=float(rng.uniform(-40, 40)),
-                           esn0_db=float(rng.choice([6.0, 10.0, 14.0, 20.0])), oqpsk=True, rms=3000.0)
-    n = int(rng.integers(2_000_000, 4_000_000))
-    iq = synth.generate_device([st], n)[0]
-    if seed >= 2:
-        g0 = int(rng.integers(n // 3, n // 2))
-        iq[g0: g0 + 200_000] = 0
-        iq[g0 + 200_000: g0 + 215_000] = -32768
-    kw = dict(tile_samples=int(rng.choice([0, 16448, 40000])), pre_samples=int(rng.choice([-1, 4096, 20000])), refine=True,
-              pilot_block=int(rng.choice([16384, 65536])), pilot_margin_symbols=int(rng.choice([0, 5000, 60000])),
-              match_symbols=int(rng.choice([64, 192])))
-    want = RecordingDemodulator(cfg, **kw).demodulate(iq)
-    soft, rep = demodulate_recording_native(cfg, iq, **kw)
-    assert rep.n_tiles == want.report.n_tiles and rep.pilot_symbols == want.report.pilot_symbols, kw
-    assert rep.weak_seams == want.report.weak_seams and rep.seam_fixes == sum(1 for s in want.report.seam_shifts if s), kw
-    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy()), kw
-
-
-@pytest.mark.parametrize("seed", range(6))
-def test_native_and_python_stitchers_agree_on_random_settings(seed, gpu_device):
-    """Random tile / warm-up / margin / match settings, offsets of both signs, noise levels down to 4 dB (weak seams,
-    unlocked pilots): the two implementations must make identical decisions."""
-    import torch
-    from meteor_demod_amd.recording import demodulate_recording_native
-    rng = np.random.default_rng(100 + seed)
-    st = synth.make_stream(500 + seed, 230000, 72000, f0_hz=float(rng.uniform(-600, 900)), clock_ppm=float(rng.uniform(-40, 40)),
-                           esn0_db=float(rng.choice([4.0, 8.0, 12.0, 20.0])))
-    n = int(rng.integers(2_000_000, 5_000_000))
-    iq = synth.generate_device([st], n)[0]
-    if seed >= 4:                          # a silent gap and a full-scale burst in the middle: unlocked tiles, weak seams
-        g0 = int(rng.integers(n // 3, n // 2))
-        iq[g0: g0 + 300_000] = 0
-        iq[g0 + 300_000: g0 + 320_000] = 32767
-    kw = dict(tile_samples=int(rng.choice([8200, 16448, 40000, 65600])), pre_samples=int(rng.choice([0, 2048, 8192, 20000])),
-              refine=bool(rng.random() < 0.6), pilot_block=int(rng.choice([16384, 65536])),
-              pilot_margin_symbols=int(rng.choice([0, 5000, 60000])), max_pilot_samples=int(rng.choice([300_000, 1 << 22])),
-              match_symbols=int(rng.choice([32, 192, 400])))
-    want = RecordingDemodulator(C1, **kw).demodulate(iq)
-    soft, rep = demodulate_recording_native(C1, iq, **kw)
-    assert rep.n_tiles == want.report.n_tiles and rep.pilot_symbols == want.report.pilot_symbols, kw
-    assert rep.weak_seams == want.report.weak_seams and rep.seam_fixes == sum(1 for s in want.report.seam_shifts if s), kw
-    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy()), kw
-
-
-def test_recording_at_one_megasample_uses_scaled_tiles(gpu_device):
-    """A 1.024 MS/s recording (default filter: mid geometry): the default tile and warm-up lengths scale with the samples
-    per symbol (292 k / 73 k samples), native == python, and the result agrees with the serial oracle."""
-    import torch
-    from meteor_demod_amd.recording import default_tiling, demodulate_recording_native
+def test_recording_at_one_megasample_default_filter(gpu_device):
+    """A 1.024 MS/s recording with the reference's default filter (mid geometry): tile, lead and estimator windows scale with
+    the samples per symbol.  rms 1500: see the AGC remark above."""
     cfg = DemodConfig(samplerate=1024000)
-    assert default_tiling(C1) == (65600, 16384) and default_tiling(cfg)[0] > 290_000
-    # rms 1500: with 14 samples per symbol a 6000-LSB signal drives the reference's AGC into its 0 <-> 0.019 limit cycle
-    # (gain += 1e-4 * (190 - |y|) overshoots below zero), in the serial run as much as in the tiles
     st = synth.make_stream(12, 1024000, 72000, f0_hz=500.0, clock_ppm=-15.0, esn0_db=14.0, rms=1500.0)
     iq = synth.generate_device([st], 24_000_000)[0]
-    want = RecordingDemodulator(cfg).demodulate(iq)
-    soft, rep = demodulate_recording_native(cfg, iq)
-    assert rep.n_tiles == want.report.n_tiles > 50 and rep.weak_seams == 0
-    assert np.array_equal(soft.cpu().numpy(), want.soft.cpu().numpy())
-    serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
-    a = agreement(soft.cpu().numpy(), serial)
-    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.95
-    assert np.array_equal(soft[: rep.pilot_symbols].cpu().numpy(), serial[: rep.pilot_symbols])
+    out, serial, rep, a = _run(cfg, iq)
+    assert rep.n_tiles > 50 and rep.weak_seams == 0 and rep.tile_samples > 8192 * 14
+    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.997, a
 
 
-def test_doppler_recording_with_spectral_carrier_seeds(gpu_device):
-    """40 Hz/s of Doppler over 52 s on the GPU (mdemod_set_carrier_seeds + torch.fft estimates): the stitched stream
-    keeps the serial run's symbol count and decisions; the per-stream seed op is checked against its definition."""
-    import torch
-    from meteor_demod_amd import Demodulator
-    st = synth.make_stream(78, 230000, 72000, f0_hz=-300.0, clock_ppm=-8.0, esn0_db=12.0, doppler_hz_per_s=40.0)
-    iq = synth.generate_device([st], 12_000_000)[0]
-    serial = O.oracle_demod(C1, iq.cpu().numpy())[0]
-    res = RecordingDemodulator(C1, carrier_seed="spectrum").demodulate(iq)
-    a = agreement(res.soft.cpu().numpy(), serial)
-    assert res.report.weak_seams == 0 and a["len_stitched"] == a["len_serial"]
-    assert a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.97
-    with Demodulator(C1, 5) as d:
-        f = torch.tensor([0.1, -0.2, 0.0, 0.05, 0.3], dtype=torch.float32, device="cuda")
-        u = torch.tensor([1, -1, 1, -1, 1], dtype=torch.int32, device="cuda")
-        d.set_carrier_seeds(f, u)
-        for i in range(5):
-            g = d.get_state(i)
-            assert np.float32(g.pll_freq) == np.float32(f[i].item()) and g.pll_updown == int(u[i]) and g.agc_gain == 1.0
+def test_repair_of_wrong_frames(gpu_device):
+    """carrier_seed=pilot: every tile starts from the pilot's carrier word, which is still 90 Hz away from the carrier at
+    the hand-over (the reference's loop needs another 1e5 symbols), so dead reckoning puts most tiles in the wrong rotation.
+    The seam check finds them and the odd ones run again from the checkpoint: same bar as with good frames.  Without the
+    repair the output is rotated back (decisions fine) but the odd tiles settled on the other rail's noise."""
+    st = synth.make_stream(1000, 230000, 72000, f0_hz=1200.0, clock_ppm=-3.5)
+    iq = synth.generate_device([st], 1 << 23)[0]
+    out, serial, rep, a = _run(C1, iq, carrier_seed="pilot")
+    assert rep.frame_misses > rep.n_tiles // 4 and rep.repaired_tiles > rep.n_tiles // 8 and rep.rotation_jumps == 0
+    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.995, a
+    out0, _, rep0, a0 = _run(C1, iq, carrier_seed="pilot", repair=False)
+    assert rep0.repaired_tiles == 0 and rep0.rotation_jumps > 0
+    assert a0["len_stitched"] == a0["len_serial"] and a0["hard_decisions_equal"] > 0.9999 and a0["within_1lsb"] < a["within_1lsb"]
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("args", ["200 55 98", "400 11 137"], ids=["oqpsk-u8-ramp", "oqpsk-f32-255552"])
+def test_rotation_jump_cases_of_round_one(args, gpu_device):
+    """The two soak recordings on which the round-1 stitcher ended a quarter turn off (profiles/r01_rotation_jump_cases.md:
+    a tile whose first pass changed rotation after it had been measured).  Frames are now fixed right after the acquisition
+    and checked again on every seam; both must come out clean with the default lead."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "recording_fuzz.py"), *args.split()], capture_output=True, text=True,
+                       cwd=str(ROOT), timeout=600)
+    assert r.returncode == 0 and "failures 0" in r.stdout and "rotation jump 0" in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("bps,oqpsk", [(16, False), (8, False), (16, True)])
-def test_native_stitcher_follows_doppler(gpu_device, bps, oqpsk):
-    """mdemod_demodulate_recording with carrier_seed=spectrum (carrier_line_kernel in csrc/recording.hip): same bar as the
-    Python stitcher on a 40 Hz/s ramp; with pilot seeds the same recording loses tiles (that is what the option is for)."""
+def test_recording_follows_doppler(gpu_device, bps, oqpsk):
+    """40 Hz/s of Doppler over 52 s: the carrier moves 11 Hz across one estimator window, its 4th-power line 13 bins; the
+    estimates are de-chirped with the neighbours' slope, the seeds carry the lag of the reference's loop (slope * alpha/beta)."""
     import dataclasses
-    from meteor_demod_amd.recording import demodulate_recording_native
     amp = dict(rms=6000.0) if bps == 16 else dict(rms=40.0, dc=(1.5, -1.0))
     symrate = 80000 if oqpsk else 72000
     # OQPSK: start above the carrier the sweep meets first.  With f0 = -300 Hz the REFERENCE declares lock at +575 Hz while
-    # sweeping up (false lock, 28 k symbols in) and only reaches the carrier 160 k symbols later; tiles seeded from the
-    # spectrum are on the carrier at once, so there is no serial stream to compare them with (DESIGN.md 3.1).
+    # sweeping up (false lock, 28 k symbols in) and only reaches the carrier 160 k symbols later
     f0, ramp = (500.0, -40.0) if oqpsk else (-300.0, 40.0)
     st = synth.make_stream(80 if oqpsk else 79, 230000, symrate, f0_hz=f0, clock_ppm=5.0, esn0_db=13.0 if oqpsk else 12.0,
                            doppler_hz_per_s=ramp, fmt=bps, oqpsk=oqpsk, **amp)
     iq = synth.generate_device([st], 12_000_000)[0]
     cfg = dataclasses.replace(C1, bps=bps, symrate=symrate, oqpsk=oqpsk)
-    serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
-    soft, rep = demodulate_recording_native(cfg, iq, carrier_seed="spectrum")
-    a = agreement(soft.cpu().numpy(), serial)
-    assert rep.weak_seams == 0 and a["len_stitched"] == a["len_serial"]
-    assert a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.97
-    soft0, rep0 = demodulate_recording_native(cfg, iq, carrier_seed="pilot")
-    a0 = agreement(soft0.cpu().numpy(), serial)
-    assert a0["hard_decisions_equal"] < a["hard_decisions_equal"] or rep0.weak_seams > 0
+    out, serial, rep, a = _run(cfg, iq)
+    assert rep.weak_seams == 0 and rep.rotation_jumps == 0 and a["len_stitched"] == a["len_serial"]
+    assert rep.frame_misses <= 2 and rep.frame_residual_rms < 0.35, (rep.frame_misses, rep.frame_residual_rms)
+    assert a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > (0.992 if oqpsk or bps == 8 else 0.996), a
 
 
-@pytest.mark.gpu
 def test_native_stitcher_bridges_a_fade_with_neighbouring_carrier_estimates(gpu_device):
     """Three tiles' worth of the recording replaced by noise while the carrier ramps 40 Hz/s: those tiles have no spectral
     line and take their neighbours' carrier (mdemod_recording_report.weak_carrier_tiles); before the fade the output is
     the serial run's, after it the two agree again up to the lock's own quarter-turn ambiguity (the serial run re-locks on
     its own after the fade, so rotation and the symbol count across the fade are not comparable)."""
     import torch
-    from meteor_demod_amd.recording import demodulate_recording_native, rotate_symbols
+    from meteor_demod_amd.recording import rotate_symbols
     st = synth.make_stream(91, 230000, 72000, f0_hz=300.0, clock_ppm=5.0, esn0_db=12.0, doppler_hz_per_s=40.0)
     iq = synth.generate_device([st], 8_000_000)[0]
     a, b = 3_000_000, 3_000_000 + 3 * 65600
     g = torch.Generator(device="cuda").manual_seed(3)
     iq[a:b] = (torch.randn((b - a, 2), device="cuda", generator=g) * 4200).to(torch.int16)
     serial, tr, ev = O.oracle_demod(C1, iq.cpu().numpy(), True)
-    soft, rep = demodulate_recording_native(C1, iq, carrier_seed="spectrum")
+    soft, rep = demodulate_recording_native(C1, iq)
     out = soft.cpu().numpy()
-    assert 2 <= rep.weak_carrier_tiles <= 5
+    assert 1 <= rep.weak_carrier_tiles <= 12
     n_before = int(a * 72000 / 230000) - 2000
     assert ((out[:n_before] >= 0) == (serial[:n_before] >= 0)).all(axis=1).mean() > 0.9999
     L = 1_000_000                                                   # the last 3.2 s, long after both have re-locked
@@ -294,15 +255,13 @@ def test_native_stitcher_bridges_a_fade_with_neighbouring_carrier_estimates(gpu_
     assert tr["locked"][-L:].all()
 
 
-@pytest.mark.gpu
 def test_native_stitcher_seeds_the_agc_on_float_input(gpu_device):
     """Float input around +-1 with the amplitude swinging 0.4..1.0 over 12 s: mdemod_demodulate_recording waits for the
     reference's AGC to settle before handing over, then gives every tile the gain of the closed-form AGC recursion
-    (mdemod_set_gain_seeds).  Without the seeds (carrier_seed=pilot) under a third of the soft symbols are within an LSB."""
+    (mdemod_set_gain_seeds)."""
     import dataclasses
     import torch
     from meteor_demod_amd import Demodulator
-    from meteor_demod_amd.recording import demodulate_recording_native
     cfg = dataclasses.replace(C1, bps=32)
     st = synth.make_stream(7, 230000, 72000, f0_hz=300.0, clock_ppm=5.0, esn0_db=12.0, fmt=32, rms=0.25, dc=(0.001, -0.002))
     n = 6_000_000
@@ -310,34 +269,31 @@ def test_native_stitcher_seeds_the_agc_on_float_input(gpu_device):
     t = torch.arange(n, device="cuda", dtype=torch.float32) / 230000
     iq *= (0.7 - 0.3 * torch.cos(2 * np.pi * t / 12.0))[:, None]
     serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
-    soft, rep = demodulate_recording_native(cfg, iq, carrier_seed="spectrum")
+    soft, rep = demodulate_recording_native(cfg, iq)
     a = agreement(soft.cpu().numpy(), serial)
     assert rep.pilot_symbols > 150_000 and rep.weak_seams == 0
     assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.99999 and a["within_1lsb"] > 0.98
-    soft0, _ = demodulate_recording_native(cfg, iq, carrier_seed="pilot")
-    assert agreement(soft0.cpu().numpy(), serial)["within_1lsb"] < 0.6
     with Demodulator(C1, 3) as d:                                        # the seed op against its definition
         d.set_gain_seeds(torch.tensor([0.5, -2.0, 700.0], dtype=torch.float32, device="cuda"))
         assert [d.get_state(i).agc_gain for i in range(3)] == [0.5, 0.0, 700.0]
 
 
-@pytest.mark.gpu
 def test_native_stitcher_opens_the_lock_gate_from_the_tiles_when_the_pilot_never_locks(gpu_device):
     """A recording that starts before the signal does: the serial head gives up after max_pilot_samples without a lock, so
     the lock gate (main.c:308-315) has to come from the tiles - the first one whose stream reports a first lock.  The
     symbols after that point are the transmitted ones (checked against the serial run where that one is locked too)."""
     import torch
-    from meteor_demod_amd.recording import demodulate_recording_native, rotate_symbols
+    from meteor_demod_amd.recording import rotate_symbols
     st = synth.make_stream(93, 230000, 72000, f0_hz=500.0, clock_ppm=5.0, esn0_db=12.0, rms=1500.0)
     n_noise, n_sig = 1_500_000, 5_000_000
     sig = synth.generate_device([st], n_sig)[0]
     g = torch.Generator(device="cuda").manual_seed(5)
     noise = (torch.randn((n_noise, 2), device="cuda", generator=g) * 500).to(torch.int16)
     iq = torch.cat((noise, sig)).contiguous()
-    soft, rep = demodulate_recording_native(C1, iq, carrier_seed="spectrum", max_pilot_samples=600_000)
+    soft, rep = demodulate_recording_native(C1, iq, max_pilot_samples=600_000)
     assert not rep.pilot_locked and rep.pilot_samples < 700_000
     sym_at_signal = int(n_noise * 72000 / 230000)
-    tile_sym = 20536
+    tile_sym = int(rep.tile_samples * 72000 / 230000) + 27500          # a tile and its lead
     assert sym_at_signal - tile_sym <= rep.first_lock_symbol <= sym_at_signal + 2 * tile_sym, rep.first_lock_symbol
     assert rep.weak_carrier_tiles >= 10                                  # the noise tiles have no carrier line
     # the serial run needs its sweep to find the carrier; compare where it is locked too, up to the quarter-turn ambiguity
@@ -356,43 +312,39 @@ def test_native_stitcher_opens_the_lock_gate_from_the_tiles_when_the_pilot_never
     assert np.abs(out[k: k + 20000].astype(int)).mean() > 45             # locked constellation (~60), not noise (~30)
 
 
-@pytest.mark.gpu
-def test_native_stitcher_needs_no_more_output_room_than_it_writes(gpu_device):
+def test_stitcher_needs_no_more_output_room_than_it_writes(gpu_device):
     """The CLI sizes the output for the nominal symbol rate + 2 % + 4096 (host/meteor_demod_amd.c).  A recording shorter
-    than one pilot block must fit in that (the pilot used to insist on room for one symbol per sample of its block), a
-    buffer that is really too small must be refused, and the byte-exact prefix must be what pilot_symbols says."""
+    than one pilot block must fit in that, a buffer that is really too small must be refused, and the byte-exact prefix
+    must be what exact_symbols says (checked by _run)."""
     from meteor_demod_amd._capi import MdemodError
-    from meteor_demod_amd.recording import demodulate_recording_native
     st = synth.make_stream(31, 230000, 72000, f0_hz=100.0, esn0_db=12.0)
     for n in (1, 1000, 100_000, 400_000):
         iq = synth.generate_device([st], n)[0]
         serial = O.oracle_demod(C1, iq.cpu().numpy())[0]
         cap = int(n * 72000 / 230000 * 1.02) + 4096
-        soft, rep = demodulate_recording_native(C1, iq, carrier_seed="spectrum", soft_capacity=cap)
+        soft, rep = demodulate_recording_native(C1, iq, soft_capacity=cap)
         out = soft.cpu().numpy()
-        assert abs(len(out) - len(serial)) <= 1 and np.array_equal(out[: rep.pilot_symbols], serial[: rep.pilot_symbols])
-        if rep.n_tiles == 0:
+        assert abs(len(out) - len(serial)) <= 1 and np.array_equal(out[: rep.exact_symbols], serial[: rep.exact_symbols])
+        if rep.n_tiles <= 1:
             assert np.array_equal(out, serial)
     with pytest.raises(MdemodError):
-        demodulate_recording_native(C1, iq, carrier_seed="spectrum", soft_capacity=1000)
-    # first seam against the pilot may drop the pilot's last symbol (no second pass): the exact prefix shrinks with it
+        demodulate_recording_native(C1, iq, soft_capacity=1000)
+    # leads that reach back to the start of the recording, no settling at all, tiny tiles: count and prefix still right
     iq = synth.generate_device([st], 1_200_000)[0]
-    serial = O.oracle_demod(C1, iq.cpu().numpy())[0]
-    for pre in (0, 1000, 16384):
-        soft, rep = demodulate_recording_native(C1, iq, refine=False, pre_samples=pre, pilot_margin_symbols=2000, tile_samples=20032)
-        out = soft.cpu().numpy()
-        assert np.array_equal(out[: rep.pilot_symbols], serial[: rep.pilot_symbols])
+    for kw in (dict(settle_samples=0), dict(settle_samples=1000, acquire_samples=500, frame_samples=100), dict(tile_samples=4160),
+               dict(acquire_samples=0, frame_samples=0, settle_samples=0)):
+        out, serial, rep, a = _run(C1, iq, pilot_margin_symbols=2000, **kw)
+        assert abs(a["len_stitched"] - a["len_serial"]) <= 2, (kw, a)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("oqpsk,bps", [(False, 16), (True, 32), (False, 8)])
 def test_estimate_carrier_entry(gpu_device, oqpsk, bps):
     """mdemod_estimate_carrier (z^4 -> boxcar decimation -> FFT in LDS -> peak, one kernel): the estimate is the synthetic
-    carrier, it agrees with the full-resolution torch.fft estimator of recording.py, the quality figure separates signal
-    from noise, windows past the end of the recording are served, and the window length is rounded as documented."""
+    carrier, the quality figure separates signal from noise, windows past the end of the recording are served, and the
+    window length is rounded as documented."""
     import dataclasses
     import torch
-    from meteor_demod_amd.recording import carrier_estimates, estimate_carrier_native
+    from meteor_demod_amd.recording import estimate_carrier_native
     symrate = 80000 if oqpsk else 72000
     cfg = dataclasses.replace(C1, symrate=symrate, oqpsk=oqpsk, bps=bps)
     amp = {8: dict(rms=40.0, dc=(1.5, -1.0)), 16: dict(rms=3000.0), 32: dict(rms=0.25, dc=(0.001, -0.002))}[bps]
@@ -409,10 +361,25 @@ def test_estimate_carrier_entry(gpu_device, oqpsk, bps):
     steps = 2 if oqpsk else 1
     want = 2 * np.pi * f0 / (symrate * steps)
     f, q = freq.cpu().numpy(), qual.cpu().numpy()
-    assert np.abs(f[:4] - want).max() < 2 * np.pi * 1.0 / (symrate * steps)          # within 1 Hz
+    assert np.abs(f[:4] - want).max() < 2 * np.pi * 0.25 / (symrate * steps)         # within 0.25 Hz
     assert q[:4].min() > 20 and q[4] < 7
-    ft, qt = carrier_estimates(both, starts[:4], 65536, 230000, symrate, nco_steps_per_symbol=steps)
-    assert np.abs(ft.cpu().numpy() - f[:4]).max() < 2 * np.pi * 0.5 / (symrate * steps)
     assert np.isfinite(f).all() and np.isfinite(q).all()
     f2, q2, used2 = estimate_carrier_native(cfg, both, starts[:2], 5000)              # short windows: 4096 samples
     assert used2 == 4096 and np.abs(f2.cpu().numpy() - want).max() < 2 * np.pi * 12.0 / (symrate * steps)
+
+
+def test_estimate_carrier_with_the_chirp_taken_out(gpu_device):
+    """A carrier that ramps 40 Hz/s moves its 4th-power line through 13 bins of a 65536-sample window: the plain estimate is a
+    broad hump, the de-chirped one a line again (quality) on the carrier of the window's middle to a tenth of a Hz."""
+    from meteor_demod_amd.recording import estimate_carrier_native
+    ramp, f0 = 40.0, 300.0
+    st = synth.make_stream(62, 230000, 72000, f0_hz=f0, esn0_db=12.0, doppler_hz_per_s=ramp)
+    iq = synth.generate_device([st], 2_000_000)[0]
+    starts = np.array([100_000, 900_000, 1_700_000])
+    mid_hz = f0 + ramp * (starts + 32768) / 230000.0
+    want = 2 * np.pi * mid_hz / 72000
+    f_plain, q_plain, _ = estimate_carrier_native(C1, iq, starts, 65536)
+    slope = 2 * np.pi * ramp / 72000 / 230000.0                                        # rad per symbol per sample
+    f_chirp, q_chirp, _ = estimate_carrier_native(C1, iq, starts, 65536, chirp=np.full(3, slope, dtype=np.float32))
+    assert (q_chirp.cpu().numpy() > 2.0 * q_plain.cpu().numpy()).all()
+    assert np.abs(f_chirp.cpu().numpy() - want).max() < 2 * np.pi * 0.1 / 72000

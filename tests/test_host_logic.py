@@ -34,12 +34,12 @@ def test_header_symbols_are_all_exported():
 
 def test_abi_version_and_struct_layouts():
     lib = _capi.lib()
-    assert lib.mdemod_abi_version() == 1
+    assert lib.mdemod_abi_version() == 2
     assert C.sizeof(_capi.MdemodParams) == 48
     assert C.sizeof(_capi.MdemodStatus) == 56
     assert C.sizeof(_capi.MdemodLockEvent) == 16
     assert C.sizeof(_capi.MdemodStreamState) == 80
-    assert C.sizeof(_capi.MdemodRecordingOpts) == 40 and C.sizeof(_capi.MdemodRecordingReport) == 80
+    assert C.sizeof(_capi.MdemodRecordingOpts) == 48 and C.sizeof(_capi.MdemodRecordingReport) == 104
     # the C compiler agrees with the ctypes mirrors
     import subprocess, tempfile
     from conftest import ROOT
@@ -50,7 +50,7 @@ def test_abi_version_and_struct_layouts():
         (Path(td) / "s.c").write_text(src)
         subprocess.run(["gcc", "-I", str(ROOT / "include"), str(Path(td) / "s.c"), "-o", str(Path(td) / "s")], check=True)
         out = subprocess.run([str(Path(td) / "s")], capture_output=True, text=True, check=True).stdout.split()
-    assert [int(x) for x in out] == [48, 56, 16, 80, 40, 80]
+    assert [int(x) for x in out] == [48, 56, 16, 80, 48, 104]
     assert lib.mdemod_strerror(-3).decode().startswith("HIP")
 
 
@@ -173,7 +173,7 @@ def test_turn_code_shortcut_proof_holds_on_the_host():
 
 
 def test_carrier_window_rounding_is_host_logic():
-    """mdemod_carrier_window_samples needs no GPU: power of two in [4096, 2^17], and no more than 16384 points after the
+    """mdemod_carrier_window_samples needs no GPU: power of two in [4096, 2^18], and no more than 16384 points after the
     decimation the z^4 band allows (at 2.5 samples per symbol only 4x decimation keeps +-4*0.33 rad/symbol inside 80 % of
     the band; at one sample per symbol none does, so the window itself shrinks to the 16384 points that fit in LDS)."""
     import ctypes as C
@@ -184,7 +184,7 @@ def test_carrier_window_rounding_is_host_logic():
         return int(lib.mdemod_carrier_window_samples(C.byref(p), want))
     assert used(230000, 72000, 100_000) == 65536 and used(230000, 72000, 5000) == 4096 and used(230000, 72000, 100) == 4096
     assert used(230000, 72000, 1 << 20) == 65536            # 16384 points x 4 (decimation by 8 would fold the band)
-    assert used(1_022_400, 72000, 1 << 20) == 131072        # 16x decimation available, window capped at 2^17
+    assert used(1_022_400, 72000, 1 << 20) == 262144        # 16x decimation available: 16384 points x 16
     assert used(80000, 72000, 100_000) == 32768             # 1.1 samples per symbol: decimation by 2 still keeps the band
     assert used(73000, 72000, 100_000) == 16384             # barely oversampled: no decimation, 16384 points
     assert lib.mdemod_carrier_window_samples(None, 4096) == 0

@@ -3,7 +3,7 @@ QPSK / OQPSK, input formats, carrier offsets, Doppler ramps, clock errors, tile 
 natively with spectral carrier seeds and compared with the serial oracle.  A case counts only if the serial run's lock
 is genuine (its PLL frequency is on the synthetic carrier when the pilot hands over), otherwise there is
 no serial stream to compare with.  Usage: recording_fuzz.py [n_cases] [seed] [only_case]
-(FUZZ_TILE / FUZZ_PRE / FUZZ_SEEDMODE in the environment override a case's tile size / carrier_seed when one case is replayed)"""
+(FUZZ_TILE / FUZZ_SETTLE / FUZZ_SEEDMODE in the environment override a case's tile size / settling length / carrier_seed when one case is replayed)"""
 import os
 import dataclasses
 import sys
@@ -19,6 +19,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 bad, jumps, skipped, t0 = [], [], 0, time.time()
+within = []
 for ci in range(n_cases):
     oqpsk = bool(rng.random() < (1.0 if os.environ.get("FUZZ_ONLY_OQPSK") else 0.35))
     symrate = 80000 if oqpsk else 72000
@@ -46,8 +47,8 @@ for ci in range(n_cases):
         if os.environ.get("FUZZ_TILE"):
             kw["tile_samples"] = int(os.environ["FUZZ_TILE"])
         mode = os.environ.get("FUZZ_SEEDMODE", mode)
-        if os.environ.get("FUZZ_PRE"):
-            kw["pre_samples"] = int(os.environ["FUZZ_PRE"])
+        if os.environ.get("FUZZ_SETTLE"):
+            kw["settle_samples"] = int(os.environ["FUZZ_SETTLE"])
         print("replay: esn0", esn0, "amp", amp)
     st = synth.make_stream(1000 + ci, samplerate, symrate, f0_hz=f0, clock_ppm=ppm, esn0_db=esn0,
                            doppler_hz_per_s=ramp, oqpsk=oqpsk, fmt=bps, **amp)
@@ -66,16 +67,20 @@ for ci in range(n_cases):
         continue
     a = agreement(soft.cpu().numpy(), serial)
     a.pop("windows", None)
+    within.append(a["within_1lsb"])
     # the very last symbol of a recording may fire in one run and not in the other (clock phases differ by a fraction of a sample)
     ok = abs(a["len_stitched"] - a["len_serial"]) <= 1 and a["hard_decisions_equal"] > 0.9995 and rep.weak_seams == 0
     if not ok and rep.rotation_jumps and abs(a["len_stitched"] - a["len_serial"]) <= 1 and rep.weak_seams == 0:
         jumps.append(tag)          # reported by the stitcher itself: one tile's first pass changed rotation
         ok = True
     print(tag, "->", "ok" if ok else "FAIL", {k_: (round(v, 5) if isinstance(v, float) else v) for k_, v in a.items()},
-          "tiles", rep.n_tiles, "weak", rep.weak_seams, "weak_carrier", rep.weak_carrier_tiles, "rotation_jumps", rep.rotation_jumps, flush=True)
+          "tiles", rep.n_tiles, "weak", rep.weak_seams, "weak_carrier", rep.weak_carrier_tiles, "frame_misses", rep.frame_misses,
+          "repaired", rep.repaired_tiles, "rotation_jumps", rep.rotation_jumps, f"dr_rms {rep.frame_residual_rms:.2f}", flush=True)
     if not ok:
         bad.append(tag)
 print(f"{n_cases} cases in {time.time() - t0:.0f} s, skipped {skipped}, with a reported rotation jump {len(jumps)}, failures {len(bad)}")
+if within:
+    print("within +-1 LSB of the serial run: min %.4f median %.4f" % (min(within), float(np.median(within))))
 for b in bad:
     print("  ", b)
 sys.exit(1 if bad else 0)

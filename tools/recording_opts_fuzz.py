@@ -26,8 +26,9 @@ for ci in range(n_cases):
     st = synth.make_stream(5000 + ci, samplerate, symrate, f0_hz=float(rng.uniform(0, 600)), clock_ppm=float(rng.uniform(-20, 20)),
                            esn0_db=12.0, oqpsk=oqpsk, fmt=bps, doppler_hz_per_s=float(rng.choice([0.0, 20.0])), **amp)
     kw = dict(tile_samples=int(rng.choice([0, 4096, 4160, 8192 + 64, 20000 // 64 * 64, 65600, 300_032])),
-              pre_samples=int(rng.choice([-1, 0, 64, 1000, 16384, 100_000])),
-              refine=bool(oqpsk or rng.random() < 0.7),
+              settle_samples=int(rng.choice([0xFFFFFFFF, 0, 64, 1000, 16384, 100_000])),
+              acquire_samples=int(rng.choice([0xFFFFFFFF, 0, 100, 6000])), frame_samples=int(rng.choice([0xFFFFFFFF, 0, 50, 5000])),
+              repair=bool(rng.random() < 0.7),
               pilot_block=int(rng.choice([4096, 65536, 100_000])),
               pilot_margin_symbols=int(rng.choice([0, 2000, 20000])),
               max_pilot_samples=int(rng.choice([50_000, 400_000, 1 << 22])),

@@ -14,11 +14,11 @@ iq = synth.generate_device([st], n)[0]
 serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
 demodulate_recording_native(cfg, iq[:3_000_000], carrier_seed="spectrum")          # warm up
 for tile in [int(a) for a in sys.argv[1:]] or [65600, 32832, 16448, 8256]:
-    for pre in (-1, 8192):
+    for pre in (0xFFFFFFFF, 8192 * 3, 16384 * 3):
         torch.cuda.synchronize(); t0 = time.time()
-        soft, rep = demodulate_recording_native(cfg, iq, carrier_seed="spectrum", tile_samples=tile, pre_samples=pre)
+        soft, rep = demodulate_recording_native(cfg, iq, carrier_seed="spectrum", tile_samples=tile, settle_samples=pre)
         torch.cuda.synchronize(); dt = time.time() - t0
         a = agreement(soft.cpu().numpy(), serial); a.pop("windows")
         print(f"tile {tile} pre {pre}: {dt*1e3:.0f} ms (pilot {rep.pilot_seconds*1e3:.0f}, tiles {rep.tiles_seconds*1e3:.0f}), tiles {rep.n_tiles}, "
               f"len {a['len_stitched'] - a['len_serial']:+d}, decisions {a['hard_decisions_equal']:.6f}, within1 {a['within_1lsb']:.4f}, "
-              f"worst {a['worst_window']:.3f}, weak {rep.weak_seams}, jumps {rep.rotation_jumps}", flush=True)
+              f"worst {a['worst_window']:.3f}, weak {rep.weak_seams}, frame misses {rep.frame_misses}, repaired {rep.repaired_tiles}, jumps {rep.rotation_jumps}", flush=True)
