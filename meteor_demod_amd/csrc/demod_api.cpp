@@ -27,6 +27,10 @@ struct mdemod_ctx {
 	DemodStateSoA st;
 	float        *d_ctab;
 	float        *d_lut;
+	float        *d_rrc;       /* plain polyphase table [bank][taps] (filter.c:18-22) for the latency kernel */
+	bool          lat_ok;      /* the latency kernel (one stream per wave) fits this configuration */
+	int           lat_ring, lat_span;
+	size_t        lat_lds;
 	std::vector<void *> allocs;
 
 	void   *pipe;      /* host_pipe.cpp: pinned staging, streams, events of mdemod_process_host (grow only) */
@@ -87,6 +91,17 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	L.ctab = ctx->d_ctab;
 	L.ctab_floats = static_cast<uint32_t>(ctx->tab.ctab.size());
 	L.tanh_lut = ctx->d_lut;
+	/* Few streams: one stream per WAVE (demod_kernel_lat.hip) instead of one per lane.  A lane runs ~0.5 M symbols/s whatever
+	 * the batch, a wave several times that, and below a few thousand streams most of the GPU idles either way.
+	 * MDEMOD_LAT=0 / 1 forces the choice (tests run every golden through both), MDEMOD_LAT_MAX_STREAMS moves the threshold. */
+	{
+		const int force = env_int("MDEMOD_LAT", -1);
+		const bool want = force >= 0 ? force != 0 : ctx->params.n_streams <= static_cast<uint32_t>(env_int("MDEMOD_LAT_MAX_STREAMS", 2048));
+		if (want && ctx->lat_ok) {
+			HIP_TRY(mdemod_launch_demod_lat(L, ctx->params.bps, ctx->d_rrc, ctx->lat_ring, ctx->lat_span, ctx->tab.use_rw ? 1 : 0, ctx->lat_lds, stream));
+			return MDEMOD_OK;
+		}
+	}
 	if (ctx->tab.use_rw)
 		HIP_TRY((ctx->tab.rw_wide || ctx->tab.rw_mid || ctx->tab.rw_far)
 		        ? mdemod_launch_demod_rw_wide(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream)
@@ -221,8 +236,11 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	CREATE_TRY(dev_alloc(ctx, &s.events, n * MDEMOD_MAX_LOCK_EVENTS));
 	CREATE_TRY(dev_alloc(ctx, &ctx->d_ctab, ctx->tab.ctab.size()));
 	CREATE_TRY(dev_alloc(ctx, &ctx->d_lut, 32));
+	CREATE_TRY(dev_alloc(ctx, &ctx->d_rrc, ctx->tab.rrc.size()));
+	ctx->lat_ok = mdemod_lat_geometry(c, static_cast<double>(ctx->tab.osf) / (params->oqpsk ? 2.0 : 1.0), &ctx->lat_ring, &ctx->lat_span, &ctx->lat_lds);
 	{
 		hipError_t e = hipMemcpy(ctx->d_ctab, ctx->tab.ctab.data(), ctx->tab.ctab.size() * sizeof(float), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(ctx->d_rrc, ctx->tab.rrc.data(), ctx->tab.rrc.size() * sizeof(float), hipMemcpyHostToDevice);
 		if (e == hipSuccess) e = hipMemcpy(ctx->d_lut, ctx->tab.tanh_lut, sizeof(ctx->tab.tanh_lut), hipMemcpyHostToDevice);
 		if (e != hipSuccess) { mdemod_destroy(ctx); return MDEMOD_ERR_HIP; }
 	}
@@ -557,6 +575,11 @@ const char *
 mdemod_kernel_name(const mdemod_ctx *ctx)
 {
 	if (!ctx) return "";
+	{
+		const int force = env_int("MDEMOD_LAT", -1);
+		const bool want = force >= 0 ? force != 0 : ctx->params.n_streams <= static_cast<uint32_t>(env_int("MDEMOD_LAT_MAX_STREAMS", 2048));
+		if (want && ctx->lat_ok) return "demod_kernel_lat (one stream per wave: FIR farm + serial scalar stage)";
+	}
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
 	if (ctx->tab.rw_wide) return "demod_kernel_rw (v2 register window, wide: 129 taps, packed)";
 	if (ctx->tab.rw_far) return "demod_kernel_rw (v2 register window, far: 65 taps at up to 30 samples per firing, packed)";

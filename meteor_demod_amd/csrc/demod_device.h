@@ -148,17 +148,30 @@ md_tanh_lut(const float *lut, float v)
 	return lut[(int)c + 16];
 }
 
+/* The same for a value every lane of the wave shares (latency kernel): a locked constellation sits around +-134, so the clamp
+ * decides almost every look-up (lut[31] = 1, lut[0] = -1, checked by mdemod_create) and the LDS round trip is only paid for
+ * the rare small value. */
+__device__ __forceinline__ float
+md_tanh_lut_uniform(const float *lut, float v)
+{
+	float t = (v >= 15.0f) ? 1.0f : -1.0f;
+	if (__any(v > -16.0f && v < 15.0f)) t = md_tanh_lut(lut, v);
+	return t;
+}
+
 struct PllState {
 	float phase, freq, err;
 	int   locked, locked_once, updown;
 };
 
 /* pll.c:100-130,143-151.  Returns 1 when `locked` changed. */
+template <bool UNIFORM = false>
 __device__ __forceinline__ int
 md_pll_update(PllState &p, const float *lut, float alpha, float beta, float fmax,
               float i, float q, int &just_locked_first)
 {
-	const float e = md_tanh_lut(lut, i) * q - md_tanh_lut(lut, q) * i;
+	const float e = UNIFORM ? md_tanh_lut_uniform(lut, i) * q - md_tanh_lut_uniform(lut, q) * i
+	                        : md_tanh_lut(lut, i) * q - md_tanh_lut(lut, q) * i;
 
 	const float ph = p.phase + alpha * e;
 	p.phase = (float)md_wrap_2pi(ph);

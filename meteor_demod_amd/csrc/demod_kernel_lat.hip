@@ -1,0 +1,454 @@
+/*
+ * demod_kernel_lat.hip — latency kernel: ONE stream per wavefront.
+ *
+ * The throughput kernels run one stream per lane: 64 streams per wave, every lane a serial recurrence at ~0.5 M symbols/s.
+ * That is the right shape for 10^5 streams and the wrong one for the serial head of a recording (the "pilot" of
+ * csrc/recording.hip: one stream, the reference's own lock acquisition, demod.c:24-91) or for a few thousand tiles: 63 of 64
+ * lanes idle and the one busy lane pays the full instruction count of the FIR (filter.c:46-65: 65 taps x 4 unfused ops).
+ *
+ * Here the 64 lanes of a wave work on the SAME stream:
+ *
+ *   farm    The FIR of a firing depends only on WHERE the symbol clock fires (input sample, polyphase bank), not on any
+ *           loop state.  Where the next ~21 firings fall is predictable to +-1 interpolated step (the clock word moves by
+ *           2^-12 at most, timing.c:84; the per-symbol correction alpha*e is ~1e-3 of a step).  Lane l computes the FIR of
+ *           firing l/3 at predicted step + (l%3 - 1): 63 complete FIRs for the price of one, each one the reference's
+ *           sequential oldest-first unfused sum.  Samples (converted floats) and the plain polyphase table live in LDS.
+ *   serial  The scalar recurrence (symbol clock, AGC, NCO, timing and Costas updates, lock detector: demod_device.h, the
+ *           same functions as the other kernels) then runs firing by firing with wave-uniform values; the exact clock tells
+ *           which candidate was the right one and its FIR value is fetched with v_readlane.  A firing outside the three
+ *           candidates (transients) computes its FIR on the spot and ends the batch.
+ *
+ * Results are bit-identical to the other kernels and to the reference (tests run every golden through this kernel).
+ * State and history live in the context's own layout, so a context may use this kernel for one call and a throughput
+ * kernel for the next.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "demod_internal.h"
+#include "demod_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kCand = 3;                 /* candidates per firing: predicted step -1, 0, +1 */
+constexpr int kFire = 21;                /* firings per batch: 63 lanes                      */
+constexpr int kMaxChunks = 20;           /* 64-sample chunks prefetched per batch            */
+
+template <int FMT> struct LFmt;
+template <> struct LFmt<16> {
+	typedef uint32_t sample_t;
+	__device__ static __forceinline__ float2 decode(uint32_t w) { return make_float2((float)(int)(int16_t)(w & 0xFFFFu), (float)((int)w >> 16)); }
+};
+template <> struct LFmt<8> {
+	typedef uint16_t sample_t;
+	__device__ static __forceinline__ float2 decode(uint16_t w) { return make_float2((float)((int)(w & 0xFFu) - 128), (float)((int)(w >> 8) - 128)); }
+};
+template <> struct LFmt<32> {
+	typedef float2 sample_t;
+	__device__ static __forceinline__ float2 decode(float2 w) { return w; }
+};
+
+__device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int FMT, int OQPSK>
+__global__ void __launch_bounds__(64)
+demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span, int float_history)
+{
+	typedef LFmt<FMT> F;
+	typedef typename F::sample_t sample_t;
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	const DemodConsts &C = L.c;
+	const int lane = threadIdx.x;
+	const uint32_t stream = blockIdx.x;
+	const int interp = C.interp, taps = C.taps, hpad = C.hpad;
+	const int mask = ring_size - 1;
+
+	float2 *ring = reinterpret_cast<float2 *>(lds);                       /* ring[v & mask] = sample v of (history ++ block) */
+	float *coef = reinterpret_cast<float *>(ring + ring_size);            /* [bank][taps], filter.c:18-22 */
+	float *lut = coef + interp * taps;
+	float2 *obuf = reinterpret_cast<float2 *>(lut + 32);                  /* demodulated symbols of this batch, quantised when flushed */
+
+	for (int i = lane; i < interp * taps; i += 64) coef[i] = rrc[i];
+	if (lane < 32) lut[lane] = L.tanh_lut[lane];
+
+	const int n = (int)(L.n_samples_arr ? L.n_samples_arr[stream] : L.n_samples);
+	const uint64_t off = L.iq_offset ? L.iq_offset[stream] : (uint64_t)stream * L.iq_stride;
+	const sample_t *src = reinterpret_cast<const sample_t *>(L.iq) + off;
+	const int v_end = hpad + n;
+
+	/* ---- state (wave-uniform) ---- */
+	float gain = L.st.agc_gain[stream], bias_re = L.st.agc_bias_re[stream], bias_im = L.st.agc_bias_im[stream];
+	PllState pll;
+	pll.phase = L.st.pll_phase[stream]; pll.freq = L.st.pll_freq[stream]; pll.err = L.st.pll_err[stream];
+	int fl = L.st.flags[stream];
+	pll.locked = fl & 1; pll.locked_once = (fl >> 1) & 1; pll.updown = (fl & 4) ? 1 : -1;
+	int dual_state = (fl >> MDEMOD_FLAG_DUAL_SHIFT) & 3;
+	float t_phase = L.st.t_phase[stream], t_freq = L.st.t_freq[stream], t_prev = L.st.t_prev[stream];
+	float inphase = L.st.inphase[stream];
+	const uint64_t nsym0 = L.st.n_symbols[stream];
+	int overflow = 0, ev_call = 0, first_lock_call = -1, last_v = -1;
+	uint32_t sym_call = 0;                   /* symbols emitted in this call, including the ones still in obuf */
+
+	/* ---- history -> ring ---- */
+	for (int k = lane; k < hpad; k += 64) {
+		float2 h;
+		if (float_history) h = reinterpret_cast<const float2 *>(L.st.hist)[(size_t)stream * hpad + k];
+		else h = F::decode(reinterpret_cast<const sample_t *>(L.st.hist)[(size_t)k * L.n_streams + stream]);
+		ring[k & mask] = h;
+	}
+	int r_hi = hpad;                         /* samples [.., r_hi) are in the ring (wave-uniform) */
+	auto load_chunk = [&](int v0) -> float2 {      /* sample v0 + lane of the virtual stream (zeros past the end) */
+		const int m = v0 + lane - hpad;
+		float2 s = make_float2(0.0f, 0.0f);
+		if (m < n) s = F::decode(src[m]);
+		return s;
+	};
+	/* two spans ahead before the first batch */
+	while (r_hi < v_end && r_hi < hpad + 2 * span) {
+		const float2 s = load_chunk(r_hi);
+		if (r_hi + lane < v_end) ring[(r_hi + lane) & mask] = s;
+		r_hi = min(v_end, r_hi + 64);
+	}
+	__syncthreads();
+
+	int v_cur = hpad - 1, isub = 0;
+	bool done = n == 0;
+	uint32_t out_base = 0; int out_cnt = 0;  /* obuf[0..out_cnt) = symbols out_base.. of this call */
+	const float U = OQPSK ? MD_PI_F : MD_TWO_PI_F;
+	const int k_safe = C.step_safe;
+	const float f_hi = C.step_fmax;
+	const uint32_t magic = C.interp_magic;
+	const uint64_t guard64 = 4ull * (uint64_t)(n + hpad) * (uint64_t)interp + 4096ull;
+	uint32_t guard = guard64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)guard64;
+	const int n_chunks = min(kMaxChunks, (span + 63) / 64 + 1);
+	int since_emit = 1 << 28;                /* interpolated steps since the last emitted symbol (same-sample rule below) */
+
+	/* position after `w - isub_at_origin` steps from (v_org, isub_org): samples pushed = ceil(w / interp) - (isub_org > 0) */
+	auto locate = [&](int v_org, int isub_org, int steps, int &v, int &isub_new) {
+		const uint32_t w = (uint32_t)(isub_org + steps);
+		const uint32_t q = (interp == 1) ? w : __umulhi(w, magic);
+		isub_new = (int)(w - q * (uint32_t)interp);
+		v = v_org + (int)q + (isub_new > 0 ? 1 : 0) - (isub_org > 0 ? 1 : 0);
+	};
+	/* FIR of a firing on sample v, bank b, by every lane at once (filter.c:55-62: sequential, oldest first, unfused) */
+	auto fir_here = [&](int v, int bank) -> cf32 {
+		while (r_hi <= v) {                                                  /* beyond what has been loaded: extend the ring first */
+			const float2 s = load_chunk(r_hi);
+			if (r_hi + lane < v_end) ring[(r_hi + lane) & mask] = s;
+			r_hi = min(v_end, r_hi + 64);
+			__syncthreads();
+		}
+		int p = (v - taps + 1) & mask;
+		const float *h = coef + bank * taps;
+		float ar = 0.0f, ai = 0.0f;
+		for (int k = 0; k < taps; k++) {
+			const float2 x = ring[p];
+			const float hk = h[k];
+			ar = ar + x.x * hk;
+			ai = ai + x.y * hk;
+			p = (p + 1) & mask;
+		}
+		cf32 y; y.re = ar; y.im = ai;
+		return y;
+	};
+	/* everything after the FIR: agc.c:13-25, pll.c:51-97, demod.c:33-47 / 62-90, timing.c:60-87, pll.c:100-130, main.c:305-306.
+	 * `same_sample`: this symbol fired on the input sample the previous one fired on. */
+	auto scalar_stage = [&](cf32 y, bool same_sample) {
+		y = md_agc(y, gain, bias_re, bias_im);
+		/* fast_sin(-phase) and fast_cos(-phase) = fast_sin((float)(-phase + pi/2)) (sincos.c:37-40): the same instructions on two
+		   arguments, lane 1 takes the cosine's */
+		const float a0 = -pll.phase;
+		const float a1 = (float)((double)a0 + MD_HALF_PI_D);
+		const float sc = md_fast_sin(lane == 1 ? a1 : a0);
+		const float sn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), 0));
+		const float cs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), 1));
+		bool emit = true;
+		float out_re, out_im;
+		if (OQPSK) {
+			if (dual_state == 1) { inphase = y.re * cs - y.im * sn; emit = false; }   /* demod.c:66-71 */
+			out_re = inphase;
+			out_im = y.re * sn + y.im * cs;                                          /* demod.c:76    */
+			dual_state = (dual_state % 2) + 1;                                       /* timing.c:52   */
+		} else {
+			out_re = y.re * cs - y.im * sn;
+			out_im = y.re * sn + y.im * cs;
+		}
+		md_nco_advance(pll.phase, pll.freq);
+		if (emit) {
+			/* only the LAST symbol fired inside one input sample survives (demod.c:33-47: `*sample` and `ret` are overwritten) */
+			if (same_sample) {
+				sym_call--;
+				if (out_cnt > 0) out_cnt--; else out_base--;
+			}
+			md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);
+			int first = 0;
+			const int changed = md_pll_update<true>(pll, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
+			if (first) first_lock_call = (int)sym_call;
+			if (changed) {
+				if (ev_call < MDEMOD_MAX_LOCK_EVENTS && lane == 0) {
+					mdemod_lock_event ev;
+					ev.symbol = nsym0 + sym_call; ev.locked = pll.locked; ev.pad = 0;
+					L.st.events[(size_t)stream * MDEMOD_MAX_LOCK_EVENTS + ev_call] = ev;
+				}
+				ev_call++;
+			}
+			obuf[out_cnt] = make_float2(out_re, out_im);                 /* every lane, same value: no exec-mask detour */
+			out_cnt++;
+			sym_call++;
+			since_emit = 0;
+		}
+	};
+	auto flush = [&]() {
+		__syncthreads();
+		if (out_cnt > 0) {
+			if (lane < out_cnt) {
+				const uint32_t pos = out_base + (uint32_t)lane;
+				const float2 o = obuf[lane];                              /* main.c:305-306, one symbol per lane */
+				const uint32_t sym = (uint32_t)(md_quantise(o.x) & 0xFF) | ((uint32_t)(md_quantise(o.y) & 0xFF) << 8);
+				if (pos < L.soft_cap) reinterpret_cast<uint16_t *>(L.soft + (size_t)stream * L.soft_stride * 2)[pos] = (uint16_t)sym;
+			}
+			if (out_base + (uint32_t)out_cnt > L.soft_cap) overflow = 1;
+			out_base += (uint32_t)out_cnt;
+			out_cnt = 0;
+		}
+		__syncthreads();
+	};
+	/* One firing the careful way (timing.c:32-57 step by step, FIR on the spot): the last samples of a block, and any firing the
+	 * prediction did not cover.  Returns false when the block ends before the clock fires. */
+	auto careful_firing = [&]() -> bool {
+		const float thr = OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F;
+		int fire_sub = 0, v_before = v_cur;
+		bool fired = false;
+		while (!fired && guard) {
+			guard--;
+			if (isub == 0) {
+				if (v_cur + 1 >= v_end) { done = true; return false; }
+				v_cur++;
+			}
+			t_phase = t_phase + t_freq;
+			fire_sub = isub;
+			isub = (isub + 1 == interp) ? 0 : isub + 1;
+			since_emit++;
+			if (t_phase >= thr) fired = true;
+		}
+		if (!fired) { done = true; return false; }
+		(void)v_before;
+		const cf32 y = fir_here(v_cur, interp - 1 - fire_sub);
+		const bool same = (v_cur == last_v);
+		scalar_stage(y, same && (!OQPSK || dual_state == 2));
+		if (since_emit == 0) last_v = v_cur;
+		return true;
+	};
+
+	while (!done && guard) {
+		/* ---- the tail of the block (and blocks shorter than a batch): firing by firing ---- */
+		if (v_end - 1 - v_cur <= span + 8) {
+			for (int j = 0; j < kFire && !done && guard; j++) careful_firing();
+			flush();
+			continue;
+		}
+		/* ---- (0) prefetch: the chunks that extend the ring by one span, committed after the farm ---- */
+		float2 pend[kMaxChunks];
+		const int r_hi0 = r_hi;
+		const int v0 = v_cur, isub0 = isub;
+#pragma unroll
+		for (int c = 0; c < kMaxChunks; c++)
+			if (c < n_chunks && r_hi0 + 64 * c < v_end && r_hi0 + 64 * c < v0 + 1 + 2 * span) pend[c] = load_chunk(r_hi0 + 64 * c);
+
+		/* ---- (1) farm: lane -> (firing j, candidate c); lane j also keeps the prediction of firing j for the serial part ---- */
+		t_phase = uni(t_phase); t_freq = uni(t_freq);                    /* wave-uniform by construction: pin them to scalars */
+		const float phase0 = t_phase, inv_f0 = 1.0f / t_freq;
+		const int k0 = OQPSK ? dual_state : 1;                         /* index of the first threshold ahead, in units of U */
+		auto predict = [&](int j) -> int {                             /* steps from the batch start to firing j (a prediction: +-1) */
+			const int s = (int)ceilf(((float)(k0 + j) * U - phase0) * inv_f0);
+			return s < 1 ? 1 : s;
+		};
+		const int pred_mine = predict(lane);
+		float yr = 0.0f, yi = 0.0f;
+		bool cand_ok = false;
+		{
+			const int j = lane / kCand, c = lane % kCand - 1;
+			const int steps = predict(j) + c;
+			if (lane < kCand * kFire && steps >= 1) {
+				int v, isub_new;
+				locate(v0, isub0, steps, v, isub_new);
+				const int fire_sub = isub_new == 0 ? interp - 1 : isub_new - 1;
+				const int bank = interp - 1 - fire_sub;                    /* filter.c:52 */
+				if (v < r_hi) {
+					cand_ok = true;
+					int p = (v - taps + 1) & mask;
+					const float *h = coef + bank * taps;
+					float ar = 0.0f, ai = 0.0f;
+					for (int k = 0; k < taps; k++) {
+						const float2 x = ring[p];
+						const float hk = h[k];
+						ar = ar + x.x * hk;
+						ai = ai + x.y * hk;
+						p = (p + 1) & mask;
+					}
+					yr = ar; yi = ai;
+				}
+			}
+		}
+		const uint64_t ok_mask = __ballot(cand_ok);
+		/* steps that may be taken blindly before the block's end needs looking at (timing.c:32-38 stops pushing samples there) */
+		const int steps_limit = (v_end - 1 - v0) * interp - isub0 - (k_safe + 4) - interp;
+
+		/* ---- (2) serial: firing by firing, wave-uniform; sample positions are only worked out when they matter ---- */
+		int steps_done = 0;                                              /* interpolated steps since the batch start */
+		int emit_steps = -1;                                             /* steps_done at the last symbol emitted in this batch */
+		auto sample_of_last_emit = [&]() -> int {
+			if (emit_steps < 0) return last_v;                           /* emitted in an earlier batch */
+			int v, is;
+			locate(v0, isub0, emit_steps, v, is);
+			return v;
+		};
+		for (int j = 0; j < kFire; j++) {
+			const float thr = OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F;
+			const bool fast = (t_phase < thr - (float)k_safe * f_hi - 1e-3f) && (steps_done < steps_limit);
+			bool regular = false;
+			int m = 0;
+			float ph = t_phase;
+			if (fast) {
+				float p = t_phase;
+				if (k_safe == 14) { for (int k = 0; k < 14; k++) p = p + t_freq; }       /* QPSK 72k @ 230 kS/s, -O 5 */
+				else if (k_safe == 6) { for (int k = 0; k < 6; k++) p = p + t_freq; }     /* OQPSK 80k @ 230 kS/s */
+				else { for (int k = 0; k < k_safe; k++) p = p + t_freq; }
+				const float p1 = p + t_freq, p2 = p1 + t_freq, p3 = p2 + t_freq, p4 = p3 + t_freq;
+				const bool c1 = p1 >= thr, c2 = p2 >= thr, c3 = p3 >= thr, c4 = p4 >= thr;
+				m = k_safe + 1 + (c1 ? 0 : 1) + (c2 ? 0 : 1) + (c3 ? 0 : 1);
+				ph = c3 ? p3 : p4;
+				ph = c2 ? p2 : ph;
+				ph = c1 ? p1 : ph;
+				regular = c4;
+			}
+			const int pj = __builtin_amdgcn_readlane(pred_mine, j);
+			const int cidx = steps_done + m - pj;                         /* -1, 0, +1 when the prediction holds */
+			const int idx = kCand * j + cidx + 1;
+			const bool hit = regular && cidx >= -1 && cidx <= 1 && ((ok_mask >> idx) & 1ull);
+			if (!hit) {
+				/* irregular firing (clock outside the blind window, block end near, candidate missing): put the position on the
+				   table and do this one the careful way; the prediction is stale after it, so the batch ends */
+				last_v = sample_of_last_emit();
+				locate(v0, isub0, steps_done, v_cur, isub);
+				careful_firing();
+				steps_done = -1;
+				break;
+			}
+			t_phase = ph;
+			steps_done += m;
+			since_emit += m;
+			guard = guard ? guard - 1 : 0;
+			cf32 y;
+			y.re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yr), idx));
+			y.im = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yi), idx));
+			/* two firings on one input sample have fewer than interp steps between them: only then look at the positions */
+			const bool emits = !OQPSK || dual_state == 2;
+			bool same = false;
+			if (emits && since_emit < interp) {
+				int v, is;
+				locate(v0, isub0, steps_done, v, is);
+				same = (v == sample_of_last_emit());
+			}
+			scalar_stage(y, same);
+			if (emits) emit_steps = steps_done;
+		}
+		if (steps_done >= 0) { last_v = sample_of_last_emit(); locate(v0, isub0, steps_done, v_cur, isub); }
+
+		/* ---- (3) flush the batch's symbols: lane i writes symbol out_base + i ---- */
+		flush();
+		/* ---- (4) commit the prefetched chunks ---- */
+#pragma unroll
+		for (int c = 0; c < kMaxChunks; c++)
+			if (c < n_chunks && r_hi0 + 64 * c < v_end && r_hi0 + 64 * c < v0 + 1 + 2 * span && r_hi0 + 64 * c >= r_hi) {
+				if (r_hi0 + 64 * c + lane < v_end) ring[(r_hi0 + 64 * c + lane) & mask] = pend[c];
+				r_hi = min(v_end, r_hi0 + 64 * c + 64);
+			}
+		__syncthreads();
+	}
+	if (guard == 0 && !done) overflow = 1;                                /* watchdog fired: reported as overflow */
+
+	/* ---- store state ---- */
+	if (lane == 0) {
+		L.st.agc_gain[stream] = gain; L.st.agc_bias_re[stream] = bias_re; L.st.agc_bias_im[stream] = bias_im;
+		L.st.pll_phase[stream] = pll.phase; L.st.pll_freq[stream] = pll.freq; L.st.pll_err[stream] = pll.err;
+		L.st.flags[stream] = (pll.locked ? 1 : 0) | (pll.locked_once ? 2 : 0) | (pll.updown > 0 ? 4 : 0) | (dual_state << MDEMOD_FLAG_DUAL_SHIFT);
+		L.st.t_phase[stream] = t_phase; L.st.t_freq[stream] = t_freq; L.st.t_prev[stream] = t_prev;
+		L.st.inphase[stream] = inphase;
+		L.st.n_samples[stream] += (uint64_t)n;
+		L.st.n_symbols[stream] = nsym0 + sym_call;
+		if (first_lock_call >= 0) L.st.first_lock[stream] = (int64_t)(nsym0 + (uint32_t)first_lock_call);
+		L.st.sym_this_call[stream] = sym_call;
+		L.st.ev_this_call[stream] = (uint32_t)ev_call;
+		L.st.overflow[stream] = overflow;
+	}
+	/* history := last hpad samples of (old history ++ block), in the context's layout; ascending k is in-place safe */
+	if (float_history) {
+		float2 *hist = reinterpret_cast<float2 *>(L.st.hist) + (size_t)stream * hpad;
+		float2 keep[4];                                                   /* hpad <= 256: four rounds of 64 lanes */
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int k = r * 64 + lane, idx = n + k;
+			if (k < hpad) keep[r] = idx < hpad ? hist[idx] : F::decode(src[idx - hpad]);
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < 4; r++) { const int k = r * 64 + lane; if (k < hpad) hist[k] = keep[r]; }
+	} else {
+		sample_t *hist = reinterpret_cast<sample_t *>(L.st.hist);
+		sample_t keep[4];
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int k = r * 64 + lane, idx = n + k;
+			if (k < hpad) keep[r] = idx < hpad ? hist[(size_t)idx * L.n_streams + stream] : src[idx - hpad];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < 4; r++) { const int k = r * 64 + lane; if (k < hpad) hist[(size_t)k * L.n_streams + stream] = keep[r]; }
+	}
+}
+
+template <int FMT>
+hipError_t
+launch_lat(const DemodLaunch &L, const float *rrc, int ring_size, int span, int float_history, size_t lds_bytes, hipStream_t stream)
+{
+	auto kq = demod_kernel_lat<FMT, 0>;
+	auto ko = demod_kernel_lat<FMT, 1>;
+	auto kfn = L.c.oqpsk ? ko : kq;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(kfn, dim3(L.n_streams), dim3(64), lds_bytes, stream, L, rrc, ring_size, span, float_history);
+	return hipGetLastError();
+}
+
+} /* namespace */
+
+/* Geometry of the latency kernel for a configuration: samples one batch of kFire firings can advance (+ slack), the LDS ring
+ * that holds history + two such spans, and the LDS bytes.  Returns false when the configuration does not fit (huge tables). */
+bool
+mdemod_lat_geometry(const DemodConsts &c, double samples_per_firing, int *ring_size, int *span, size_t *lds_bytes)
+{
+	if (c.hpad > 256) return false;
+	const int sp = static_cast<int>(kFire * samples_per_firing * 1.01) + 8;
+	if ((sp + 63) / 64 + 1 > kMaxChunks) return false;
+	int ring = 256;
+	while (ring < c.hpad + 3 * sp + 128) ring *= 2;
+	const size_t bytes = static_cast<size_t>(ring) * 8 + (static_cast<size_t>(c.interp) * c.taps + 32) * 4 + 64 * 8 + 64;
+	if (bytes > 64 * 1024) return false;
+	*ring_size = ring; *span = sp; *lds_bytes = bytes;
+	return true;
+}
+
+hipError_t
+mdemod_launch_demod_lat(const DemodLaunch &L, int fmt, const float *rrc_dev, int ring_size, int span, int float_history, size_t lds_bytes, hipStream_t stream)
+{
+	switch (fmt) {
+	case 16: return launch_lat<16>(L, rrc_dev, ring_size, span, float_history, lds_bytes, stream);
+	case 8:  return launch_lat<8>(L, rrc_dev, ring_size, span, float_history, lds_bytes, stream);
+	case 32: return launch_lat<32>(L, rrc_dev, ring_size, span, float_history, lds_bytes, stream);
+	default: return hipErrorInvalidValue;
+	}
+}

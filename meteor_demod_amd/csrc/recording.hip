@@ -281,8 +281,15 @@ carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, 
 	if (tid == 0) {
 		const int k = redi[0];
 		const float a = sqrtf(mag(k - 1)), b = sqrtf(mag(k)), c = sqrtf(mag(k + 1));
-		const float den = a - 2.0f * b + c;
-		const float delta = den != 0.0f ? 0.5f * (a - c) / den : 0.0f;
+		/* Hann-windowed line between two bins: the ratio of the two largest magnitudes gives its position (Grandke); a
+		   parabola through three magnitudes is biased by up to 0.03 bin here, which is 0.1 rad over a tile of dead reckoning */
+		float delta = 0.0f;
+		if (b > 0.0f) {
+			const float al = (c >= a ? c : a) / b;
+			delta = (2.0f * al - 1.0f) / (al + 1.0f);
+			delta = fminf(fmaxf(delta, 0.0f), 0.5f);
+			if (c < a) delta = -delta;
+		}
 		freq_out[blockIdx.x] = ((float)k + delta) * hz_per_bin_over4 * rad_per_hz;
 		quality_out[blockIdx.x] = b / (red[2][0] / (float)(2 * kmax + 1) + 1e-30f);
 	}
@@ -632,7 +639,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		/* as short as fills the lanes (latency of a small recording is the samples ONE lane runs: lead + tile), as long as the
 		   lead stays a small part of the work once the GPU is full; kept off powers of two (lanes read at base + l * tile) */
 		const double rest_sym = static_cast<double>(n_samples - P) / osf;
-		const double b_sym = std::min(41072.0, std::max(8192.0, rest_sym / 65536.0));
+		const double b_sym = std::min(41072.0, std::max(8192.0, rest_sym / 131072.0));
 		o.tile_samples = std::max<uint32_t>(4096, static_cast<uint32_t>(b_sym * osf) / 64 * 64);
 		if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
 	}
@@ -713,6 +720,23 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 				for (size_t g : good) { gx.push_back(centre[g]); gv.push_back(fh[g]); }
 				for (size_t i = 0; i < T; i++)
 					fbar[i] = qh[i] >= min_quality ? static_cast<double>(fh[i]) : interp_at(gx, gv, std::min(std::max(centre[i], gx.front()), gx.back()));
+			}
+			/* one estimate far off the line through its neighbours (a spur, a burst: 1 in 1e5 windows) would put every later tile
+			   in the wrong frame: the carrier is smooth, the neighbours decide */
+			if (T >= 5) {
+				std::vector<double> fixed = fbar;
+				for (size_t i = 1; i + 1 < T; i++) {
+					const double w = (centre[i] - centre[i - 1]) / (centre[i + 1] - centre[i - 1]);
+					const double pred = fbar[i - 1] + (fbar[i + 1] - fbar[i - 1]) * w;
+					if (std::fabs(fbar[i] - pred) > 6e-6 / nco) {
+						/* which of the three is the odd one?  the one whose own neighbours agree with each other without it */
+						const size_t a = i >= 2 ? i - 2 : i - 1, b = std::min(T - 1, i + 2);
+						const double wa = (centre[i] - centre[a]) / (centre[b] - centre[a]);
+						const double pred2 = fbar[a] + (fbar[b] - fbar[a]) * wa;
+						if (std::fabs(pred - pred2) < std::fabs(fbar[i] - pred2)) fixed[i] = pred;
+					}
+				}
+				fbar = fixed;
 			}
 			for (size_t i = 0; i < T; i++) {
 				const size_t lo = i ? i - 1 : 0, hi = std::min(T - 1, i + 1);

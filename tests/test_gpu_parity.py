@@ -24,9 +24,12 @@ def _torch():
 
 
 KERNEL_VARIANTS = {
-    "v2-float": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0"},     # default: register window, converted floats
-    "v2-packed": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "1"},    # register window, raw samples (3 waves/SIMD)
-    "v1-ring": {"MDEMOD_KERNEL": "v1", "MDEMOD_RW_PACKED": "1"},    # LDS ring (generic fallback, > 65 taps)
+    # MDEMOD_LAT=0: contexts with few streams would otherwise pick the latency kernel (one stream per wave) by themselves
+    "v2-float": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "0"},     # register window, converted floats
+    "v2-packed": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "1", "MDEMOD_LAT": "0"},    # register window, raw samples (3 waves/SIMD)
+    "v1-ring": {"MDEMOD_KERNEL": "v1", "MDEMOD_RW_PACKED": "1", "MDEMOD_LAT": "0"},    # LDS ring (generic fallback, > 65 taps)
+    "lat": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "1"},          # one stream per wave, v2 state layout
+    "lat-v1-state": {"MDEMOD_KERNEL": "v1", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "1"},   # ... on the ring kernel's state layout
 }
 
 
@@ -652,7 +655,7 @@ def _check_cfg_against_oracle(cfg):
         assert all(s.overflow == 0 for s in d.status())
 
 
-def test_float_input_ring_kernel_ignores_stale_lds(gpu_device):
+def test_float_input_ring_kernel_ignores_stale_lds(gpu_device, monkeypatch):
     """Float input on the LDS-ring kernel: ring slots outside a lane's window are multiplied by zero coefficients, so they
     must never hold stale NaN bits (0 * NaN = NaN).  A first context fills the CUs' LDS with NaN samples."""
     torch = _torch()
@@ -662,6 +665,7 @@ def test_float_input_ring_kernel_ignores_stale_lds(gpu_device):
         torch.cuda.synchronize()
     streams = [synth.make_stream(40 + i, cfg.samplerate, cfg.symrate, f0_hz=300.0, esn0_db=15.0, rms=0.7, oqpsk=True, fmt=32) for i in range(6)]
     iqs = [synth.generate_host(s, 9051) for s in streams]
+    monkeypatch.setenv("MDEMOD_LAT", "0")
     with Demodulator(cfg, 29) as d:
         assert "ring" in d.kernel_name
         got = [[] for _ in range(29)]
