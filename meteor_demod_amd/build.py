@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
     units = [(CSRC / "demod_kernel.hip", "demod_kernel", []),
              (rw, "demod_kernel_rw_std", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
              (rw, "demod_kernel_rw_wide", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=2"]),
-             (CSRC / "demod_kernel_lat.hip", "demod_kernel_lat", ["-fno-slp-vectorize"]),
+             (CSRC / "demod_kernel_lat.hip", "demod_kernel_lat", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
              (CSRC / "demod_aux.hip", "demod_aux", []), (CSRC / "recording.hip", "recording", []),
              (CSRC / "demod_api.cpp", "demod_api", []), (CSRC / "host_pipe.cpp", "host_pipe", []),
              (CSRC / "demod_host.cpp", "demod_host", [])]

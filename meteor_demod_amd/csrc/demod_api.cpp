@@ -193,6 +193,7 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	auto lds_need = [&](int threads) {
 		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
 		       (ctx->tab.use_rw ? static_cast<size_t>((ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
+		                          + static_cast<size_t>(ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) * 64     /* soft-symbol staging: a 32-symbol ring (4 x 16 B) per thread */
 		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes);
 	};
 	if (ctx->tab.use_rw && lds_need(ctx->block_threads) > 160 * 1024) {

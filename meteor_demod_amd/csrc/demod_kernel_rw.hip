@@ -57,6 +57,9 @@
 #ifndef MDEMOD_RW_SETPRIO
 #define MDEMOD_RW_SETPRIO 1           /* the scalar stage of a firing runs at raised wave priority, see the main loop */
 #endif
+#ifndef MDEMOD_RW_STAGE
+#define MDEMOD_RW_STAGE 2             /* soft symbols leave in 64-byte runs: 2 = a 32-symbol ring per lane in LDS; 1 = groups of 8 collected in registers, three of them staged in LDS; 0 = 16-byte stores */
+#endif
 #ifndef MDEMOD_RW_PREFETCH
 #define MDEMOD_RW_PREFETCH 2          /* FIR coefficient prefetch distance (chunks) of the float std variant */
 #endif
@@ -309,6 +312,8 @@ demod_kernel_rw(const DemodLaunch L)
 	static_assert(S_COUNT == MDEMOD_RW_STATE_SLOTS, "host LDS sizing");
 	float *sl = lut + 32 + (threadIdx.x >> 6) * (S_COUNT * 64) + (threadIdx.x & 63);
 	int *sli = reinterpret_cast<int *>(sl);
+	/* soft-symbol staging: 4 groups of 8 symbols per lane, [group][thread] x 16 B (conflict free), written out as one 64-byte run */
+	uint4 *stage = reinterpret_cast<uint4 *>(lut + 32 + (G::BLOCK / 64) * (S_COUNT * 64)) + threadIdx.x;
 
 	const DemodConsts &C = L.c;
 	const uint32_t stream = blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,6 +579,27 @@ demod_kernel_rw(const DemodLaunch L)
 				}
 				}
 				const uint32_t sym = (uint32_t)(md_quantise(out_re) & 0xFF) | ((uint32_t)(md_quantise(out_im) & 0xFF) << 8);
+				if (MDEMOD_RW_STAGE == 2) {
+					/* symbol k of the stream lives at ring slot k & 31: group (k >> 3) & 3 of 16 bytes, [group][thread] so that the
+					 * 16-byte reads of the flush are conflict free.  A replaced symbol (sym_call was decremented above) lands on
+					 * its predecessor's slot; if that one had completed a run, the run is simply written again. */
+					const uint32_t k = sym_call & 31u;
+					reinterpret_cast<uint16_t *>(stage + (k >> 3) * G::BLOCK)[k & 7u] = (uint16_t)sym;
+					sym_call++;
+					if ((sym_call & 31u) == 0) {
+						int8_t *soft_out = L.soft + (size_t)stream * L.soft_stride * 2;
+						if (sym_call <= L.soft_cap) {
+							const uint4 a = stage[0], b = stage[G::BLOCK], c = stage[2 * G::BLOCK], d = stage[3 * G::BLOCK];
+							uint4 *dst = reinterpret_cast<uint4 *>(soft_out + 2 * (size_t)(sym_call - 32));
+							dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+						} else {
+							fl |= 8;
+							for (uint32_t i = 0; i < 32 && sym_call - 32 + i < L.soft_cap; i++)
+								*reinterpret_cast<uint16_t *>(soft_out + 2 * (size_t)(sym_call - 32 + i)) =
+								    reinterpret_cast<const uint16_t *>(stage + (i >> 3) * G::BLOCK)[i & 7u];
+						}
+					}
+				} else {
 				if (any_again && again) {
 					ob3 = (ob3 & 0xFFFFu) | (sym << 16);                    /* replace the newest buffered symbol */
 				} else {
@@ -586,7 +612,20 @@ demod_kernel_rw(const DemodLaunch L)
 				if ((sym_call & 7u) == 0) {
 					const uint32_t sb = sym_call - 8;
 					int8_t *soft_out = L.soft + (size_t)stream * L.soft_stride * 2;
-					if (sym_call <= L.soft_cap) {
+					if (MDEMOD_RW_STAGE == 1 && sym_call <= L.soft_cap) {
+						/* A 16-byte store per lane every 8 symbols is a quarter of a 64-byte request and the line has left the L2 by
+						 * the time the lane comes back to it (measured: 2.2 bytes written to HBM per byte of soft symbols).  Three
+						 * groups wait in LDS, the fourth goes out with them: four back-to-back stores, one full 64-byte run. */
+						uint4 v; v.x = ob0; v.y = ob1; v.z = ob2; v.w = ob3;
+						const uint32_t g = (sb >> 3) & 3u;
+						if (g != 3u) {
+							stage[g * G::BLOCK] = v;
+						} else {
+							const uint4 a = stage[0], b = stage[G::BLOCK], c = stage[2 * G::BLOCK];
+							uint4 *dst = reinterpret_cast<uint4 *>(soft_out + 2 * (size_t)(sb - 24));
+							dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = v;
+						}
+					} else if (sym_call <= L.soft_cap) {
 						uint4 v; v.x = ob0; v.y = ob1; v.z = ob2; v.w = ob3;
 						__builtin_memcpy(soft_out + 2 * (size_t)sb, &v, 16);
 					} else {
@@ -596,6 +635,7 @@ demod_kernel_rw(const DemodLaunch L)
 							*reinterpret_cast<uint16_t *>(soft_out + 2 * (size_t)(sb + i)) =
 							    (uint16_t)(w4[i >> 1] >> ((i & 1) * 16));
 					}
+				}
 				}
 			}
 			if (REGSTATE) { r_phase = pll.phase; r_freq = pll.freq; }
@@ -615,8 +655,38 @@ demod_kernel_rw(const DemodLaunch L)
 	int8_t *soft_e = L.soft + (size_t)stream_e * L.soft_stride * 2;
 	int overflow = (sli[S_FLAGS * 64] >> 3) & 1;
 
-	/* ---- flush the partial group of soft symbols ---- */
-	if (valid) {
+	/* ---- flush the staged groups, then the partial group of soft symbols ---- */
+	if (valid && MDEMOD_RW_STAGE == 2) {
+		const uint32_t r = sym_call & 31u, sb = sym_call - r;              /* symbols still in the ring: complete groups as 16 bytes, the rest singly */
+		for (uint32_t g = 0; g < (r >> 3); g++) {
+			if (sb + 8 * g + 8 <= L.soft_cap) *reinterpret_cast<uint4 *>(soft_e + 2 * (size_t)(sb + 8 * g)) = stage[g * G::BLOCK];
+			else for (uint32_t i = 0; i < 8; i++) {
+				if (sb + 8 * g + i < L.soft_cap) *reinterpret_cast<uint16_t *>(soft_e + 2 * (size_t)(sb + 8 * g + i)) = reinterpret_cast<const uint16_t *>(stage + g * G::BLOCK)[i];
+				else overflow = 1;
+			}
+		}
+		for (uint32_t i = r & ~7u; i < r; i++) {
+			if (sb + i < L.soft_cap) *reinterpret_cast<uint16_t *>(soft_e + 2 * (size_t)(sb + i)) = reinterpret_cast<const uint16_t *>(stage + (i >> 3) * G::BLOCK)[i & 7u];
+			else overflow = 1;
+		}
+	}
+	if (valid && MDEMOD_RW_STAGE == 1) {
+		const uint32_t full = sym_call >> 3;                               /* complete groups of 8 so far */
+		const uint32_t pending = full & 3u;                                /* ... of which this many still sit in LDS */
+		for (uint32_t g = 0; g < pending; g++) {
+			const uint32_t sb = (full - pending + g) * 8;
+			if (sb + 8 <= L.soft_cap) *reinterpret_cast<uint4 *>(soft_e + 2 * (size_t)sb) = stage[g * G::BLOCK];
+			else {
+				const uint4 v = stage[g * G::BLOCK];
+				const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+				for (uint32_t i = 0; i < 8; i++) {
+					if (sb + i < L.soft_cap) *reinterpret_cast<uint16_t *>(soft_e + 2 * (size_t)(sb + i)) = (uint16_t)(w4[i >> 1] >> ((i & 1) * 16));
+					else overflow = 1;
+				}
+			}
+		}
+	}
+	if (valid && MDEMOD_RW_STAGE != 2) {
 		const uint32_t r = sym_call & 7u;
 		const uint32_t sb = sym_call - r;
 		const uint32_t w4[4] = { ob0, ob1, ob2, ob3 };

@@ -1,0 +1,14 @@
+# rocprofv3 passes behind profiles/r02_*.md: kernel stats and PMC (separate passes, no trace domains with --pmc)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/${1:-r02}; mkdir -p $O
+CFGS=${2:-"c1 c3 c4"}
+for c in $CFGS; do
+  B="python3 bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-check"
+  rocprofv3 --kernel-trace --stats -d $O/${c}_stats -o x -- $B > $O/${c}_stats.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE -d $O/${c}_FETCH -o x -- $B > $O/${c}_F.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $O/${c}_WRITE -o x -- $B > $O/${c}_W.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/${c}_sq -o x -- $B > $O/${c}_sq.log 2>&1
+  for d in stats FETCH WRITE sq; do python tools/rocpd_summary.py $(find $O/${c}_$d -name "*.db" | head -1) > $O/${c}_$d.md 2>&1; done
+  rm -rf $O/${c}_stats $O/${c}_FETCH $O/${c}_WRITE $O/${c}_sq
+done
+grep -h "demod_kernel_rw" $O/*.md | cut -c1-200 | head -60
