@@ -53,7 +53,9 @@ template <> struct LFmt<32> {
 __device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int FMT, int OQPSK>
+/* KSAFE: the number of blind symbol-clock steps when it is one of the two everyday values (14: QPSK 72k at 230 kS/s -O 5; 6: OQPSK
+ * 80k), so that the adds are straight-line code; 0 = read it from the launch constants. */
+template <int FMT, int OQPSK, int KSAFE>
 __global__ void __launch_bounds__(64)
 demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span, int float_history)
 {
@@ -118,7 +120,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 	bool done = n == 0;
 	uint32_t out_base = 0; int out_cnt = 0;  /* obuf[0..out_cnt) = symbols out_base.. of this call */
 	const float U = OQPSK ? MD_PI_F : MD_TWO_PI_F;
-	const int k_safe = C.step_safe;
+	const int k_safe = KSAFE ? KSAFE : C.step_safe;
 	const float f_hi = C.step_fmax;
 	const uint32_t magic = C.interp_magic;
 	const uint64_t guard64 = 4ull * (uint64_t)(n + hpad) * (uint64_t)interp + 4096ull;
@@ -300,6 +302,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		/* ---- (2) serial: firing by firing, wave-uniform; sample positions are only worked out when they matter ---- */
 		int steps_done = 0;                                              /* interpolated steps since the batch start */
 		int emit_steps = -1;                                             /* steps_done at the last symbol emitted in this batch */
+		bool miss = false;
 		auto sample_of_last_emit = [&]() -> int {
 			if (emit_steps < 0) return last_v;                           /* emitted in an earlier batch */
 			int v, is;
@@ -314,9 +317,12 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 			float ph = t_phase;
 			if (fast) {
 				float p = t_phase;
-				if (k_safe == 14) { for (int k = 0; k < 14; k++) p = p + t_freq; }       /* QPSK 72k @ 230 kS/s, -O 5 */
-				else if (k_safe == 6) { for (int k = 0; k < 6; k++) p = p + t_freq; }     /* OQPSK 80k @ 230 kS/s */
-				else { for (int k = 0; k < k_safe; k++) p = p + t_freq; }
+				if (KSAFE) {
+#pragma unroll
+					for (int k = 0; k < KSAFE; k++) p = p + t_freq;
+				} else {
+					for (int k = 0; k < k_safe; k++) p = p + t_freq;
+				}
 				const float p1 = p + t_freq, p2 = p1 + t_freq, p3 = p2 + t_freq, p4 = p3 + t_freq;
 				const bool c1 = p1 >= thr, c2 = p2 >= thr, c3 = p3 >= thr, c4 = p4 >= thr;
 				m = k_safe + 1 + (c1 ? 0 : 1) + (c2 ? 0 : 1) + (c3 ? 0 : 1);
@@ -329,15 +335,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 			const int cidx = steps_done + m - pj;                         /* -1, 0, +1 when the prediction holds */
 			const int idx = kCand * j + cidx + 1;
 			const bool hit = regular && cidx >= -1 && cidx <= 1 && ((ok_mask >> idx) & 1ull);
-			if (!hit) {
-				/* irregular firing (clock outside the blind window, block end near, candidate missing): put the position on the
-				   table and do this one the careful way; the prediction is stale after it, so the batch ends */
-				last_v = sample_of_last_emit();
-				locate(v0, isub0, steps_done, v_cur, isub);
-				careful_firing();
-				steps_done = -1;
-				break;
-			}
+			if (!hit) { miss = true; break; }                             /* irregular firing: handled after the loop, the batch ends */
 			t_phase = ph;
 			steps_done += m;
 			since_emit += m;
@@ -356,7 +354,11 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 			scalar_stage(y, same);
 			if (emits) emit_steps = steps_done;
 		}
-		if (steps_done >= 0) { last_v = sample_of_last_emit(); locate(v0, isub0, steps_done, v_cur, isub); }
+		last_v = sample_of_last_emit();
+		locate(v0, isub0, steps_done, v_cur, isub);
+		/* an irregular firing (clock outside the blind window, block end near, candidate missing): with the position on the table
+		   it is done the careful way; the prediction is stale after it, so the batch ended there */
+		if (miss) careful_firing();
 
 		/* ---- (3) flush the batch's symbols: lane i writes symbol out_base + i ---- */
 		flush();
@@ -415,9 +417,8 @@ template <int FMT>
 hipError_t
 launch_lat(const DemodLaunch &L, const float *rrc, int ring_size, int span, int float_history, size_t lds_bytes, hipStream_t stream)
 {
-	auto kq = demod_kernel_lat<FMT, 0>;
-	auto ko = demod_kernel_lat<FMT, 1>;
-	auto kfn = L.c.oqpsk ? ko : kq;
+	auto kfn = L.c.oqpsk ? (L.c.step_safe == 6 ? demod_kernel_lat<FMT, 1, 6> : demod_kernel_lat<FMT, 1, 0>)
+	                     : (L.c.step_safe == 14 ? demod_kernel_lat<FMT, 0, 14> : demod_kernel_lat<FMT, 0, 0>);
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(kfn, dim3(L.n_streams), dim3(64), lds_bytes, stream, L, rrc, ring_size, span, float_history);
