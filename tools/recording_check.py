@@ -22,6 +22,8 @@ for tag in tags:
     t0 = time.time(); serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]; t_cpu = time.time() - t0
     osf = cfg.samplerate / cfg.symrate
     kw = dict(tile_samples=int(float(kv.get("tile", 0)) * osf), carrier_seed=kv.get("seed", "spectrum"), repair=bool(int(kv.get("repair", 1))))
+    if "margin" in kv: kw["pilot_margin_symbols"] = int(kv["margin"])
+    if "pblock" in kv: kw["pilot_block"] = int(kv["pblock"])
     for k, name in (("settle", "settle_samples"), ("acquire", "acquire_samples"), ("frame", "frame_samples")):
         if k in kv: kw[name] = int(float(kv[k]) * osf)
     demodulate_recording_native(cfg, iq[: 1 << 21], **kw)
