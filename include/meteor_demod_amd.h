@@ -289,7 +289,7 @@ typedef struct {
 	uint32_t pilot_block;           /* pilot granularity in samples               (65536)  */
 	uint32_t pilot_margin_symbols;  /* symbols the pilot stays locked before tiles start (20000) */
 	uint64_t max_pilot_samples;     /* give up waiting for lock after this many   (1 << 22) */
-	uint32_t match_symbols;         /* symbols compared across a seam             (192)    */
+	uint32_t match_symbols;         /* symbols compared across a seam; at least 32 are used (192) */
 	int32_t  repair;                /* 1: tiles whose seam shows an odd residual rotation run settle + body again (1)    */
 	uint32_t carrier_seed;          /* 1: every tile from its own 4th-power spectrum (follows Doppler); 0: all tiles from
 	                                   the pilot's carrier estimate (dead reckoning then rarely holds: repair does the work) (1) */

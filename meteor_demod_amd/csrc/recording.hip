@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -66,8 +67,8 @@ __global__ void
 match_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *rot_out, int32_t *weak_out)
 {
 	const TailPair p = pairs[blockIdx.x];
-	__shared__ long long acc[7][64];
-	long long s[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	__shared__ long long acc[8][64];
+	long long s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	auto load = [&](const int8_t *base, uint32_t cnt, int x, int rot, int &i, int &q) {
 		const long long idx = (long long)cnt - (K + 1) + x;
 		if (idx < 0) { i = 0; q = 0; return; }
@@ -82,12 +83,13 @@ match_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *rot_out,
 		s[2] += a0i * b1i + a0q * b1q;  s[3] += a0q * b1i - a0i * b1q;      /* shift +1 */
 		s[4] += a1i * b0i + a1q * b0q;  s[5] += a1q * b0i - a1i * b0q;      /* shift -1 */
 		s[6] += a1i * a1i + a1q * a1q;                                      /* energy of a[1..K] */
+		s[7] += b1i * b1i + b1q * b1q;                                      /* ... and of b[1..K]  */
 	}
-	for (int k = 0; k < 7; k++) acc[k][threadIdx.x] = s[k];
+	for (int k = 0; k < 8; k++) acc[k][threadIdx.x] = s[k];
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		long long t[7];
-		for (int k = 0; k < 7; k++) { t[k] = 0; for (unsigned l = 0; l < blockDim.x; l++) t[k] += acc[k][l]; }
+		long long t[8];
+		for (int k = 0; k < 8; k++) { t[k] = 0; for (unsigned l = 0; l < blockDim.x; l++) t[k] += acc[k][l]; }
 		const int shifts[3] = { 0, 1, -1 };
 		long long best = 0; int bs = 0, br = 0; bool have = false;
 		for (int c = 0; c < 3; c++) {
@@ -97,7 +99,9 @@ match_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *rot_out,
 			for (int k = 1; k < 4; k++) if (sc4[k] > sc4[r]) r = k;
 			if (!have || sc4[r] > best) { best = sc4[r]; bs = shifts[c]; br = r; have = true; }
 		}
-		const bool weak = (best * 2 < t[6]) || p.force_weak;
+		/* less than half of a perfect match, amplitudes taken out: the two runs may sit at different AGC gains (float input:
+		   the reference's AGC needs seconds), which says nothing about their rotation */
+		const bool weak = (best <= 0) || (4.0 * (double)best * (double)best < (double)t[6] * (double)t[7]) || p.force_weak;
 		shift_out[blockIdx.x] = weak ? 0 : bs;
 		rot_out[blockIdx.x] = weak ? 0 : br;
 		weak_out[blockIdx.x] = weak ? 1 : 0;
@@ -112,9 +116,9 @@ __global__ void
 match_rails_kernel(const TailPair *pairs, int K, int32_t *rot_out, int32_t *weak_out)
 {
 	const TailPair p = pairs[blockIdx.x];
-	__shared__ long long acc[25][64];                      /* [r][rail][d] = 24 sums + energy */
-	long long s[25];
-	for (int k = 0; k < 25; k++) s[k] = 0;
+	__shared__ long long acc[26][64];                      /* [r][rail][d] = 24 sums + the two energies */
+	long long s[26];
+	for (int k = 0; k < 26; k++) s[k] = 0;
 	auto load = [&](const int8_t *base, uint32_t cnt, int x, int &i, int &q) {     /* x in 0..K+1 from the tail start */
 		const long long idx = (long long)cnt - (K + 2) + x;
 		if (idx < 0) { i = 0; q = 0; return; }
@@ -128,19 +132,20 @@ match_rails_kernel(const TailPair *pairs, int K, int32_t *rot_out, int32_t *weak
 			for (int r = 0; r < 4; r++) { s[r * 6 + d] += ai * mI[r]; s[r * 6 + 3 + d] += aq * mQ[r]; }
 		}
 		s[24] += ai * ai + aq * aq;
+		{ int bi, bq; load(p.b, p.b_cnt, j + 1, bi, bq); s[25] += bi * bi + bq * bq; }
 	}
-	for (int k = 0; k < 25; k++) acc[k][threadIdx.x] = s[k];
+	for (int k = 0; k < 26; k++) acc[k][threadIdx.x] = s[k];
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		long long t[25];
-		for (int k = 0; k < 25; k++) { t[k] = 0; for (unsigned l = 0; l < blockDim.x; l++) t[k] += acc[k][l]; }
+		long long t[26];
+		for (int k = 0; k < 26; k++) { t[k] = 0; for (unsigned l = 0; l < blockDim.x; l++) t[k] += acc[k][l]; }
 		long long best = 0; int br = 0;
 		for (int r = 0; r < 4; r++) {
 			long long sI = t[r * 6], sQ = t[r * 6 + 3];
 			for (int d = 1; d < 3; d++) { if (t[r * 6 + d] > sI) sI = t[r * 6 + d]; if (t[r * 6 + 3 + d] > sQ) sQ = t[r * 6 + 3 + d]; }
 			if (r == 0 || sI + sQ > best) { best = sI + sQ; br = r; }
 		}
-		const bool weak = (best * 2 < t[24]) || p.force_weak;
+		const bool weak = (best <= 0) || (4.0 * (double)best * (double)best < (double)t[24] * (double)t[25]) || p.force_weak;
 		rot_out[blockIdx.x] = weak ? 0 : br;
 		weak_out[blockIdx.x] = weak ? 1 : 0;
 	}
@@ -150,8 +155,8 @@ __global__ void
 match_heads_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *rot_out, int32_t *weak_out)
 {
 	const TailPair p = pairs[blockIdx.x];
-	__shared__ long long acc[7][64];
-	long long s[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	__shared__ long long acc[8][64];
+	long long s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	auto load = [&](const int8_t *base, uint32_t cnt, int x, int &i, int &q) {
 		if ((uint32_t)x >= cnt) { i = 0; q = 0; return; }
 		i = base[2 * x]; q = base[2 * x + 1];
@@ -164,12 +169,13 @@ match_heads_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *ro
 		s[2] += a1i * b0i + a1q * b0q;  s[3] += a1q * b0i - a1i * b0q;      /* shift +1: a[1..K]   vs b[0..K-1] */
 		s[4] += a0i * b1i + a0q * b1q;  s[5] += a0q * b1i - a0i * b1q;      /* shift -1: a[0..K-1] vs b[1..K]   */
 		s[6] += a0i * a0i + a0q * a0q;
+		s[7] += b0i * b0i + b0q * b0q;
 	}
-	for (int k = 0; k < 7; k++) acc[k][threadIdx.x] = s[k];
+	for (int k = 0; k < 8; k++) acc[k][threadIdx.x] = s[k];
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		long long t[7];
-		for (int k = 0; k < 7; k++) { t[k] = 0; for (unsigned l = 0; l < blockDim.x; l++) t[k] += acc[k][l]; }
+		long long t[8];
+		for (int k = 0; k < 8; k++) { t[k] = 0; for (unsigned l = 0; l < blockDim.x; l++) t[k] += acc[k][l]; }
 		const int shifts[3] = { 0, 1, -1 };
 		long long best = 0; int bs = 0, br = 0; bool have = false;
 		for (int c = 0; c < 3; c++) {
@@ -179,7 +185,7 @@ match_heads_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *ro
 			for (int k = 1; k < 4; k++) if (sc4[k] > sc4[r]) r = k;
 			if (!have || sc4[r] > best) { best = sc4[r]; bs = shifts[c]; br = r; have = true; }
 		}
-		const bool weak = best * 2 < t[6];
+		const bool weak = (best <= 0) || (4.0 * (double)best * (double)best < (double)t[6] * (double)t[7]);
 		shift_out[blockIdx.x] = weak ? 0 : bs;
 		rot_out[blockIdx.x] = weak ? 0 : br;
 		weak_out[blockIdx.x] = weak ? 1 : 0;
@@ -587,7 +593,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	rep->first_lock_symbol = -1;
 	const size_t sb = 2 * static_cast<size_t>(params->bps) / 8;
 	const unsigned char *iq = static_cast<const unsigned char *>(iq_dev);
-	const int K = static_cast<int>(o.match_symbols);
+	const int K = static_cast<int>(std::max<uint32_t>(o.match_symbols, 32));     /* fewer symbols cannot tell 4 rotations x 3 shifts apart at 12 dB */
 
 	const auto t_start = std::chrono::steady_clock::now();
 	auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
@@ -755,8 +761,9 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	auto f_seed = [&](size_t i, double t) {
 		const double lag = slope[i] * osf / nco * tau_pll;
 		/* before the hand-over (a lead that starts inside the pilot) the serial run was further away still: same exponential, back to
-		   where the pilot's margin began at most */
-		const double back = -static_cast<double>(o.pilot_margin_symbols) * nco / std::max(tau_pll, 1.0);
+		   where the pilot's margin began at most, and by no more than one time constant (OQPSK's loop has a quarter of QPSK's: 74x
+		   the pilot's offset is not a seed) */
+		const double back = -std::min(1.0, static_cast<double>(o.pilot_margin_symbols) * nco / std::max(tau_pll, 1.0));   /* never past the lock, never more than one time constant */
 		const double gone = tau_pll > 0 ? std::exp(-std::max(back, (t - static_cast<double>(P)) / osf * nco / tau_pll)) : 0.0;
 		const double f = f_at(t) - lag + (o.carrier_seed == 1 ? (static_cast<double>(seed.pll_freq) - f_pilot_target) * gone : 0.0);
 		return std::max(-fmax, std::min(fmax, f));
@@ -929,6 +936,13 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		for (size_t i = 1; i < T; i++) C[i] = (C[i - 1] + rot[i]) & 3;
 		bool odd = false;
 		for (size_t i = 1; i < T; i++) odd = odd || (C[i] & 1);
+		if (getenv("MDEMOD_RECORDING_DEBUG")) {
+			fprintf(stderr, "[recording] round %d: T=%zu tile=%u lead=%u+%u+%u\n", round, T, o.tile_samples, o.acquire_samples, o.frame_samples, o.settle_samples);
+			for (size_t i = 1; i < T; i++)
+				if (rot[i] || weak[i] || shift[i] || run[i] != 1 || getenv("MDEMOD_RECORDING_DEBUG")[0] == '2')
+					fprintf(stderr, "[recording]   seam %zu: rot %d weak %d shift %d C %d run %d R %d cnt_pre %u cnt1 %u locked %d f0 %.6f q %.1f\n", i, rot[i], weak[i], shift[i], C[i], (int)run[i], R[i],
+					        cnt_pre[i], cnt1[i], status_body.size() > i ? status_body[i].locked : -1, fbar[i], 0.0);
+		}
 		if (round == 0) {
 			for (size_t i = 1; i < T; i++) rep->frame_misses += rot[i] ? 1 : 0;
 			out_rot = C;
