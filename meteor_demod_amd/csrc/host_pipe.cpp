@@ -8,8 +8,10 @@
  * memory and copied in while sub-block k is demodulated and sub-block k-1 is copied out and
  * handed back to the caller's buffers:
  *
- *     CPU pack(k+1) | H2D(k+1)  [stream in]  |  kernel(k) [stream cmp]  |  D2H(k-1) [stream out] | CPU unpack(k-2)
+ *     CPU pack(k+1) | H2D(k+1)  [stream in]  |  kernel(k) [stream cmp]  |  D2H(k-1) [stream out] | CPU unpack(k-1)
  *
+ * (the host unpacks k-1 after it has enqueued kernel k and its copies, so the GPU never waits for the CPU; every sub-block's
+ * lock events are copied aside on the compute stream because the next launch overwrites the context's list).
  * Two sets of pinned + device staging buffers (grow only), three HIP streams, events for the
  * four hand-offs.  Packing and unpacking are spread over a few host threads.
  * After the last sub-block the per-call counters of the context (symbols / lock events of "this
@@ -46,6 +48,7 @@ struct Slot {                    /* one of the two staging sets */
 	uint32_t pitch = 0;          /* nominal pitch (symbols) of d_pack / h_soft for the sub-block in flight */
 	uint64_t *h_off = nullptr, *d_off = nullptr;
 	uint32_t *h_cnt = nullptr, *d_cnt = nullptr, *h_prod = nullptr, *h_ev = nullptr;
+	mdemod_lock_event *d_events = nullptr;   /* this sub-block's lock events: the next launch overwrites the context's list */
 	hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
 	bool used_in = false, used_k = false, used_out = false;
 	uint32_t cap = 0;            /* symbol stride of the DEVICE soft buffer for the sub-block in flight: one symbol per input
@@ -103,20 +106,22 @@ int
 pipe_init(HostPipe *p, uint32_t ns)
 {
 	if (p->ready) return MDEMOD_OK;
+	/* every resource is created only if it is missing: a call that failed part-way is picked up where it stopped, nothing leaks */
 	p->ns = ns;
-	PIPE_TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
-	PIPE_TRY(hipStreamCreateWithFlags(&p->s_cmp, hipStreamNonBlocking));
-	PIPE_TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+	if (!p->s_in) PIPE_TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+	if (!p->s_cmp) PIPE_TRY(hipStreamCreateWithFlags(&p->s_cmp, hipStreamNonBlocking));
+	if (!p->s_out) PIPE_TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
 	for (Slot &s : p->slot) {
-		PIPE_TRY(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
-		PIPE_TRY(hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming));
-		PIPE_TRY(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
-		PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_off), sizeof(uint64_t) * ns, hipHostMallocDefault));
-		PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_cnt), sizeof(uint32_t) * ns, hipHostMallocDefault));
-		PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_prod), sizeof(uint32_t) * ns, hipHostMallocDefault));
-		PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_ev), sizeof(uint32_t) * ns, hipHostMallocDefault));
-		PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_off), sizeof(uint64_t) * ns));
-		PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_cnt), sizeof(uint32_t) * ns));
+		if (!s.ev_in) PIPE_TRY(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+		if (!s.ev_k) PIPE_TRY(hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming));
+		if (!s.ev_out) PIPE_TRY(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
+		if (!s.h_off) PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_off), sizeof(uint64_t) * ns, hipHostMallocDefault));
+		if (!s.h_cnt) PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_cnt), sizeof(uint32_t) * ns, hipHostMallocDefault));
+		if (!s.h_prod) PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_prod), sizeof(uint32_t) * ns, hipHostMallocDefault));
+		if (!s.h_ev) PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_ev), sizeof(uint32_t) * ns, hipHostMallocDefault));
+		if (!s.d_off) PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_off), sizeof(uint64_t) * ns));
+		if (!s.d_cnt) PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_cnt), sizeof(uint32_t) * ns));
+		if (!s.d_events) PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_events), sizeof(mdemod_lock_event) * MDEMOD_MAX_LOCK_EVENTS * ns));
 	}
 	p->ready = true;
 	return MDEMOD_OK;
@@ -163,6 +168,7 @@ mdemod_hostpipe_free(void *opaque)
 		if (s.h_ev) (void)hipHostFree(s.h_ev);
 		if (s.d_off) (void)hipFree(s.d_off);
 		if (s.d_cnt) (void)hipFree(s.d_cnt);
+		if (s.d_events) (void)hipFree(s.d_events);
 		if (s.ev_in) (void)hipEventDestroy(s.ev_in);
 		if (s.ev_k) (void)hipEventDestroy(s.ev_k);
 		if (s.ev_out) (void)hipEventDestroy(s.ev_out);
@@ -242,9 +248,9 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 				const uint32_t have = std::min<uint32_t>(events[s], MDEMOD_MAX_LOCK_EVENTS);
 				const uint32_t take = std::min<uint32_t>(n_new, MDEMOD_MAX_LOCK_EVENTS - have);
 				if (take) {
-					uint32_t got = 0;
-					int r2 = mdemod_get_lock_events(ctx, s, &ev_store[static_cast<size_t>(s) * MDEMOD_MAX_LOCK_EVENTS + have], take, &got, p->s_cmp);
-					if (r2) return r2;
+					/* from the slot's own copy (taken on the compute stream right after its kernel; ev_out follows it) */
+					PIPE_TRY(hipMemcpy(&ev_store[static_cast<size_t>(s) * MDEMOD_MAX_LOCK_EVENTS + have],
+					                   sl.d_events + static_cast<size_t>(s) * MDEMOD_MAX_LOCK_EVENTS, sizeof(mdemod_lock_event) * take, hipMemcpyDeviceToHost));
 				}
 			}
 		}
@@ -297,19 +303,20 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		/* ---- kernel: after the copy-in, and after the copy-out that last read this slot's device output ---- */
 		PIPE_TRY(hipStreamWaitEvent(p->s_cmp, sl.ev_in, 0));
 		if (sl.used_out) PIPE_TRY(hipStreamWaitEvent(p->s_cmp, sl.ev_out, 0));
-		/* the previous sub-block's unpack reads lock events through s_cmp before this launch overwrites them */
-		if (k >= 1) { rc = unpack(p->slot[(k - 1) & 1]); if (rc) return rc; }
 		sl.cap = cap; sl.pitch = pitch;
 		rc = mdemod_process_device(ctx, sl.d_iq, sl.d_off, sl.d_cnt, sl.d_soft, cap, cap, p->s_cmp);
 		if (rc) return rc;
 		PIPE_TRY(mdemod_launch_compact_rows(sl.d_soft, cap, sl.d_pack, pitch, st.sym_this_call, ns, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_prod, st.sym_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_ev, st.ev_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
+		if (K > 1) PIPE_TRY(hipMemcpyAsync(sl.d_events, st.events, sizeof(mdemod_lock_event) * MDEMOD_MAX_LOCK_EVENTS * ns, hipMemcpyDeviceToDevice, p->s_cmp));
 		PIPE_TRY(hipEventRecord(sl.ev_k, p->s_cmp)); sl.used_k = true;
 		/* ---- D2H of the nominal-pitch copy ---- */
 		PIPE_TRY(hipStreamWaitEvent(p->s_out, sl.ev_k, 0));
 		PIPE_TRY(hipMemcpyAsync(sl.h_soft, sl.d_pack, pack_bytes, hipMemcpyDeviceToHost, p->s_out));
 		PIPE_TRY(hipEventRecord(sl.ev_out, p->s_out)); sl.used_out = true;
+		/* ---- hand sub-block k-1 back to the caller while the GPU works on k ---- */
+		if (k >= 1) { rc = unpack(p->slot[(k - 1) & 1]); if (rc) return rc; }
 	}
 	rc = unpack(p->slot[(K - 1) & 1]);
 	if (rc) return rc;
