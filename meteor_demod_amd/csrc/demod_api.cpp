@@ -584,7 +584,8 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
 	if (ctx->tab.rw_wide) return "demod_kernel_rw (v2 register window, wide: 129 taps, packed)";
 	if (ctx->tab.rw_far) return "demod_kernel_rw (v2 register window, far: 65 taps at up to 30 samples per firing, packed)";
-	if (ctx->tab.rw_mid) return "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, packed)";
+	if (ctx->tab.rw_mid) return ctx->params.bps == 32 ? "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, float pairs)"
+	                                                  : "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, packed)";
 	return (ctx->params.bps != 32 && env_int("MDEMOD_RW_PACKED", 0))
 	       ? "demod_kernel_rw (v2 register window, packed)" : "demod_kernel_rw (v2 register window, float)";
 }

@@ -129,7 +129,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 	const double per_firing = static_cast<double>(out.osf) / (p.oqpsk ? 2.0 : 1.0);   /* samples consumed per firing */
 	const bool std_ok = c.taps <= 65 && per_firing <= 3.6;
 	/* wide: packed window only (s16 / u8), up to 129 taps, up to 15 samples per firing */
-	const bool wide_ok = !std_ok && c.taps <= 129 && per_firing <= 15.0 && p.bps != 32;
+	const bool wide_ok = !std_ok && per_firing <= 15.0 && (p.bps != 32 ? c.taps <= 129 : c.taps <= 65);   /* float input: only the 96-slot mid window fits as float pairs */
 	/* mid: the short filter at a high sample rate (e.g. the default -f 32 at 1.024 MS/s): same lane spread as wide, but
 	 * a 96-slot window instead of 160 */
 	const bool mid_ok = wide_ok && c.taps <= 65;

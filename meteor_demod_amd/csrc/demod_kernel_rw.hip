@@ -299,7 +299,7 @@ demod_kernel_rw(const DemodLaunch L)
 	constexpr int NST = SG * G::MAXSL;           /* granules staged ahead of the window */
 	/* The float window of the std geometry leaves ~20 VGPRs: AGC and NCO state stay in registers there
 	 * (5 LDS reads + 5 writes per symbol less, and no exposed LDS latency right after the FIR). */
-	constexpr bool REGSTATE = MDEMOD_RW_REGSTATE && !PACKED && G::KT <= 65;
+	constexpr bool REGSTATE = MDEMOD_RW_REGSTATE && !PACKED && G::KT <= 65 && G::NW <= 80;
 	/* wave priority (see the main loop): 1 = raised for the scalar stage of a firing; 2 = and for the symbol clock's add
 	 * chain that follows it (std QPSK: +2 % more; OQPSK and the compact geometries: -0.3 %, so they stay at 1) */
 	constexpr int PRIO = !MDEMOD_RW_SETPRIO ? 0 : (!OQPSK && !G::COMPACT) ? 2 : 1;
@@ -764,9 +764,16 @@ template <int FMT>
 hipError_t
 launch_rw_wide(const DemodLaunch &L, int mid, size_t lds_bytes, hipStream_t stream)
 {
+	if constexpr (FMT == 32) {
+		/* float input has no packed form: its window is converted-float pairs (2 VGPRs per slot), which fits the 96 slots of the
+		 * mid geometry (65 taps at up to 15 samples per firing) and nothing larger */
+		if (mid != 1) return hipErrorInvalidValue;
+		return L.c.oqpsk ? launch_rw<32, 1, false, GeoMid>(L, lds_bytes, stream) : launch_rw<32, 0, false, GeoMid>(L, lds_bytes, stream);
+	} else {
 	if (mid == 1) return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoMid>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoMid>(L, lds_bytes, stream);
 	if (mid == 2) return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoFar>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoFar>(L, lds_bytes, stream);
 	return L.c.oqpsk ? launch_rw<FMT, 1, true, GeoWide>(L, lds_bytes, stream) : launch_rw<FMT, 0, true, GeoWide>(L, lds_bytes, stream);
+	}
 }
 #endif
 
@@ -794,6 +801,7 @@ mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, int mid, size_t lds_b
 	switch (fmt) {
 	case 16: return launch_rw_wide<16>(L, mid, lds_bytes, stream);
 	case 8:  return launch_rw_wide<8>(L, mid, lds_bytes, stream);
+	case 32: return launch_rw_wide<32>(L, mid, lds_bytes, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

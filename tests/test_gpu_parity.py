@@ -33,6 +33,14 @@ KERNEL_VARIANTS = {
 }
 
 
+@pytest.fixture(autouse=True)
+def _lane_kernels_unless_asked(monkeypatch):
+    """The tests of this module are about the lane-per-stream kernels and their geometries; most of them use a few dozen
+    streams, for which a context would pick the latency kernel on its own.  `kernel_variant` (below) overrides this for its
+    two latency variants; tests/test_gpu_recording.py and the tools run with the library's own choice."""
+    monkeypatch.setenv("MDEMOD_LAT", "0")
+
+
 @pytest.fixture(params=list(KERNEL_VARIANTS))
 def kernel_variant(request, monkeypatch):
     """Every kernel implementation must produce the same bytes (selection knobs are env vars
@@ -216,7 +224,12 @@ WIDE_CFGS = {
     "defaults_1024k_oqpsk_u8": DemodConfig(samplerate=1024000, oqpsk=True, bps=8),
     "defaults_2048k": DemodConfig(samplerate=2048000),                                    # 28.4 samples per symbol: far geometry
     "far_edge_u8": DemodConfig(samplerate=2150000, rrc_order=20, interp_factor=3, bps=8), # 29.9 samples per symbol
+    "defaults_1024k_f32": DemodConfig(samplerate=1024000, bps=32),                        # float input: mid geometry with a float-pair window
+    "oqpsk_640k_f32": DemodConfig(samplerate=640000, symrate=80000, oqpsk=True, rrc_order=24, interp_factor=4, bps=32),
 }
+WIDE_KERNEL = {"c4_s16": "wide", "c4_u8": "wide", "oqpsk80k_1M": "wide", "taps97_os6": "wide", "edge_15_per_symbol": "wide",
+               "taps65_slow_clock": "mid", "defaults_1024k": "mid", "defaults_1024k_oqpsk_u8": "mid", "defaults_2048k": "far",
+               "far_edge_u8": "far", "defaults_1024k_f32": "mid", "oqpsk_640k_f32": "mid"}
 
 
 @pytest.mark.parametrize("name", list(WIDE_CFGS))
@@ -226,12 +239,13 @@ def test_wide_window_batch_chained(name, gpu_device):
     every symbol phase) x chained blocks, byte-identical to the oracle, loop state included."""
     torch = _torch()
     cfg = WIDE_CFGS[name]
-    rms = {8: 50.0, 16: 5000.0}[cfg.bps]
+    rms = {8: 50.0, 16: 5000.0, 32: 0.3}[cfg.bps]
     ns, blocks = 70, [5000, 3, 9000, 1, 2047]
     streams = [synth.make_stream(8100 + i, cfg.samplerate, cfg.symrate, f0_hz=(i % 9 - 4) * 350.0, clock_ppm=(i % 7 - 3) * 15.0,
                                  esn0_db=15.0, rms=rms, oqpsk=cfg.oqpsk, fmt=cfg.bps) for i in range(ns)]
     iqs = [synth.generate_host(s, sum(blocks)) for s in streams]
     with Demodulator(cfg, ns) as d:
+        assert "v2 register window, " + WIDE_KERNEL[name] in d.kernel_name, d.kernel_name
         parts = [[] for _ in range(ns)]
         pos = 0
         for b in blocks:
@@ -665,7 +679,6 @@ def test_float_input_ring_kernel_ignores_stale_lds(gpu_device, monkeypatch):
         torch.cuda.synchronize()
     streams = [synth.make_stream(40 + i, cfg.samplerate, cfg.symrate, f0_hz=300.0, esn0_db=15.0, rms=0.7, oqpsk=True, fmt=32) for i in range(6)]
     iqs = [synth.generate_host(s, 9051) for s in streams]
-    monkeypatch.setenv("MDEMOD_LAT", "0")
     with Demodulator(cfg, 29) as d:
         assert "ring" in d.kernel_name
         got = [[] for _ in range(29)]
