@@ -214,17 +214,22 @@ def other_configs(skip: str, T: int, L: int, local: int) -> dict:
     res = {}
     from meteor_demod_amd import DemodConfig
     extra = {"x1": (DemodConfig(samplerate=1024000), "not in BASELINE.json: QPSK 72k, 1.024 MS/s s16, default RRC order 32, oversamp 5"),
-             "x2": (DemodConfig(samplerate=1800000), "not in BASELINE.json: QPSK 72k, 1.8 MS/s s16, default RRC order 32, oversamp 5")}
-    for tag in ("c3", "c4", "x1", "x2"):
+             "x2": (DemodConfig(samplerate=1800000), "not in BASELINE.json: QPSK 72k, 1.8 MS/s s16, default RRC order 32, oversamp 5"),
+             "x3": (DemodConfig(samplerate=1024000, bps=32), "not in BASELINE.json: QPSK 72k, 1.024 MS/s f32, default RRC order 32, oversamp 5"),
+             "x4": (DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),
+                    "not in BASELINE.json: QPSK 72k, 1 MS/s f32, RRC order 64, oversamp 8 (a geometry still on the v1 ring kernel)")}
+    for tag in ("c3", "c4", "x1", "x2", "x3", "x4"):
         if tag == skip:
             continue
         cfg, workload = extra[tag] if tag in extra else demod_config(tag)
-        rec = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0)
-        buf = torch.empty((T * L, 2), dtype=torch.int16, device=f"cuda:{local}")
-        synth.generate_device([rec], T * L, out=buf.view(1, T * L, 2), device=local)
-        x = buf.view(T, L, 2)
-        with Demodulator(cfg, T, device=local) as d:
-            soft = torch.empty((T, d.max_symbols(L), 2), dtype=torch.int8, device=f"cuda:{local}")
+        Tc = T // 2 if cfg.bps == 32 else T        # 8 bytes per sample: half the tiles
+        rec = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, fmt=cfg.bps,
+                                **(dict(rms=0.25, dc=(0.001, -0.002)) if cfg.bps == 32 else {}))
+        buf = torch.empty((Tc * L, 2), dtype=torch.float32 if cfg.bps == 32 else torch.int16, device=f"cuda:{local}")
+        synth.generate_device([rec], Tc * L, out=buf.view(1, Tc * L, 2), device=local)
+        x = buf.view(Tc, L, 2)
+        with Demodulator(cfg, Tc, device=local) as d:
+            soft = torch.empty((Tc, d.max_symbols(L), 2), dtype=torch.int8, device=f"cuda:{local}")
             d.process(x, soft=soft)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -234,8 +239,8 @@ def other_configs(skip: str, T: int, L: int, local: int) -> dict:
             torch.cuda.synchronize()
             ms = a.elapsed_time(b) / 3
             bps = cfg.bps / 4 + 2 * cfg.symrate / cfg.samplerate
-            res[workload.split(";")[0]] = {"msamples_per_s": round(T * L / ms / 1e3, 1), "kernel_ms": round(ms, 3),
-                                           "hbm_frac": round(T * L * bps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": d.kernel_name}
+            res[workload.split(";")[0]] = {"msamples_per_s": round(Tc * L / ms / 1e3, 1), "kernel_ms": round(ms, 3), "tiles": Tc,
+                                           "hbm_frac": round(Tc * L * bps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": d.kernel_name}
         del buf, x, soft
         torch.cuda.empty_cache()
     return res

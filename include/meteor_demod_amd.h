@@ -316,6 +316,9 @@ typedef struct {
 	uint32_t rotation_jumps;        /* seams that still show a residual rotation after the repair (a cycle slip inside a
 	                                   body): the output is rotated from there on, like a serial run after a cycle slip  */
 	float    frame_residual_rms;    /* rad: dead-reckoned minus measured NCO phase, after removing the quarter turns (0.785 = limit) */
+	uint32_t odd_tiles_kept;        /* tiles left an odd number of quarter turns off because they were too few to be worth a repair
+	                                   pass (< 0.5 % of the tiles): output turned (decisions exact), soft values on the other rail's timing */
+	uint32_t reserved;
 } mdemod_recording_report;
 
 void mdemod_recording_default_opts(mdemod_recording_opts *opts);

@@ -74,7 +74,7 @@ class MdemodRecordingReport(C.Structure):
                 ("pilot_locked", C.c_int32), ("weak_carrier_tiles", C.c_uint32),
                 ("pilot_seconds", C.c_double), ("tiles_seconds", C.c_double),
                 ("frame_misses", C.c_uint32), ("repaired_tiles", C.c_uint32), ("rotation_jumps", C.c_uint32),
-                ("frame_residual_rms", C.c_float)]
+                ("frame_residual_rms", C.c_float), ("odd_tiles_kept", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # name -> (restype, argtypes); this table is also what the symbol-export test walks.

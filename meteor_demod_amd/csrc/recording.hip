@@ -334,20 +334,51 @@ window_power_kernel(const void *iq, const uint64_t *starts, const uint32_t *lens
 	if (threadIdx.x == 0) power_out[blockIdx.x] = n ? red[0][0] / n : 0.0f;
 }
 
+/* 8 symbols (16 bytes) of a tile, rotated by k quarter turns: (i + jq) * j^k on int8 lanes (|values| <= 127: negation is exact) */
+__device__ __forceinline__ uint4
+rot_group(uint4 v, int k)
+{
+	k &= 3;
+	if (k == 0) return v;
+	uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		uint32_t o = 0;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int i = (int)(int8_t)(w[j] >> (16 * h)), q = (int)(int8_t)(w[j] >> (16 * h + 8));
+			int ri, rq;
+			rot_pair(i, q, k, ri, rq);
+			o |= ((uint32_t)(ri & 0xFF) | ((uint32_t)(rq & 0xFF) << 8)) << (16 * h);
+		}
+		w[j] = o;
+	}
+	return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+/* One block per (tile, slice): the tile's kept symbols go to their place in the output, 16 bytes per thread and step (rows
+ * start 16-byte aligned; the destination is only 2-byte aligned, which global stores take).  gridDim.y slices share a tile. */
 __global__ void
 assemble_kernel(const TileCopy *tiles, int8_t *out)
 {
 	const TileCopy t = tiles[blockIdx.x];
 	int8_t *dst = out + 2 * t.dst;
-	if (t.head && threadIdx.x == 0) {
+	if (t.head && threadIdx.x == 0 && blockIdx.y == 0) {
 		int i, q; rot_pair(t.head[0], t.head[1], t.head_rot, i, q);
 		dst[0] = (int8_t)i; dst[1] = (int8_t)q;
 	}
 	if (t.head) dst += 2;
-	for (uint32_t k = threadIdx.x; k < t.keep; k += blockDim.x) {
-		int i, q; rot_pair(t.src[2 * k], t.src[2 * k + 1], t.rot, i, q);
-		dst[2 * k] = (int8_t)i; dst[2 * k + 1] = (int8_t)q;
+	const uint32_t groups = t.keep / 8;
+	const uint4 *src16 = reinterpret_cast<const uint4 *>(t.src);
+	for (uint32_t g = blockIdx.y * blockDim.x + threadIdx.x; g < groups; g += gridDim.y * blockDim.x) {
+		const uint4 v = rot_group(src16[g], t.rot);
+		__builtin_memcpy(dst + 16 * (size_t)g, &v, 16);
 	}
+	if (blockIdx.y == 0)
+		for (uint32_t k = groups * 8 + threadIdx.x; k < t.keep; k += blockDim.x) {
+			int i, q; rot_pair(t.src[2 * k], t.src[2 * k + 1], t.rot, i, q);
+			dst[2 * k] = (int8_t)i; dst[2 * k + 1] = (int8_t)q;
+		}
 }
 
 /* ---- host side ----------------------------------------------------------------------------- */
@@ -638,6 +669,12 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	rep->exact_symbols = n_pilot_sym;
 	rep->pilot_seconds = seconds_since(t_start);
 	const auto t_tiles = std::chrono::steady_clock::now();
+	const bool dbg = getenv("MDEMOD_RECORDING_DEBUG") != nullptr;
+	auto mark = [&](const char *what) {
+		if (!dbg) return;
+		(void)hipStreamSynchronize(st);
+		fprintf(stderr, "[recording] %8.2f ms  %s\n", seconds_since(t_tiles) * 1e3, what);
+	};
 
 	/* ---- plan: tile i emits [E_i, E_i + len_i); its stream starts `lead` samples early -------------------------- */
 	if (P >= n_samples) { rep->n_symbols = n_pilot_sym; return MDEMOD_OK; }
@@ -645,8 +682,8 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		/* as short as fills the lanes (latency of a small recording is the samples ONE lane runs: lead + tile), as long as the
 		   lead stays a small part of the work once the GPU is full; kept off powers of two (lanes read at base + l * tile) */
 		const double rest_sym = static_cast<double>(n_samples - P) / osf;
-		const double b_sym = std::min(41072.0, std::max(8192.0, rest_sym / 131072.0));
-		o.tile_samples = std::max<uint32_t>(4096, static_cast<uint32_t>(b_sym * osf) / 64 * 64);
+		const double b_sym = std::min(41072.0, std::max(8192.0, rest_sym / 126976.0));     /* one residency round of the v2 kernels (131 072 lanes), with slack */
+		o.tile_samples = std::max<uint32_t>(4096, (static_cast<uint32_t>(b_sym * osf) + 63) / 64 * 64);
 		if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
 	}
 	rep->tile_samples = o.tile_samples;
@@ -665,7 +702,9 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 
 	mdemod_params bp = *params; bp.n_streams = static_cast<uint32_t>(T);
 	Ctx bank, saved;
+	mark("plan");
 	TRY(mdemod_create(&bp, &bank.c));
+	mark("bank created");
 	DevMem mem;
 	float consts[8];
 	TRY(mdemod_get_loop_constants(bank.c, consts));
@@ -680,7 +719,10 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	std::vector<double> centre(T), fbar(T), slope(T, 0.0);         /* rad per NCO step at centre[i]; slope in rad per NCO step per sample */
 	/* about 20 000 symbols per window (65 536 samples at 72k in 230 kS/s, 262 144 at 1 MS/s): the frames are dead-reckoned over a
 	   tile, the estimate has to be good to a fraction of a radian over that many symbols */
-	const int nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(std::min(262144.0, 20536.0 * osf))));
+	/* ... but no longer than a tile needs: the error of the estimate falls with the window^1.5 and is multiplied by the tile
+	   length, and 131 072 windows of 65 536 samples are 100 GB of reads over the three passes */
+	const int nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(
+	                     std::min(std::min(262144.0, 20536.0 * osf), std::max(5000.0 * osf, static_cast<double>(B))))));
 	std::vector<uint64_t> wstart(T);
 	for (size_t i = 0; i < T; i++) {
 		const double c = i == 0 ? static_cast<double>(P) : 0.5 * (static_cast<double>(i == 1 ? P : q[i - 1]) + static_cast<double>(q[i]));
@@ -752,6 +794,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	} else {
 		for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
 	}
+	mark("carrier estimates");
 	auto f_at = [&](double t) { return interp_at(centre, fbar, t); };
 	/* The carrier loop is heavily overdamped: its frequency word follows a moving carrier with the lag slope * tau (pll.c:115
 	   integrates beta * e, the phase term alpha * e does the tracking), and right after the pilot's hand-over the serial run is
@@ -786,9 +829,19 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		HTRY(hipStreamSynchronize(st));
 		return mdemod_set_carrier_seeds(bank.c, d_f0, d_ud, st);
 	};
-	if (T > 1) {
+	/* the reference's AGC moves by 1e-4 * 190 / gain of itself per symbol (agc.c:13-25): with s16-scale input (gain ~ 0.03) it is
+	   there within a few symbols whatever it starts from; only a slow one (float input around +-1: tens of thousands of symbols)
+	   needs a seed per tile, and only then is the recording read once more for its power */
+	const bool slow_agc = 6.0 * static_cast<double>(seed.agc_gain) / (1e-4 * 190.0) > 0.25 * static_cast<double>(A) / osf;
+	if (T > 1 && !slow_agc) {
+		HTRY(hipMemcpyAsync(d_gain, gains.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+		HTRY(hipMemcpyAsync(d_tf, tf.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+		HTRY(hipStreamSynchronize(st));
+		TRY(put_carrier_seeds(false));
+	}
+	if (T > 1 && slow_agc) {
 		/* AGC gain seeds: g* = c / sqrt(sample power), c fitted on the pilot's last blocks, then the reference's AGC in closed
-		   form over the tiles' powers (agc.c:13-25; for s16-scale input: each tile its own equilibrium) */
+		   form over the tiles' powers (agc.c:13-25) */
 		const size_t nb = std::min<size_t>(10, pilot_blocks.size());
 		const size_t b0 = pilot_blocks.size() - nb;
 		std::vector<uint64_t> ws; std::vector<uint32_t> wl;
@@ -833,35 +886,44 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	}
 
 	/* ---- launches ------------------------------------------------------------------------------------------- */
+	/* discard: the streams run and their state advances, nothing is written (capacity 0; the kernels then raise the overflow flag,
+	   which means nothing here) - acquisition, frame and most of the settling are only run for their end state */
 	auto launch = [&](const std::vector<uint64_t> &off, const std::vector<uint64_t> &cnt, int8_t *soft, uint64_t stride,
-	                  std::vector<uint32_t> &produced, std::vector<mdemod_status> *status_out = nullptr) -> int {
+	                  std::vector<uint32_t> &produced, std::vector<mdemod_status> *status_out = nullptr, bool discard = false) -> int {
 		std::vector<uint32_t> c32(cnt.begin(), cnt.end());
 		uint64_t *d_off; uint32_t *d_cnt;
 		TRY(upload(mem, off, &d_off, st));
 		TRY(upload(mem, c32, &d_cnt, st));
 		HTRY(hipStreamSynchronize(st));              /* the uploads come from stack vectors */
-		TRY(mdemod_process_device(bank.c, iq_dev, d_off, d_cnt, soft, stride, static_cast<uint32_t>(stride), st));
-		TRY(counts_of(bank.c, static_cast<uint32_t>(T), produced, st, status_out));
+		TRY(mdemod_process_device(bank.c, iq_dev, d_off, d_cnt, soft, stride, discard ? 0u : static_cast<uint32_t>(stride), st));
+		if (discard) HTRY(hipStreamSynchronize(st));
+		else TRY(counts_of(bank.c, static_cast<uint32_t>(T), produced, st, status_out));
 		for (uint64_t c : cnt) rep->samples_demodulated += c;
 		return MDEMOD_OK;
 	};
-	const uint64_t cap_lead = std::max<uint64_t>(8, mdemod_max_symbols(bank.c, std::max<uint64_t>(std::max(A, KP), WS)));
+	mark("seeds");
+	/* of the lead only the last symbols are kept: what the seam check compares with the predecessor's tail */
+	const uint64_t tail_samples = static_cast<uint64_t>((K + 24) * osf * 1.05) + 16;
+	const uint64_t cap_lead = std::max<uint64_t>(8, mdemod_max_symbols(bank.c, tail_samples));
 	const uint64_t cap = mdemod_max_symbols(bank.c, B);
 	int8_t *soft_pre, *soft1;
 	TRY(mem.alloc(&soft_pre, T * cap_lead * 2));
 	TRY(mem.alloc(&soft1, T * cap * 2));
+	mark("output buffers allocated");
 	std::vector<uint32_t> cnt_tmp, cnt_pre(T, 0), cnt1(T, 0);
 	std::vector<mdemod_status> status_body;
 	std::vector<int32_t> R(T, 0);
 	std::vector<mdemod_stream_state> qs(T);
 	if (T > 1) {
 		/* acquire, then the two integrators back on their seeds (the gain keeps what it found) */
-		TRY(launch(s0, acq, soft_pre, cap_lead, cnt_tmp));
+		TRY(launch(s0, acq, soft_pre, cap_lead, cnt_tmp, nullptr, true));
+		mark("acquire");
 		TRY(put_carrier_seeds(true));
 		TRY(mdemod_set_clock_seeds(bank.c, d_tf, st));
 		std::vector<uint64_t> off(T);
 		for (size_t i = 0; i < T; i++) off[i] = s0[i] + acq[i];
-		TRY(launch(off, frm, soft_pre, cap_lead, cnt_tmp));
+		TRY(launch(off, frm, soft_pre, cap_lead, cnt_tmp, nullptr, true));
+		mark("frame");
 
 		/* ---- frames by dead reckoning along the chain pilot -> tile 1 -> tile 2 ... ---------------------------------- */
 		TRY(mdemod_get_states(bank.c, 0, static_cast<uint32_t>(T), qs.data(), st));
@@ -882,6 +944,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 			TRY(mdemod_create(&bp, &saved.c));
 			TRY(mdemod_copy_state(saved.c, bank.c, st));
 		}
+		mark("frames dead-reckoned, checkpoint");
 	}
 	int32_t *d_rot;
 	TRY(mem.alloc(&d_rot, T));
@@ -910,9 +973,16 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		TRY(mdemod_rotate_carrier(bank.c, d_rot, st));
 		auto masked = [&](const std::vector<uint64_t> &c) { std::vector<uint64_t> m(T); for (size_t i = 0; i < T; i++) m[i] = run[i] ? c[i] : 0; return m; };
 		std::vector<mdemod_status> stat;
-		TRY(launch(stl_off, masked(stl), soft_pre, cap_lead, cnt_tmp));
+		{
+			std::vector<uint64_t> stl_a(T), stl_b(T), off_b(T);
+			for (size_t i = 0; i < T; i++) { stl_b[i] = std::min<uint64_t>(stl[i], tail_samples); stl_a[i] = stl[i] - stl_b[i]; off_b[i] = q[i] + stl_a[i]; }
+			TRY(launch(stl_off, masked(stl_a), soft_pre, cap_lead, cnt_tmp, nullptr, true));
+			TRY(launch(off_b, masked(stl_b), soft_pre, cap_lead, cnt_tmp));
+		}
+		mark("settle");
 		for (size_t i = 0; i < T; i++) if (run[i]) cnt_pre[i] = cnt_tmp[i];
 		TRY(launch(E, masked(len), soft1, cap, cnt_tmp, &stat));
+		mark("body");
 		if (status_body.empty()) status_body = stat;
 		for (size_t i = 0; i < T; i++) if (run[i]) { cnt1[i] = cnt_tmp[i]; status_body[i] = stat[i]; }
 		if (params->oqpsk) {
@@ -930,6 +1000,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		}
 		std::vector<int32_t> sh, ro, we;
 		TRY(run_match(mem, pairs, K, sh, ro, we, st, params->oqpsk ? 1 : 0));
+		mark("seams");
 		for (size_t i = 1; i < T; i++) { shift[i] = params->oqpsk ? 0 : sh[i - 1]; rot[i] = we[i - 1] ? 0 : (ro[i - 1] & 3); weak[i] = we[i - 1]; }
 		/* rotation each stream's output still needs to sit in the serial run's frame: b * j^rot matches a, summed along the chain */
 		std::vector<int32_t> C(T, 0);
@@ -947,7 +1018,16 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 			for (size_t i = 1; i < T; i++) rep->frame_misses += rot[i] ? 1 : 0;
 			out_rot = C;
 			if (!odd) break;
-			if (!o.repair || !saved.c) { for (size_t i = 1; i < T; i++) rep->rotation_jumps += (rot[i] & 1); break; }
+			size_t n_odd = 0;
+			for (size_t i = 1; i < T; i++) n_odd += (C[i] & 1);
+			/* A repair is one more settle + body for the lanes concerned - as long as for all of them.  It pays when dead reckoning
+			   failed broadly; one odd tile in 10^5 (its decisions are exact once the output is turned, only its soft values sit on
+			   the other rail's timing noise: 2 % of them off by more than an LSB) does not move the result by 1e-6. */
+			if (!o.repair || !saved.c || n_odd * 200 < T) {
+				for (size_t i = 1; i < T; i++) rep->rotation_jumps += (!o.repair && (rot[i] & 1)) ? 1 : 0;
+				rep->odd_tiles_kept = static_cast<uint32_t>(n_odd);
+				break;
+			}
 			/* repair: a stream an odd number of quarter turns off has settled on the other rail's noise (timing.c:65-66).  It
 			   starts again from the checkpoint with the measured rotation taken out of its state; streams that are 0 or 180
 			   degrees off keep their run (180 degrees is exact on the output).  The checkpoint restores every stream, the ones
@@ -1018,9 +1098,12 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	}
 	TileCopy *d_copies;
 	TRY(upload(mem, copies, &d_copies, st));
-	hipLaunchKernelGGL(assemble_kernel, dim3(static_cast<unsigned>(T)), dim3(256), 0, st, d_copies, soft_dev);
+	/* few tiles: several blocks per tile, so that the copy still fills the GPU */
+	const unsigned slices = static_cast<unsigned>(std::min<uint64_t>(64, std::max<uint64_t>(1, 4096 / T)));
+	hipLaunchKernelGGL(assemble_kernel, dim3(static_cast<unsigned>(T), slices), dim3(256), 0, st, d_copies, soft_dev);
 	HTRY(hipGetLastError());
 	HTRY(hipStreamSynchronize(st));
+	mark("assembled");
 	rep->n_symbols = out_pos;
 	rep->tiles_seconds = seconds_since(t_tiles);
 	return MDEMOD_OK;
