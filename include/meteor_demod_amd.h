@@ -287,7 +287,7 @@ typedef struct {
 	uint32_t frame_samples;         /* 0xFFFFFFFF = 1 500 symbols worth                                                  */
 	uint32_t settle_samples;        /* 0xFFFFFFFF = 24 000 symbols worth                                                 */
 	uint32_t pilot_block;           /* pilot granularity in samples               (65536)  */
-	uint32_t pilot_margin_symbols;  /* symbols the pilot stays locked before tiles start (20000) */
+	uint32_t pilot_margin_symbols;  /* symbols between the first lock and the hand-over; 0xFFFFFFFF = 20 000 (OQPSK: 30 000) */
 	uint64_t max_pilot_samples;     /* give up waiting for lock after this many   (1 << 22) */
 	uint32_t match_symbols;         /* symbols compared across a seam; at least 32 are used (192) */
 	int32_t  repair;                /* 1: tiles whose seam shows an odd residual rotation run settle + body again (1)    */
