@@ -281,8 +281,8 @@ int  mdemod_estimate_carrier_chirp(const mdemod_params *params, const void *iq_d
  * Tile 0 is the exact continuation of the pilot.  iq_dev: n_samples IQ samples in the format of params->bps, in device
  * memory; soft_dev: device buffer for soft_cap_symbols int8 pairs.  params->n_streams is ignored.  Synchronous on hip_stream. */
 typedef struct {
-	uint32_t tile_samples;          /* body samples per tile; 0 = automatic: 8 192 ... 41 072 symbols worth, as short as
-	                                   keeps the tiles of this recording within 131 072 lanes                             */
+	uint32_t tile_samples;          /* body samples per tile; 0 = automatic: 8 192 ... 41 072 symbols worth: ~1000 tiles (one per
+	                                   wave: latency kernel) while that fits, else as short as keeps them within 131 072 lanes */
 	uint32_t acquire_samples;       /* 0xFFFFFFFF = 2 000 symbols worth                                                  */
 	uint32_t frame_samples;         /* 0xFFFFFFFF = 1 500 symbols worth                                                  */
 	uint32_t settle_samples;        /* 0xFFFFFFFF = 24 000 symbols worth                                                 */

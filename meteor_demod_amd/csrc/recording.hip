@@ -694,7 +694,11 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		/* as short as fills the lanes (latency of a small recording is the samples ONE lane runs: lead + tile), as long as the
 		   lead stays a small part of the work once the GPU is full; kept off powers of two (lanes read at base + l * tile) */
 		const double rest_sym = static_cast<double>(n_samples - P) / osf;
-		const double b_sym = std::min(41072.0, std::max(8192.0, rest_sym / 126976.0));     /* one residency round of the v2 kernels (131 072 lanes), with slack */
+		/* Up to ~1000 tiles run one per WAVE (latency kernel, 1.9x a lane's rate with a SIMD to itself): a recording of up to
+		   1000 x 41 072 symbols is cut into that many; a longer one into tiles for one residency round of the lane kernels
+		   (131 072 lanes, with slack). */
+		const double b_sym = rest_sym / 1000.0 <= 41072.0 ? std::max(8192.0, rest_sym / 1000.0)
+		                                                   : std::min(41072.0, std::max(8192.0, rest_sym / 126976.0));
 		o.tile_samples = std::max<uint32_t>(4096, (static_cast<uint32_t>(b_sym * osf) + 63) / 64 * 64);
 		if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
 	}
