@@ -209,7 +209,7 @@ template <> struct RawIQ<32> { typedef float t;   __device__ static float2 get(c
  *      magnitude of the searched band (noise alone: 3-4; a 12 dB signal: 40-50). */
 template <int FMT>
 __global__ void __launch_bounds__(1024)
-carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, const float *chirp, float chirp_scale, int log2_nf, int decim, int kmax,
+carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, const float *chirp, float chirp_scale, int log2_nf, int decim, int pre, int kmax,
                     float hz_per_bin_over4, float rad_per_hz, float *freq_out, float *quality_out)
 {
 	extern __shared__ float2 spec[];                      /* NF complex floats */
@@ -236,13 +236,17 @@ carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, 
 	const float c4 = chirp ? chirp[blockIdx.x] * chirp_scale : 0.0f;
 	for (int m = tid; m < NF; m += nth) {
 		float ar = 0.0f, ai = 0.0f;
-		for (int d = 0; d < decim; d++) {
-			float2 v = sample(m * decim + d);
-			v.x -= mr; v.y -= mi;
+		for (int d = 0; d < decim; d += pre) {
+			/* `pre` samples are averaged BEFORE the 4th power: at 14 samples per symbol the noise of the whole sampled band goes
+			   into z^4 otherwise (its line-to-floor ratio falls with the 4th power of the per-sample SNR), while the signal
+			   lives in the lowest ~1/6 of it; a boxcar of pre <= osf/3 samples takes 6 dB (pre = 4) of that noise away first */
+			float2 v = make_float2(0.0f, 0.0f);
+			for (int e = 0; e < pre; e++) { const float2 u = sample(m * decim + d + e); v.x += u.x; v.y += u.y; }
+			v.x -= mr * (float)pre; v.y -= mi * (float)pre;
 			const float2 z2 = make_float2(v.x * v.x - v.y * v.y, 2.0f * v.x * v.y);
 			float2 z4 = make_float2(z2.x * z2.x - z2.y * z2.y, 2.0f * z2.x * z2.y);
 			if (c4 != 0.0f) {
-				const double t = (double)(m * decim + d) - 0.5 * (double)nwin;
+				const double t = (double)(m * decim + d) + 0.5 * (double)(pre - 1) - 0.5 * (double)nwin;
 				const double turns = -(double)c4 * t * t;                 /* -4 * 0.5 * c * t^2 in turns */
 				float sn, cs;
 				sincospif(2.0f * (float)(turns - floor(turns)), &sn, &cs);
@@ -250,7 +254,7 @@ carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, 
 			}
 			ar += z4.x; ai += z4.y;
 		}
-		const float w = (0.5f - 0.5f * cospif(wstep * (float)m)) * 1e-12f;   /* Hann; the scale keeps |z|^4 of full-scale s16 far from overflow */
+		const float w = (0.5f - 0.5f * cospif(wstep * (float)m)) * (1e-12f / (float)(pre * pre * pre * pre));   /* Hann; the scale keeps |z|^4 of full-scale s16 far from overflow */
 		spec[__brev((unsigned)m) >> (32 - log2_nf)] = make_float2(ar * w, ai * w);
 	}
 	__syncthreads();
@@ -522,6 +526,9 @@ mdemod_estimate_carrier_chirp(const mdemod_params *params, const void *iq_dev, u
 	const double symrate = params->symrate, fs = params->samplerate;
 	const int nco = params->oqpsk ? 2 : 1;                       /* OQPSK: the NCO steps twice a symbol (pll.c:77,93) */
 	const dim3 grid(n_windows);
+	/* samples averaged in front of the 4th power: the largest power of two up to a third of a symbol (and a divisor of decim) */
+	int pre = 1;
+	while (pre * 2 <= decim && pre * 2 * 3.0 <= fs / symrate) pre *= 2;
 	const size_t lds = (static_cast<size_t>(nwin) / decim) * sizeof(float2);
 	const float hz_per_bin_over4 = static_cast<float>(fs / nwin / 4.0);
 	const float rad_per_hz = static_cast<float>(2 * 3.141592653589793 / (symrate * nco));
@@ -529,7 +536,7 @@ mdemod_estimate_carrier_chirp(const mdemod_params *params, const void *iq_dev, u
 	const float chirp_scale = static_cast<float>(nco * symrate / fs / 3.141592653589793);
 #define LAUNCH_LINE(F) do { \
 		HTRY(hipFuncSetAttribute(reinterpret_cast<const void *>(carrier_line_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
-		hipLaunchKernelGGL(carrier_line_kernel<F>, grid, dim3(1024), lds, st, iq_dev, n_samples, starts_dev, chirp_dev, chirp_scale, log2_nf, decim, kmax, \
+		hipLaunchKernelGGL(carrier_line_kernel<F>, grid, dim3(1024), lds, st, iq_dev, n_samples, starts_dev, chirp_dev, chirp_scale, log2_nf, decim, pre, kmax, \
 		                   hz_per_bin_over4, rad_per_hz, freq_dev, quality_dev); } while (0)
 	switch (params->bps) {
 	case 16: LAUNCH_LINE(16); break;

@@ -37,6 +37,8 @@ for ci in range(n_cases):
     amp = {8: dict(rms=40.0, dc=(1.5, -1.0)), 16: dict(rms=float(rng.choice([1500.0, 6000.0])) * min(1.0, 3.2 / osf)),
            32: dict(rms=0.25, dc=(0.001, -0.002))}[bps]
     esn0 = float(rng.choice([10.0, 12.0, 15.0]))
+    if os.environ.get("FUZZ_ESN0"):
+        esn0 = float(os.environ["FUZZ_ESN0"])           # e.g. 7: where the reference's own loops start to struggle
     kw = {}
     if rng.random() < 0.5:
         kw["tile_samples"] = int(rng.choice([32768 + 64, 50000 // 64 * 64, 131072 + 64]) * max(1.0, osf / 3.2)) // 64 * 64
