@@ -1046,7 +1046,9 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 			/* A repair is one more settle + body for the lanes concerned - as long as for all of them.  It pays when dead reckoning
 			   failed broadly; one odd tile in 10^5 (its decisions are exact once the output is turned, only its soft values sit on
 			   the other rail's timing noise: 2 % of them off by more than an LSB) does not move the result by 1e-6. */
-			if (!o.repair || !saved.c || n_odd * 200 < T) {
+			/* OQPSK has no such choice: a tile a quarter turn off pairs its rails one symbol apart (demod.c:66-76), which turning
+			   the output cannot undo */
+			if (!o.repair || !saved.c || (!params->oqpsk && n_odd * 200 < T)) {
 				for (size_t i = 1; i < T; i++) rep->rotation_jumps += (!o.repair && (rot[i] & 1)) ? 1 : 0;
 				rep->odd_tiles_kept = static_cast<uint32_t>(n_odd);
 				break;
