@@ -297,7 +297,8 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		}
 		const uint64_t ok_mask = __ballot(cand_ok);
 		/* steps that may be taken blindly before the block's end needs looking at (timing.c:32-38 stops pushing samples there) */
-		const int steps_limit = (v_end - 1 - v0) * interp - isub0 - (k_safe + 4) - interp;
+		const long long steps_room = (long long)(v_end - 1 - v0) * interp - isub0 - (k_safe + 4) - interp;     /* 2^30 samples x 64 steps: not an int */
+		const int steps_limit = steps_room > 0x3FFFFFFF ? 0x3FFFFFFF : (int)steps_room;
 
 		/* ---- (2) serial: firing by firing, wave-uniform; sample positions are only worked out when they matter ---- */
 		int steps_done = 0;                                              /* interpolated steps since the batch start */
