@@ -410,7 +410,10 @@ int
 upload(DevMem &m, const std::vector<T> &h, T **dev, hipStream_t st)
 {
 	TRY(m.alloc(dev, h.size()));
-	if (!h.empty()) HTRY(hipMemcpyAsync(*dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+	if (!h.empty()) {
+		HTRY(hipMemcpyAsync(*dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+		HTRY(hipStreamSynchronize(st));          /* h is pageable and may die with the caller's scope: small tables, wait here */
+	}
 	return MDEMOD_OK;
 }
 
@@ -917,8 +920,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		uint64_t *d_off; uint32_t *d_cnt;
 		TRY(upload(mem, off, &d_off, st));
 		TRY(upload(mem, c32, &d_cnt, st));
-		HTRY(hipStreamSynchronize(st));              /* the uploads come from stack vectors */
-		TRY(mdemod_process_device(bank.c, iq_dev, d_off, d_cnt, soft, stride, discard ? 0u : static_cast<uint32_t>(stride), st));
+			TRY(mdemod_process_device(bank.c, iq_dev, d_off, d_cnt, soft, stride, discard ? 0u : static_cast<uint32_t>(stride), st));
 		if (discard) HTRY(hipStreamSynchronize(st));
 		else TRY(counts_of(bank.c, static_cast<uint32_t>(T), produced, st, status_out));
 		for (uint64_t c : cnt) rep->samples_demodulated += c;
