@@ -75,6 +75,33 @@ def test_long_recording_on_many_lanes_agrees_with_the_serial_reference(gpu_devic
     assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.996, a
 
 
+def test_recordings_on_concurrent_host_threads_give_the_results_they_give_alone(gpu_device):
+    """Distinct calls are independent (own contexts, the caller's stream): three recordings, one host thread and one HIP
+    stream each, give byte for byte what each gives alone (tools/recordings_concurrent.py measures the aggregate rate)."""
+    import threading
+    import torch
+    cfgs = [C1, C3, C1]
+    recs = [synth.generate_device([synth.make_stream(300 + k, c.samplerate, c.symrate, f0_hz=400.0 * (k + 1), oqpsk=c.oqpsk)], 3_000_000 + 70_001 * k)[0]
+            for k, c in enumerate(cfgs)]
+    alone = [demodulate_recording_native(c, r)[0].clone() for c, r in zip(cfgs, recs)]
+    out, err = [None] * 3, []
+    def work(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                out[k] = demodulate_recording_native(cfgs[k], recs[k])[0]
+                s.synchronize()
+        except Exception as e:                                       # noqa: BLE001 - reported below
+            err.append((k, repr(e)))
+    for _ in range(2):
+        th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not err, err
+        for k in range(3):
+            assert out[k].shape == alone[k].shape and bool((out[k] == alone[k]).all()), k
+
+
 def test_state_broadcast_and_carrier_rotation_primitives(gpu_device):
     """mdemod_set_state_all / mdemod_rotate_carrier against their definitions."""
     import math
