@@ -260,6 +260,17 @@ int  mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, ui
 int  mdemod_estimate_carrier_chirp(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
                                    const uint64_t *starts_dev, const float *chirp_dev, uint32_t n_windows, uint32_t window_samples,
                                    float *freq_dev, float *quality_dev, void *hip_stream);
+/* Feed-forward symbol-clock estimate of the same windows: the symbol-rate line of |z|^2 (QPSK) or the two lines of z^2 at twice
+ * the carrier +- the symbol rate (OQPSK: carrier_dev[w] = that window's carrier in rad per NCO step, e.g. from
+ * mdemod_estimate_carrier; chirp_dev as above; both may be NULL, and are not read for QPSK).  t_freq_dev[w]: the symbol clock in
+ * rad per interpolated step, as mm_omega() / timing.c:14 would hold it when locked (2 pi * symrate / samplerate / interp for a
+ * perfect clock), searched within the reference's own +-1/4096 of the nominal rate; quality_dev[w]: line / mean of +-128 bins
+ * (noise alone 2-4, a 12 dB signal 20-30).  window_samples is rounded down to a power of two in [4096, 2^18].  At 12 dB and
+ * 2^18 samples the estimate is good to 1e-7 of the rate (the reference's own loop wanders by 3e-6 around it).  Asynchronous on
+ * hip_stream; samplerate, symrate, interp_factor, oqpsk and bps of params are used. */
+int  mdemod_estimate_clock(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
+                           const uint64_t *starts_dev, const float *carrier_dev, const float *chirp_dev,
+                           uint32_t n_windows, uint32_t window_samples, float *t_freq_dev, float *quality_dev, void *hip_stream);
 
 /* ONE recording on many lanes.  The reference runs a recording as one serial recurrence (main.c:303-316);
  * here only its head runs serially (the "pilot": from the reference's power-on state until the carrier loop has locked and
@@ -287,13 +298,14 @@ typedef struct {
 	uint32_t frame_samples;         /* 0xFFFFFFFF = 1 500 symbols worth                                                  */
 	uint32_t settle_samples;        /* 0xFFFFFFFF = 24 000 symbols worth                                                 */
 	uint32_t pilot_block;           /* pilot granularity in samples               (65536)  */
-	uint32_t pilot_margin_symbols;  /* symbols between the first lock and the hand-over; 0xFFFFFFFF = 20 000 (OQPSK: 30 000) */
+	uint32_t pilot_margin_symbols;  /* symbols between the first lock and the hand-over; 0xFFFFFFFF = 15 000 (OQPSK: 20 000); 20 000 (30 000) when the tiles take the pilot's clock or carrier word */
 	uint64_t max_pilot_samples;     /* give up waiting for lock after this many   (1 << 22) */
 	uint32_t match_symbols;         /* symbols compared across a seam; at least 32 are used (192) */
 	int32_t  repair;                /* 1: tiles whose seam shows an odd residual rotation run settle + body again (1)    */
 	uint32_t carrier_seed;          /* 1: every tile from its own 4th-power spectrum (follows Doppler); 0: all tiles from
 	                                   the pilot's carrier estimate (dead reckoning then rarely holds: repair does the work) (1) */
-	uint32_t reserved;
+	uint32_t clock_seed;            /* 0: every tile's symbol clock from its own spectral line (mdemod_estimate_clock: follows the
+	                                   Doppler on the clock, good to a tenth of the loop's own wander); 1: the pilot's omega for all (0) */
 } mdemod_recording_opts;
 
 typedef struct {
@@ -318,7 +330,7 @@ typedef struct {
 	float    frame_residual_rms;    /* rad: dead-reckoned minus measured NCO phase, after removing the quarter turns (0.785 = limit) */
 	uint32_t odd_tiles_kept;        /* tiles left an odd number of quarter turns off because they were too few to be worth a repair
 	                                   pass (< 0.5 % of the tiles): output turned (decisions exact), soft values on the other rail's timing */
-	uint32_t reserved;
+	uint32_t weak_clock_tiles;      /* clock_seed=0: tiles without a clear symbol-rate line, seeded from their neighbours (or the pilot) */
 } mdemod_recording_report;
 
 void mdemod_recording_default_opts(mdemod_recording_opts *opts);

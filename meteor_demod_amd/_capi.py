@@ -64,7 +64,7 @@ class MdemodRecordingOpts(C.Structure):
     _fields_ = [("tile_samples", C.c_uint32), ("acquire_samples", C.c_uint32), ("frame_samples", C.c_uint32),
                 ("settle_samples", C.c_uint32), ("pilot_block", C.c_uint32), ("pilot_margin_symbols", C.c_uint32),
                 ("max_pilot_samples", C.c_uint64), ("match_symbols", C.c_uint32), ("repair", C.c_int32),
-                ("carrier_seed", C.c_uint32), ("reserved", C.c_uint32)]
+                ("carrier_seed", C.c_uint32), ("clock_seed", C.c_uint32)]
 
 
 class MdemodRecordingReport(C.Structure):
@@ -74,7 +74,7 @@ class MdemodRecordingReport(C.Structure):
                 ("pilot_locked", C.c_int32), ("weak_carrier_tiles", C.c_uint32),
                 ("pilot_seconds", C.c_double), ("tiles_seconds", C.c_double),
                 ("frame_misses", C.c_uint32), ("repaired_tiles", C.c_uint32), ("rotation_jumps", C.c_uint32),
-                ("frame_residual_rms", C.c_float), ("odd_tiles_kept", C.c_uint32), ("reserved", C.c_uint32)]
+                ("frame_residual_rms", C.c_float), ("odd_tiles_kept", C.c_uint32), ("weak_clock_tiles", C.c_uint32)]
 
 
 # name -> (restype, argtypes); this table is also what the symbol-export test walks.
@@ -111,6 +111,8 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_estimate_carrier_chirp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdemod_estimate_clock": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_kernel_name": (C.c_char_p, [C.c_void_p]),
     "mdemod_demodulate_recording_host": (C.c_int, [_P(MdemodParams), _P(MdemodRecordingOpts), C.c_void_p, C.c_uint64,
                                                    C.c_void_p, C.c_uint64, _P(MdemodRecordingReport)]),

@@ -199,6 +199,39 @@ template <> struct RawIQ<16> { typedef int16_t t; __device__ static float2 get(c
 template <> struct RawIQ<8>  { typedef uint8_t t; __device__ static float2 get(const void *p, uint64_t i) { const uint8_t *q = static_cast<const uint8_t *>(p) + 2 * i; return make_float2((float)((int)q[0] - 128), (float)((int)q[1] - 128)); } };
 template <> struct RawIQ<32> { typedef float t;   __device__ static float2 get(const void *p, uint64_t i) { const float *q = static_cast<const float *>(p) + 2 * i; return make_float2(q[0], q[1]); } };
 
+/* In-place radix-2 FFT of 2^log2_nf points in LDS by the whole block: input stored bit-reversed, output in natural order.
+ * Ends with a barrier. */
+__device__ __forceinline__ void
+lds_fft(float2 *spec, int log2_nf, int tid, int nth)
+{
+	const int NF = 1 << log2_nf;
+	for (int st = 0; st < log2_nf; st++) {                /* decimation in time */
+		const int half = 1 << st;
+		for (int b = tid; b < NF / 2; b += nth) {
+			const int j = b & (half - 1), i0 = ((b >> st) << (st + 1)) + j, i1 = i0 + half;
+			float sn, cs;
+			sincospif(-(float)j / (float)half, &sn, &cs);
+			const float2 u = spec[i0], v = spec[i1];
+			const float2 t = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+			spec[i0] = make_float2(u.x + t.x, u.y + t.y);
+			spec[i1] = make_float2(u.x - t.x, u.y - t.y);
+		}
+		__syncthreads();
+	}
+}
+
+/* Position of a Hann-windowed line from the largest bin k and its two neighbours (magnitudes a, b, c): the ratio of the two
+ * largest gives it (Grandke); a parabola through three magnitudes is biased by up to 0.03 bin. */
+__device__ __forceinline__ float
+grandke_offset(float a, float b, float c)
+{
+	if (!(b > 0.0f)) return 0.0f;
+	const float al = (c >= a ? c : a) / b;
+	float delta = (2.0f * al - 1.0f) / (al + 1.0f);
+	delta = fminf(fmaxf(delta, 0.0f), 0.5f);
+	return c < a ? -delta : delta;
+}
+
 /* One block (1024 threads) per tile, the whole estimate in one kernel and in LDS (no FFT library: hipFFT compiles its
  * kernels at run time, 1.6 s in every new process - more than a whole recording takes):
  *   1. mean of the window's nwin = NF * D samples;
@@ -258,19 +291,7 @@ carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, 
 		spec[__brev((unsigned)m) >> (32 - log2_nf)] = make_float2(ar * w, ai * w);
 	}
 	__syncthreads();
-	for (int st = 0; st < log2_nf; st++) {                /* decimation in time, natural-order output */
-		const int half = 1 << st;
-		for (int b = tid; b < NF / 2; b += nth) {
-			const int j = b & (half - 1), i0 = ((b >> st) << (st + 1)) + j, i1 = i0 + half;
-			float sn, cs;
-			sincospif(-(float)j / (float)half, &sn, &cs);
-			const float2 u = spec[i0], v = spec[i1];
-			const float2 t = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
-			spec[i0] = make_float2(u.x + t.x, u.y + t.y);
-			spec[i1] = make_float2(u.x - t.x, u.y - t.y);
-		}
-		__syncthreads();
-	}
+	lds_fft(spec, log2_nf, tid, nth);
 	auto mag = [&](int k) { const float2 v = spec[(k + NF) & (NF - 1)]; return v.x * v.x + v.y * v.y; };
 	float best = -1.0f, sum = 0.0f; int bidx = 0;
 	for (int k = -kmax + tid; k <= kmax; k += nth) {
@@ -291,17 +312,122 @@ carrier_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, 
 	if (tid == 0) {
 		const int k = redi[0];
 		const float a = sqrtf(mag(k - 1)), b = sqrtf(mag(k)), c = sqrtf(mag(k + 1));
-		/* Hann-windowed line between two bins: the ratio of the two largest magnitudes gives its position (Grandke); a
-		   parabola through three magnitudes is biased by up to 0.03 bin here, which is 0.1 rad over a tile of dead reckoning */
-		float delta = 0.0f;
-		if (b > 0.0f) {
-			const float al = (c >= a ? c : a) / b;
-			delta = (2.0f * al - 1.0f) / (al + 1.0f);
-			delta = fminf(fmaxf(delta, 0.0f), 0.5f);
-			if (c < a) delta = -delta;
-		}
+		/* (a parabola's 0.03 bin would be 0.1 rad over a tile of dead reckoning) */
+		const float delta = grandke_offset(a, b, c);
 		freq_out[blockIdx.x] = ((float)k + delta) * hz_per_bin_over4 * rad_per_hz;
 		quality_out[blockIdx.x] = b / (red[2][0] / (float)(2 * kmax + 1) + 1e-30f);
+	}
+}
+
+/* Feed-forward symbol-clock estimate, one block per window (same windows as the carrier estimate).  QPSK: |z|^2 of an RRC-shaped
+ * signal has a spectral line at the symbol rate.  OQPSK: there the two rails' lines cancel (half a symbol apart); z^2 carries
+ * them instead, at twice the carrier +- the symbol rate - their distance is twice the symbol rate whatever the carrier.
+ * The line is moved to zero with the nominal rate (phase in double), summed in groups of D samples (boxcar: the searched band
+ * is +-1/4096 of the rate, timing.c:80-86), Hann window, 4096-point FFT in LDS, Grandke peak.  Result: rad per interpolated
+ * step as timing.c:14 `freq` holds it.  12 dB, 262 144 samples: 1e-7 of the rate; the reference's own loop wanders by 3e-6. */
+template <int FMT>
+__global__ void __launch_bounds__(1024)
+clock_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, const float *carrier, const float *chirp,
+                  double carrier_scale, double chirp_scale, int oqpsk, int log2_nf, int decim, int kmax, int knoise,
+                  double f_nom, double t_freq_scale, float *t_freq_out, float *quality_out)
+{
+	extern __shared__ float2 spec[];                      /* NF (QPSK) or 2 * NF (OQPSK) complex floats */
+	__shared__ float red[3][1024];
+	__shared__ int redi[1024];
+	const int NF = 1 << log2_nf, nwin = NF * decim, tid = threadIdx.x, nth = blockDim.x;
+	const uint64_t s0 = starts[blockIdx.x];
+	auto sample = [&](int k) {
+		const uint64_t i = s0 + (uint64_t)k < n_samples ? s0 + (uint64_t)k : n_samples - 1;
+		return RawIQ<FMT>::get(iq, i);
+	};
+	float sr = 0.0f, si = 0.0f, sp = 0.0f;
+	for (int k = tid; k < nwin; k += nth) { const float2 v = sample(k); sr += v.x; si += v.y; sp += v.x * v.x + v.y * v.y; }
+	red[0][tid] = sr; red[1][tid] = si; red[2][tid] = sp;
+	__syncthreads();
+	for (int o = nth / 2; o > 0; o >>= 1) {
+		if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red[2][tid] += red[2][tid + o]; }
+		__syncthreads();
+	}
+	const float mr = red[0][0] / nwin, mi = red[1][0] / nwin;
+	const float pw = red[2][0] / nwin - (mr * mr + mi * mi);            /* power of the mean-free samples */
+	const float norm = 1.0f / (pw > 0.0f ? pw : 1.0f);
+	__syncthreads();
+	const float wstep = 2.0f / (float)(NF - 1);
+	/* OQPSK: lines of z^2 at 2 fc +- f_nom (cycles per sample); the chirp of z^2 is twice the carrier's */
+	const double fc2 = (oqpsk && carrier) ? 2.0 * (double)carrier[blockIdx.x] * carrier_scale : 0.0;
+	const double c2 = (oqpsk && chirp) ? (double)chirp[blockIdx.x] * chirp_scale : 0.0;
+	const int nline = oqpsk ? 2 : 1;
+	for (int m = tid; m < NF; m += nth) {
+		const double n0 = (double)(m * decim);
+		float2 acc[2] = { make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f) };
+		float2 rot[2], stp[2];
+		for (int l = 0; l < nline; l++) {
+			const double f = oqpsk ? fc2 + (l == 0 ? f_nom : -f_nom) : f_nom;
+			double ph = n0 * f; ph -= floor(ph);
+			double fs1 = f - floor(f);
+			float sn, cs;
+			sincospif(-2.0f * (float)ph, &sn, &cs); rot[l] = make_float2(cs, sn);
+			sincospif(-2.0f * (float)fs1, &sn, &cs); stp[l] = make_float2(cs, sn);
+		}
+		for (int d = 0; d < decim; d++) {
+			float2 v = sample(m * decim + d);
+			v.x -= mr; v.y -= mi;
+			float2 u;
+			if (oqpsk) {
+				u = make_float2((v.x * v.x - v.y * v.y) * norm, 2.0f * v.x * v.y * norm);
+				if (c2 != 0.0) {
+					const double t = n0 + (double)d - 0.5 * (double)nwin;
+					const double turns = -c2 * t * t;
+					float sn, cs;
+					sincospif(2.0f * (float)(turns - floor(turns)), &sn, &cs);
+					u = make_float2(u.x * cs - u.y * sn, u.x * sn + u.y * cs);
+				}
+			} else {
+				u = make_float2((v.x * v.x + v.y * v.y) * norm - 1.0f, 0.0f);
+			}
+			for (int l = 0; l < nline; l++) {
+				acc[l].x += u.x * rot[l].x - u.y * rot[l].y;
+				acc[l].y += u.x * rot[l].y + u.y * rot[l].x;
+				rot[l] = make_float2(rot[l].x * stp[l].x - rot[l].y * stp[l].y, rot[l].x * stp[l].y + rot[l].y * stp[l].x);
+			}
+		}
+		const float w = 0.5f - 0.5f * cospif(wstep * (float)m);
+		const unsigned br = __brev((unsigned)m) >> (32 - log2_nf);
+		for (int l = 0; l < nline; l++) spec[l * NF + br] = make_float2(acc[l].x * w, acc[l].y * w);
+	}
+	__syncthreads();
+	float pos[2] = { 0.0f, 0.0f }, qual[2] = { 0.0f, 0.0f };
+	for (int l = 0; l < nline; l++) {
+		float2 *sp2 = spec + l * NF;
+		lds_fft(sp2, log2_nf, tid, nth);
+		auto mag = [&](int k) { const float2 v = sp2[(k + NF) & (NF - 1)]; return v.x * v.x + v.y * v.y; };
+		float best = -1.0f, sum = 0.0f; int bidx = 0;
+		for (int k = -knoise + tid; k <= knoise; k += nth) {
+			const float m = mag(k);
+			sum += sqrtf(m);
+			if (m > best && k > -kmax && k < kmax) { best = m; bidx = k; }
+		}
+		red[0][tid] = best; redi[tid] = bidx; red[2][tid] = sum;
+		__syncthreads();
+		for (int o = nth / 2; o > 0; o >>= 1) {
+			if (tid < o) {
+				const float ov = red[0][tid + o]; const int oi = redi[tid + o];
+				if (ov > red[0][tid] || (ov == red[0][tid] && oi < redi[tid])) { red[0][tid] = ov; redi[tid] = oi; }
+				red[2][tid] += red[2][tid + o];
+			}
+			__syncthreads();
+		}
+		const int k = redi[0];
+		const float a = sqrtf(mag(k - 1)), b = sqrtf(mag(k)), c = sqrtf(mag(k + 1));
+		pos[l] = (float)k + grandke_offset(a, b, c);
+		qual[l] = b / (red[2][0] / (float)(2 * knoise + 1) + 1e-30f);
+		__syncthreads();
+	}
+	if (tid == 0) {
+		/* QPSK: the line sits pos[0] bins above the nominal rate; OQPSK: half the distance of the two lines is the rate */
+		const double dev = (oqpsk ? 0.5 * ((double)pos[0] - (double)pos[1]) : (double)pos[0]) / (double)nwin;
+		t_freq_out[blockIdx.x] = (float)((f_nom + dev) * t_freq_scale);
+		quality_out[blockIdx.x] = oqpsk ? fminf(qual[0], qual[1]) : qual[0];
 	}
 }
 
@@ -559,6 +685,44 @@ mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_
 	return mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, starts_dev, nullptr, n_windows, window_samples, freq_dev, quality_dev, hip_stream);
 }
 
+extern "C" int
+mdemod_estimate_clock(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
+                      const uint64_t *starts_dev, const float *carrier_dev, const float *chirp_dev,
+                      uint32_t n_windows, uint32_t window_samples, float *t_freq_dev, float *quality_dev, void *hip_stream)
+{
+	if (!params || !iq_dev || !starts_dev || !t_freq_dev || !quality_dev || n_samples == 0) return MDEMOD_ERR_PARAM;
+	if (params->samplerate <= 0 || params->symrate <= 0 || params->interp_factor <= 0 || (params->bps != 8 && params->bps != 16 && params->bps != 32)) return MDEMOD_ERR_PARAM;
+	if (n_windows == 0) return MDEMOD_OK;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	const double symrate = params->symrate, fs = params->samplerate;
+	int nwin = 4096;
+	while (nwin * 2 <= static_cast<int>(std::min<uint32_t>(window_samples, 1u << 18))) nwin *= 2;
+	const int log2_nf = 12, decim = nwin >> log2_nf;
+	const double f_nom = symrate / fs;                             /* cycles per sample */
+	const int nco = params->oqpsk ? 2 : 1;
+	/* the reference's loop keeps its rate within 1/4096 of the nominal one (timing.c:80-86); OQPSK: each line also carries twice
+	   the error of the carrier it was moved by (an estimate: a few bins at most) */
+	const int kmax = std::min((1 << log2_nf) / 2 - 2, static_cast<int>(f_nom / 4096.0 * nwin) + (params->oqpsk ? 12 : 3));
+	const int knoise = std::min((1 << log2_nf) / 2 - 2, std::max(128, 2 * kmax));
+	const double carrier_scale = symrate * nco / fs / (2 * 3.141592653589793);          /* rad per NCO step -> cycles per sample */
+	/* chirp in rad per NCO step per sample -> carrier turns per sample^2 = x nco * symrate / fs / 2 pi; phase 0.5 c t^2, doubled by z^2 */
+	const double chirp_scale = nco * symrate / fs / (2 * 3.141592653589793);
+	const double t_freq_scale = 2 * 3.141592653589793 / params->interp_factor;
+	const size_t lds = (static_cast<size_t>(1) << log2_nf) * sizeof(float2) * (params->oqpsk ? 2 : 1);
+#define LAUNCH_CLK(F) do { \
+		HTRY(hipFuncSetAttribute(reinterpret_cast<const void *>(clock_line_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+		hipLaunchKernelGGL(clock_line_kernel<F>, dim3(n_windows), dim3(1024), lds, st, iq_dev, n_samples, starts_dev, carrier_dev, chirp_dev, \
+		                   carrier_scale, chirp_scale, params->oqpsk ? 1 : 0, log2_nf, decim, kmax, knoise, f_nom, t_freq_scale, t_freq_dev, quality_dev); } while (0)
+	switch (params->bps) {
+	case 16: LAUNCH_CLK(16); break;
+	case 8:  LAUNCH_CLK(8); break;
+	default: LAUNCH_CLK(32); break;
+	}
+#undef LAUNCH_CLK
+	HTRY(hipGetLastError());
+	return MDEMOD_OK;
+}
+
 extern "C" void
 mdemod_recording_default_opts(mdemod_recording_opts *o)
 {
@@ -566,7 +730,7 @@ mdemod_recording_default_opts(mdemod_recording_opts *o)
 	o->tile_samples = 0;                     /* automatic, see the header */
 	o->acquire_samples = o->frame_samples = o->settle_samples = 0xFFFFFFFFu;
 	o->pilot_block = 65536; o->pilot_margin_symbols = 0xFFFFFFFFu;
-	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->repair = 1; o->carrier_seed = 1; o->reserved = 0;
+	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->repair = 1; o->carrier_seed = 1; o->clock_seed = 0;
 }
 
 namespace {
@@ -631,7 +795,8 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	/* symbols between the reference's first lock and the hand-over: the tiles right after it are seeded with a model of the serial
 	   loop's remaining convergence, which holds once the lock is this old (measured: the first tiles lose 5 % of their +-1 LSB
 	   agreement with 10 000 symbols less; OQPSK's loop, at twice the bandwidth, wanders more and wants 30 000) */
-	if (o.pilot_margin_symbols == 0xFFFFFFFFu) o.pilot_margin_symbols = params->oqpsk ? 30000 : 20000;
+	if (o.pilot_margin_symbols == 0xFFFFFFFFu) o.pilot_margin_symbols = (o.clock_seed || !o.carrier_seed) ? (params->oqpsk ? 30000 : 20000)      /* tiles that start from the pilot's own omega / carrier word: those need longer */
+		                                                                                 : (params->oqpsk ? 20000 : 15000);
 	if (!o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
 	memset(rep, 0, sizeof(*rep));
@@ -742,6 +907,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	TRY(mdemod_get_history(pilot.c, 0, seed_hist.data(), st));
 
 	/* ---- carrier of every tile: window i is centred on the span its frame is dead-reckoned over, [q_{i-1}, q_i] ---------------- */
+	std::vector<double> tclk(T, static_cast<double>(seed.t_freq));   /* symbol clock seeds, rad per interpolated step */
 	std::vector<double> centre(T), fbar(T), slope(T, 0.0);         /* rad per NCO step at centre[i]; slope in rad per NCO step per sample */
 	/* about 20 000 symbols per window (65 536 samples at 72k in 230 kS/s, 262 144 at 1 MS/s): the frames are dead-reckoned over a
 	   tile, the estimate has to be good to a fraction of a radian over that many symbols */
@@ -817,6 +983,43 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 				slope[i] = centre[hi] > centre[lo] ? (fbar[hi] - fbar[lo]) / (centre[hi] - centre[lo]) : 0.0;
 			}
 		}
+		if (o.clock_seed == 0) {
+			/* ---- symbol clock of every tile from the same windows (a pass moves the clock with the carrier: 20 ppm and more
+			   between the pilot and the far end; the loop's integrator needs 8 000 symbols per e-fold to make that up) ---- */
+			for (size_t i = 0; i < T; i++) { fh[i] = static_cast<float>(fbar[i]); chirp[i] = static_cast<float>(slope[i]); }
+			HTRY(hipMemcpyAsync(d_freq, fh.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+			HTRY(hipMemcpyAsync(d_chirp, chirp.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+			HTRY(hipStreamSynchronize(st));
+			float *d_tfq, *d_cq;
+			TRY(mem.alloc(&d_tfq, T)); TRY(mem.alloc(&d_cq, T));
+			TRY(mdemod_estimate_clock(params, iq_dev, n_samples, d_starts, d_freq, d_chirp, static_cast<uint32_t>(T), static_cast<uint32_t>(nfft), d_tfq, d_cq, st));
+			std::vector<float> th(T), cq(T);
+			HTRY(hipMemcpyAsync(th.data(), d_tfq, T * sizeof(float), hipMemcpyDeviceToHost, st));
+			HTRY(hipMemcpyAsync(cq.data(), d_cq, T * sizeof(float), hipMemcpyDeviceToHost, st));
+			HTRY(hipStreamSynchronize(st));
+			/* one window's estimate is good to (window / 65 536)^-1.5 * 6e-7 of the rate, the clock moves by < 1e-6 of it per second:
+			   a straight line through the good estimates within 2^18 samples either side takes the short windows' noise out */
+			size_t lo = 0, hi = 0, weak = 0;
+			const double span = 262144.0;
+			for (size_t i = 0; i < T; i++) {
+				while (centre[lo] < centre[i] - span) lo++;
+				while (hi + 1 < T && centre[hi + 1] <= centre[i] + span) hi++;
+				double sw = 0, sx = 0, sy = 0, sxx = 0, sxy = 0;
+				for (size_t j = lo; j <= hi; j++) {
+					if (cq[j] < min_quality) continue;
+					const double x = centre[j] - centre[i], y = static_cast<double>(th[j]) - static_cast<double>(seed.t_freq);
+					sw += 1; sx += x; sy += y; sxx += x * x; sxy += x * y;
+				}
+				if (cq[i] < min_quality) weak++;
+				if (sw < 1) continue;                                   /* nothing usable near: the pilot's omega stays */
+				const double det = sw * sxx - sx * sx;
+				const double at_centre = (sw >= 3 && det > 1e-6 * sw * sxx) ? (sy * sxx - sx * sxy) / det : sy / sw;
+				const double lim = static_cast<double>(consts[6]);   /* timing.c:80-86 keeps the loop within this of its centre */
+				tclk[i] = static_cast<double>(consts[5]) + std::max(-lim, std::min(lim, static_cast<double>(seed.t_freq) + at_centre - static_cast<double>(consts[5])));
+			}
+			rep->weak_clock_tiles = static_cast<uint32_t>(weak);
+			if (dbg) fprintf(stderr, "[recording] clock seeds: pilot %.9g, tiles %.9g .. %.9g (weak %zu)\n", static_cast<double>(seed.t_freq), tclk[T > 1 ? 1 : 0], tclk[T - 1], weak);
+		}
 	} else {
 		for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
 	}
@@ -843,6 +1046,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	TRY(mdemod_set_state(bank.c, 0, &seed, st));
 	TRY(mdemod_set_history(bank.c, 0, seed_hist.data(), st));
 	std::vector<float> f0(T), tf(T, seed.t_freq), gains(T, seed.agc_gain); std::vector<int32_t> ud(T);
+	for (size_t i = 1; i < T; i++) tf[i] = static_cast<float>(tclk[i]);
 	float *d_f0, *d_tf, *d_gain; int32_t *d_ud;
 	TRY(mem.alloc(&d_f0, T)); TRY(mem.alloc(&d_tf, T)); TRY(mem.alloc(&d_gain, T)); TRY(mem.alloc(&d_ud, T));
 	auto put_carrier_seeds = [&](bool at_acquired) -> int {

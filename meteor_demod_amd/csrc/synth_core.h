@@ -49,7 +49,23 @@ typedef struct {
 	int32_t  oqpsk;         /* Q rail delayed by half a symbol                   */
 	int32_t  fmt;           /* 8, 16, 32 — the reference's --bps values          */
 	int64_t  car_ramp48;    /* Doppler ramp: change of car_step per sample, units of 2^-48 turn per sample^2 */
+	int64_t  clk_ramp64;    /* Doppler on the symbol clock: change of sym_step per sample, units of 2^-64 symbol per sample^2 */
 } synth_stream;
+
+/* (a * b) >> 32 for a < 2^63 and a signed b, exact through the 128-bit product */
+SYNTH_HD uint64_t
+synth_mul_shr32(uint64_t a, int64_t b)
+{
+	const uint64_t m = b < 0 ? (uint64_t)(-b) : (uint64_t)b;
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint64_t hi = __umul64hi(a, m), lo = a * m;
+#else
+	const unsigned __int128 pr = (unsigned __int128)a * m;
+	const uint64_t hi = (uint64_t)(pr >> 64), lo = (uint64_t)pr;
+#endif
+	const uint64_t r = (hi << 32) | (lo >> 32);
+	return b < 0 ? (uint64_t)0 - r : r;
+}
 
 SYNTH_HD uint64_t
 synth_mix64(uint64_t z)
@@ -115,13 +131,13 @@ synth_noise(uint64_t seed, uint64_t n, uint64_t salt)
 SYNTH_HD void
 synth_sample(const synth_tables *tb, const synth_stream *st, uint64_t n, double *oi, double *oq)
 {
-	const uint64_t t = st->sym_phase0 + n * st->sym_step;
+	const uint64_t tri = (n & 1) ? n * ((n - 1) >> 1) : (n >> 1) * (n - 1);       /* n(n-1)/2 */
+	const uint64_t t = st->sym_phase0 + n * st->sym_step + (st->clk_ramp64 ? synth_mul_shr32(tri, st->clk_ramp64) : 0);
 	const double bi = synth_rail(tb, st->seed, t, 0);
 	const double bq = synth_rail(tb, st->seed, st->oqpsk ? t - 0x80000000ull : t, 1);
 
 	/* phase = phase0 + n*step + ramp*n(n-1)/2, all modulo one turn: only bits 16..47 of the 2^-48 product matter, so the
 	 * 64-bit wrap-around of the multiplication is harmless */
-	const uint64_t tri = (n & 1) ? n * ((n - 1) >> 1) : (n >> 1) * (n - 1);
 	const uint32_t th = st->car_phase0 + (uint32_t)n * st->car_step + (uint32_t)((tri * (uint64_t)st->car_ramp48) >> 16);
 	const uint32_t hi = th >> 22, lo = (th >> 12) & 0x3FFu;
 	const double c = tb->cos_hi[hi] * tb->cos_lo[lo] - tb->sin_hi[hi] * tb->sin_lo[lo];

@@ -52,10 +52,34 @@ def estimate_carrier_native(cfg, iq, starts, window_samples: int, device: int = 
     return freq, qual, used
 
 
+def estimate_clock_native(cfg, iq, starts, window_samples: int, device: int = 0, carrier=None, chirp=None):
+    """``mdemod_estimate_clock`` on a device tensor [n, 2]: (t_freq [T] float32 rad per interpolated step, quality [T]).
+    ``carrier`` (OQPSK): each window's carrier in rad per NCO step, ``chirp``: its slope per sample."""
+    import ctypes as C
+    import torch
+    from . import _capi
+    lib = _capi.lib()
+    assert iq.is_cuda and iq.dim() == 2 and iq.shape[1] == 2 and iq.is_contiguous()
+    p = cfg.to_c(1, device)
+    st = torch.as_tensor(np.ascontiguousarray(starts, dtype=np.int64), device=iq.device)
+    T = int(st.numel())
+    tf = torch.empty(T, dtype=torch.float32, device=iq.device)
+    qual = torch.empty(T, dtype=torch.float32, device=iq.device)
+    dev = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a.cpu().numpy() if hasattr(a, "cpu") else a, dtype=np.float32), device=iq.device)
+    ca, ch = dev(carrier), dev(chirp)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _capi.check(lib.mdemod_estimate_clock(C.byref(p), C.c_void_p(iq.data_ptr()), int(iq.shape[0]), C.c_void_p(st.data_ptr()),
+                                          C.c_void_p(ca.data_ptr()) if ca is not None else None,
+                                          C.c_void_p(ch.data_ptr()) if ch is not None else None, T, int(window_samples),
+                                          C.c_void_p(tf.data_ptr()), C.c_void_p(qual.data_ptr()), stream), "mdemod_estimate_clock")
+    torch.cuda.current_stream(device).synchronize()
+    return tf, qual
+
+
 def demodulate_recording_native(cfg, iq, tile_samples: int = 0, acquire_samples: int = AUTO, frame_samples: int = AUTO,
                                 settle_samples: int = AUTO, repair: bool = True, pilot_block: int = 65536,
                                 pilot_margin_symbols: int = AUTO, max_pilot_samples: int = 1 << 22, match_symbols: int = 192,
-                                device: int = 0, carrier_seed: str = "spectrum", soft_capacity: int = 0):
+                                device: int = 0, carrier_seed: str = "spectrum", soft_capacity: int = 0, clock_seed: str = "spectrum"):
     """``mdemod_demodulate_recording`` on a device tensor [n, 2]: returns (soft int8 [m, 2] device tensor, report).
     Lengths in samples; 0 / AUTO take the library's defaults (see include/meteor_demod_amd.h).
     ``soft_capacity`` (symbols; 0 = nominal rate + 5 % + 65536) is what the callee checks its output against."""
@@ -68,11 +92,11 @@ def demodulate_recording_native(cfg, iq, tile_samples: int = 0, acquire_samples:
     want = {8: torch.uint8, 16: torch.int16, 32: torch.float32}[cfg.bps]
     if iq.dtype != want or iq.device.index != device:
         raise ValueError(f"iq is {iq.dtype} on {iq.device}; expected {want} on cuda:{device}")
-    if carrier_seed not in ("pilot", "spectrum"):
-        raise ValueError("carrier_seed is 'pilot' or 'spectrum'")
+    if carrier_seed not in ("pilot", "spectrum") or clock_seed not in ("pilot", "spectrum"):
+        raise ValueError("carrier_seed and clock_seed are 'pilot' or 'spectrum'")
     opts = _capi.MdemodRecordingOpts(int(tile_samples), int(acquire_samples), int(frame_samples), int(settle_samples),
                                      int(pilot_block), int(pilot_margin_symbols), int(max_pilot_samples), int(match_symbols),
-                                     int(bool(repair)), 1 if carrier_seed == "spectrum" else 0, 0)
+                                     int(bool(repair)), 1 if carrier_seed == "spectrum" else 0, 0 if clock_seed == "spectrum" else 1)
     n = int(iq.shape[0])
     p = cfg.to_c(1, device)
     cap = int(soft_capacity) or int(n * cfg.symrate / cfg.samplerate * 1.05) + 65536   # stitched output: nominal rate + slack (checked by the callee)

@@ -31,7 +31,7 @@ class SynthStream(C.Structure):
                 ("car_step", C.c_uint32), ("car_phase0", C.c_uint32),
                 ("amp", C.c_double), ("noise_scale", C.c_double),
                 ("dc_i", C.c_double), ("dc_q", C.c_double),
-                ("oqpsk", C.c_int32), ("fmt", C.c_int32), ("car_ramp48", C.c_int64)]
+                ("oqpsk", C.c_int32), ("fmt", C.c_int32), ("car_ramp48", C.c_int64), ("clk_ramp64", C.c_int64)]
 
 
 _lib = None
@@ -72,8 +72,9 @@ def tables() -> SynthTables:
 def make_stream(seed: int, samplerate: float, symrate: float, *, f0_hz: float = 1200.0,
                 phase0_rad: float = 0.7, clock_ppm: float = 0.0, esn0_db: float = 12.0,
                 rms: float = 6000.0, dc=(30.0, -20.0), oqpsk: bool = False, fmt: int = 16,
-                sym_phase0: float = 0.25, doppler_hz_per_s: float = 0.0) -> SynthStream:
-    """Stream descriptor: `rms` is the complex RMS amplitude in LSB of the output format."""
+                sym_phase0: float = 0.25, doppler_hz_per_s: float = 0.0, clock_ppm_per_s: float = 0.0) -> SynthStream:
+    """Stream descriptor: `rms` is the complex RMS amplitude in LSB of the output format.  A satellite pass moves the carrier
+    (`doppler_hz_per_s`) and the symbol clock (`clock_ppm_per_s`) together: ppm/s = Hz/s divided by the RF frequency in MHz."""
     sps = samplerate / (symrate * (1.0 + clock_ppm * 1e-6))
     sym_step = int(round((1.0 / sps) * 2.0 ** 32))
     car_step = int(round((f0_hz / samplerate) * 2.0 ** 32)) & 0xFFFFFFFF
@@ -85,7 +86,8 @@ def make_stream(seed: int, samplerate: float, symrate: float, *, f0_hz: float = 
     ih_std = math.sqrt(8.0 * (65536.0 ** 2 - 1.0) / 12.0)  # std of the 8-uniform integer sum
     return SynthStream(seed & (2 ** 64 - 1), sym_step, int(sym_phase0 * 2 ** 32) + (SPAN << 32),
                        car_step, car_phase0, amp, sigma / ih_std, dc[0], dc[1], int(oqpsk), fmt,
-                       int(round(doppler_hz_per_s / samplerate ** 2 * 2.0 ** 48)))
+                       int(round(doppler_hz_per_s / samplerate ** 2 * 2.0 ** 48)),
+                       int(round(clock_ppm_per_s * 1e-6 / samplerate * (1.0 / sps) * 2.0 ** 64)))
 
 
 def generate_host(st: SynthStream, count: int, n0: int = 0) -> np.ndarray:

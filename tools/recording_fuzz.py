@@ -53,7 +53,8 @@ for ci in range(n_cases):
             kw["settle_samples"] = int(os.environ["FUZZ_SETTLE"])
         print("replay: esn0", esn0, "amp", amp)
     st = synth.make_stream(1000 + ci, samplerate, symrate, f0_hz=f0, clock_ppm=ppm, esn0_db=esn0,
-                           doppler_hz_per_s=ramp, oqpsk=oqpsk, fmt=bps, **amp)
+                           doppler_hz_per_s=ramp, clock_ppm_per_s=0.0 if os.environ.get("FUZZ_CLOCK_RAMP", "1") == "0" else ramp / 137.1,   # a pass moves the clock with the carrier
+                           oqpsk=oqpsk, fmt=bps, **amp)
     iq = synth.generate_device([st], n)[0]
     serial, tr, ev = O.oracle_demod(cfg, iq.cpu().numpy(), True)
     soft, rep = demodulate_recording_native(cfg, iq, carrier_seed=mode, **kw)
