@@ -172,7 +172,7 @@ def test_cli_tiled_short_file_is_the_serial_file(tmp_path, gpu_device):
     of a 65 536-sample block in a buffer sized for the file.)"""
     from golden_cases import wav_header
     from meteor_demod_amd import synth
-    for n in (8192 * 3, 8192 * 12):
+    for n in (8192 * 3, 8192 * 6):                    # 15 400 symbols at most: the hand-over is 15 000 symbols after the lock
         iq = synth.generate_host(synth.make_stream(77, 230000, 72000, f0_hz=0.0, esn0_db=14.0), n)
         inp, a, b = tmp_path / "short.wav", tmp_path / "a.s", tmp_path / "b.s"
         inp.write_bytes(wav_header(230000, 16, iq.nbytes) + iq.tobytes())
