@@ -330,7 +330,7 @@ typedef struct {
 	float    frame_residual_rms;    /* rad: dead-reckoned minus measured NCO phase, after removing the quarter turns (0.785 = limit) */
 	uint32_t odd_tiles_kept;        /* tiles left an odd number of quarter turns off because they were too few to be worth a repair
 	                                   pass (< 0.5 % of the tiles): output turned (decisions exact), soft values on the other rail's timing */
-	uint32_t weak_clock_tiles;      /* clock_seed=0: tiles without a clear symbol-rate line, seeded from their neighbours (or the pilot) */
+	uint32_t weak_clock_tiles;      /* clock_seed=0: tiles with no clear symbol-rate line in any window around them: they start from the pilot's omega */
 } mdemod_recording_report;
 
 void mdemod_recording_default_opts(mdemod_recording_opts *opts);

@@ -195,7 +195,7 @@ match_heads_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *ro
 /* ---- per-tile carrier estimate (Doppler): z^4 of the samples has a line at 4x the carrier offset -------- */
 
 template <int FMT> struct RawIQ;
-template <> struct RawIQ<16> { typedef int16_t t; __device__ static float2 get(const void *p, uint64_t i) { const int16_t *q = static_cast<const int16_t *>(p) + 2 * i; return make_float2((float)q[0], (float)q[1]); } };
+template <> struct RawIQ<16> { typedef int16_t t; __device__ static float2 get(const void *p, uint64_t i) { uint32_t w; __builtin_memcpy(&w, static_cast<const int16_t *>(p) + 2 * i, 4); return make_float2((float)(int16_t)(w & 0xFFFFu), (float)((int32_t)w >> 16)); } };   /* one load per pair */
 template <> struct RawIQ<8>  { typedef uint8_t t; __device__ static float2 get(const void *p, uint64_t i) { const uint8_t *q = static_cast<const uint8_t *>(p) + 2 * i; return make_float2((float)((int)q[0] - 128), (float)((int)q[1] - 128)); } };
 template <> struct RawIQ<32> { typedef float t;   __device__ static float2 get(const void *p, uint64_t i) { const float *q = static_cast<const float *>(p) + 2 * i; return make_float2(q[0], q[1]); } };
 
@@ -340,60 +340,60 @@ clock_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, co
 		const uint64_t i = s0 + (uint64_t)k < n_samples ? s0 + (uint64_t)k : n_samples - 1;
 		return RawIQ<FMT>::get(iq, i);
 	};
-	float sr = 0.0f, si = 0.0f, sp = 0.0f;
-	for (int k = tid; k < nwin; k += nth) { const float2 v = sample(k); sr += v.x; si += v.y; sp += v.x * v.x + v.y * v.y; }
-	red[0][tid] = sr; red[1][tid] = si; red[2][tid] = sp;
-	__syncthreads();
-	for (int o = nth / 2; o > 0; o >>= 1) {
-		if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red[2][tid] += red[2][tid + o]; }
-		__syncthreads();
-	}
-	const float mr = red[0][0] / nwin, mi = red[1][0] / nwin;
-	const float pw = red[2][0] / nwin - (mr * mr + mi * mi);            /* power of the mean-free samples */
-	const float norm = 1.0f / (pw > 0.0f ? pw : 1.0f);
-	__syncthreads();
+	/* No mean removal and no normalisation (one pass over the samples): a DC offset m adds 2 Re(z conj(m)) to |z|^2, and z has no
+	   energy at the symbol rate (the RRC band ends at 0.8 of it); the power term of |z|^2 sits at DC, a rate away from the line,
+	   and does not add up coherently over the D samples of a boxcar as the line does.  Quality is a ratio. */
 	const float wstep = 2.0f / (float)(NF - 1);
 	/* OQPSK: lines of z^2 at 2 fc +- f_nom (cycles per sample); the chirp of z^2 is twice the carrier's */
 	const double fc2 = (oqpsk && carrier) ? 2.0 * (double)carrier[blockIdx.x] * carrier_scale : 0.0;
 	const double c2 = (oqpsk && chirp) ? (double)chirp[blockIdx.x] * chirp_scale : 0.0;
 	const int nline = oqpsk ? 2 : 1;
-	for (int m = tid; m < NF; m += nth) {
-		const double n0 = (double)(m * decim);
-		float2 acc[2] = { make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f) };
-		float2 rot[2], stp[2];
-		for (int l = 0; l < nline; l++) {
-			const double f = oqpsk ? fc2 + (l == 0 ? f_nom : -f_nom) : f_nom;
-			double ph = n0 * f; ph -= floor(ph);
-			double fs1 = f - floor(f);
-			float sn, cs;
-			sincospif(-2.0f * (float)ph, &sn, &cs); rot[l] = make_float2(cs, sn);
-			sincospif(-2.0f * (float)fs1, &sn, &cs); stp[l] = make_float2(cs, sn);
-		}
-		for (int d = 0; d < decim; d++) {
-			float2 v = sample(m * decim + d);
-			v.x -= mr; v.y -= mi;
-			float2 u;
-			if (oqpsk) {
-				u = make_float2((v.x * v.x - v.y * v.y) * norm, 2.0f * v.x * v.y * norm);
-				if (c2 != 0.0) {
-					const double t = n0 + (double)d - 0.5 * (double)nwin;
-					const double turns = -c2 * t * t;
-					float sn, cs;
-					sincospif(2.0f * (float)(turns - floor(turns)), &sn, &cs);
-					u = make_float2(u.x * cs - u.y * sn, u.x * sn + u.y * cs);
-				}
-			} else {
-				u = make_float2((v.x * v.x + v.y * v.y) * norm - 1.0f, 0.0f);
-			}
+	/* Thread t takes samples t, t + 1024, ...: a wave reads 64 consecutive samples (one or more whole groups of D), the D lanes
+	   of a group add up with xor shuffles and the first lane stores the decimated point.  (One thread per point and D strided
+	   samples per thread was 3x slower at D = 64: 64 lanes on 64 different cache lines with every load; 4 samples per thread
+	   4x slower still, for the same reason.)  The rotation of each thread's samples advances by a constant per step; it is
+	   set from the double-precision phase every 64 steps. */
+	const int lg = __ffs(decim) - 1;                                   /* decim is a power of two */
+	double fl[2];
+	float2 rot[2], stp[2];
+	for (int l = 0; l < nline; l++) {
+		fl[l] = oqpsk ? fc2 + (l == 0 ? f_nom : -f_nom) : f_nom;
+		double sp = (double)nth * fl[l]; sp -= floor(sp);
+		float sn, cs;
+		sincospif(-2.0f * (float)sp, &sn, &cs); stp[l] = make_float2(cs, sn);
+		rot[l] = make_float2(1.0f, 0.0f);
+	}
+	for (int it = 0; it < nwin / nth; it++) {
+		const int n = it * nth + tid;
+		if ((it & 63) == 0)
 			for (int l = 0; l < nline; l++) {
-				acc[l].x += u.x * rot[l].x - u.y * rot[l].y;
-				acc[l].y += u.x * rot[l].y + u.y * rot[l].x;
-				rot[l] = make_float2(rot[l].x * stp[l].x - rot[l].y * stp[l].y, rot[l].x * stp[l].y + rot[l].y * stp[l].x);
+				double ph = (double)n * fl[l]; ph -= floor(ph);
+				float sn, cs;
+				sincospif(-2.0f * (float)ph, &sn, &cs); rot[l] = make_float2(cs, sn);
 			}
+		const float2 v = sample(n);
+		float2 u;
+		if (oqpsk) {
+			u = make_float2(v.x * v.x - v.y * v.y, 2.0f * v.x * v.y);
+			if (c2 != 0.0) {
+				const double t = (double)n - 0.5 * (double)nwin;
+				const double turns = -c2 * t * t;
+				float sn, cs;
+				sincospif(2.0f * (float)(turns - floor(turns)), &sn, &cs);
+				u = make_float2(u.x * cs - u.y * sn, u.x * sn + u.y * cs);
+			}
+		} else {
+			u = make_float2(v.x * v.x + v.y * v.y, 0.0f);
 		}
+		const int m = n >> lg;
 		const float w = 0.5f - 0.5f * cospif(wstep * (float)m);
 		const unsigned br = __brev((unsigned)m) >> (32 - log2_nf);
-		for (int l = 0; l < nline; l++) spec[l * NF + br] = make_float2(acc[l].x * w, acc[l].y * w);
+		for (int l = 0; l < nline; l++) {
+			float ax = u.x * rot[l].x - u.y * rot[l].y, ay = u.x * rot[l].y + u.y * rot[l].x;
+			rot[l] = make_float2(rot[l].x * stp[l].x - rot[l].y * stp[l].y, rot[l].x * stp[l].y + rot[l].y * stp[l].x);
+			for (int off = decim >> 1; off > 0; off >>= 1) { ax += __shfl_xor(ax, off); ay += __shfl_xor(ay, off); }
+			if ((tid & (decim - 1)) == 0) spec[l * NF + br] = make_float2(ax * w, ay * w);
+		}
 	}
 	__syncthreads();
 	float pos[2] = { 0.0f, 0.0f }, qual[2] = { 0.0f, 0.0f };
@@ -983,42 +983,55 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 				slope[i] = centre[hi] > centre[lo] ? (fbar[hi] - fbar[lo]) / (centre[hi] - centre[lo]) : 0.0;
 			}
 		}
-		if (o.clock_seed == 0) {
-			/* ---- symbol clock of every tile from the same windows (a pass moves the clock with the carrier: 20 ppm and more
-			   between the pilot and the far end; the loop's integrator needs 8 000 symbols per e-fold to make that up) ---- */
-			for (size_t i = 0; i < T; i++) { fh[i] = static_cast<float>(fbar[i]); chirp[i] = static_cast<float>(slope[i]); }
-			HTRY(hipMemcpyAsync(d_freq, fh.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
-			HTRY(hipMemcpyAsync(d_chirp, chirp.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+		if (o.clock_seed == 0 && n_samples >= 4096) {
+			/* ---- symbol clock of every tile (a pass moves the clock with the carrier: 20 ppm and more between the pilot and the far
+			   end; the loop's integrator needs 8 000 symbols per e-fold to make that up).  The clock is smooth, so its windows are
+			   the estimator's longest (2^18 samples: 5e-8 of the rate), side by side over the tiled part, whatever the tile length;
+			   every tile reads a straight line through the estimates around it. ---- */
+			uint32_t wc = 4096;
+			while (wc * 2 <= std::min<uint64_t>(n_samples, 1u << 18)) wc *= 2;
+			const uint64_t first = std::min<uint64_t>(s0[1], n_samples - wc);
+			std::vector<uint64_t> cst;
+			for (uint64_t a = first; ; a += wc) {
+				if (a + wc >= n_samples) { cst.push_back(n_samples - wc); break; }
+				cst.push_back(a);
+			}
+			const size_t Tc = cst.size();
+			std::vector<float> cf(Tc), cc(Tc);
+			std::vector<double> cx(Tc);
+			for (size_t j = 0; j < Tc; j++) {
+				cx[j] = static_cast<double>(cst[j]) + 0.5 * wc;
+				cf[j] = static_cast<float>(interp_at(centre, fbar, std::min(std::max(cx[j], centre.front()), centre.back())));     /* OQPSK: where its two lines are */
+				cc[j] = static_cast<float>(interp_at(centre, slope, std::min(std::max(cx[j], centre.front()), centre.back())));
+			}
+			uint64_t *d_cst; float *d_cf, *d_cc, *d_tfq, *d_cq;
+			TRY(upload(mem, cst, &d_cst, st)); TRY(upload(mem, cf, &d_cf, st)); TRY(upload(mem, cc, &d_cc, st));
+			TRY(mem.alloc(&d_tfq, Tc)); TRY(mem.alloc(&d_cq, Tc));
+			TRY(mdemod_estimate_clock(params, iq_dev, n_samples, d_cst, d_cf, d_cc, static_cast<uint32_t>(Tc), wc, d_tfq, d_cq, st));
+			std::vector<float> th(Tc), cq(Tc);
+			HTRY(hipMemcpyAsync(th.data(), d_tfq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
+			HTRY(hipMemcpyAsync(cq.data(), d_cq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
 			HTRY(hipStreamSynchronize(st));
-			float *d_tfq, *d_cq;
-			TRY(mem.alloc(&d_tfq, T)); TRY(mem.alloc(&d_cq, T));
-			TRY(mdemod_estimate_clock(params, iq_dev, n_samples, d_starts, d_freq, d_chirp, static_cast<uint32_t>(T), static_cast<uint32_t>(nfft), d_tfq, d_cq, st));
-			std::vector<float> th(T), cq(T);
-			HTRY(hipMemcpyAsync(th.data(), d_tfq, T * sizeof(float), hipMemcpyDeviceToHost, st));
-			HTRY(hipMemcpyAsync(cq.data(), d_cq, T * sizeof(float), hipMemcpyDeviceToHost, st));
-			HTRY(hipStreamSynchronize(st));
-			/* one window's estimate is good to (window / 65 536)^-1.5 * 6e-7 of the rate, the clock moves by < 1e-6 of it per second:
-			   a straight line through the good estimates within 2^18 samples either side takes the short windows' noise out */
 			size_t lo = 0, hi = 0, weak = 0;
-			const double span = 262144.0;
+			const double span = 2.5 * wc;                            /* five windows: the clock moves by < 1e-6 of the rate per second */
 			for (size_t i = 0; i < T; i++) {
-				while (centre[lo] < centre[i] - span) lo++;
-				while (hi + 1 < T && centre[hi + 1] <= centre[i] + span) hi++;
+				const double t = static_cast<double>(s0[i]);
+				while (lo + 1 < Tc && cx[lo] < t - span) lo++;
+				while (hi + 1 < Tc && cx[hi + 1] <= t + span) hi++;
 				double sw = 0, sx = 0, sy = 0, sxx = 0, sxy = 0;
 				for (size_t j = lo; j <= hi; j++) {
 					if (cq[j] < min_quality) continue;
-					const double x = centre[j] - centre[i], y = static_cast<double>(th[j]) - static_cast<double>(seed.t_freq);
+					const double x = cx[j] - t, y = static_cast<double>(th[j]) - static_cast<double>(seed.t_freq);
 					sw += 1; sx += x; sy += y; sxx += x * x; sxy += x * y;
 				}
-				if (cq[i] < min_quality) weak++;
-				if (sw < 1) continue;                                   /* nothing usable near: the pilot's omega stays */
+				if (sw < 1) { weak++; continue; }                       /* no line anywhere near: the pilot's omega stays */
 				const double det = sw * sxx - sx * sx;
-				const double at_centre = (sw >= 3 && det > 1e-6 * sw * sxx) ? (sy * sxx - sx * sxy) / det : sy / sw;
+				const double at_t = (sw >= 3 && det > 1e-6 * sw * sxx) ? (sy * sxx - sx * sxy) / det : sy / sw;
 				const double lim = static_cast<double>(consts[6]);   /* timing.c:80-86 keeps the loop within this of its centre */
-				tclk[i] = static_cast<double>(consts[5]) + std::max(-lim, std::min(lim, static_cast<double>(seed.t_freq) + at_centre - static_cast<double>(consts[5])));
+				tclk[i] = static_cast<double>(consts[5]) + std::max(-lim, std::min(lim, static_cast<double>(seed.t_freq) + at_t - static_cast<double>(consts[5])));
 			}
 			rep->weak_clock_tiles = static_cast<uint32_t>(weak);
-			if (dbg) fprintf(stderr, "[recording] clock seeds: pilot %.9g, tiles %.9g .. %.9g (weak %zu)\n", static_cast<double>(seed.t_freq), tclk[T > 1 ? 1 : 0], tclk[T - 1], weak);
+			if (dbg) fprintf(stderr, "[recording] clock seeds from %zu windows of %u: pilot %.9g, tiles %.9g .. %.9g (weak %zu)\n", Tc, wc, static_cast<double>(seed.t_freq), tclk[T > 1 ? 1 : 0], tclk[T - 1], weak);
 		}
 	} else {
 		for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
@@ -1156,15 +1169,18 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 
 		/* ---- frames by dead reckoning along the chain pilot -> tile 1 -> tile 2 ... ---------------------------------- */
 		TRY(mdemod_get_states(bank.c, 0, static_cast<uint32_t>(T), qs.data(), st));
-		const double steps_per_nco = 2 * kPi / static_cast<double>(seed.t_freq) / nco;
 		double th_prev = seed.pll_phase, t_prev = last_nco_time(seed, static_cast<double>(P), interp, params->oqpsk);
 		int32_t accr = 0; double res2 = 0.0;
 		for (size_t i = 1; i < T; i++) {
 			const double th = qs[i].pll_phase, tt = last_nco_time(qs[i], static_cast<double>(q[i]), interp, params->oqpsk);
 			const double t_mid = 0.5 * (t_prev + tt) / interp;
 			double res;
+			/* NCO steps between the two: the symbol period of THIS stretch of the recording (a pass moves the clock: 50 ppm over a
+			   41 072-symbol tile would be two steps with the pilot's period) */
+			const double steps_per_nco = 2 * kPi / (0.5 * (tclk[i - 1] + tclk[i])) / nco;
 			accr = (accr + frame_between(th_prev, t_prev, th, tt, f_at(t_mid), steps_per_nco, &res)) & 3;
 			R[i] = accr; res2 += res * res;
+			if (dbg && std::fabs(res) > 0.3) fprintf(stderr, "[recording]   frame %zu: dead-reckoning residual %.3f rad (theta %.4f, f %.6g, t_freq %.9g, locked %d)\n", i, res, th, f_at(t_mid), static_cast<double>(qs[i].t_freq), qs[i].pll_locked);
 			th_prev = th; t_prev = tt;
 		}
 		rep->frame_residual_rms = static_cast<float>(std::sqrt(res2 / static_cast<double>(T - 1)));

@@ -453,7 +453,7 @@ def test_estimate_clock_entry(gpu_device, oqpsk, bps, ppm, ramp):
     assert np.abs(t[:4] / true - 1).max() < 3e-6, t[:4] / true - 1
     assert q[:4].min() > 15 and q[4] < 6, q
     nominal = 2 * np.pi * symrate / 230000 / cfg.interp_factor
-    assert abs(t[4] / nominal - 1) <= 1.001 / 4096                                    # searched within the loop's own range only
+    assert abs(t[4] / nominal - 1) <= 2.0 / 4096                                      # searched within the loop's own range (+ 3 bins) only
     t2, q2 = estimate_clock_native(cfg, both, starts[:2], 5000, carrier=fc[:2].astype(np.float32) if oqpsk else None)   # 4096 samples
     assert np.abs(t2.cpu().numpy() / true - 1).max() < 2e-4
 

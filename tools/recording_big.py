@@ -1,4 +1,4 @@
-"""End-to-end time of ONE huge recording (configs[1] signal, no oracle check): recording_big.py [log2_samples=32] [key=value: tile= settle= (symbols)]"""
+"""End-to-end time of ONE huge recording (configs[1] signal, no oracle check): recording_big.py [log2_samples=32] [key=value: tile= settle= margin= (symbols) clkseed=pilot|spectrum]"""
 import sys, time
 sys.path.insert(0, '.')
 import torch
@@ -10,6 +10,8 @@ kv = dict(a.split("=") for a in sys.argv[2:] if "=" in a)
 osf = 230000 / 72000
 kw = {}
 if "tile" in kv: kw["tile_samples"] = int(float(kv["tile"]) * osf) // 64 * 64
+if "clkseed" in kv: kw["clock_seed"] = kv["clkseed"]
+if "margin" in kv: kw["pilot_margin_symbols"] = int(kv["margin"])
 if "settle" in kv: kw["settle_samples"] = int(float(kv["settle"]) * osf)
 st = synth.make_stream(1000, 230000, 72000, f0_hz=1200.0, clock_ppm=-3.5)
 buf = torch.empty((n, 2), dtype=torch.int16, device="cuda")
