@@ -385,15 +385,19 @@ clock_line_kernel(const void *iq, uint64_t n_samples, const uint64_t *starts, co
 		} else {
 			u = make_float2(v.x * v.x + v.y * v.y, 0.0f);
 		}
-		const int m = n >> lg;
-		const float w = 0.5f - 0.5f * cospif(wstep * (float)m);
-		const unsigned br = __brev((unsigned)m) >> (32 - log2_nf);
+		const unsigned br = __brev((unsigned)(n >> lg)) >> (32 - log2_nf);
 		for (int l = 0; l < nline; l++) {
 			float ax = u.x * rot[l].x - u.y * rot[l].y, ay = u.x * rot[l].y + u.y * rot[l].x;
 			rot[l] = make_float2(rot[l].x * stp[l].x - rot[l].y * stp[l].y, rot[l].x * stp[l].y + rot[l].y * stp[l].x);
 			for (int off = decim >> 1; off > 0; off >>= 1) { ax += __shfl_xor(ax, off); ay += __shfl_xor(ay, off); }
-			if ((tid & (decim - 1)) == 0) spec[l * NF + br] = make_float2(ax * w, ay * w);
+			if ((tid & (decim - 1)) == 0) spec[l * NF + br] = make_float2(ax, ay);
 		}
+	}
+	__syncthreads();
+	for (int m = tid; m < NF; m += nth) {                               /* Hann window, once per point */
+		const float w = 0.5f - 0.5f * cospif(wstep * (float)m);
+		const unsigned br = __brev((unsigned)m) >> (32 - log2_nf);
+		for (int l = 0; l < nline; l++) { float2 &v = spec[l * NF + br]; v = make_float2(v.x * w, v.y * w); }
 	}
 	__syncthreads();
 	float pos[2] = { 0.0f, 0.0f }, qual[2] = { 0.0f, 0.0f };
@@ -983,6 +987,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 				slope[i] = centre[hi] > centre[lo] ? (fbar[hi] - fbar[lo]) / (centre[hi] - centre[lo]) : 0.0;
 			}
 		}
+		mark("carrier lines");
 		if (o.clock_seed == 0 && n_samples >= 4096) {
 			/* ---- symbol clock of every tile (a pass moves the clock with the carrier: 20 ppm and more between the pilot and the far
 			   end; the loop's integrator needs 8 000 symbols per e-fold to make that up).  The clock is smooth, so its windows are
@@ -1170,19 +1175,32 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		/* ---- frames by dead reckoning along the chain pilot -> tile 1 -> tile 2 ... ---------------------------------- */
 		TRY(mdemod_get_states(bank.c, 0, static_cast<uint32_t>(T), qs.data(), st));
 		double th_prev = seed.pll_phase, t_prev = last_nco_time(seed, static_cast<double>(P), interp, params->oqpsk);
-		int32_t accr = 0; double res2 = 0.0;
+		size_t i_prev = 0;                                     /* the chain's last trusted link */
+		int32_t acc_prev = 0; double res2 = 0.0; size_t hung = 0;
 		for (size_t i = 1; i < T; i++) {
 			const double th = qs[i].pll_phase, tt = last_nco_time(qs[i], static_cast<double>(q[i]), interp, params->oqpsk);
 			const double t_mid = 0.5 * (t_prev + tt) / interp;
 			double res;
 			/* NCO steps between the two: the symbol period of THIS stretch of the recording (a pass moves the clock: 50 ppm over a
 			   41 072-symbol tile would be two steps with the pilot's period) */
-			const double steps_per_nco = 2 * kPi / (0.5 * (tclk[i - 1] + tclk[i])) / nco;
-			accr = (accr + frame_between(th_prev, t_prev, th, tt, f_at(t_mid), steps_per_nco, &res)) & 3;
+			const double steps_per_nco = 2 * kPi / (0.5 * (tclk[i_prev] + tclk[i])) / nco;
+			const int32_t accr = (acc_prev + frame_between(th_prev, t_prev, th, tt, f_at(t_mid), steps_per_nco, &res)) & 3;
 			R[i] = accr; res2 += res * res;
-			if (dbg && std::fabs(res) > 0.3) fprintf(stderr, "[recording]   frame %zu: dead-reckoning residual %.3f rad (theta %.4f, f %.6g, t_freq %.9g, locked %d)\n", i, res, th, f_at(t_mid), static_cast<double>(qs[i].t_freq), qs[i].pll_locked);
-			th_prev = th; t_prev = tt;
+			/* Two streams that are on the symbols are a whole number of steps apart (seen: +-0.02).  One in 1e5 tiles is still hung
+			   up between two symbols after acquire + frame (the Mueller-Mueller detector's unstable equilibrium): its own phase
+			   says little (best guess kept: the seam check will see), and the chain must not go through it - its successor is
+			   reckoned from the last stream that was on the symbols.  (Found on the 6.5 G-sample recording: tile 121 764 was
+			   0.44 of a step off, both its links had a residual of -0.7 rad, one rounded the wrong way and 5 184 tiles behind
+			   it were repaired for it.) */
+			const double steps = (tt - t_prev) / steps_per_nco, off_grid = std::fabs(steps - std::nearbyint(steps));
+			const bool trusted = off_grid <= 0.2 || i - i_prev > 4;
+			if (dbg && getenv("MDEMOD_RECORDING_TRACE_TILE") && std::llabs(static_cast<long long>(i) - atoll(getenv("MDEMOD_RECORDING_TRACE_TILE"))) <= 2)
+				fprintf(stderr, "[recording]   trace %zu (from %zu): theta %.5f t %.3f (dt %.3f steps = %.4f nco) f %.9g res %.4f R %d t_freq %.9g t_phase %.5f locked %d pll_freq %.9g\n", i, i_prev, th, tt, tt - t_prev,
+				        steps, f_at(t_mid), res, accr, static_cast<double>(qs[i].t_freq), static_cast<double>(qs[i].t_phase), qs[i].pll_locked, static_cast<double>(qs[i].pll_freq));
+			if (dbg && (std::fabs(res) > 0.5 || !trusted)) fprintf(stderr, "[recording]   frame %zu: dead-reckoning residual %.3f rad, %.3f of a step off the symbols%s\n", i, res, off_grid, trusted ? "" : " (not chained through)");
+			if (trusted) { th_prev = th; t_prev = tt; i_prev = i; acc_prev = accr; } else hung++;
 		}
+		if (dbg) fprintf(stderr, "[recording] %zu tiles not on the symbols when their frame was taken\n", hung);
 		rep->frame_residual_rms = static_cast<float>(std::sqrt(res2 / static_cast<double>(T - 1)));
 		/* checkpoint of the bank before any rotation: what a repair starts from */
 		if (o.repair) {

@@ -4,7 +4,7 @@ import numpy as np, torch
 import oracle_py as O
 from meteor_demod_amd import DemodConfig, synth
 from meteor_demod_amd.recording import estimate_carrier_native
-for tag, dop in (("c1", 0.0), ("c1", 40.0), ("c3", 0.0), ("c4", 0.0)):
+for tag, dop in (("c1", 0.0), ("c1", 20.0), ("c3", 0.0), ("c4", 0.0)):      # (20 Hz/s over 2^24 samples: +1460 Hz, inside the searched band)
     cfg = {"c1": DemodConfig(samplerate=230000), "c3": DemodConfig(samplerate=230000, symrate=80000, oqpsk=True),
            "c4": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8)}[tag]
     n = 1 << 24
