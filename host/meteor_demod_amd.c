@@ -26,6 +26,7 @@
 #include <getopt.h>
 #include <math.h>
 #include <stdint.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -120,6 +121,16 @@ static void
 write_gated(struct stream_io *io, const int8_t *soft, uint32_t n, int64_t first_lock)
 {
 	for (uint32_t k = 0; k < n; k++) {
+		/* whole chunks with the gate open (it never closes again): straight from the caller's buffer */
+		if (io->ring_idx == 0 && n - k >= RINGSIZE && first_lock >= 0 && (uint64_t)first_lock <= io->symbols + RINGSIZE - 1) {
+			const uint32_t chunks = (n - k) / RINGSIZE;
+			fwrite(soft + 2 * (size_t)k, 2 * RINGSIZE, chunks, io->out);
+			io->symbols += (uint64_t)chunks * RINGSIZE;
+			io->bytes_out += 2ull * RINGSIZE * chunks;
+			k += chunks * RINGSIZE;
+			memcpy(io->ring, soft + 2 * (size_t)(k - RINGSIZE), 2 * RINGSIZE);     /* the ring holds the last chunk: the final flush writes stale bytes of it (main.c:321) */
+			if (k >= n) break;
+		}
 		io->ring[io->ring_idx++] = soft[2 * k];
 		io->ring[io->ring_idx++] = soft[2 * k + 1];
 		io->symbols++;
@@ -142,6 +153,13 @@ close_all(struct stream_io *io, int n)
 		if (io[i].in && io[i].in != stdin) fclose(io[i].in);
 		io[i].out = NULL; io[i].in = NULL;
 	}
+}
+
+static void *
+init_device_thread(void *arg)        /* the HIP runtime comes up (0.1-0.2 s) while --tiled reads its file */
+{
+	(void)mdemod_init_device(*(int *)arg);
+	return NULL;
 }
 
 static double
@@ -260,8 +278,13 @@ main(int argc, char **argv)
 	p.bps = bps; p.device = device; p.n_streams = (uint32_t)n_files;
 	if (tiled) {
 		/* ---- each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file ---- */
+		const int timing = getenv("MDEMOD_CLI_TIMING") != NULL;       /* where the wall time of a --tiled run goes (stderr) */
+		pthread_t init_thr;
+		const int init_started = pthread_create(&init_thr, NULL, init_device_thread, &device) == 0;
 		for (int f = 0; f < n_files; f++) {
+			const double t_begin = now_ms();
 			size_t cap_bytes = 1u << 26, len = 0;
+			if (io[f].file_len + 2 * FILE_BUFFER_SIZE > cap_bytes) cap_bytes = io[f].file_len + 2 * FILE_BUFFER_SIZE;   /* a regular file: one allocation, no copies */
 			unsigned char *data = malloc(cap_bytes);
 			for (;;) {
 				if (len + FILE_BUFFER_SIZE > cap_bytes) {
@@ -284,7 +307,10 @@ main(int argc, char **argv)
 			if (pilot_margin >= 0) ro.pilot_margin_symbols = (uint32_t)pilot_margin;
 			if (carrier_seed >= 0) ro.carrier_seed = (uint32_t)carrier_seed;
 			mdemod_recording_report rr;
+			const double t_read = now_ms();
+			if (f == 0 && init_started) pthread_join(init_thr, NULL);
 			int rc2 = mdemod_demodulate_recording_host(&p, &ro, data, n_samples, soft_all, cap_sym, &rr);
+			const double t_lib = now_ms();
 			if (rc2 != MDEMOD_OK) {
 				fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2));
 				free(data); free(soft_all); close_all(io, n_files);
@@ -304,6 +330,9 @@ main(int argc, char **argv)
 			if (io[f].in != stdin) fclose(io[f].in);
 			io[f].out = NULL; io[f].in = NULL;
 			free(data); free(soft_all);
+			if (timing)
+				fprintf(stderr, "%s: read %.0f ms, library call %.0f ms (pilot %.0f + tiles %.0f on the device), write %.0f ms\n", io[f].in_name,
+				        t_read - t_begin, t_lib - t_read, rr.pilot_seconds * 1e3, rr.tiles_seconds * 1e3, now_ms() - t_lib);
 		}
 		return 0;
 	}

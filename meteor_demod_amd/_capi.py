@@ -82,6 +82,7 @@ _P = C.POINTER
 SIGNATURES = {
     "mdemod_abi_version": (C.c_uint32, []),
     "mdemod_strerror": (C.c_char_p, [C.c_int]),
+    "mdemod_init_device": (C.c_int, [C.c_int]),
     "mdemod_create": (C.c_int, [_P(MdemodParams), _P(C.c_void_p)]),
     "mdemod_destroy": (None, [C.c_void_p]),
     "mdemod_reset": (C.c_int, [C.c_void_p, C.c_void_p]),

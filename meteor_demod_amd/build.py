@@ -93,7 +93,7 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
         exe = LIB / "meteor_demod_amd"
         if force or _stale(exe, [host_src, ROOT / "include" / "meteor_demod_amd.h", so]):
             cc = shutil.which("gcc") or shutil.which("cc")
-            _run([cc, "-std=gnu11", "-O2", "-Wall", f"-I{ROOT / 'include'}", str(host_src), "-o", str(exe),
+            _run([cc, "-std=gnu11", "-O2", "-Wall", "-pthread", f"-I{ROOT / 'include'}", str(host_src), "-o", str(exe),
                   f"-L{LIB}", "-lmeteor_demod_amd", f"-Wl,-rpath,$ORIGIN", "-lm"])
         out["cli"] = exe
     return out

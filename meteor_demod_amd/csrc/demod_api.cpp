@@ -130,6 +130,13 @@ mdemod_abi_version(void)
 	return MDEMOD_ABI_VERSION;
 }
 
+int
+mdemod_init_device(int device)
+{
+	if (hipSetDevice(device) != hipSuccess) return MDEMOD_ERR_HIP;
+	return hipFree(nullptr) == hipSuccess ? MDEMOD_OK : MDEMOD_ERR_HIP;     /* forces the context */
+}
+
 const char *
 mdemod_strerror(int code)
 {

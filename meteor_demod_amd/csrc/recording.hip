@@ -28,8 +28,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "meteor_demod_amd.h"
@@ -780,11 +783,13 @@ frame_between(double th_a, double t_a, double th_b, double t_b, double f_mean, d
 
 } /* namespace */
 
-extern "C" int
-mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_opts *opts_in,
-                            const void *iq_dev, uint64_t n_samples,
-                            int8_t *soft_dev, uint64_t soft_cap_symbols,
-                            mdemod_recording_report *rep, void *hip_stream)
+/* The entry proper.  `need(upto)`, when given, returns once samples [0, upto) of iq_dev are there: the host-buffer entry copies
+ * the recording in behind the serial head. */
+static int
+demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_opts *opts_in,
+                          const void *iq_dev, uint64_t n_samples,
+                          int8_t *soft_dev, uint64_t soft_cap_symbols,
+                          mdemod_recording_report *rep, void *hip_stream, const std::function<void(uint64_t)> *need)
 {
 	if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
 	if (params->samplerate <= 0 || params->symrate <= 0) return MDEMOD_ERR_PARAM;
@@ -831,6 +836,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		   it does produce: the kernel checks the capacity it is given and reports an overflow */
 		const uint64_t cap = std::min<uint64_t>(mdemod_max_symbols(pilot.c, b), soft_cap_symbols - std::min(nsym, soft_cap_symbols));
 		if (cap == 0) return MDEMOD_ERR_OVERFLOW;
+		if (need) (*need)(pos + b);
 		TRY(mdemod_process_device_uniform(pilot.c, iq + pos * sb, 0, b, soft_dev + 2 * nsym, cap, static_cast<uint32_t>(cap), st));
 		mdemod_status s1;
 		TRY(mdemod_get_status(pilot.c, 0, 1, &s1, st));
@@ -853,6 +859,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 		if (pos >= o.max_pilot_samples) break;
 	}
 	const uint64_t P = pos;
+	if (need) (*need)(n_samples);                          /* everything after the head reads all over the recording */
 	rep->pilot_samples = P; rep->pilot_symbols = seed.n_symbols;
 	rep->pilot_locked = seed.pll_locked; rep->first_lock_symbol = seed.first_lock_symbol;
 	rep->samples_demodulated = P;
@@ -1374,7 +1381,18 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
 	return MDEMOD_OK;
 }
 
-/* Host-buffer convenience (PCIe inclusive): what the C CLI's --tiled mode calls. */
+extern "C" int
+mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_opts *opts_in,
+                            const void *iq_dev, uint64_t n_samples,
+                            int8_t *soft_dev, uint64_t soft_cap_symbols,
+                            mdemod_recording_report *rep, void *hip_stream)
+{
+	return demodulate_recording_impl(params, opts_in, iq_dev, n_samples, soft_dev, soft_cap_symbols, rep, hip_stream, nullptr);
+}
+
+/* Host-buffer convenience (PCIe inclusive): what the C CLI's --tiled mode calls.  The head goes in first; the rest of the
+ * recording is copied by a second thread on its own stream while the serial head runs (one wave, ~0.1 s: about what 1 GB of
+ * pageable memory takes). */
 extern "C" int
 mdemod_demodulate_recording_host(const mdemod_params *params, const mdemod_recording_opts *opts,
                                  const void *iq_host, uint64_t n_samples,
@@ -1382,14 +1400,51 @@ mdemod_demodulate_recording_host(const mdemod_params *params, const mdemod_recor
                                  mdemod_recording_report *rep)
 {
 	if (!params || !iq_host || !soft_host || !rep) return MDEMOD_ERR_PARAM;
+	const bool dbg = getenv("MDEMOD_RECORDING_DEBUG") != nullptr;
+	const auto t_in = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) {
+		if (dbg) fprintf(stderr, "[recording host] %8.2f ms  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count() * 1e3, what);
+	};
 	if (hipSetDevice(params->device) != hipSuccess) return MDEMOD_ERR_HIP;
+	mark("device set");
 	const size_t sb = 2 * static_cast<size_t>(params->bps) / 8;
 	DevMem mem;
 	unsigned char *d_iq; int8_t *d_soft;
 	TRY(mem.alloc(&d_iq, static_cast<size_t>(n_samples) * sb));
 	TRY(mem.alloc(&d_soft, static_cast<size_t>(soft_cap_symbols) * 2));
-	if (n_samples) HTRY(hipMemcpy(d_iq, iq_host, static_cast<size_t>(n_samples) * sb, hipMemcpyHostToDevice));
-	TRY(mdemod_demodulate_recording(params, opts, d_iq, n_samples, d_soft, soft_cap_symbols, rep, nullptr));
+	mark("buffers allocated");
+	const uint64_t head = std::min<uint64_t>(n_samples, 1u << 20);
+	if (head) HTRY(hipMemcpy(d_iq, iq_host, static_cast<size_t>(head) * sb, hipMemcpyHostToDevice));
+	mark("head copied");
+	std::atomic<uint64_t> there{head};
+	std::atomic<int> copy_failed{0};
+	struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } copier;
+	if (head < n_samples) {
+		const int device = params->device;
+		copier.t = std::thread([&, device]() {
+			hipStream_t cs = nullptr;
+			if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { copy_failed = 1; there = n_samples; return; }
+			const uint64_t chunk = 1u << 23;                  /* samples per copy: progress in steps of 8-64 MB */
+			for (uint64_t at = head; at < n_samples; at += chunk) {
+				const uint64_t c = std::min<uint64_t>(chunk, n_samples - at);
+				if (hipMemcpyAsync(d_iq + at * sb, static_cast<const unsigned char *>(iq_host) + at * sb, static_cast<size_t>(c) * sb, hipMemcpyHostToDevice, cs) != hipSuccess ||
+				    hipStreamSynchronize(cs) != hipSuccess) { copy_failed = 1; break; }
+				there = at + c;
+			}
+			mark("recording copied in");
+			there = n_samples;                                /* also after a failure: nobody may wait for ever */
+			(void)hipStreamDestroy(cs);
+		});
+	}
+	const std::function<void(uint64_t)> need = [&](uint64_t upto) {
+		while (there.load() < std::min(upto, n_samples)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+	};
+	const int rc = demodulate_recording_impl(params, opts, d_iq, n_samples, d_soft, soft_cap_symbols, rep, nullptr, &need);
+	if (copier.t.joinable()) copier.t.join();
+	mark("demodulated");
+	if (copy_failed.load()) return MDEMOD_ERR_HIP;
+	TRY(rc);
 	if (rep->n_symbols) HTRY(hipMemcpy(soft_host, d_soft, static_cast<size_t>(rep->n_symbols) * 2, hipMemcpyDeviceToHost));
+	mark("symbols copied out");
 	return MDEMOD_OK;
 }
