@@ -247,15 +247,19 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	CREATE_TRY(dev_alloc(ctx, &ctx->d_rrc, ctx->tab.rrc.size()));
 	ctx->lat_ok = mdemod_lat_geometry(c, static_cast<double>(ctx->tab.osf) / (params->oqpsk ? 2.0 : 1.0), &ctx->lat_ring, &ctx->lat_span, &ctx->lat_lds);
 	{
-		hipError_t e = hipMemcpy(ctx->d_ctab, ctx->tab.ctab.data(), ctx->tab.ctab.size() * sizeof(float), hipMemcpyHostToDevice);
-		if (e == hipSuccess) e = hipMemcpy(ctx->d_rrc, ctx->tab.rrc.data(), ctx->tab.rrc.size() * sizeof(float), hipMemcpyHostToDevice);
-		if (e == hipSuccess) e = hipMemcpy(ctx->d_lut, ctx->tab.tanh_lut, sizeof(ctx->tab.tanh_lut), hipMemcpyHostToDevice);
-		if (e != hipSuccess) { mdemod_destroy(ctx); return MDEMOD_ERR_HIP; }
-	}
-	CREATE_TRY(mdemod_reset(ctx, nullptr));
-	{
-		hipError_t e = hipDeviceSynchronize();
-		if (e != hipSuccess) { mdemod_destroy(ctx); return MDEMOD_ERR_HIP; }
+		/* tables and the power-on state go in on a stream of their own, and only that stream is waited for: a context made while
+		   other contexts run (a second host thread, a recording's tile bank next to its serial head) must not wait for their
+		   kernels, which hipDeviceSynchronize and the null stream's copies did */
+		hipStream_t s0 = nullptr;
+		hipError_t e = hipStreamCreateWithFlags(&s0, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_ctab, ctx->tab.ctab.data(), ctx->tab.ctab.size() * sizeof(float), hipMemcpyHostToDevice, s0);
+		if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_rrc, ctx->tab.rrc.data(), ctx->tab.rrc.size() * sizeof(float), hipMemcpyHostToDevice, s0);
+		if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_lut, ctx->tab.tanh_lut, sizeof(ctx->tab.tanh_lut), hipMemcpyHostToDevice, s0);
+		int rc_reset = MDEMOD_OK;
+		if (e == hipSuccess) rc_reset = mdemod_reset(ctx, s0);
+		if (e == hipSuccess) e = hipStreamSynchronize(s0);
+		if (s0) (void)hipStreamDestroy(s0);
+		if (e != hipSuccess || rc_reset != MDEMOD_OK) { mdemod_destroy(ctx); return rc_reset != MDEMOD_OK ? rc_reset : MDEMOD_ERR_HIP; }
 	}
 #undef CREATE_TRY
 	*out = ctx;

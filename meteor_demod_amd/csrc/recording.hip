@@ -783,48 +783,30 @@ frame_between(double th_a, double t_a, double th_b, double t_b, double f_mean, d
 
 } /* namespace */
 
-/* The entry proper.  `need(upto)`, when given, returns once samples [0, upto) of iq_dev are there: the host-buffer entry copies
- * the recording in behind the serial head. */
+/* What the serial head leaves behind. */
+struct PilotOut {
+	uint64_t P = 0, nsym = 0;            /* samples demodulated serially, symbols written to the output */
+	mdemod_stream_state seed;            /* loop state at P */
+	std::vector<PilotBlock> blocks;      /* AGC calibration */
+	std::vector<float> hist;             /* filter history at P */
+	double seconds = 0.0;
+};
+
+/* ---- pilot: the reference's own serial run of the head, from the power-on state until the PLL has locked and stayed locked for
+ * the margin (the reference's own symbols into soft_dev, first-lock index included) ---- */
 static int
-demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_opts *opts_in,
-                          const void *iq_dev, uint64_t n_samples,
-                          int8_t *soft_dev, uint64_t soft_cap_symbols,
-                          mdemod_recording_report *rep, void *hip_stream, const std::function<void(uint64_t)> *need)
+run_pilot(const mdemod_params *params, const mdemod_recording_opts &o, const void *iq_dev, uint64_t n_samples,
+          int8_t *soft_dev, uint64_t soft_cap_symbols, hipStream_t st, const std::function<void(uint64_t)> *need, PilotOut &po)
 {
-	if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
-	if (params->samplerate <= 0 || params->symrate <= 0) return MDEMOD_ERR_PARAM;
-	mdemod_recording_opts o;
-	if (opts_in) o = *opts_in; else mdemod_recording_default_opts(&o);
-	const double osf = static_cast<double>(params->samplerate) / static_cast<double>(params->symrate);
-	const double symrate = params->symrate, fs = params->samplerate;
-	const int nco = params->oqpsk ? 2 : 1;
-	if (o.acquire_samples == 0xFFFFFFFFu) o.acquire_samples = static_cast<uint32_t>(2000 * osf);
-	if (o.frame_samples == 0xFFFFFFFFu) o.frame_samples = static_cast<uint32_t>(1500 * osf);
-	if (o.settle_samples == 0xFFFFFFFFu) o.settle_samples = static_cast<uint32_t>(24000 * osf);
-	/* symbols between the reference's first lock and the hand-over: the tiles right after it are seeded with a model of the serial
-	   loop's remaining convergence, which holds once the lock is this old (measured: the first tiles lose 5 % of their +-1 LSB
-	   agreement with 10 000 symbols less; OQPSK's loop, at twice the bandwidth, wanders more and wants 30 000) */
-	if (o.pilot_margin_symbols == 0xFFFFFFFFu) o.pilot_margin_symbols = (o.clock_seed || !o.carrier_seed) ? (params->oqpsk ? 30000 : 20000)      /* tiles that start from the pilot's own omega / carrier word: those need longer */
-		                                                                                 : (params->oqpsk ? 20000 : 15000);
-	if (!o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
-	hipStream_t st = static_cast<hipStream_t>(hip_stream);
-	memset(rep, 0, sizeof(*rep));
-	rep->first_lock_symbol = -1;
 	const size_t sb = 2 * static_cast<size_t>(params->bps) / 8;
 	const unsigned char *iq = static_cast<const unsigned char *>(iq_dev);
-	const int K = static_cast<int>(std::max<uint32_t>(o.match_symbols, 32));     /* fewer symbols cannot tell 4 rotations x 3 shifts apart at 12 dB */
-
 	const auto t_start = std::chrono::steady_clock::now();
-	auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
-		return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-	};
-	/* ---- pilot: the reference's own serial run of the head -------------------------------- */
 	mdemod_params pp = *params; pp.n_streams = 1;
 	Ctx pilot;
 	TRY(mdemod_create(&pp, &pilot.c));
 	uint64_t pos = 0, nsym = 0; bool have_lock = false, lost_lock = false; uint64_t locked_at = 0;
-	std::vector<PilotBlock> pilot_blocks;                /* AGC calibration */
-	mdemod_stream_state seed;
+	std::vector<PilotBlock> &pilot_blocks = po.blocks;
+	mdemod_stream_state &seed = po.seed;
 	memset(&seed, 0, sizeof(seed));
 	TRY(mdemod_get_state(pilot.c, 0, &seed, st));
 	while (pos < n_samples) {
@@ -858,6 +840,51 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 		if (have_lock && seed.n_symbols - locked_at >= o.pilot_margin_symbols && static_cast<double>(seed.n_symbols) >= agc_settle) break;
 		if (pos >= o.max_pilot_samples) break;
 	}
+	po.P = pos; po.nsym = nsym;
+	po.hist.resize(2 * static_cast<size_t>(mdemod_history_len(pilot.c)));
+	TRY(mdemod_get_history(pilot.c, 0, po.hist.data(), st));
+	po.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+	return MDEMOD_OK;
+}
+
+/* The entry proper.  `need(upto)`, when given, returns once samples [0, upto) of iq_dev are there: the host-buffer entry copies
+ * the recording in behind the serial head. */
+static int
+demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_opts *opts_in,
+                          const void *iq_dev, uint64_t n_samples,
+                          int8_t *soft_dev, uint64_t soft_cap_symbols,
+                          mdemod_recording_report *rep, void *hip_stream, const std::function<void(uint64_t)> *need)
+{
+	if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
+	if (params->samplerate <= 0 || params->symrate <= 0) return MDEMOD_ERR_PARAM;
+	mdemod_recording_opts o;
+	if (opts_in) o = *opts_in; else mdemod_recording_default_opts(&o);
+	const double osf = static_cast<double>(params->samplerate) / static_cast<double>(params->symrate);
+	const double symrate = params->symrate, fs = params->samplerate;
+	const int nco = params->oqpsk ? 2 : 1;
+	if (o.acquire_samples == 0xFFFFFFFFu) o.acquire_samples = static_cast<uint32_t>(2000 * osf);
+	if (o.frame_samples == 0xFFFFFFFFu) o.frame_samples = static_cast<uint32_t>(1500 * osf);
+	if (o.settle_samples == 0xFFFFFFFFu) o.settle_samples = static_cast<uint32_t>(24000 * osf);
+	/* symbols between the reference's first lock and the hand-over: the tiles right after it are seeded with a model of the serial
+	   loop's remaining convergence, which holds once the lock is this old (measured: the first tiles lose 5 % of their +-1 LSB
+	   agreement with 10 000 symbols less; OQPSK's loop, at twice the bandwidth, wanders more and wants 30 000) */
+	if (o.pilot_margin_symbols == 0xFFFFFFFFu) o.pilot_margin_symbols = (o.clock_seed || !o.carrier_seed) ? (params->oqpsk ? 30000 : 20000)      /* tiles that start from the pilot's own omega / carrier word: those need longer */
+		                                                                                 : (params->oqpsk ? 20000 : 15000);
+	if (!o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	memset(rep, 0, sizeof(*rep));
+	rep->first_lock_symbol = -1;
+	const int K = static_cast<int>(std::max<uint32_t>(o.match_symbols, 32));     /* fewer symbols cannot tell 4 rotations x 3 shifts apart at 12 dB */
+
+	auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
+		return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	};
+	/* ---- pilot ---- */
+	PilotOut po;
+	TRY(run_pilot(params, o, iq_dev, n_samples, soft_dev, soft_cap_symbols, st, need, po));
+	const mdemod_stream_state seed = po.seed;
+	const std::vector<PilotBlock> &pilot_blocks = po.blocks;
+	const uint64_t nsym = po.nsym, pos = po.P;
 	const uint64_t P = pos;
 	if (need) (*need)(n_samples);                          /* everything after the head reads all over the recording */
 	rep->pilot_samples = P; rep->pilot_symbols = seed.n_symbols;
@@ -865,7 +892,7 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 	rep->samples_demodulated = P;
 	const uint64_t n_pilot_sym = nsym;
 	rep->exact_symbols = n_pilot_sym;
-	rep->pilot_seconds = seconds_since(t_start);
+	rep->pilot_seconds = po.seconds;
 	const auto t_tiles = std::chrono::steady_clock::now();
 	const bool dbg = getenv("MDEMOD_RECORDING_DEBUG") != nullptr;
 	auto mark = [&](const char *what) {
@@ -914,8 +941,7 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 	const double tau_pll = pll_beta > 0 ? pll_alpha / pll_beta : 0.0;     /* slow pole of the (overdamped) carrier loop, in NCO steps: pll.c:133-140 */
 	const int interp = params->interp_factor;
 
-	std::vector<float> seed_hist(2 * static_cast<size_t>(mdemod_history_len(pilot.c)));
-	TRY(mdemod_get_history(pilot.c, 0, seed_hist.data(), st));
+	const std::vector<float> &seed_hist = po.hist;
 
 	/* ---- carrier of every tile: window i is centred on the span its frame is dead-reckoned over, [q_{i-1}, q_i] ---------------- */
 	std::vector<double> tclk(T, static_cast<double>(seed.t_freq));   /* symbol clock seeds, rad per interpolated step */
