@@ -49,6 +49,10 @@ for ci in range(n_cases):
         if os.environ.get("FUZZ_TILE"):
             kw["tile_samples"] = int(os.environ["FUZZ_TILE"])
         mode = os.environ.get("FUZZ_SEEDMODE", mode)
+        if os.environ.get("FUZZ_CLOCKSEED"):
+            kw["clock_seed"] = os.environ["FUZZ_CLOCKSEED"]
+        if os.environ.get("FUZZ_MARGIN"):
+            kw["pilot_margin_symbols"] = int(os.environ["FUZZ_MARGIN"])
         if os.environ.get("FUZZ_SETTLE"):
             kw["settle_samples"] = int(os.environ["FUZZ_SETTLE"])
         print("replay: esn0", esn0, "amp", amp)
