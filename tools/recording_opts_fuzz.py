@@ -1,7 +1,7 @@
 """Robustness soak of mdemod_demodulate_recording's option space: tiny and huge tiles, no warm-up, short seams, no second
 pass, short recordings, pilots that end at the cap - every call must return MDEMOD_OK with a symbol count within a few
 symbols of the serial oracle's and the pilot part byte-exact.  Accuracy is recording_fuzz.py's job; this one looks for
-crashes, overflows and miscounts.  Usage: recording_opts_fuzz.py [n_cases] [seed]"""
+crashes, overflows and miscounts.  Usage: recording_opts_fuzz.py [n_cases] [seed] [only this case]"""
 import sys
 import time
 
@@ -13,6 +13,7 @@ from meteor_demod_amd.recording import demodulate_recording_native
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 bad, t0 = [], time.time()
 for ci in range(n_cases):
     oqpsk = bool(rng.random() < 0.3)
@@ -34,6 +35,8 @@ for ci in range(n_cases):
               max_pilot_samples=int(rng.choice([50_000, 400_000, 1 << 22])),
               match_symbols=int(rng.choice([8, 64, 192, 1000])),
               carrier_seed=str(rng.choice(["spectrum", "pilot"])))
+    if only is not None and ci != only:
+        continue
     iq = synth.generate_device([st], n)[0]
     tag = f"case {ci}: {'oqpsk' if oqpsk else 'qpsk'} fs={samplerate} bps={bps} n={n} {kw}"
     try:
@@ -45,10 +48,14 @@ for ci in range(n_cases):
     serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
     out = soft.cpu().numpy()
     slack = max(2, rep.weak_seams + rep.n_tiles // 20 + 2)          # absurd tilings (no warm-up) may slip a symbol per tile
-    if (kw["pilot_margin_symbols"] < 2000 or not rep.pilot_locked) and kw["carrier_seed"] == "pilot":
+    if (kw["pilot_margin_symbols"] <= 2000 or not rep.pilot_locked) and kw["carrier_seed"] == "pilot":
         slack += 4 * rep.n_tiles                                     # tiles seeded from a pilot that has only just seen its lock flag: they acquire on their own time
     ok = abs(len(out) - len(serial)) <= slack and len(out) == rep.n_symbols
-    ok = ok and np.array_equal(out[: rep.pilot_symbols], serial[: rep.pilot_symbols])
+    prefix_ok = np.array_equal(out[: rep.pilot_symbols], serial[: rep.pilot_symbols])
+    if only is not None:
+        print("   slack", slack, "pilot_locked", rep.pilot_locked, "pilot_samples", rep.pilot_samples, "n_symbols", rep.n_symbols, "prefix equal", prefix_ok, "first_lock", rep.first_lock_symbol,
+              "jumps", rep.rotation_jumps, "misses", rep.frame_misses, "fixes", rep.seam_fixes)
+    ok = ok and prefix_ok
     print(tag, "->", "ok" if ok else "FAIL", len(out), len(serial), "tiles", rep.n_tiles, "weak", rep.weak_seams, "pilot", rep.pilot_symbols, flush=True)
     if not ok:
         bad.append(tag)
