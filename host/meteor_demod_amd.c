@@ -316,6 +316,9 @@ main(int argc, char **argv)
 				free(data); free(soft_all); close_all(io, n_files);
 				return 2;
 			}
+			if (rr.pilot_locked == 2)
+				fprintf(stderr, "%s: note: the reference's PLL reports lock far from this signal's carrier (a false lock, common with "
+				        "-m oqpsk): the exact mode would write what it produces from there on; --tiled demodulates the signal\n", io[f].in_name);
 			if (!quiet)
 				fprintf(stderr, "%s: %llu samples: %llu serial (pilot) + %u tiles, %llu symbols, first lock at symbol %lld, %u seam fixes, "
 				        "%u weak seams, %u rotation jumps, %u tiles without a carrier line, %.2f s\n", io[f].in_name, (unsigned long long)n_samples,

@@ -302,7 +302,8 @@ typedef struct {
 	uint32_t settle_samples;        /* 0xFFFFFFFF = 24 000 symbols worth                                                 */
 	uint32_t pilot_block;           /* pilot granularity in samples               (65536)  */
 	uint32_t pilot_margin_symbols;  /* symbols between the first lock and the hand-over; 0xFFFFFFFF = 15 000 (OQPSK: 20 000); 20 000 (30 000) when the tiles take the pilot's clock or carrier word */
-	uint64_t max_pilot_samples;     /* give up waiting for lock after this many   (1 << 22) */
+	uint64_t max_pilot_samples;     /* give up waiting for lock after this many; 0xFFFFFFFFFFFFFFFF = 1 500 000 symbols worth: the reference's
+	                                   sweep (1e-6 rad per symbol, up first, pll.c:125) has been to +fmax and down to -fmax by then */
 	uint32_t match_symbols;         /* symbols compared across a seam; at least 32 are used (192) */
 	int32_t  repair;                /* 1: tiles whose seam shows an odd residual rotation run settle + body again (1)    */
 	uint32_t carrier_seed;          /* 1: every tile from its own 4th-power spectrum (follows Doppler); 0: all tiles from
@@ -322,7 +323,10 @@ typedef struct {
 	uint32_t tile_samples;          /* body samples per tile actually used                   */
 	uint32_t weak_seams;            /* seams whose correlation was too weak to trust         */
 	uint32_t seam_fixes;            /* one-symbol duplicates / gaps repaired                 */
-	int32_t  pilot_locked;
+	int32_t  pilot_locked;          /* 0: the head gave up unlocked; 1: locked; 2: the reference's PLL reports lock but its carrier word is more
+	                                   than 250 Hz from the signal's own spectral line at the hand-over - a false lock of the reference (its
+	                                   OQPSK loop does that on about half of all recordings with a carrier offset): from there on the
+	                                   reference's output is not a demodulation of this signal, the tiles' is, and the two cannot agree */
 	uint32_t weak_carrier_tiles;    /* carrier_seed=1: tiles without a clear spectral line, seeded from their neighbours */
 	double   pilot_seconds;         /* wall time of the serial head                          */
 	double   tiles_seconds;         /* wall time of everything after it                      */

@@ -737,7 +737,7 @@ mdemod_recording_default_opts(mdemod_recording_opts *o)
 	o->tile_samples = 0;                     /* automatic, see the header */
 	o->acquire_samples = o->frame_samples = o->settle_samples = 0xFFFFFFFFu;
 	o->pilot_block = 65536; o->pilot_margin_symbols = 0xFFFFFFFFu;
-	o->max_pilot_samples = 1ull << 22; o->match_symbols = 192; o->repair = 1; o->carrier_seed = 1; o->clock_seed = 0;
+	o->max_pilot_samples = 0xFFFFFFFFFFFFFFFFull; o->match_symbols = 192; o->repair = 1; o->carrier_seed = 1; o->clock_seed = 0;
 }
 
 namespace {
@@ -870,6 +870,7 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 	   agreement with 10 000 symbols less; OQPSK's loop, at twice the bandwidth, wanders more and wants 30 000) */
 	if (o.pilot_margin_symbols == 0xFFFFFFFFu) o.pilot_margin_symbols = (o.clock_seed || !o.carrier_seed) ? (params->oqpsk ? 30000 : 20000)      /* tiles that start from the pilot's own omega / carrier word: those need longer */
 		                                                                                 : (params->oqpsk ? 20000 : 15000);
+	if (o.max_pilot_samples == 0xFFFFFFFFFFFFFFFFull) o.max_pilot_samples = static_cast<uint64_t>(1.5e6 * osf);
 	if (!o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
 	memset(rep, 0, sizeof(*rep));
@@ -1081,6 +1082,10 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 	   still converging with the same time constant.  A tile settles for less than tau, so it is seeded with the frequency the
 	   SERIAL loop has at that point, not with the carrier: estimate - lag + what is left of the pilot's own offset. */
 	const double f_pilot_target = f_at(static_cast<double>(P)) - (T > 1 ? slope[0] * osf / nco * tau_pll : 0.0);
+	/* a lock the reference declares far from the carrier (its OQPSK loop does on about half of all recordings with an offset, and
+	   never leaves it) is reported: the tiles demodulate the signal, the reference from there on does not */
+	if (o.carrier_seed == 1 && T > 1 && seed.pll_locked && rep->weak_carrier_tiles < T / 2 &&
+	    std::fabs(static_cast<double>(seed.pll_freq) - f_pilot_target) > 2 * kPi * 250.0 / (symrate * nco)) rep->pilot_locked = 2;
 	auto f_seed = [&](size_t i, double t) {
 		const double lag = slope[i] * osf / nco * tau_pll;
 		/* before the hand-over (a lead that starts inside the pilot) the serial run was further away still: same exponential, back to

@@ -78,7 +78,7 @@ def estimate_clock_native(cfg, iq, starts, window_samples: int, device: int = 0,
 
 def demodulate_recording_native(cfg, iq, tile_samples: int = 0, acquire_samples: int = AUTO, frame_samples: int = AUTO,
                                 settle_samples: int = AUTO, repair: bool = True, pilot_block: int = 65536,
-                                pilot_margin_symbols: int = AUTO, max_pilot_samples: int = 1 << 22, match_symbols: int = 192,
+                                pilot_margin_symbols: int = AUTO, max_pilot_samples: int = 0xFFFFFFFFFFFFFFFF, match_symbols: int = 192,
                                 device: int = 0, carrier_seed: str = "spectrum", soft_capacity: int = 0, clock_seed: str = "spectrum"):
     """``mdemod_demodulate_recording`` on a device tensor [n, 2]: returns (soft int8 [m, 2] device tensor, report).
     Lengths in samples; 0 / AUTO take the library's defaults (see include/meteor_demod_amd.h).

@@ -471,3 +471,32 @@ def test_recording_follows_the_doppler_on_the_symbol_clock(cfg, bar, gpu_device)
     assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > bar, a
     out1, _, rep1, a1 = _run(cfg, iq, clock_seed="pilot")
     assert a1["len_stitched"] == a1["len_serial"] and a1["within_1lsb"] < a["within_1lsb"] - 0.0005, (a, a1)
+
+
+def test_false_lock_of_the_reference_is_reported(gpu_device):
+    """The reference's OQPSK loop declares lock hundreds of Hz off the carrier on about half of all recordings with an offset
+    (here: 424 Hz below a carrier at +858 Hz, 34 000 symbols in) and never leaves it: its output from there on is not a
+    demodulation of the signal.  The tiles sit on the carrier, so the two cannot agree; the stitcher says so (pilot_locked == 2:
+    the head's carrier word against the signal's own 4th-power line).  A recording the reference locks on properly reports 1."""
+    st = synth.make_stream(3000, 230000, 80000, oqpsk=True, f0_hz=857.7969256274791, clock_ppm=3.0703173480189108)
+    iq = synth.generate_device([st], 1 << 22)[0]
+    serial, tr, ev = O.oracle_demod(C3, iq.cpu().numpy(), True)
+    soft, rep = demodulate_recording_native(C3, iq)
+    k = min(int(rep.pilot_symbols), len(tr) - 1)
+    err_hz = float(tr["pll_freq"][k]) * 80000 * 2 / (2 * np.pi) - 857.8
+    assert tr["locked"][k] and abs(err_hz) > 300 and len(ev) == 1             # the oracle agrees: locked, far off, for good
+    assert rep.pilot_locked == 2 and rep.weak_carrier_tiles == 0
+    st = synth.make_stream(3003, 230000, 80000, oqpsk=True, f0_hz=709.4739940303612, clock_ppm=-28.89487219041574)
+    out, serial, rep, a = _run(C3, synth.generate_device([st], 1 << 22)[0])
+    assert rep.pilot_locked == 1 and a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.994, a
+
+
+def test_serial_head_waits_for_the_far_side_of_the_sweep(gpu_device):
+    """-243 Hz at 1 MS/s: the reference's sweep goes up first (pll.c:112,125) and comes by after 620 000 symbols = 8.7 M samples.
+    The head's patience is 1.5 M symbols by default (round 2 gave up after 4 M samples, i.e. 0.3 M symbols at this rate, and the
+    tiles then disagreed with a serial run that was not locked yet)."""
+    st = synth.make_stream(3001, 1000000, 72000, f0_hz=-243.410736509034, clock_ppm=24.90811822737014, rms=2000.0)
+    iq = synth.generate_device([st], 12_000_000)[0]
+    out, serial, rep, a = _run(C4, iq)
+    assert rep.pilot_locked == 1 and 8_000_000 < rep.pilot_samples < 10_000_000
+    assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > 0.997, a
