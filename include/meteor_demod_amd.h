@@ -323,10 +323,11 @@ typedef struct {
 	uint32_t tile_samples;          /* body samples per tile actually used                   */
 	uint32_t weak_seams;            /* seams whose correlation was too weak to trust         */
 	uint32_t seam_fixes;            /* one-symbol duplicates / gaps repaired                 */
-	int32_t  pilot_locked;          /* 0: the head gave up unlocked; 1: locked; 2: the reference's PLL reports lock but its carrier word is more
-	                                   than 250 Hz from the signal's own spectral line at the hand-over - a false lock of the reference (its
-	                                   OQPSK loop does that on about half of all recordings with a carrier offset): from there on the
-	                                   reference's output is not a demodulation of this signal, the tiles' is, and the two cannot agree */
+	int32_t  pilot_locked;          /* 0: the head gave up unlocked; 1: locked; 2: handed over on a FALSE lock of the reference - its PLL reports
+	                                   lock, but its carrier word is still more than 100 Hz from the signal's own spectral line after
+	                                   max_pilot_samples (the head does not hand over on such a lock while it has patience left: the
+	                                   reference's OQPSK loop and any float recording's first seconds produce them).  From there on the
+	                                   reference's output is not a demodulation of this signal, the tiles' is: the two cannot agree */
 	uint32_t weak_carrier_tiles;    /* carrier_seed=1: tiles without a clear spectral line, seeded from their neighbours */
 	double   pilot_seconds;         /* wall time of the serial head                          */
 	double   tiles_seconds;         /* wall time of everything after it                      */

@@ -805,6 +805,7 @@ run_pilot(const mdemod_params *params, const mdemod_recording_opts &o, const voi
 	Ctx pilot;
 	TRY(mdemod_create(&pp, &pilot.c));
 	uint64_t pos = 0, nsym = 0; bool have_lock = false, lost_lock = false; uint64_t locked_at = 0;
+	DevMem est_mem; unsigned char *d_est = nullptr; unsigned false_checks = 0; bool waiting_for_genuine = false;
 	std::vector<PilotBlock> &pilot_blocks = po.blocks;
 	mdemod_stream_state &seed = po.seed;
 	memset(&seed, 0, sizeof(seed));
@@ -837,7 +838,34 @@ run_pilot(const mdemod_params *params, const mdemod_recording_opts &o, const voi
 		/* ... and not before the reference's AGC has settled: its step is absolute (agc.c:13-25), 6 time constants =
 		   6 * gain / (1e-4 * 190) symbols - nothing for s16-scale input, ~200 k symbols for float input around +-1 */
 		const double agc_settle = 6.0 * static_cast<double>(seed.agc_gain) / (1e-4 * 190.0);
-		if (have_lock && seed.n_symbols - locked_at >= o.pilot_margin_symbols && static_cast<double>(seed.n_symbols) >= agc_settle) break;
+		if (have_lock && seed.n_symbols - locked_at >= o.pilot_margin_symbols && static_cast<double>(seed.n_symbols) >= agc_settle) {
+			/* ... and not on a lock that is none: the reference's detector (pll.c:117-123: mean |e| < 85) also fires far from the
+			   carrier - always while a float recording's AGC is still coming up (small |e| because everything is small), and for
+			   good on every other OQPSK recording.  As long as the loop's carrier word is more than 100 Hz from the signal's own
+			   4th-power line here, the head goes on (it IS the reference: whatever that does, these are its bytes); looked at every
+			   fourth block, given up at max_pilot_samples like the wait for a lock. */
+			bool genuine = true;
+			if (o.carrier_seed == 1 && pos < n_samples) {
+				if ((false_checks++ & 3) == 0) {
+					if (!d_est) TRY(est_mem.alloc(&d_est, 32));
+					const uint32_t win = mdemod_carrier_window_samples(params, static_cast<uint32_t>(std::min(262144.0, 20536.0 * params->samplerate / params->symrate)));
+					const uint64_t w0 = pos > win ? pos - win : 0;
+					HTRY(hipMemcpyAsync(d_est, &w0, sizeof(w0), hipMemcpyHostToDevice, st));
+					HTRY(hipStreamSynchronize(st));
+					float *d_f = reinterpret_cast<float *>(d_est + 8), *d_q = reinterpret_cast<float *>(d_est + 16);
+					TRY(mdemod_estimate_carrier(params, iq_dev, std::min<uint64_t>(n_samples, pos), reinterpret_cast<const uint64_t *>(d_est), 1, win, d_f, d_q, st));
+					float fq[4];
+					HTRY(hipMemcpyAsync(fq, d_est + 8, sizeof(fq), hipMemcpyDeviceToHost, st));
+					HTRY(hipStreamSynchronize(st));
+					const double thr = 2 * kPi * 100.0 / (static_cast<double>(params->symrate) * (params->oqpsk ? 2 : 1));     /* genuine locks are within 40 Hz by then, false ones start at 160 */
+					genuine = !(fq[2] >= 8.0f && std::fabs(static_cast<double>(seed.pll_freq) - static_cast<double>(fq[0])) > thr);
+					waiting_for_genuine = !genuine;
+				} else {
+					genuine = !waiting_for_genuine;         /* between two looks: what the last look said */
+				}
+			}
+			if (genuine) break;
+		}
 		if (pos >= o.max_pilot_samples) break;
 	}
 	po.P = pos; po.nsym = nsym;
@@ -1085,7 +1113,7 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 	/* a lock the reference declares far from the carrier (its OQPSK loop does on about half of all recordings with an offset, and
 	   never leaves it) is reported: the tiles demodulate the signal, the reference from there on does not */
 	if (o.carrier_seed == 1 && T > 1 && seed.pll_locked && rep->weak_carrier_tiles < T / 2 &&
-	    std::fabs(static_cast<double>(seed.pll_freq) - f_pilot_target) > 2 * kPi * 250.0 / (symrate * nco)) rep->pilot_locked = 2;
+	    std::fabs(static_cast<double>(seed.pll_freq) - f_pilot_target) > 2 * kPi * 100.0 / (symrate * nco)) rep->pilot_locked = 2;
 	auto f_seed = [&](size_t i, double t) {
 		const double lag = slope[i] * osf / nco * tau_pll;
 		/* before the hand-over (a lead that starts inside the pilot) the serial run was further away still: same exponential, back to
