@@ -1294,6 +1294,8 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 	std::vector<char> run(T, 1);
 	std::vector<int32_t> state_rot = R;                    /* output rotation taken out of each stream's state before it settles */
 	std::vector<int32_t> out_rot(T, 0), expect(T, 0);     /* rotation left for the output; what the second round should find */
+	std::vector<char> jump_at(T, 0);                       /* seams that still show a rotation after the repair */
+	bool second_round = false;
 	for (int round = 0; round < 2; round++) {
 		std::vector<int32_t> qt(T);
 		for (size_t i = 0; i < T; i++) qt[i] = run[i] ? (4 - state_rot[i]) & 3 : 0;
@@ -1371,22 +1373,81 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 			}
 		} else {
 			out_rot = C;
-			for (size_t i = 1; i < T; i++)
-				rep->rotation_jumps += (((C[i] - C[i - 1]) - (expect[i] - expect[i - 1])) & 3) ? 1 : 0;
+			second_round = true;
+			for (size_t i = 1; i < T; i++) jump_at[i] = (((C[i] - C[i - 1]) - (expect[i] - expect[i - 1])) & 3) ? 1 : 0;
 		}
 	}
+
+	/* ---- tiles the repair did not cure --------------------------------------------------------------------------------------
+	   A stream that slips a quarter turn on its way in one run and not in the other (seen on OQPSK at low resolution / under a
+	   ramp: 2 of 260 soak recordings) comes out odd again, the other way round, when it is re-run with its state turned.  Its
+	   samples are then demodulated by its PREDECESSOR instead: that stream runs again from the checkpoint through its own tile
+	   (the same bytes as before) and on through the next one - no seam, no rotation to get wrong. ---- */
+	std::vector<char> merged(T, 0);                         /* tile i is the second half of stream i-1's long run */
+	std::vector<const int8_t *> src_of(T, nullptr);
+	if (second_round && saved.c) {
+		std::vector<size_t> preds;
+		for (size_t i = 1; i < T; i++)
+			if (run[i] && (out_rot[i] & 1) && !(out_rot[i - 1] & 1) && (i + 1 >= T || !(out_rot[i + 1] & 1)) && !merged[i - 1] && len[i] > 0) { merged[i] = 1; preds.push_back(i - 1); }
+		if (!preds.empty()) {
+			const uint64_t cap_fix = mdemod_max_symbols(bank.c, 2 * B);
+			int8_t *soft_fix;
+			TRY(mem.alloc(&soft_fix, T * cap_fix * 2));
+			TRY(mdemod_copy_state(bank.c, saved.c, st));
+			std::vector<int32_t> qt(T, 0);
+			std::vector<uint64_t> c_stl(T, 0), c_body(T, 0), c_post(T, 0), o_post(T, 0);
+			for (size_t j : preds) { qt[j] = (4 - state_rot[j]) & 3; c_stl[j] = stl[j]; c_body[j] = len[j] + len[j + 1]; o_post[j] = ends[j + 1]; c_post[j] = post_len[j + 1]; }
+			HTRY(hipMemcpyAsync(d_rot, qt.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+			HTRY(hipStreamSynchronize(st));
+			TRY(mdemod_rotate_carrier(bank.c, d_rot, st));
+			std::vector<uint32_t> cnt_fix;
+			TRY(launch(stl_off, c_stl, soft_pre, cap_lead, cnt_tmp, nullptr, true));
+			TRY(launch(E, c_body, soft_fix, cap_fix, cnt_fix));
+			if (params->oqpsk) {
+				TRY(launch(o_post, c_post, soft_post, cap_post, cnt_tmp));
+				for (size_t j : preds) cnt_post[j] = cnt_tmp[j];
+			}
+			/* the seam behind the long run: its tail against the next tile's settled tail */
+			std::vector<TailPair> pairs;
+			std::vector<size_t> at;
+			for (size_t j : preds) {
+				const size_t i = j + 1;
+				src_of[j] = soft_fix + j * cap_fix * 2; cnt1[j] = cnt_fix[j]; cnt1[i] = 0;
+				out_rot[i] = out_rot[j]; shift[i] = 0; weak[i] = 0; jump_at[i] = 0;
+				rep->repaired_tiles++;
+				if (i + 1 < T) {
+					TailPair p;
+					p.a = src_of[j]; p.a_cnt = cnt1[j]; p.b = soft_pre + (i + 1) * cap_lead * 2; p.b_cnt = cnt_pre[i + 1]; p.b_rot = 0; p.force_weak = stl[i + 1] == 0;
+					pairs.push_back(p); at.push_back(i + 1);
+				}
+			}
+			std::vector<int32_t> sh, ro, we;
+			TRY(run_match(mem, pairs, K, sh, ro, we, st, params->oqpsk ? 1 : 0));
+			for (size_t k = 0; k < at.size(); k++) {
+				const size_t n = at[k];
+				if (!params->oqpsk) shift[n] = sh[k];
+				weak[n] = we[k];
+				/* measured: tile n needs ro[k] quarter turns against the long run; it was given out_rot[n] against the chain */
+				jump_at[n] = (!we[k] && ((out_rot[n - 1] + ro[k] - out_rot[n]) & 3)) ? 1 : 0;
+			}
+			if (dbg) fprintf(stderr, "[recording] %zu tiles handed to their predecessors' streams\n", preds.size());
+			mark("merged");
+		}
+	}
+	for (size_t i = 1; i < T; i++) rep->rotation_jumps += jump_at[i];
 	if (params->oqpsk && T > 1) {
 		/* rails come from firings half a symbol apart: the one-symbol disagreement is looked for on heads, tile i-1's
 		   look-ahead past its end against tile i's body (both start on the same sample) */
 		std::vector<TailPair> heads(T - 1);
 		for (size_t i = 1; i < T; i++) {
-			heads[i - 1].a = soft_post + (i - 1) * cap_post * 2; heads[i - 1].a_cnt = cnt_post[i - 1];
+			const size_t pr = merged[i - 1] ? i - 2 : i - 1;       /* the stream that ran up to this tile's first sample */
+			heads[i - 1].a = soft_post + pr * cap_post * 2;     heads[i - 1].a_cnt = cnt_post[pr];
 			heads[i - 1].b = soft1 + i * cap * 2;               heads[i - 1].b_cnt = cnt1[i];
-			heads[i - 1].b_rot = 0; heads[i - 1].force_weak = 0;
+			heads[i - 1].b_rot = 0; heads[i - 1].force_weak = merged[i] ? 1 : 0;
 		}
 		std::vector<int32_t> sh2, r2, w2;
 		TRY(run_match(mem, heads, K, sh2, r2, w2, st, 2));
-		for (size_t i = 1; i < T; i++) { shift[i] = w2[i - 1] ? 0 : -sh2[i - 1]; if (w2[i - 1]) weak[i] = 1; }
+		for (size_t i = 1; i < T; i++) { if (merged[i]) continue; shift[i] = w2[i - 1] ? 0 : -sh2[i - 1]; if (w2[i - 1]) weak[i] = 1; }
 	}
 	const std::vector<int32_t> &Rtot = out_rot;
 	for (size_t i = 0; i < T; i++) rep->weak_seams += weak[i];
@@ -1394,18 +1455,20 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 	/* ---- concatenate: pilot ++ tiles, with the seam fixes and what rotation is left on the output ---- */
 	std::vector<TileCopy> copies(T);
 	for (size_t i = 0; i < T; i++) {
-		copies[i].src = soft1 + i * cap * 2; copies[i].rot = Rtot[i]; copies[i].keep = cnt1[i];
+		copies[i].src = src_of[i] ? src_of[i] : soft1 + i * cap * 2; copies[i].rot = Rtot[i]; copies[i].keep = cnt1[i];
 		copies[i].head = nullptr; copies[i].head_rot = 0;
 		if (i && shift[i] == -1) {
 			/* the symbol straddling the seam is missing on both sides: take it from tile i's own settled run (its last symbol
 			   before the body; OQPSK: from the predecessor's look-ahead) */
-			if (params->oqpsk) { if (cnt_post[i - 1] > 0) { copies[i].head = soft_post + (i - 1) * cap_post * 2; copies[i].head_rot = Rtot[i - 1]; } }
+			const size_t pr = merged[i - 1] ? i - 2 : i - 1;
+			if (params->oqpsk) { if (cnt_post[pr] > 0) { copies[i].head = soft_post + pr * cap_post * 2; copies[i].head_rot = Rtot[pr]; } }
 			else if (cnt_pre[i] > 0) { copies[i].head = soft_pre + (i * cap_lead + cnt_pre[i] - 1) * 2; copies[i].head_rot = Rtot[i]; }
 		}
 	}
 	uint64_t out_pos = n_pilot_sym;
 	for (size_t i = 0; i < T; i++) {
-		const uint32_t drop = (i + 1 < T && shift[i + 1] == 1) ? 1 : 0;      /* the successor emits this tile's last symbol too */
+		const size_t nx = (i + 1 < T && merged[i + 1]) ? i + 2 : i + 1;      /* (a merged tile is part of this one's run) */
+		const uint32_t drop = (!merged[i] && nx < T && shift[nx] == 1) ? 1 : 0;      /* the successor emits this tile's last symbol too */
 		copies[i].keep = copies[i].keep > drop ? copies[i].keep - drop : 0;
 		if (shift[i] == -1 && !copies[i].head) shift[i] = 0;
 		copies[i].dst = out_pos;

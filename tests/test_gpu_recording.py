@@ -245,6 +245,22 @@ def test_rotation_jump_cases_of_round_one(args, gpu_device):
     assert r.returncode == 0 and "failures 0" in r.stdout and "rotation jump 0" in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("args", ["150 9404 51", "150 9304 142"], ids=["oqpsk-u8-255552", "oqpsk-f32-1136000"])
+def test_tiles_the_repair_does_not_cure_are_handed_to_their_predecessors(args, gpu_device):
+    """The two OQPSK soak recordings of round 2 (of 260) on which a tile came out a quarter turn off AGAIN, the other way round,
+    after its re-run from the checkpoint (it slips on its way in one run and not in the other): one symbol too many, the rest
+    of the recording misaligned.  Such a tile's samples are now demodulated by its predecessor's stream, run again from the
+    checkpoint through both tiles: no rotation jump, symbol count and hard decisions equal to the serial run."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "recording_fuzz.py"), *args.split()], capture_output=True, text=True,
+                       cwd=str(ROOT), timeout=600, env=dict(os.environ, FUZZ_ONLY_OQPSK="1", MDEMOD_RECORDING_DEBUG="1"))
+    assert r.returncode == 0 and "failures 0" in r.stdout and "rotation jump 0" in r.stdout, r.stdout[-2000:]
+    assert "'hard_decisions_equal': 1.0" in r.stdout and "handed to their predecessors" in r.stderr, (r.stdout[-1500:], r.stderr[-500:])
+
+
 @pytest.mark.parametrize("bps,oqpsk", [(16, False), (8, False), (16, True)])
 def test_recording_follows_doppler(gpu_device, bps, oqpsk):
     """40 Hz/s of Doppler over 52 s: the carrier moves 11 Hz across one estimator window, its 4th-power line 13 bins; the
