@@ -77,9 +77,9 @@ for ci in range(n_cases):
     within.append(a["within_1lsb"])
     # the very last symbol of a recording may fire in one run and not in the other (clock phases differ by a fraction of a sample)
     ok = abs(a["len_stitched"] - a["len_serial"]) <= 1 and a["hard_decisions_equal"] > 0.9995 and rep.weak_seams == 0
-    if not ok and rep.rotation_jumps and abs(a["len_stitched"] - a["len_serial"]) <= 1 and rep.weak_seams == 0:
-        jumps.append(tag)          # reported by the stitcher itself: one tile's first pass changed rotation
-        ok = True
+    if rep.rotation_jumps:
+        jumps.append(tag)          # reported by the stitcher itself (round 1 tolerated these; since the predecessor hand-over none is left)
+        ok = False
     print(tag, "->", "ok" if ok else "FAIL", {k_: (round(v, 5) if isinstance(v, float) else v) for k_, v in a.items()},
           "tiles", rep.n_tiles, "weak", rep.weak_seams, "weak_carrier", rep.weak_carrier_tiles, "frame_misses", rep.frame_misses,
           "repaired", rep.repaired_tiles, "rotation_jumps", rep.rotation_jumps, f"dr_rms {rep.frame_residual_rms:.2f}", flush=True)
