@@ -141,7 +141,8 @@ def single_recording(cfg, iq, check: bool = True) -> dict:
            "tiles": int(rep.n_tiles), "tile_samples": int(rep.tile_samples),
            "work_per_sample": round(rep.samples_demodulated / n, 2), "symbols": int(rep.n_symbols),
            "seam_fixes": int(rep.seam_fixes), "weak_seams": int(rep.weak_seams), "frame_misses": int(rep.frame_misses),
-           "repaired_tiles": int(rep.repaired_tiles), "rotation_jumps": int(rep.rotation_jumps),
+           "repaired_tiles": int(rep.repaired_tiles), "rotation_jumps": int(rep.rotation_jumps), "pilot_locked": int(rep.pilot_locked),
+           "weak_carrier_tiles": int(rep.weak_carrier_tiles), "weak_clock_tiles": int(rep.weak_clock_tiles),
            "dead_reckoning_residual_rms_rad": round(float(rep.frame_residual_rms), 3)}
     if check:
         import oracle_py as O
