@@ -333,8 +333,10 @@ typedef struct {
 	double   tiles_seconds;         /* wall time of everything after it                      */
 	uint32_t frame_misses;          /* seams where dead reckoning put the tile in another rotation than the correlation found */
 	uint32_t repaired_tiles;        /* tiles that ran settle + body a second time (odd residual rotation)               */
-	uint32_t rotation_jumps;        /* seams that still show a residual rotation after the repair (a cycle slip inside a
-	                                   body): the output is rotated from there on, like a serial run after a cycle slip  */
+	uint32_t rotation_jumps;        /* seams that still show an unexpected rotation after the repairs (a cycle slip inside a
+	                                   body): the output is rotated from there on, like a serial run after a cycle slip.
+	                                   (A re-run tile that sits half a turn off on both its seams is not one: its output is
+	                                   turned, which is exact, and continuous with its neighbours.) */
 	float    frame_residual_rms;    /* rad: dead-reckoned minus measured NCO phase, after removing the quarter turns (0.785 = limit) */
 	uint32_t odd_tiles_kept;        /* tiles left an odd number of quarter turns off because they were too few to be worth a repair
 	                                   pass (< 0.5 % of the tiles): output turned (decisions exact), soft values on the other rail's timing */

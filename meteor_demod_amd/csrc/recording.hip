@@ -1374,7 +1374,15 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 		} else {
 			out_rot = C;
 			second_round = true;
-			for (size_t i = 1; i < T; i++) jump_at[i] = (((C[i] - C[i - 1]) - (expect[i] - expect[i - 1])) & 3) ? 1 : 0;
+			/* what the second round was not expected to find.  A re-run tile that sits half a turn off on BOTH its seams is no jump:
+			   its output is turned (exact) and continuous with its neighbours */
+			std::vector<int32_t> D(T);
+			for (size_t i = 0; i < T; i++) D[i] = (C[i] - expect[i]) & 3;
+			for (size_t i = 1; i < T; i++) {
+				if (D[i] == D[i - 1]) continue;
+				if (!((D[i] - D[i - 1]) & 1) && (i + 1 >= T || D[i + 1] == D[i - 1])) { i++; continue; }
+				jump_at[i] = 1;
+			}
 		}
 	}
 
