@@ -28,6 +28,7 @@ struct mdemod_ctx {
 	float        *d_ctab;
 	float        *d_lut;
 	float        *d_rrc;       /* plain polyphase table [bank][taps] (filter.c:18-22) for the latency kernel */
+	bool          use_rot;     /* std geometry on the v3 rotating-window kernel (demod_kernel_rot.hip) instead of v2 */
 	bool          lat_ok;      /* the latency kernel (one stream per wave) fits this configuration */
 	int           lat_ring, lat_span;
 	size_t        lat_lds;
@@ -102,7 +103,9 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 			return MDEMOD_OK;
 		}
 	}
-	if (ctx->tab.use_rw)
+	if (ctx->tab.use_rw && ctx->use_rot)
+		HIP_TRY(mdemod_launch_demod_rot(L, ctx->params.bps, ctx->lds_bytes, stream));
+	else if (ctx->tab.use_rw)
 		HIP_TRY((ctx->tab.rw_wide || ctx->tab.rw_mid || ctx->tab.rw_far)
 		        ? mdemod_launch_demod_rw_wide(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream)
 		                         : mdemod_launch_demod_rw_std(L, ctx->params.bps, env_int("MDEMOD_RW_PACKED", 0), ctx->lds_bytes, stream));
@@ -187,6 +190,10 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	int rc = mdemod_host_derive(*params, ctx->tab, !(kforce && !strcmp(kforce, "v1")));
 	if (rc) { delete ctx; return rc; }
 	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
+	/* v3 drops the range test of the NCO's turn code (demod_device.h): it needs |phase| < 16, which pll.c's own clamp gives
+	 * for fmax < 8 rad/symbol (the default is 0.3) */
+	ctx->use_rot = ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && ctx->tab.c.pll_fmax < 8.0f &&
+	               !(kforce && !strcmp(kforce, "v2"));
 
 	/* tunables (experiments only; defaults are the measured best) */
 	DemodConsts &c = ctx->tab.c;
@@ -597,6 +604,7 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (ctx->tab.rw_far) return "demod_kernel_rw (v2 register window, far: 65 taps at up to 30 samples per firing, packed)";
 	if (ctx->tab.rw_mid) return ctx->params.bps == 32 ? "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, float pairs)"
 	                                                  : "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, packed)";
+	if (ctx->use_rot) return "demod_kernel_rot (v3 rotating register window)";
 	return (ctx->params.bps != 32 && env_int("MDEMOD_RW_PACKED", 0))
 	       ? "demod_kernel_rw (v2 register window, packed)" : "demod_kernel_rw (v2 register window, float)";
 }

@@ -39,6 +39,7 @@ md_turn_code_div(float fx)
  * tools/proofs/verify_sincos_shortcut.cpp enumerates every float with |fx| < 16 (the PLL
  * produces |fx| < 8.9): no such float exists, 0 mismatches in 2 197 815 296.  The device
  * self-test mdemod_selftest_turncode() repeats the enumeration on the GPU. */
+template <bool CHECKED = true>
 __device__ __forceinline__ int32_t
 md_turn_code(float fx)
 {
@@ -49,10 +50,15 @@ md_turn_code(float fx)
 	n = (r < 0.0) ? n - 1 : ((r >= MD_TWO_PI_D) ? n + 1 : n);
 	n = (xd < 0.0) ? -n : n;
 	/* outside the proven range: the real division (one wave-uniform test instead of a divergent branch
-	 * per call; the PLL keeps |fx| < 8.9, so this is never taken in practice) */
-	const bool out_of_range = !(fabsf(fx) < 16.0f);
-	if (__any(out_of_range)) {
-		if (out_of_range) n = md_turn_code_div(fx);
+	 * per call; the PLL keeps |fx| < 8.9, so this is never taken in practice).  CHECKED = false drops the
+	 * test: for kernels that only run when the host has established |fx| < 16 (pll_fmax < 8: the phase
+	 * leaves pll.c:113's fmod inside (-2pi, 2pi) and pll.c:60 adds at most fmax; mdemod_set_state refuses
+	 * anything else; a NaN phase gives 0 on both paths, as cvttsd2si's 0x80000000 does in the reference). */
+	if (CHECKED) {
+		const bool out_of_range = !(fabsf(fx) < 16.0f);
+		if (__any(out_of_range)) {
+			if (out_of_range) n = md_turn_code_div(fx);
+		}
 	}
 	return n;
 }
@@ -69,17 +75,19 @@ md_sin_from_code(int32_t wide)
 	return (float)(sign < 0 ? -y : y) * (1.0f / 16384.0f);  /* sincos.c:34 (exact: power of two) */
 }
 
+template <bool CHECKED = true>
 __device__ __forceinline__ float
 md_fast_sin(float fx)
 {
-	return md_sin_from_code(md_turn_code(fx));
+	return md_sin_from_code(md_turn_code<CHECKED>(fx));
 }
 
 /* dsp/sincos.c:37-40 */
+template <bool CHECKED = true>
 __device__ __forceinline__ float
 md_fast_cos(float fx)
 {
-	return md_fast_sin((float)((double)fx + MD_HALF_PI_D));
+	return md_fast_sin<CHECKED>((float)((double)fx + MD_HALF_PI_D));
 }
 
 /* cabsf as glibc 2.35 computes it: one double sqrt of the exact double sum of
@@ -118,22 +126,22 @@ md_nco_advance(float &phase, float freq)
 		phase = (float)((double)phase - MD_TWO_PI_D);
 }
 
-/* fmod(x, 2*pi) with the dividend's sign (pll.c:113).  |x| < 2*pi needs no work;
- * one period off is an exact double subtraction; anything larger takes libm's
- * exact fmod. */
-__device__ __forceinline__ double
+/* (float)fmod(x, 2*pi) with the dividend's sign (pll.c:113) for a float x.  |x| < 2*pi needs no work; one period off
+ * is an exact double subtraction (Sterbenz: 2pi <= |x| < 4pi) and happens to some lane of a wave on most firings (a
+ * carrier offset walks the phase round the circle), so it is computed branch-free; anything larger takes libm's exact
+ * fmod behind a wave-uniform test that is practically never taken (|alpha * e| would have to exceed 2*pi). */
+#define MD_FOUR_PI_F 12.56637096405029296875f          /* the float just above 4*pi: |x| < this  <=>  (double)|x| < 4*pi */
+__device__ __forceinline__ float
 md_wrap_2pi(float xf)
 {
 	const double x = (double)xf;
-	const double ax = fabs(x);
-	double r = x;
 	/* |x| < 2*pi (double)  <=>  |xf| < 6.2831855f for a float argument (see md_nco_advance) */
 	const bool wraps = !(fabsf(xf) < MD_TWO_PI_F);
-	if (__any(wraps)) {
-		if (wraps) {
-			if (ax < 2.0 * MD_TWO_PI_D) r = (x < 0.0) ? x + MD_TWO_PI_D : x - MD_TWO_PI_D;
-			else r = fmod(x, MD_TWO_PI_D);
-		}
+	const float once = (float)(x + ((xf < 0.0f) ? MD_TWO_PI_D : -MD_TWO_PI_D));
+	float r = wraps ? once : xf;
+	const bool far = !(fabsf(xf) < MD_FOUR_PI_F);              /* also NaN and inf: fmod's business */
+	if (__builtin_expect(__any(far), 0)) {
+		if (far) r = (float)fmod(x, MD_TWO_PI_D);
 	}
 	return r;
 }
@@ -174,7 +182,7 @@ md_pll_update(PllState &p, const float *lut, float alpha, float beta, float fmax
 	                        : md_tanh_lut(lut, i) * q - md_tanh_lut(lut, q) * i;
 
 	const float ph = p.phase + alpha * e;
-	p.phase = (float)md_wrap_2pi(ph);
+	p.phase = md_wrap_2pi(ph);
 	p.freq = p.freq + beta * e;
 
 	const float decayed = p.err * (1.0f - 0.001f);

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generates rotwin_asm.h: the gfx950 assembly of the ROTATING register window (demod_kernel_rot.hip).
+
+Why assembly, and why generated.  The v2 kernel kept its FIR window (80 samples x (re, im) = 160 VGPRs per lane) in a
+C++ array and slid it with register moves: 144 v_mov_b32 per slide plus ~30 PHI copies per iteration that hipcc adds
+around them - 13 % of the kernel's VALU instructions, none of them the reference's arithmetic (profiles/r02_kernels.md).
+Renaming instead of moving needs one copy of the FIR code per window rotation, each with its own physical registers;
+hipcc merges such copies behind PHI moves and spills (tried in r01).  So the window registers are taken away from the
+compiler (`amdgpu_num_vgpr` keeps it below v80; v80..v95 are the FIR's coefficient buffers, v96..v255 the window) and
+the three pieces of code that touch them are written here, one copy per rotation, entered through a computed jump:
+
+  FIR     filter.c:46-65 - the sequential, oldest-first, unfused sum over the 80 window slots (twenty half-chunks of 4
+          taps; coefficients three half-chunks ahead in four rotating buffers; an edge chunk of 8 slots that is all
+          padding for the whole wave is skipped).  Per tap: v_mul, v_mul, v_add, v_add - what the reference's `acc += mem * coeff` is.
+  PUT     converts two granules (8 samples) of raw input into one physical chunk: the slide.  Nothing moves.
+  PUTF    the same for 16 ready floats (history at kernel start, float input).
+
+Physical chunk q (8 slots) = v[WB + 16 q .. WB + 16 q + 15], slot s of it = (re, im) at +2s, +2s+1.  Logical chunk c of
+rotation r is physical chunk (c + r) mod 10.
+
+Run:  python3 gen_rotwin_asm.py > rotwin_asm.h      (build.py does it when the header is older than this script)
+"""
+import sys
+
+WB = 96          # first window register
+CB = 80          # coefficient buffers: 4 x 4 registers
+NCH = 10         # chunks of 8 slots
+CHB = 32         # bytes of coefficients per chunk
+
+
+def q(lines):
+    """C string literal lines for an asm statement."""
+    return "\n".join('\t"%s\\n\\t"' % l for l in lines)
+
+
+def jump(tag, n):
+    """Computed jump to copy %[rot] of `tag` (all copies have the same size)."""
+    return [
+        "s_getpc_b64 vcc",
+        ".L%s_pc_%%=:" % tag,
+        "s_mul_i32 %%[tmp], %%[rot], (.L%s_1_%%= - .L%s_0_%%=)" % (tag, tag),
+        "s_add_u32 %%[tmp], %%[tmp], (.L%s_0_%%= - .L%s_pc_%%=)" % (tag, tag),
+        "s_add_u32 vcc_lo, vcc_lo, %[tmp]",
+        "s_addc_u32 vcc_hi, vcc_hi, 0",
+        "s_setpc_b64 vcc",
+    ]
+
+
+def fir():
+    """Half-chunks of 4 taps: one ds_read_b128 each, four rotating buffers of 4 registers, three half-chunks ahead."""
+    NH, D = 2 * NCH, 3
+    def load(h):
+        b = CB + 4 * (h % 4)
+        return "ds_read_b128 v[%d:%d], %%[addr] offset:%d" % (b, b + 3, 16 * h)
+    L = []
+    L += ["v_mov_b32 %[ar], 0", "v_mov_b32 %[ai], 0"]
+    L += [load(h) for h in range(D)]                     # on their way before the jump (the same for every rotation)
+    L += jump("fir", NCH)
+    for r in range(NCH):
+        L += [".Lfir_%d_%%=:" % r]
+        for h in range(NH):
+            c = h // 2
+            if h + D < NH:
+                L += [load(h + D)]
+            # chunk 0 = half-chunks 0 and 1: each is jumped over on its own, so that half-chunk 1's prefetch is still issued
+            if h < 2:
+                L += ["s_bitcmp1_b32 %[flags], 0", "s_cbranch_scc1 .Lfir_%d_s%d_%%=" % (r, h)]
+            if h == NH - 2:
+                L += ["s_bitcmp1_b32 %[flags], 1", "s_cbranch_scc1 .Lfir_%d_s9_%%=" % r]
+            L += ["s_waitcnt lgkmcnt(%d)" % min(D, NH - 1 - h)]
+            hb = CB + 4 * (h % 4)
+            wq = WB + 16 * ((c + r) % NCH) + 8 * (h & 1)
+            # products one tap ahead of the sums, two temporaries per tap
+            def mul(j):
+                t = "%%[t%d]" % (2 * (j & 1)), "%%[t%d]" % (2 * (j & 1) + 1)
+                return ["v_mul_f32 %s, v%d, v%d" % (t[0], hb + j, wq + 2 * j),
+                        "v_mul_f32 %s, v%d, v%d" % (t[1], hb + j, wq + 2 * j + 1)]
+            def add(j):
+                t = "%%[t%d]" % (2 * (j & 1)), "%%[t%d]" % (2 * (j & 1) + 1)
+                return ["v_add_f32 %%[ar], %%[ar], %s" % t[0], "v_add_f32 %%[ai], %%[ai], %s" % t[1]]
+            L += mul(0)
+            for j in range(4):
+                if j + 1 < 4:
+                    L += mul(j + 1)
+                L += add(j)
+            if h < 2:
+                L += [".Lfir_%d_s%d_%%=:" % (r, h)]
+        L += [".Lfir_%d_s9_%%=:" % r, "s_branch .Lfir_end_%="]
+    L += [".Lfir_end_%=:", "s_waitcnt lgkmcnt(0)"]
+    return L
+
+
+def put(kind):
+    """16 conversions of 8 raw samples (s16: 8 dwords g0..g7; u8: 4 dwords g0..g3, already xor-ed with 0x80808080) or 16
+    moves of ready floats (f0..f15) into physical chunk %[rot]."""
+    L = ["s_nop 1"] if kind == "u8" else []          # the xor that feeds the SDWA selects may be the instruction before
+    L += jump("put", NCH)
+    for r in range(NCH):
+        L += [".Lput_%d_%%=:" % r]
+        wq = WB + 16 * r
+        for s in range(8):
+            for comp in range(2):
+                dst = wq + 2 * s + comp
+                if kind == "s16":
+                    L += ["v_cvt_f32_i32_sdwa v%d, sext(%%[g%d]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d" % (dst, s, comp)]
+                elif kind == "u8":
+                    L += ["v_cvt_f32_i32_sdwa v%d, sext(%%[g%d]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_%d" % (dst, s // 2, 2 * (s & 1) + comp)]
+                else:
+                    L += ["v_mov_b32 v%d, %%[f%d]" % (dst, 2 * s + comp)]
+        L += ["s_branch .Lput_end_%="]
+    L += [".Lput_end_%=:"]
+    return L
+
+
+def main():
+    out = []
+    out.append("/* GENERATED by gen_rotwin_asm.py - do not edit.  gfx950 assembly of the rotating register window. */")
+    out.append("#ifndef MDEMOD_ROTWIN_ASM_H")
+    out.append("#define MDEMOD_ROTWIN_ASM_H")
+    out.append("#define ROTWIN_WB %d" % WB)
+    out.append("#define ROTWIN_CB %d" % CB)
+    out.append("#define ROTWIN_NCH %d" % NCH)
+    out.append("#define ROTWIN_FIR_ASM \\\n" + q(fir()).replace("\n", " \\\n"))
+    for kind in ("s16", "u8", "f32"):
+        out.append("#define ROTWIN_PUT_%s_ASM \\\n" % kind.upper() + q(put(kind)).replace("\n", " \\\n"))
+    # clobber lists
+    out.append("#define ROTWIN_COEF_CLOBBERS " + ", ".join('"v%d"' % (CB + i) for i in range(16)))
+    out.append("#endif")
+    sys.stdout.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -25,8 +25,9 @@ def _torch():
 
 KERNEL_VARIANTS = {
     # MDEMOD_LAT=0: contexts with few streams would otherwise pick the latency kernel (one stream per wave) by themselves
-    "v2-float": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "0"},     # register window, converted floats
-    "v2-packed": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "1", "MDEMOD_LAT": "0"},    # register window, raw samples (3 waves/SIMD)
+    "v3-rot": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "0"},       # rotating register window (std geometry; the other geometries: v2)
+    "v2-float": {"MDEMOD_KERNEL": "v2", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "0"},   # register window, converted floats
+    "v2-packed": {"MDEMOD_KERNEL": "v2", "MDEMOD_RW_PACKED": "1", "MDEMOD_LAT": "0"},  # register window, raw samples (3 waves/SIMD)
     "v1-ring": {"MDEMOD_KERNEL": "v1", "MDEMOD_RW_PACKED": "1", "MDEMOD_LAT": "0"},    # LDS ring (generic fallback, > 65 taps)
     "lat": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "1"},          # one stream per wave, v2 state layout
     "lat-v1-state": {"MDEMOD_KERNEL": "v1", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "1"},   # ... on the ring kernel's state layout
