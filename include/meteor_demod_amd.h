@@ -204,6 +204,8 @@ int  mdemod_get_lock_events(mdemod_ctx *ctx, uint32_t stream,
                             void *hip_stream);
 int  mdemod_get_state(mdemod_ctx *ctx, uint32_t stream, mdemod_stream_state *out,
                       void *hip_stream);
+/* MDEMOD_ERR_PARAM for a carrier state the reference's loop cannot hold: |pll_phase| + |pll_freq| >= 12.5 (pll.c:113
+ * keeps the phase inside (-2pi, 2pi), pll.c:126-128 the frequency word inside +-fmax). */
 int  mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in,
                       void *hip_stream);
 /* Filter history: the last mdemod_history_len() input samples, oldest first,

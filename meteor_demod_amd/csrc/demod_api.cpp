@@ -190,9 +190,9 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	int rc = mdemod_host_derive(*params, ctx->tab, !(kforce && !strcmp(kforce, "v1")));
 	if (rc) { delete ctx; return rc; }
 	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
-	/* v3 drops the range test of the NCO's turn code (demod_device.h): it needs |phase| < 16, which pll.c's own clamp gives
-	 * for fmax < 8 rad/symbol (the default is 0.3) */
-	ctx->use_rot = ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && ctx->tab.c.pll_fmax < 8.0f &&
+	/* v3 drops the range test of the NCO's turn code and wraps the NCO phase in float arithmetic (demod_device.h): both need
+	 * phase + freq < 4pi, which pll.c's own clamp gives for fmax < 2pi rad/symbol (the default is 0.3) */
+	ctx->use_rot = ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && ctx->tab.c.pll_fmax < 6.0f &&
 	               !(kforce && !strcmp(kforce, "v2"));
 
 	/* tunables (experiments only; defaults are the measured best) */
@@ -441,12 +441,23 @@ mdemod_get_state(mdemod_ctx *ctx, uint32_t stream, mdemod_stream_state *out, voi
 	return MDEMOD_OK;
 }
 
+/* A carrier phase / frequency word the reference's loop can hold: pll.c:113 leaves the phase inside (-2pi, 2pi), pll.c:60 adds
+ * the frequency word, pll.c:126-128 clamp that to +-fmax.  The kernels' NCO relies on |phase| + |freq| < 4pi (demod_device.h:
+ * md_turn_code, md_nco_advance); NaN (what NaN input makes of them) goes through every path as in the reference. */
+static bool
+carrier_in_domain(const mdemod_stream_state &v)
+{
+	const float a = fabsf(v.pll_phase) + fabsf(v.pll_freq);
+	return !(a >= 12.5f);
+}
+
 int
 mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in, void *hip_stream)
 {
 	if (!ctx || !in) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	if (in->t_dual_state != 1 && in->t_dual_state != 2) return MDEMOD_ERR_PARAM;
+	if (!carrier_in_domain(*in)) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
@@ -468,6 +479,7 @@ mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void *hip
 {
 	if (!ctx || !seed) return MDEMOD_ERR_PARAM;
 	if (seed->t_dual_state != 1 && seed->t_dual_state != 2) return MDEMOD_ERR_PARAM;
+	if (!carrier_in_domain(*seed)) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	const int32_t flags = (seed->pll_locked ? MDEMOD_FLAG_LOCKED : 0) | (seed->pll_locked_once ? MDEMOD_FLAG_LOCKED_ONCE : 0) |

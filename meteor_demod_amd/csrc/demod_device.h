@@ -31,32 +31,28 @@ md_turn_code_div(float fx)
 	return __double2int_rz((double)(fx * 65536.0f) / MD_TWO_PI_D);
 }
 
-/* The same integer without the division (a correctly rounded f64 divide is ~35 instructions,
- * and there are two per symbol): n0 = trunc(|x| * RN(1/2pi)) is within 1 of the answer, the
- * residual |x| - n0*2pi is EXACT in one fma (a multiple of 2^-50 below 8), one compare fixes
- * n0.  This yields trunc of the exact quotient; the reference truncates the ROUNDED quotient,
- * which could differ only if the exact quotient sat within 2^-53 below an integer.
- * tools/proofs/verify_sincos_shortcut.cpp enumerates every float with |fx| < 16 (the PLL
- * produces |fx| < 8.9): no such float exists, 0 mismatches in 2 197 815 296.  The device
- * self-test mdemod_selftest_turncode() repeats the enumeration on the GPU. */
+/* The same integer with ONE double multiplication (a correctly rounded f64 divide is ~35 instructions, and there are two
+ * per symbol).  The quotient RN(x / 2pi) and the product RN(x * RN(1/2pi)) are two roundings of almost the same real
+ * number, so their truncations differ only if an integer lies between them - and for the 2.2e9 floats with |fx| < 16
+ * none does: tools/proofs/verify_turncode_mul.cpp enumerates them all (0 mismatches, also for the constant 1..3 ulp
+ * either side: there is margin), the CPU test-suite runs it, and the device self-test mdemod_selftest_turncode()
+ * repeats the enumeration on the GPU against the real division.  Scaling by 65536 is exact, so it is folded into the
+ * constant.  (Until round 3 this was n0 = trunc(|x| * RN(1/2pi)) plus an exact fma residual and one correction: 7 f64-rate
+ * instructions instead of 3; the enumeration shows the correction never fires.)  The PLL produces |fx| < 8.9. */
+#define MD_TURNS_PER_RAD_X65536 (65536.0 * (1.0 / MD_TWO_PI_D))
 template <bool CHECKED = true>
 __device__ __forceinline__ int32_t
 md_turn_code(float fx)
 {
-	const double xd = (double)(fx * 65536.0f);
-	const double ax = fabs(xd);
-	int32_t n = __double2int_rz(ax * (1.0 / MD_TWO_PI_D));
-	const double r = fma(-(double)n, MD_TWO_PI_D, ax);
-	n = (r < 0.0) ? n - 1 : ((r >= MD_TWO_PI_D) ? n + 1 : n);
-	n = (xd < 0.0) ? -n : n;
-	/* outside the proven range: the real division (one wave-uniform test instead of a divergent branch
-	 * per call; the PLL keeps |fx| < 8.9, so this is never taken in practice).  CHECKED = false drops the
-	 * test: for kernels that only run when the host has established |fx| < 16 (pll_fmax < 8: the phase
-	 * leaves pll.c:113's fmod inside (-2pi, 2pi) and pll.c:60 adds at most fmax; mdemod_set_state refuses
-	 * anything else; a NaN phase gives 0 on both paths, as cvttsd2si's 0x80000000 does in the reference). */
+	int32_t n = __double2int_rz((double)fx * MD_TURNS_PER_RAD_X65536);
+	/* outside the proven range: the real division (one wave-uniform test instead of a divergent branch per call; never
+	 * taken in practice).  CHECKED = false drops the test: for kernels that only run when the host has established
+	 * |fx| < 16 (pll_fmax < 6: the phase leaves pll.c:113's fmod inside (-2pi, 2pi) and pll.c:60 adds at most fmax;
+	 * mdemod_set_state refuses anything else; a NaN phase gives 0 on both paths, as cvttsd2si's 0x80000000 does in the
+	 * reference). */
 	if (CHECKED) {
 		const bool out_of_range = !(fabsf(fx) < 16.0f);
-		if (__any(out_of_range)) {
+		if (__builtin_expect(__any(out_of_range), 0)) {
 			if (out_of_range) n = md_turn_code_div(fx);
 		}
 	}
@@ -90,13 +86,33 @@ md_fast_cos(float fx)
 	return md_fast_sin<CHECKED>((float)((double)fx + MD_HALF_PI_D));
 }
 
+/* Correctly rounded sqrt of a double that is the sum of two squared floats: 0, or in [2^-298, 2^257], or inf/NaN.  This is
+ * the device library's own sequence (v_rsq_f64 + two Goldschmidt/Newton steps with exact fma residuals) without the
+ * range scaling it needs for arguments below 2^-767 (two v_ldexp_f64, a compare and two selects less); 0 and inf keep
+ * their special-case select.  mdemod_selftest_hypot compares it with the host's sqrt on the device. */
+__device__ __forceinline__ double
+md_sqrt_sumsq(double s)
+{
+	const double y = __builtin_amdgcn_rsq(s);
+	double g = s * y;
+	double h = 0.5 * y;
+	const double r = __builtin_fma(-h, g, 0.5);
+	g = __builtin_fma(g, r, g);
+	h = __builtin_fma(h, r, h);
+	double d = __builtin_fma(-g, g, s);
+	g = __builtin_fma(d, h, g);
+	d = __builtin_fma(-g, g, s);
+	g = __builtin_fma(d, h, g);
+	return __builtin_amdgcn_class(s, 0x260) ? s : g;       /* -0, +0, +inf: sqrt(s) == s */
+}
+
 /* cabsf as glibc 2.35 computes it: one double sqrt of the exact double sum of
  * squares, narrowed to float (agc.c:21). */
 __device__ __forceinline__ float
 md_cabsf(float re, float im)
 {
 	const double s = (double)re * (double)re + (double)im * (double)im;
-	return (float)__dsqrt_rn(s);
+	return (float)md_sqrt_sumsq(s);
 }
 
 /* dsp/agc.c:13-25 */
@@ -116,32 +132,42 @@ md_agc(cf32 x, float &gain, float &bias_re, float &bias_im)
 	return x;
 }
 
-/* NCO phase advance: pll.c:60-61 */
+/* 2*M_PI = MD_TWO_PI_F + MD_TWO_PI_LO with MD_TWO_PI_F the float above it.  For a float x with 2pi <= |x| < 4pi,
+ * (float)((double)x -+ 2*M_PI) == (x -+ MD_TWO_PI_F) -+ MD_TWO_PI_LO in FLOAT arithmetic (the first step is exact: Sterbenz):
+ * tools/proofs/verify_wrap_f32.cpp enumerates all 16 777 216 such floats, in the CPU test-suite. */
+#define MD_TWO_PI_LO (-0x1.777a5cp-23f)                /* (float)(2*M_PI - (double)MD_TWO_PI_F) = -1.74845553e-07 */
+
+/* NCO phase advance: pll.c:60-61.  F32: the wrap in float arithmetic (needs phase + freq < 4pi, i.e. fmax < 2pi: the
+ * v3 kernel, whose host side checks it); otherwise the reference's double subtraction. */
+template <bool F32 = false>
 __device__ __forceinline__ void
 md_nco_advance(float &phase, float freq)
 {
 	phase = phase + freq;
 	/* (double)phase >= 2*pi  <=>  phase >= 6.2831855f: 2*pi lies strictly between the floats 6.2831850 and 6.2831855 */
-	if (phase >= MD_TWO_PI_F)
+	if (F32) {
+		const float w = (phase - MD_TWO_PI_F) - MD_TWO_PI_LO;
+		phase = (phase >= MD_TWO_PI_F) ? w : phase;
+	} else if (phase >= MD_TWO_PI_F)
 		phase = (float)((double)phase - MD_TWO_PI_D);
 }
 
 /* (float)fmod(x, 2*pi) with the dividend's sign (pll.c:113) for a float x.  |x| < 2*pi needs no work; one period off
- * is an exact double subtraction (Sterbenz: 2pi <= |x| < 4pi) and happens to some lane of a wave on most firings (a
+ * is exact in float arithmetic (MD_TWO_PI_LO above) and happens to some lane of a wave on most firings (a
  * carrier offset walks the phase round the circle), so it is computed branch-free; anything larger takes libm's exact
  * fmod behind a wave-uniform test that is practically never taken (|alpha * e| would have to exceed 2*pi). */
 #define MD_FOUR_PI_F 12.56637096405029296875f          /* the float just above 4*pi: |x| < this  <=>  (double)|x| < 4*pi */
 __device__ __forceinline__ float
 md_wrap_2pi(float xf)
 {
-	const double x = (double)xf;
 	/* |x| < 2*pi (double)  <=>  |xf| < 6.2831855f for a float argument (see md_nco_advance) */
 	const bool wraps = !(fabsf(xf) < MD_TWO_PI_F);
-	const float once = (float)(x + ((xf < 0.0f) ? MD_TWO_PI_D : -MD_TWO_PI_D));
+	/* one period, in float arithmetic (exact for 2pi <= |x| < 4pi, see MD_TWO_PI_LO) */
+	const float once = (xf < 0.0f) ? (xf + MD_TWO_PI_F) + MD_TWO_PI_LO : (xf - MD_TWO_PI_F) - MD_TWO_PI_LO;
 	float r = wraps ? once : xf;
 	const bool far = !(fabsf(xf) < MD_FOUR_PI_F);              /* also NaN and inf: fmod's business */
 	if (__builtin_expect(__any(far), 0)) {
-		if (far) r = (float)fmod(x, MD_TWO_PI_D);
+		if (far) r = (float)fmod((double)xf, MD_TWO_PI_D);
 	}
 	return r;
 }

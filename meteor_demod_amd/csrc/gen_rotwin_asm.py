@@ -20,11 +20,13 @@ rotation r is physical chunk (c + r) mod 10.
 
 Run:  python3 gen_rotwin_asm.py > rotwin_asm.h      (build.py does it when the header is older than this script)
 """
+import os
 import sys
 
 WB = 96          # first window register
 CB = 80          # coefficient buffers: 4 x 4 registers
 NCH = 10         # chunks of 8 slots
+PK = int(os.environ.get("ROTWIN_PK", "0"))     # 1: the FIR's tap = v_pk_mul_f32 + v_pk_add_f32 on (re, im) pairs instead of 2 + 2 scalar ops
 CHB = 32         # bytes of coefficients per chunk
 
 
@@ -53,7 +55,8 @@ def fir():
         b = CB + 4 * (h % 4)
         return "ds_read_b128 v[%d:%d], %%[addr] offset:%d" % (b, b + 3, 16 * h)
     L = []
-    L += ["v_mov_b32 %[ar], 0", "v_mov_b32 %[ai], 0"]
+    if not PK:
+        L += ["v_mov_b32 %[ar], 0", "v_mov_b32 %[ai], 0"]
     L += [load(h) for h in range(D)]                     # on their way before the jump (the same for every rotation)
     L += jump("fir", NCH)
     for r in range(NCH):
@@ -70,14 +73,22 @@ def fir():
             L += ["s_waitcnt lgkmcnt(%d)" % min(D, NH - 1 - h)]
             hb = CB + 4 * (h % 4)
             wq = WB + 16 * ((c + r) % NCH) + 8 * (h & 1)
-            # products one tap ahead of the sums, two temporaries per tap
-            def mul(j):
-                t = "%%[t%d]" % (2 * (j & 1)), "%%[t%d]" % (2 * (j & 1) + 1)
-                return ["v_mul_f32 %s, v%d, v%d" % (t[0], hb + j, wq + 2 * j),
-                        "v_mul_f32 %s, v%d, v%d" % (t[1], hb + j, wq + 2 * j + 1)]
-            def add(j):
-                t = "%%[t%d]" % (2 * (j & 1)), "%%[t%d]" % (2 * (j & 1) + 1)
-                return ["v_add_f32 %%[ar], %%[ar], %s" % t[0], "v_add_f32 %%[ai], %%[ai], %s" % t[1]]
+            if PK:
+                # (re, im) of a slot are an even-aligned register pair, the coefficient is broadcast with op_sel
+                def mul(j):
+                    return ["v_pk_mul_f32 %%[p%d], v[%d:%d], v[%d:%d] op_sel:[0,%d] op_sel_hi:[1,%d]"
+                            % (j & 1, wq + 2 * j, wq + 2 * j + 1, hb + 2 * (j // 2), hb + 2 * (j // 2) + 1, j & 1, j & 1)]
+                def add(j):
+                    return ["v_pk_add_f32 %%[acc], %%[acc], %%[p%d]" % (j & 1)]
+            else:
+                # products one tap ahead of the sums, two temporaries per tap
+                def mul(j):
+                    t = "%%[t%d]" % (2 * (j & 1)), "%%[t%d]" % (2 * (j & 1) + 1)
+                    return ["v_mul_f32 %s, v%d, v%d" % (t[0], hb + j, wq + 2 * j),
+                            "v_mul_f32 %s, v%d, v%d" % (t[1], hb + j, wq + 2 * j + 1)]
+                def add(j):
+                    t = "%%[t%d]" % (2 * (j & 1)), "%%[t%d]" % (2 * (j & 1) + 1)
+                    return ["v_add_f32 %%[ar], %%[ar], %s" % t[0], "v_add_f32 %%[ai], %%[ai], %s" % t[1]]
             L += mul(0)
             for j in range(4):
                 if j + 1 < 4:
@@ -120,6 +131,7 @@ def main():
     out.append("#define ROTWIN_WB %d" % WB)
     out.append("#define ROTWIN_CB %d" % CB)
     out.append("#define ROTWIN_NCH %d" % NCH)
+    out.append("#define ROTWIN_PK %d" % PK)
     out.append("#define ROTWIN_FIR_ASM \\\n" + q(fir()).replace("\n", " \\\n"))
     for kind in ("s16", "u8", "f32"):
         out.append("#define ROTWIN_PUT_%s_ASM \\\n" % kind.upper() + q(put(kind)).replace("\n", " \\\n"))
