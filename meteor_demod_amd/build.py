@@ -48,6 +48,34 @@ def _run(cmd: list[str]) -> None:
         raise RuntimeError("build failed: " + " ".join(cmd))
 
 
+ROT_FLAGS = ["-fno-slp-vectorize", "-Wno-inline-asm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+
+
+def check_rot_partition() -> list[str]:
+    """Compiles demod_kernel_rot.hip to assembly and returns the compiler-generated instructions (outside the #ASMSTART/#ASMEND
+    blocks) that touch a VGPR at or above ROTWIN_LIMIT - there must be none (see the kernel's header comment)."""
+    import re
+    import tempfile
+    limit = int(re.search(r"#define ROTWIN_LIMIT (\d+)", (CSRC / "rotwin_asm.h").read_text()).group(1))
+    with tempfile.TemporaryDirectory() as td:
+        out = Path(td) / "rot.s"
+        _run([_hipcc(), *COMMON, *ROT_FLAGS, "-x", "hip", "--offload-device-only", "-S", str(CSRC / "demod_kernel_rot.hip"), "-o", str(out)])
+        bad, inasm = [], False
+        for n, line in enumerate(out.read_text().split("\n"), 1):
+            if "#ASMSTART" in line:
+                inasm = True
+            elif "#ASMEND" in line:
+                inasm = False
+            elif not inasm:
+                t = line.strip()
+                if not t or t[0] in ";." or t.endswith(":"):
+                    continue
+                regs = [int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", t)] + [int(m.group(2)) for m in re.finditer(r"\bv\[(\d+):(\d+)\]", t)]
+                if any(r >= limit for r in regs):
+                    bad.append(f"{n}: {t}")
+    return bad
+
+
 def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
     LIB.mkdir(exist_ok=True)
     hipcc = _hipcc()
@@ -62,7 +90,7 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
     units = [(CSRC / "demod_kernel.hip", "demod_kernel", []),
              (rw, "demod_kernel_rw_std", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
              (rw, "demod_kernel_rw_wide", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=2"]),
-             (CSRC / "demod_kernel_rot.hip", "demod_kernel_rot", ["-fno-slp-vectorize", "-Wno-inline-asm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+             (CSRC / "demod_kernel_rot.hip", "demod_kernel_rot", ROT_FLAGS),
              (CSRC / "demod_kernel_lat.hip", "demod_kernel_lat", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
              (CSRC / "demod_aux.hip", "demod_aux", []), (CSRC / "recording.hip", "recording", []),
              (CSRC / "demod_api.cpp", "demod_api", []), (CSRC / "host_pipe.cpp", "host_pipe", []),

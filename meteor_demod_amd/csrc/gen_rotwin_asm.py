@@ -11,7 +11,8 @@ the three pieces of code that touch them are written here, one copy per rotation
 
   FIR     filter.c:46-65 - the sequential, oldest-first, unfused sum over the 80 window slots (twenty half-chunks of 4
           taps; coefficients three half-chunks ahead in four rotating buffers; an edge chunk of 8 slots that is all
-          padding for the whole wave is skipped).  Per tap: v_mul, v_mul, v_add, v_add - what the reference's `acc += mem * coeff` is.
+          padding for the whole wave is skipped).  Per tap: v_pk_mul_f32 + v_pk_add_f32 on the (re, im) register pair - the two
+          rounded products and two rounded sums of the reference's `acc += mem * coeff` (no fused multiply-add).
   PUT     converts two granules (8 samples) of raw input into one physical chunk: the slide.  Nothing moves.
   PUTF    the same for 16 ready floats (history at kernel start, float input).
 
@@ -26,7 +27,14 @@ import sys
 WB = 96          # first window register
 CB = 80          # coefficient buffers: 4 x 4 registers
 NCH = 10         # chunks of 8 slots
-PK = int(os.environ.get("ROTWIN_PK", "0"))     # 1: the FIR's tap = v_pk_mul_f32 + v_pk_add_f32 on (re, im) pairs instead of 2 + 2 scalar ops
+# the FIR's tap: 0 = v_mul x2 + v_add x2; 1 = v_pk_mul_f32 + v_pk_add_f32 on (re, im) pairs (the default); 2 = v_pk_mul_f32 +
+# v_add x2; 3 = v_mul x2 + v_pk_add_f32.  2 and 3 keep their products in v[TB:TB+3] (taken from the compiler like the coefficient
+# buffers).  All four are the reference's two rounded products and two rounded sums per tap (filter.c:58-59); measured on
+# MI355X (configs[1] / configs[2], GS/s, one box): 0: 240.9 / 109.3, 1: 242.7 / 111.0, 2: 230.3 / 104.8, 3: 232.2 / 103.2 - a wave
+# issues one instruction per ~4.7 cycles whatever it is, and the packed form halves the FIR's instruction count while its
+# longer pipe time is paid by the other wave of the SIMD.
+PK = int(os.environ.get("ROTWIN_PK", "1"))
+TB = 76          # product temporaries of the mixed forms
 CHB = 32         # bytes of coefficients per chunk
 
 
@@ -55,7 +63,7 @@ def fir():
         b = CB + 4 * (h % 4)
         return "ds_read_b128 v[%d:%d], %%[addr] offset:%d" % (b, b + 3, 16 * h)
     L = []
-    if not PK:
+    if PK in (0, 2):
         L += ["v_mov_b32 %[ar], 0", "v_mov_b32 %[ai], 0"]
     L += [load(h) for h in range(D)]                     # on their way before the jump (the same for every rotation)
     L += jump("fir", NCH)
@@ -73,13 +81,28 @@ def fir():
             L += ["s_waitcnt lgkmcnt(%d)" % min(D, NH - 1 - h)]
             hb = CB + 4 * (h % 4)
             wq = WB + 16 * ((c + r) % NCH) + 8 * (h & 1)
-            if PK:
+            if PK == 1:
                 # (re, im) of a slot are an even-aligned register pair, the coefficient is broadcast with op_sel
                 def mul(j):
                     return ["v_pk_mul_f32 %%[p%d], v[%d:%d], v[%d:%d] op_sel:[0,%d] op_sel_hi:[1,%d]"
                             % (j & 1, wq + 2 * j, wq + 2 * j + 1, hb + 2 * (j // 2), hb + 2 * (j // 2) + 1, j & 1, j & 1)]
                 def add(j):
                     return ["v_pk_add_f32 %%[acc], %%[acc], %%[p%d]" % (j & 1)]
+            elif PK == 2:
+                def mul(j):
+                    t = TB + 2 * (j & 1)
+                    return ["v_pk_mul_f32 v[%d:%d], v[%d:%d], v[%d:%d] op_sel:[0,%d] op_sel_hi:[1,%d]"
+                            % (t, t + 1, wq + 2 * j, wq + 2 * j + 1, hb + 2 * (j // 2), hb + 2 * (j // 2) + 1, j & 1, j & 1)]
+                def add(j):
+                    t = TB + 2 * (j & 1)
+                    return ["v_add_f32 %%[ar], %%[ar], v%d" % t, "v_add_f32 %%[ai], %%[ai], v%d" % (t + 1)]
+            elif PK == 3:
+                def mul(j):
+                    t = TB + 2 * (j & 1)
+                    return ["v_mul_f32 v%d, v%d, v%d" % (t, hb + j, wq + 2 * j), "v_mul_f32 v%d, v%d, v%d" % (t + 1, hb + j, wq + 2 * j + 1)]
+                def add(j):
+                    t = TB + 2 * (j & 1)
+                    return ["v_pk_add_f32 %%[acc], %%[acc], v[%d:%d]" % (t, t + 1)]
             else:
                 # products one tap ahead of the sums, two temporaries per tap
                 def mul(j):
@@ -130,13 +153,14 @@ def main():
     out.append("#define MDEMOD_ROTWIN_ASM_H")
     out.append("#define ROTWIN_WB %d" % WB)
     out.append("#define ROTWIN_CB %d" % CB)
+    out.append("#define ROTWIN_LIMIT %d   /* first register the compiler may not use */" % (TB if PK in (2, 3) else CB))
     out.append("#define ROTWIN_NCH %d" % NCH)
     out.append("#define ROTWIN_PK %d" % PK)
     out.append("#define ROTWIN_FIR_ASM \\\n" + q(fir()).replace("\n", " \\\n"))
     for kind in ("s16", "u8", "f32"):
         out.append("#define ROTWIN_PUT_%s_ASM \\\n" % kind.upper() + q(put(kind)).replace("\n", " \\\n"))
     # clobber lists
-    out.append("#define ROTWIN_COEF_CLOBBERS " + ", ".join('"v%d"' % (CB + i) for i in range(16)))
+    out.append("#define ROTWIN_COEF_CLOBBERS " + ", ".join('"v%d"' % i for i in range(TB if PK in (2, 3) else CB, CB + 16)))
     out.append("#endif")
     sys.stdout.write("\n".join(out) + "\n")
 

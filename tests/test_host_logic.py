@@ -158,18 +158,39 @@ def test_synth_signal_is_what_it_claims():
     assert abs(peak - 4 * f0) < 20.0
 
 
-def test_turn_code_shortcut_proof_holds_on_the_host():
-    """tools/proofs/verify_sincos_shortcut.cpp: the division-free turn code of fast_sin equals the
-    reference's double division for every float |x| < 16 (exhaustive, ~10 CPU-seconds)."""
+def _run_proof(name, *flags):
     import subprocess
     import tempfile
-    src = ROOT / "tools" / "proofs" / "verify_sincos_shortcut.cpp"
+    src = ROOT / "tools" / "proofs" / name
     with tempfile.TemporaryDirectory() as td:
         exe = Path(td) / "verify"
-        subprocess.run(["g++", "-O2", "-ffp-contract=off", "-pthread", str(src), "-o", str(exe)], check=True)
+        subprocess.run(["g++", "-O2", "-ffp-contract=off", *flags, str(src), "-o", str(exe)], check=True)
         out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
-    assert "mismatches 0" in out.stdout
+    return out.stdout
+
+
+def test_turn_code_by_multiplication_proof_holds_on_the_host():
+    """tools/proofs/verify_turncode_mul.cpp: fast_sin's turn code as ONE double multiplication (demod_device.h: md_turn_code)
+    equals the reference's double division for every float |x| < 16 (exhaustive, ~10 CPU-seconds), with the constant 3 ulp
+    either side as well (margin)."""
+    out = _run_proof("verify_turncode_mul.cpp", "-pthread")
+    assert out.count(": mismatches 0") == 7, out
+
+
+def test_period_wrap_in_float_arithmetic_proof_holds_on_the_host():
+    """tools/proofs/verify_wrap_f32.cpp: (float)((double)x -+ 2*M_PI) == (x -+ C_HI) -+ C_LO in float arithmetic for every float
+    with 2pi <= |x| < 4pi (demod_device.h: md_nco_advance<true>, md_wrap_2pi)."""
+    out = _run_proof("verify_wrap_f32.cpp")
+    assert "checked 16777216 floats" in out and "mismatches 0" in out, out
+
+
+def test_rotating_window_register_partition():
+    """demod_kernel_rot.hip hands v[ROTWIN_LIMIT..255] to hand-written assembly and keeps hipcc below with `amdgpu_num_vgpr`,
+    whose unit is an observed property of the compiler (two registers on gfx90a+), not a documented one: check the emitted
+    assembly - no compiler-generated instruction may touch a register of the window or of the coefficient buffers."""
+    from meteor_demod_amd.build import check_rot_partition
+    assert check_rot_partition() == []
 
 
 def test_carrier_window_rounding_is_host_logic():

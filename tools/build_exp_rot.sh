@@ -9,5 +9,5 @@ $HC $COMMON -fno-slp-vectorize -Wno-inline-asm -mllvm -amdgpu-sched-strategy=max
 cp /tmp/exp_$name/demod_kernel_rot-hip-amdgcn-amd-amdhsa-gfx950.s /tmp/exp_$name/rot.s
 objs=$(ls meteor_demod_amd/lib/*.o | grep -v demod_kernel_rot.o | tr '\n' ' ')
 $HC -shared -fPIC -pthread --offload-arch=gfx950 -o gpurun_exp/$name.so $objs /tmp/exp_$name/rot.o
-python3 tools/isa_loop_stats.py /tmp/exp_$name/rot.s demod_kernel_rotILi16ELi0 | grep -v whole | tr '\n' ' '; echo
+python3 tools/isa_loop_stats.py /tmp/exp_$name/rot.s demod_kernel_rotILi16ELi0ELi14 | grep -v whole | tr '\n' ' '; echo
 ls -la gpurun_exp/$name.so
