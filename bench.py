@@ -75,8 +75,10 @@ def cpu_baseline(cfg) -> dict:
         iq = synth.generate_device([st], n).cpu().numpy()[0]
     except Exception:
         iq = synth.generate_host(st, n)
-    cores = len(os.sched_getaffinity(0))
-    procs = max(1, cores)                      # one single-threaded process per core this process may run on
+    host = host_cpu_facts()
+    # one single-threaded process per PHYSICAL core this process may run on, and no more than the cgroup's CPU quota
+    # lets run at once: 256 processes under a 16-CPU quota measure the throttle, not the cores (r02: 2.06 MS/s per "core")
+    procs = max(1, min(host["physical_cores"] or len(os.sched_getaffinity(0)), host["quota_cpus"] or 1 << 30))
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         path = Path(td) / "in.raw"
         iq.tofile(path)
@@ -92,6 +94,10 @@ def cpu_baseline(cfg) -> dict:
                     return None, None               # e.g. SIGILL: built for a newer ISA than this host
                 return [float(o.split()[0]) for o in outs], time.time() - t0
 
+            # one process on the otherwise idle host first: what ONE core does with the reference when nothing competes
+            cmd1 = [str(O.REF_HARNESS), "time", *O._ref_args(cfg), str(path)]
+            idle = [float(subprocess.run(cmd1, capture_output=True, text=True).stdout.split()[0]) for _ in range(2)]
+            host["one_process_idle_msps"] = round(n / min(idle) / 1e6, 2)
             per, wall = run_all(O.REF_HARNESS)
             builds = {"strict -O2 -ffp-contract=off (the parity build)": round(procs * n / max(per) / 1e6, 2)}
             if O.REF_HARNESS_SHIPPED.exists():
@@ -115,13 +121,47 @@ def cpu_baseline(cfg) -> dict:
             per = [float(o.split()[-1]) for o in outs]
     agg = procs * n / max(per) / 1e6
     extra = {"builds_msps": builds} if kind == "reference" else {}
-    return {"value": round(agg, 2), "unit": "Msamples/s", "cores": procs, "nproc": os.cpu_count(), "kind": kind, **extra,
+    return {"value": round(agg, 2), "unit": "Msamples/s", "cores": procs, "nproc": os.cpu_count(), "kind": kind, **extra, "host": host,
             "per_core_msps": round(n / (sum(per) / len(per)) / 1e6, 2),
-            "sample": f"{procs} processes x 2^23-sample {cfg.symrate // 1000}k recording "
+            "sample": f"{procs} single-threaded processes (one per physical core, capped by the cgroup CPU quota) x 2^23-sample {cfg.symrate // 1000}k recording "
                       f"({procs * n / 1e6:.0f} M samples, {sum(per):.1f} s CPU, {wall:.1f} s wall); value = the faster of the builds listed"}
 
 
-def single_recording(cfg, iq, check: bool = True) -> dict:
+def host_cpu_facts() -> dict:
+    """What `cores` means on this host: logical CPUs in the affinity mask, distinct physical cores behind them (sysfs topology),
+    the cgroup CPU quota if there is one.  256 busy processes on 128 physical cores with SMT are not 256 cores."""
+    cpus = sorted(os.sched_getaffinity(0))
+    phys = set()
+    for c in cpus:
+        try:
+            base = Path(f"/sys/devices/system/cpu/cpu{c}/topology")
+            phys.add(((base / "physical_package_id").read_text().strip(), (base / "core_id").read_text().strip()))
+        except OSError:
+            pass
+    quota = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            quota = Path(f).read_text().strip()
+            break
+        except OSError:
+            continue
+    model = None
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in Path("/proc/cpuinfo").read_text().splitlines() if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    quota_cpus = None
+    try:
+        a, b = quota.split()[:2] if quota and " " in quota else (quota, "100000")
+        if a not in (None, "max", "-1"):
+            quota_cpus = max(1, int(int(a) / int(b)))
+    except (ValueError, AttributeError):
+        pass
+    return {"logical_cpus_in_affinity_mask": len(cpus), "physical_cores": len(phys) or None, "cgroup_cpu_max": quota, "quota_cpus": quota_cpus,
+            "cpu_model": model}
+
+
+def single_recording(cfg, iq, check: bool = True, serial=None, label_unchecked: bool = False) -> dict:
     """The north star's overlapped tiling of ONE recording: end-to-end latency of
     mdemod_demodulate_recording on the device tensor `iq` [n, 2] and, with `check`, agreement with the untiled serial
     oracle (symbol count, hard decisions, +-1 LSB, the exact prefix byte for byte).  Part of the CPU leg when checked."""
@@ -144,18 +184,43 @@ def single_recording(cfg, iq, check: bool = True) -> dict:
            "repaired_tiles": int(rep.repaired_tiles), "rotation_jumps": int(rep.rotation_jumps), "pilot_locked": int(rep.pilot_locked),
            "weak_carrier_tiles": int(rep.weak_carrier_tiles), "weak_clock_tiles": int(rep.weak_clock_tiles),
            "dead_reckoning_residual_rms_rad": round(float(rep.frame_residual_rms), 3)}
-    if check:
+    if check or serial is not None:
+        import numpy as np
         import oracle_py as O
-        t0 = time.time()
-        serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
-        t_cpu = time.time() - t0
-        got = soft.cpu().numpy()
+        t_cpu = None
+        if serial is None:
+            t0 = time.time()
+            serial = O.oracle_demod(cfg, iq.cpu().numpy())[0]
+            t_cpu = time.time() - t0
+            compared = "the whole recording"
+        else:
+            compared = f"the first {len(serial)} symbols (the serial run of the first samples); the rest of this recording is UNCHECKED"
+        m = len(serial)
+        got = soft[: m + 64].cpu().numpy() if label_unchecked else soft.cpu().numpy()
+        if label_unchecked:
+            got = got[:m]                      # a serial run of a prefix IS the prefix of the serial run (the path is causal)
         a = agreement(got, serial)
-        ex = int(rep.exact_symbols)
-        out.update({"serial_oracle_one_core_seconds": round(t_cpu, 2), "symbols": [a["len_stitched"], a["len_serial"]],
+        ex = min(int(rep.exact_symbols), m)
+        # agreement by position in a tile's body: do tiles start badly?  (symbol -> input sample by proportion)
+        mm = min(len(got), m)
+        ok = np.abs(got[:mm].astype(np.int16) - serial[:mm].astype(np.int16)).max(axis=1) <= 1
+        sps = int(rep.n_symbols) / n
+        idx = np.arange(mm)
+        pos = ((idx / sps - rep.pilot_samples) % rep.tile_samples) * sps
+        tiled = idx >= int(rep.exact_symbols)
+        head, rest = ok[tiled & (pos < 4096)], ok[tiled & (pos >= 4096)]
+        out.update({"checked_against_serial_oracle": compared,
+                    "symbols": [int(rep.n_symbols) if label_unchecked else a["len_stitched"], a["len_serial"]],
                     "exact_prefix_symbols": ex, "exact_prefix_bytes_equal": bool((got[:ex] == serial[:ex]).all()),
                     "within_1lsb": round(a["within_1lsb"], 5), "hard_decisions_equal": round(a["hard_decisions_equal"], 6),
-                    "worst_window_4096": round(a["worst_window"], 4)})
+                    "worst_window_4096": round(a["worst_window"], 4),
+                    "within_1lsb_first_4096_of_a_tile_body": round(float(head.mean()), 5) if len(head) else None,
+                    "within_1lsb_rest_of_the_tile_bodies": round(float(rest.mean()), 5) if len(rest) else None})
+        if t_cpu is not None:
+            out["serial_oracle_one_core_seconds"] = round(t_cpu, 2)
+        out["_serial"] = serial
+    elif label_unchecked:
+        out["checked_against_serial_oracle"] = "UNCHECKED"
     return out
 
 
@@ -173,14 +238,19 @@ def perturbation_floor(cfg, iq) -> dict:
     m = min(len(a), len(b))
     d = np.abs(a[:m].astype(np.int16) - b[:m].astype(np.int16)).max(axis=1)
     first = int(np.argmax(d > 0))
+    okf = d[first:] <= 1
+    wins = [float(okf[i:i + 4096].mean()) for i in range(0, len(okf) - 4095, 4096)]
     return {"what": "serial reference vs itself with ONE input sample changed by 1 LSB, symbols after the first difference",
-            "samples": int(len(x)), "within_1lsb": round(float((d[first:] <= 1).mean()), 5), "symbols_compared": int(m - first)}
+            "samples": int(len(x)), "within_1lsb": round(float(okf.mean()), 5), "worst_window_4096": round(min(wins), 4) if wins else None,
+            "symbols_compared": int(m - first)}
 
 
 def recordings_leg(cfg_tag: str, buf, local: int) -> dict:
-    """One long buffer as ONE recording on every BASELINE single-GPU configuration (2^26 samples each, checked against the
-    serial oracle), then configs[1] end to end at SURVEY C2's 2^28 samples and on the whole bench buffer (unchecked: the
-    serial oracle needs minutes for those)."""
+    """One long buffer as ONE recording on every BASELINE single-GPU configuration (2^26 samples each), then configs[1] end to
+    end at SURVEY C2's 2^28 samples and on the whole bench buffer.  Everything that is timed is checked against the serial oracle
+    (symbol count, hard decisions, +-1 LSB overall / at the start of a tile body / in the worst 4096-symbol window, the exact
+    prefix byte for byte); of the whole buffer the first 2^28 samples' worth of symbols are, the rest is labelled UNCHECKED.  The
+    reference's own 1-LSB-perturbation floor is measured for every configuration."""
     import torch
     from meteor_demod_amd import synth
     res = {}
@@ -194,16 +264,27 @@ def recordings_leg(cfg_tag: str, buf, local: int) -> dict:
             # gain += 1e-4 * (190 - |y|) overshoot through zero: the serial run itself is unlocked 42 % of the time)
             rec = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, rms=2000.0 if tag == "c4" else 6000.0)
             iq = synth.generate_device([rec], n, device=local)[0]
-        res[workload.split(":")[0]] = single_recording(cfg, iq.contiguous())
-        if tag == "c1":
-            res["perturbation_floor_configs[1]"] = perturbation_floor(cfg, iq[: 1 << 25])
+        key = workload.split(":")[0]
+        res[key] = single_recording(cfg, iq.contiguous())
+        res[key].pop("_serial", None)
+        res["perturbation_floor_" + key] = perturbation_floor(cfg, iq[: 1 << 25])
         del iq
         torch.cuda.empty_cache()
     if cfg_tag == "c1" and buf is not None:
         cfg, _ = demod_config("c1")
-        for label, m in (("configs[1] 2^28 samples", 1 << 28), ("configs[1] whole buffer", int(buf.shape[0]))):
-            if buf.shape[0] >= m:
-                res[label] = single_recording(cfg, buf[:m], check=False)
+        serial28 = None
+        if buf.shape[0] >= (1 << 28):
+            r = single_recording(cfg, buf[: 1 << 28])
+            serial28 = r.pop("_serial", None)
+            res["configs[1] 2^28 samples"] = r
+        if buf.shape[0] > (1 << 28) and serial28 is not None:
+            # the last symbols of the prefix run depend on samples past 2^28 only through nothing (the path is causal), but keep
+            # clear of the very end
+            r = single_recording(cfg, buf, check=False, serial=serial28[: len(serial28) - 64], label_unchecked=True)
+            r.pop("_serial", None)
+            res["configs[1] whole buffer"] = r
+        elif buf.shape[0] > (1 << 28):
+            res["configs[1] whole buffer"] = single_recording(cfg, buf, check=False, label_unchecked=True)
     return res
 
 
@@ -367,7 +448,9 @@ def main() -> None:
     algo_bytes = T * L * bytes_per_sample                                   # per launch, per GPU
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
 
-    traffic = None
+    # counters cannot be collected inside a timed run: traffic and the instruction mix are READ from the tracked rocprofv3 profile
+    # of this exact command (profiles/hbm_traffic.json, written by tools/make_profile_md.py), keyed by configuration and shape
+    traffic = valu_per_firing = prof_round = None
     tfile = ROOT / "profiles" / "hbm_traffic.json"
     if tfile.exists():
         try:
@@ -375,8 +458,15 @@ def main() -> None:
             key = f"{args.config}:{T}x{L}"
             if key in rec_t:
                 traffic = rec_t[key]["hbm_bytes_per_launch"]
+                valu_per_firing = rec_t[key].get("valu_per_wave_firing")
+                prof_round = rec_t[key].get("round")
         except Exception:
             traffic = None
+    # unfused flops per input sample = 2*interp + (symrate/fs) * (4*taps*F + ~100*F'), F = firings per symbol
+    F = 2 if cfg.oqpsk else 1
+    flops_per_sample = 2 * cfg.interp_factor + (cfg.symrate / cfg.samplerate) * (4 * (2 * cfg.rrc_order + 1) * F + 100 * (1.7 if cfg.oqpsk else 1.0))
+    VALU_PEAK_TOPS = 78.6         # MI355X: 157.3 TFLOP/s FP32 vector counts FMAs; the reference's unfused mul/add get half of it
+    valu_tops = flops_per_sample * (T * L) / (kernel_ms * 1e-3) / 1e12
 
     out = {
         "metric": "IQ Msamples/s demodulated (whole node)", "value": round(value, 1), "unit": "Msamples/s",
@@ -387,8 +477,17 @@ def main() -> None:
                                "one tile per lane, bit-exact per tile",
                    "tiles_per_gpu": T, "tile_samples": L, "samples_per_step": samples_per_step,
                    "input_bytes_per_gpu": T * L * 4},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "valu" if valu_tops / VALU_PEAK_TOPS > achieved / HBM_PEAK_GBS else "hbm",
+                     "bound_note": "achieved/peak/frac are the HBM figures BASELINE.json asks for; the resource that binds is FP32 VALU issue "
+                                   "(SURVEY H3: the reference's unfused arithmetic caps configs[1] at 0.37 of the HBM peak): see `valu`",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": (f"profiles/hbm_traffic.json[{args.config}:{T}x{L}] (round {prof_round}): rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of "
+                                        "this command, separate --pmc passes; not measured by this run") if traffic else None,
+                     "valu": {"achieved_top_s": round(valu_tops, 2), "peak_top_s": VALU_PEAK_TOPS, "frac": round(valu_tops / VALU_PEAK_TOPS, 4),
+                              "algorithmic_unfused_flops_per_sample": round(flops_per_sample, 1),
+                              "valu_instructions_per_wave_firing": valu_per_firing,
+                              "valu_instructions_source": f"profiles/hbm_traffic.json (round {prof_round}, SQ_INSTS_VALU)" if valu_per_firing else None},
                      "kernel": d.kernel_name,
                      "kernel_ms": round(kernel_ms, 3),
                      "algorithmic_bytes_per_sample": round(bytes_per_sample, 4)},

@@ -142,10 +142,22 @@ class MdemodError(RuntimeError):
         super().__init__(f"{what}: error {code} ({strerror(code)})")
 
 
+def hip_runtime_first() -> None:
+    """One process, one HIP runtime.  PyTorch-ROCm ships its own libamdhip64; the library here is linked against the system's
+    (/opt/rocm).  Whichever is loaded first serves both (same soname) - but when the system's comes first and torch then brings
+    its own, torch's runtime holds the device and HIP calls of this library fail with "no ROCm-capable device is detected"
+    (seen when a CPU-only test had loaded the library before the first GPU test).  So: torch first, whenever it is there."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib() -> C.CDLL:
     """The loaded C-ABI library; raises if the HIP extension is not built."""
     global _lib
     if _lib is None:
+        hip_runtime_first()
         if not LIB_PATH.exists():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first "

@@ -5,6 +5,7 @@
  * signal source).  Host and device versions are bit-identical by construction.
  */
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -95,6 +96,7 @@ mdemod_synth_device(const synth_tables *tb, const synth_stream *streams, uint32_
 	if (e == hipSuccess) e = hipDeviceSynchronize();
 	if (d_tb) (void)hipFree(d_tb);
 	if (d_st) (void)hipFree(d_st);
+	if (e != hipSuccess) fprintf(stderr, "mdemod_synth_device: %s\n", hipGetErrorString(e));
 	return e == hipSuccess ? 0 : -3;
 }
 

@@ -44,6 +44,8 @@ def lib() -> C.CDLL:
     if _lib is None:
         if not LIB_PATH.exists():
             raise RuntimeError(f"{LIB_PATH} missing: run python -m meteor_demod_amd.build")
+        from ._capi import hip_runtime_first
+        hip_runtime_first()
         h = C.CDLL(str(LIB_PATH))
         h.mdemod_synth_tables_size.restype = C.c_size_t
         h.mdemod_synth_stream_size.restype = C.c_size_t

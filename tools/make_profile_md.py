@@ -42,7 +42,10 @@ for c, (name, symrate, fs, fires) in CFG.items():
                  f"{hbm/algo:.3f} | {valu/wave_fir:.0f} | {salu/wave_fir:.0f} | {lds/wave_fir:.0f} | {br/wave_fir:.0f} | {wc*4/wave_fir:.0f} | {wa/wc:.2f} |")
     traffic[f"{c}:{T}x{L}"] = {"hbm_bytes_per_launch": int(hbm), "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
                                "correction": "reads x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B: MI355X_MICROARCH.md HBM section); writes as counted; L2-miss (fabric) bytes, Infinity-Cache hits included",
-                               "algorithmic_bytes_per_launch": int(algo), "kernel": kname[:90], "round": tag, "kernel_ms_under_profiler": avg}
+                               "algorithmic_bytes_per_launch": int(algo), "kernel": kname[:90], "round": tag, "kernel_ms_under_profiler": avg,
+                               "valu_per_wave_firing": round(valu / wave_fir, 1), "salu_per_wave_firing": round(salu / wave_fir, 1),
+                               "lds_per_wave_firing": round(lds / wave_fir, 1), "wave_cycles_per_firing": round(wc * 4 / wave_fir, 0),
+                               "wait_any_over_wave_cycles": round(wa / wc, 3)}
 lines.append("\n(wave-firing = one firing of the symbol clock for each of the 64 streams of a wave; QPSK: one per symbol, OQPSK: two.  SQ_WAVE_CYCLES counts 4-cycle quanta.)\n")
 for c in CFG:
     for kind in ("stats", "FETCH", "WRITE", "sq"):

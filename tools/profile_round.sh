@@ -1,6 +1,6 @@
-# rocprofv3 passes behind profiles/r02_*.md: kernel stats and PMC (separate passes, no trace domains with --pmc)
+# rocprofv3 passes behind profiles/rNN_kernels.md (tools/profile_round.sh <dir under gpurun_out> ["c1 c3 c4"]; then tools/make_profile_md.py): kernel stats and PMC (separate passes, no trace domains with --pmc)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r02}; mkdir -p $O
+O=gpurun_out/${1:-r03}; mkdir -p $O
 CFGS=${2:-"c1 c3 c4"}
 for c in $CFGS; do
   B="python3 bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-check"
@@ -11,4 +11,4 @@ for c in $CFGS; do
   for d in stats FETCH WRITE sq; do python tools/rocpd_summary.py $(find $O/${c}_$d -name "*.db" | head -1) > $O/${c}_$d.md 2>&1; done
   rm -rf $O/${c}_stats $O/${c}_FETCH $O/${c}_WRITE $O/${c}_sq
 done
-grep -h "demod_kernel_rw" $O/*.md | cut -c1-200 | head -60
+grep -h "demod_kernel" $O/*.md | cut -c1-200 | head -60
