@@ -49,6 +49,7 @@ def _run(cmd: list[str]) -> None:
 
 
 ROT_FLAGS = ["-fno-slp-vectorize", "-Wno-inline-asm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+ROTP_FLAGS = ["-fno-slp-vectorize", "-Wno-inline-asm"]
 
 
 def check_rot_partition() -> list[str]:
@@ -91,16 +92,17 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
              (rw, "demod_kernel_rw_std", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
              (rw, "demod_kernel_rw_wide", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=2"]),
              (CSRC / "demod_kernel_rot.hip", "demod_kernel_rot", ROT_FLAGS),
+             (CSRC / "demod_kernel_rotp.hip", "demod_kernel_rotp", ROTP_FLAGS),
              (CSRC / "demod_kernel_lat.hip", "demod_kernel_lat", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
              (CSRC / "demod_aux.hip", "demod_aux", []), (CSRC / "recording.hip", "recording", []),
              (CSRC / "demod_api.cpp", "demod_api", []), (CSRC / "host_pipe.cpp", "host_pipe", []),
              (CSRC / "demod_host.cpp", "demod_host", [])]
     # the assembly of the rotating register window is generated (csrc/gen_rotwin_asm.py -> csrc/rotwin_asm.h)
-    gen, inc = CSRC / "gen_rotwin_asm.py", CSRC / "rotwin_asm.h"
-    if force or _stale(inc, [gen]):
-        text = subprocess.run([sys.executable, str(gen)], capture_output=True, text=True, check=True).stdout
-        inc.write_text(text)
-        headers = sorted(CSRC.glob("*.h")) + [ROOT / "include" / "meteor_demod_amd.h"]
+    for gen, inc in ((CSRC / "gen_rotwin_asm.py", CSRC / "rotwin_asm.h"), (CSRC / "gen_rotpk_asm.py", CSRC / "rotpk_asm.h")):
+        if force or _stale(inc, [gen]):
+            text = subprocess.run([sys.executable, str(gen)], capture_output=True, text=True, check=True).stdout
+            inc.write_text(text)
+            headers = sorted(CSRC.glob("*.h")) + [ROOT / "include" / "meteor_demod_amd.h"]
     objs = []
     for src, stem, extra in units:
         obj = LIB / (stem + ".o")

@@ -105,6 +105,8 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	}
 	if (ctx->tab.use_rw && ctx->use_rot)
 		HIP_TRY(mdemod_launch_demod_rot(L, ctx->params.bps, ctx->lds_bytes, stream));
+	else if (ctx->tab.use_rw && ctx->tab.rw_compact4)
+		HIP_TRY(mdemod_launch_demod_rotp(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw)
 		HIP_TRY((ctx->tab.rw_wide || ctx->tab.rw_mid || ctx->tab.rw_far)
 		        ? mdemod_launch_demod_rw_wide(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream)
@@ -185,15 +187,21 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	ctx->params = *params;
 	ctx->pipe = nullptr;
 
-	/* MDEMOD_KERNEL=v1 forces the LDS-ring kernel (tests cover both) */
+	/* MDEMOD_KERNEL=v1 forces the LDS-ring kernel, =v2 the moving register window (tests cover all three generations).  The v3
+	 * kernels drop the range test of the NCO's turn code and wrap the NCO phase in float arithmetic (demod_device.h): both need
+	 * phase + freq < 4pi, which pll.c's own clamp gives for fmax < 2pi rad/symbol (the default is 0.3) */
 	const char *kforce = getenv("MDEMOD_KERNEL");
-	int rc = mdemod_host_derive(*params, ctx->tab, !(kforce && !strcmp(kforce, "v1")));
+	int generation = (kforce && !strcmp(kforce, "v1")) ? 0 : ((kforce && !strcmp(kforce, "v2")) ? 1 : 2);
+	{
+		HostTables probe;
+		int rc0 = mdemod_host_derive(*params, probe, 1);
+		if (rc0) { delete ctx; return rc0; }
+		if (!(probe.c.pll_fmax < 6.0f) && generation == 2) generation = 1;
+	}
+	int rc = mdemod_host_derive(*params, ctx->tab, generation);
 	if (rc) { delete ctx; return rc; }
 	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
-	/* v3 drops the range test of the NCO's turn code and wraps the NCO phase in float arithmetic (demod_device.h): both need
-	 * phase + freq < 4pi, which pll.c's own clamp gives for fmax < 2pi rad/symbol (the default is 0.3) */
-	ctx->use_rot = ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && ctx->tab.c.pll_fmax < 6.0f &&
-	               !(kforce && !strcmp(kforce, "v2"));
+	ctx->use_rot = generation == 2 && ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far;
 
 	/* tunables (experiments only; defaults are the measured best) */
 	DemodConsts &c = ctx->tab.c;
@@ -213,7 +221,8 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	if (ctx->tab.use_rw && lds_need(ctx->block_threads) > 160 * 1024) {
 		/* The per-alignment coefficient rows of the v2 std geometry grow with -O (16 alignments x interp x 84 floats: past the
 		 * 160 KB of LDS from -O 29 on); the v1 ring kernel keeps 4 alignments and still fits: fall back to it. */
-		rc = mdemod_host_derive(*params, ctx->tab, false);
+		rc = mdemod_host_derive(*params, ctx->tab, 0);
+		ctx->use_rot = false;
 		if (rc) { delete ctx; return rc; }
 		c.ring_granules = c.hpad / 4 + env_int("MDEMOD_RING_EXTRA", 8);
 		if (c.ring_granules < c.hpad / 4 + 4) c.ring_granules = c.hpad / 4 + 4;
@@ -612,6 +621,9 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 		if (want && ctx->lat_ok) return "demod_kernel_lat (one stream per wave: FIR farm + serial scalar stage)";
 	}
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
+	if (ctx->tab.rw_compact4) return ctx->tab.rw_wide ? "demod_kernel_rotp (v3 rotating packed window, wide: 129 taps)"
+	                                 : (ctx->tab.rw_mid ? "demod_kernel_rotp (v3 rotating packed window, mid: 65 taps at up to 15 samples per firing)"
+	                                                    : "demod_kernel_rotp (v3 rotating packed window, far: 65 taps at up to 30 samples per firing)");
 	if (ctx->tab.rw_wide) return "demod_kernel_rw (v2 register window, wide: 129 taps, packed)";
 	if (ctx->tab.rw_far) return "demod_kernel_rw (v2 register window, far: 65 taps at up to 30 samples per firing, packed)";
 	if (ctx->tab.rw_mid) return ctx->params.bps == 32 ? "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, float pairs)"

@@ -61,7 +61,7 @@ rrc_tap(int stage, unsigned n_taps, float osf, float alpha)
 } /* namespace */
 
 int
-mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
+mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 {
 	if (p.interp_factor < 1 || p.interp_factor > 64) return MDEMOD_ERR_PARAM;
 	if (p.rrc_order < 1 || p.rrc_order > 256) return MDEMOD_ERR_PARAM;
@@ -135,6 +135,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 	const bool mid_ok = wide_ok && c.taps <= 65;
 	/* far: the short filter at 2 MS/s-class rates: up to 30 samples per firing, two 16-slot slides per iteration */
 	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= 30.0 && p.bps != 32;
+	const bool allow_rw = generation >= 1;
 	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok);
 	out.rw_mid = out.use_rw && !std_ok && mid_ok;
 	out.rw_far = out.use_rw && far_ok;
@@ -155,6 +156,33 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw)
 				float *row = &out.ctab[(static_cast<size_t>(a) * banks + b) * c.ctab_row_stride];
 				for (int k = 0; k < c.taps; k++) row[a + lead + k] = out.rrc[b * taps + k];
 			}
+		return MDEMOD_OK;
+	}
+	out.rw_compact4 = generation >= 2 && (out.rw_wide || out.rw_mid || out.rw_far) && p.bps != 32;
+	if (out.rw_compact4) {
+		/* v3 packed rotating window: per bank the padded sequence P = AMAX zeros ++ taps ++ AMAX zeros, stored FOUR times:
+		 * copy (bank, k)[i] = P[i + k].  A lane at alignment a reads P[(AMAX - a) + s] for slot s, i.e. copy ((AMAX - a) & 3) at the
+		 * 16-byte aligned index ((AMAX - a) & ~3) + s: every group of four taps is one ds_read_b128.  The FIR's prefetch runs up
+		 * to six groups (24 floats) past the last tap it uses: rows carry that much padding. */
+		const int kTaps = out.rw_wide ? 129 : 65;
+		const int NW = out.rw_mid ? MDEMOD_RW_MID_NW : (out.rw_far ? MDEMOD_RW_FAR_NW : MDEMOD_RW_WIDE_NW), AMAX = NW - kTaps;
+		const int LP = kTaps + 2 * AMAX;
+		c.hpad = kTaps - 1;
+		c.win_granules = NW / 4;
+		c.ring_granules = 0;
+		c.ctab_row_floats = LP;
+		c.ctab_row_stride = (LP + 3 + 24 + 3) / 4 * 4;                    /* whole 16-byte groups ...            */
+		if ((c.ctab_row_stride / 4) % 2 == 0) c.ctab_row_stride += 4;    /* ... an odd number of them           */
+		out.ctab.assign(static_cast<size_t>(4) * banks * c.ctab_row_stride + 32, 0.0f);
+		const int lead = kTaps - c.taps;
+		for (unsigned b = 0; b < banks; b++) {
+			std::vector<float> P(static_cast<size_t>(LP) + 4, 0.0f);
+			for (int k = 0; k < c.taps; k++) P[AMAX + lead + k] = out.rrc[b * taps + k];
+			for (int k = 0; k < 4; k++) {
+				float *row = &out.ctab[(static_cast<size_t>(b) * 4 + k) * c.ctab_row_stride];
+				for (int i = 0; i < LP; i++) row[i] = P[i + k];
+			}
+		}
 		return MDEMOD_OK;
 	}
 	if (out.rw_wide || out.rw_mid || out.rw_far) {

@@ -19,10 +19,12 @@ struct HostTables {
 	bool               rw_wide;   /* v2 wide geometry (129-tap packed window, compact table, 512-thread blocks) */
 	bool               rw_far;    /* v2 far geometry: <= 65 taps at 15..30 samples per firing (112-slot packed window, two slides per iteration) */
 	bool               rw_mid;    /* v2 mid geometry: <= 65 taps at 3.6..15 samples per firing (96-slot packed window, compact table) */
+	bool               rw_compact4; /* wide / mid / far on the v3 packed rotating window (demod_kernel_rotp.hip): four shifted copies per bank, 16-byte reads */
 	bool               use_rw;    /* v2 register-window kernel eligible (taps <= 65, <= 3.6 samples per firing) */
 };
 
 /* Returns MDEMOD_OK or MDEMOD_ERR_PARAM. */
-int mdemod_host_derive(const mdemod_params &p, HostTables &out, bool allow_rw = true);
+/* generation: 0 = v1 LDS ring only, 1 = v2 register window where it applies, 2 = v3 rotating windows where they apply (default) */
+int mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation = 2);
 
 #endif

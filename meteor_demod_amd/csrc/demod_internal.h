@@ -88,6 +88,7 @@ struct DemodLaunch {
 hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_rw_std(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_rot(const DemodLaunch &L, int fmt, size_t lds_bytes, hipStream_t stream);   /* v3: rotating register window (std geometry) */
+hipError_t mdemod_launch_demod_rotp(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mid, 2 far */, size_t lds_bytes, hipStream_t stream);   /* v3: rotating packed window */
 hipError_t mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mid, 2 far */, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_lat(const DemodLaunch &L, int fmt, const float *rrc_dev, int ring_size, int span, int float_history, size_t lds_bytes, hipStream_t stream);
 bool mdemod_lat_geometry(const DemodConsts &c, double samples_per_firing, int *ring_size, int *span, size_t *lds_bytes);

@@ -1,0 +1,154 @@
+/*
+ * demod_kernel_rotp.hip — v3 rotating PACKED register window: the wide (up to 129 taps, <= 15 samples per firing), mid
+ * (<= 65 taps, <= 15) and far (<= 65 taps, <= 30) geometries for s16 and u8 input.
+ *
+ * The kernel body is rotwin_body.h (shared with demod_kernel_rot.hip); this file is the window policy: 96..160 slots of RAW
+ * samples in registers that belong to the generated assembly of rotpk_asm.h (gen_rotpk_asm.py: ring of per-chunk FIR code,
+ * 4 instructions per tap, nothing moves on a slide), compact4 coefficient table (demod_host.cpp).  What it replaces is the
+ * packed-window C++ of demod_kernel_rw.hip: 6 instructions per tap, 144 v_mov_b32 per slide (one slide per firing at 1 MS/s)
+ * and the PHI copies around them - 1 502 VALU instructions per wave-firing on configs[3] where the reference's arithmetic
+ * needs 516 (profiles/r02_kernels.md).
+ */
+#include "rotwin_body.h"
+#include "rotpk_asm.h"
+
+namespace {
+
+typedef float pair_t __attribute__((ext_vector_type(2)));
+
+template <int GEO> struct GeoP;
+template <> struct GeoP<0> { static constexpr int kTaps = 129, NW = MDEMOD_RW_WIDE_NW, MAXSL = 1, BLOCK = MDEMOD_RW_WIDE_BLOCK; };
+template <> struct GeoP<1> { static constexpr int kTaps = 65, NW = MDEMOD_RW_MID_NW, MAXSL = 1, BLOCK = MDEMOD_RW_BLOCK; };
+template <> struct GeoP<2> { static constexpr int kTaps = 65, NW = MDEMOD_RW_FAR_NW, MAXSL = 2, BLOCK = MDEMOD_RW_BLOCK; };
+static_assert(MDEMOD_RW_WIDE_NW == 160 && MDEMOD_RW_MID_NW == 96 && MDEMOD_RW_FAR_NW == 112, "gen_rotpk_asm.py: GEOS");
+
+/* the assembly of one (geometry, format): FIR over chunks [entry, entry + cnt] of the ring, and the slide */
+template <int GEO, int FMT> struct AsmP;
+#define ROTP_ASM(GEO, NAME, FMT)                                                                                              \
+	template <> struct AsmP<GEO, FMT> {                                                                                       \
+		__device__ static __forceinline__ void fir(uint32_t addr, int entry, int cnt, float &re, float &im)                   \
+		{                                                                                                                     \
+			pair_t acc = { 0.0f, 0.0f };                                                                                      \
+			int tmp;                                                                                                          \
+			asm volatile(ROTPK_##NAME##_##FMT##_FIR_ASM                                                                       \
+			             : [acc] "+v"(acc), [addr] "+v"(addr), [cnt] "+s"(cnt), [tmp] "=&s"(tmp)                              \
+			             : [entry] "s"(entry)                                                                                 \
+			             : "vcc", "scc", ROTPK_##NAME##_##FMT##_CLOBBERS);                                                    \
+			re = acc.x; im = acc.y;                                                                                           \
+		}                                                                                                                     \
+		__device__ static __forceinline__ void put(const uint32_t (&g)[FMT == 16 ? 16 : 8], int q);                           \
+	};
+ROTP_ASM(0, WIDE, 16) ROTP_ASM(0, WIDE, 8) ROTP_ASM(1, MID, 16) ROTP_ASM(1, MID, 8) ROTP_ASM(2, FAR, 16) ROTP_ASM(2, FAR, 8)
+
+/* "memory": the refill loads that follow a slide may not be hoisted above it (see demod_kernel_rot.hip) */
+#define ROTP_PUT16(GEO, NAME)                                                                                                 \
+	__device__ __forceinline__ void AsmP<GEO, 16>::put(const uint32_t (&g)[16], int q)                                        \
+	{                                                                                                                         \
+		int tmp;                                                                                                              \
+		asm volatile(ROTPK_##NAME##_16_PUT_ASM                                                                                \
+		             : [tmp] "=&s"(tmp)                                                                                       \
+		             : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]),  \
+		               [g7] "v"(g[7]), [g8] "v"(g[8]), [g9] "v"(g[9]), [g10] "v"(g[10]), [g11] "v"(g[11]), [g12] "v"(g[12]),  \
+		               [g13] "v"(g[13]), [g14] "v"(g[14]), [g15] "v"(g[15]), [rot] "s"(q)                                     \
+		             : "vcc", "scc", "v255", "memory");                                                                       \
+	}
+#define ROTP_PUT8(GEO, NAME)                                                                                                  \
+	__device__ __forceinline__ void AsmP<GEO, 8>::put(const uint32_t (&g)[8], int q)                                          \
+	{                                                                                                                         \
+		int tmp;                                                                                                              \
+		asm volatile(ROTPK_##NAME##_8_PUT_ASM                                                                                 \
+		             : [tmp] "=&s"(tmp)                                                                                       \
+		             : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]),  \
+		               [g7] "v"(g[7]), [rot] "s"(q)                                                                           \
+		             : "vcc", "scc", "v255", "memory");                                                                       \
+	}
+ROTP_PUT16(0, WIDE) ROTP_PUT16(1, MID) ROTP_PUT16(2, FAR) ROTP_PUT8(0, WIDE) ROTP_PUT8(1, MID) ROTP_PUT8(2, FAR)
+
+/* window policy: NW raw samples, slides of 16 slots, AMAX + 1 alignments, compact4 coefficient table */
+template <int GEO, int FMT>
+struct WinP {
+	static constexpr int kTaps = GeoP<GEO>::kTaps, kBack = kTaps - 1, NW = GeoP<GEO>::NW, SLIDE = 16, AMAX = NW - kTaps,
+	                     MAXSL = GeoP<GEO>::MAXSL, BLOCK = GeoP<GEO>::BLOCK, NCH = NW / SLIDE, GD = FMT == 16 ? 16 : 8;
+	static_assert(kBack % SLIDE == 0 && NW % SLIDE == 0, "history and window are whole chunks");
+
+	/* wavfile.c:58-69 backwards: the raw sample a history value (an exactly converted input sample) came from */
+	__device__ static __forceinline__ void put_history(const float2 *hist, bool valid, int q)
+	{
+		uint32_t g[GD];
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			float2 h = hist[k];
+			if (!valid) h = make_float2(0.0f, 0.0f);
+			if (FMT == 16) {
+				g[k] = ((uint32_t)(int)h.x & 0xFFFFu) | ((uint32_t)(int)h.y << 16);
+			} else {
+				const uint32_t s = (uint32_t)(((int)h.x + 128) & 0xFF) | ((uint32_t)(((int)h.y + 128) & 0xFF) << 8);
+				if (k & 1) g[k / 2] |= s << 16; else g[k / 2] = s;
+			}
+		}
+		AsmP<GEO, FMT>::put(g, q);
+	}
+	__device__ static __forceinline__ void put(const RGran<FMT> (&gr)[4], int q)
+	{
+		uint32_t g[GD];
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+#pragma unroll
+			for (int j = 0; j < GD / 4; j++) g[i * (GD / 4) + j] = gr[i].w[j];
+		AsmP<GEO, FMT>::put(g, q);
+	}
+	__device__ static __forceinline__ void fir(uint32_t ctab_addr, int a, int bank, const DemodConsts &C, int rot, float &re, float &im)
+	{
+		/* compact4 table: per bank the taps padded with AMAX zeros either side, four copies shifted by 0..3 floats: the lane at
+		 * alignment a reads P[(AMAX - a) + s] for slot s = copy ((AMAX - a) & 3) at the 16-byte aligned index ((AMAX - a) & ~3) + s */
+		const int o = AMAX - a;
+		uint32_t addr = ctab_addr + 4u * (uint32_t)(__mul24(bank * 4 + (o & 3), C.ctab_row_stride) + (o & ~3));
+		/* chunks that are padding for every lane of the wave are not entered: the first tap of a lane is in chunk a / 16, its
+		 * last in chunk (a + kTaps - 1) / 16 */
+		int c_lo = 0;
+#pragma unroll
+		for (int k = 1; 16 * k <= AMAX; k++) c_lo += __all(a >= 16 * k) ? 1 : 0;
+		constexpr int C_HI_MAX = (AMAX + kTaps - 1) / 16;
+		int c_hi = C_HI_MAX;
+#pragma unroll
+		for (int k = C_HI_MAX; 16 * k - kTaps >= 0; k--) c_hi -= __all(a <= 16 * k - kTaps) ? 1 : 0;
+		int entry = rot + c_lo;
+		entry = entry >= NCH ? entry - NCH : entry;
+		AsmP<GEO, FMT>::fir(addr + 64u * (uint32_t)c_lo, __builtin_amdgcn_readfirstlane(entry), __builtin_amdgcn_readfirstlane(c_hi - c_lo), re, im);
+	}
+};
+
+/* amdgpu_num_vgpr wants a literal: one kernel per (geometry, format, modulation), all of them the shared body */
+#define ROTP_KERNEL(GEO, NAME, FMT, OQ)                                                                                       \
+	__global__ void __launch_bounds__(GeoP<GEO>::BLOCK, 2) __attribute__((amdgpu_num_vgpr(ROTPK_##NAME##_##FMT##_LIMIT / 2)))  \
+	demod_kernel_rotp_##NAME##_##FMT##_##OQ(const DemodLaunch L) { rotwin_demod<WinP<GEO, FMT>, FMT, OQ, 0>(L); }
+ROTP_KERNEL(0, WIDE, 16, 0) ROTP_KERNEL(0, WIDE, 16, 1) ROTP_KERNEL(0, WIDE, 8, 0) ROTP_KERNEL(0, WIDE, 8, 1)
+ROTP_KERNEL(1, MID, 16, 0) ROTP_KERNEL(1, MID, 16, 1) ROTP_KERNEL(1, MID, 8, 0) ROTP_KERNEL(1, MID, 8, 1)
+ROTP_KERNEL(2, FAR, 16, 0) ROTP_KERNEL(2, FAR, 16, 1) ROTP_KERNEL(2, FAR, 8, 0) ROTP_KERNEL(2, FAR, 8, 1)
+
+typedef void (*rotp_kernel_t)(const DemodLaunch);
+
+hipError_t
+launch_rotp(rotp_kernel_t kfn, int block, const DemodLaunch &L, size_t lds_bytes, hipStream_t stream)
+{
+	const uint32_t blocks = (L.n_streams + block - 1) / block;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(kfn, dim3(blocks), dim3(block), lds_bytes, stream, L);
+	return hipGetLastError();
+}
+
+} /* namespace */
+
+hipError_t
+mdemod_launch_demod_rotp(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mid, 2 far */, size_t lds_bytes, hipStream_t stream)
+{
+	if ((fmt != 16 && fmt != 8) || geom < 0 || geom > 2) return hipErrorInvalidValue;
+	static const rotp_kernel_t table[3][2][2] = {
+		{ { demod_kernel_rotp_WIDE_16_0, demod_kernel_rotp_WIDE_16_1 }, { demod_kernel_rotp_WIDE_8_0, demod_kernel_rotp_WIDE_8_1 } },
+		{ { demod_kernel_rotp_MID_16_0, demod_kernel_rotp_MID_16_1 }, { demod_kernel_rotp_MID_8_0, demod_kernel_rotp_MID_8_1 } },
+		{ { demod_kernel_rotp_FAR_16_0, demod_kernel_rotp_FAR_16_1 }, { demod_kernel_rotp_FAR_8_0, demod_kernel_rotp_FAR_8_1 } },
+	};
+	static const int blocks[3] = { GeoP<0>::BLOCK, GeoP<1>::BLOCK, GeoP<2>::BLOCK };
+	return launch_rotp(table[geom][fmt == 16 ? 0 : 1][L.c.oqpsk ? 1 : 0], blocks[geom], L, lds_bytes, stream);
+}

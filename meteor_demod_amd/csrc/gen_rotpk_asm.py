@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generates rotpk_asm.h: the gfx950 assembly of the rotating PACKED register window (demod_kernel_rotp.hip) - the wide, mid
+and far geometries: filters up to 129 taps and / or up to 30 input samples per firing, s16 and u8 input.
+
+Same idea as gen_rotwin_asm.py (the window registers belong to this assembly, a slide renames instead of moving), other
+trade-offs, because a 96..160-slot window only fits as RAW samples (one VGPR per s16 sample pair, one per two u8 pairs),
+converted at every use:
+
+  tap     v_cvt_f32_i32_sdwa x2 (re, im out of the raw word)  +  v_pk_mul_f32 by the broadcast coefficient  +  v_pk_add_f32
+          into the accumulator pair: 4 instructions where the v2 kernel's C++ needed 6 - the reference's two rounded products
+          and two rounded sums (filter.c:58-59), oldest tap first.
+  ring    one copy of the FIR code per PHYSICAL chunk of 16 slots (not per rotation: ten rotations x 160 taps x 32 bytes would
+          be 51 KB of a 64 KB instruction cache): P_0 .. P_{n-1} laid out in a ring, entered at the chunk that holds the first
+          tap any lane of the wave needs, left after the chunk that holds the last one (chunks that are padding for every lane
+          are never entered).  Two scalar instructions of loop control per 16 taps.
+  coefs   four shifted copies of every polyphase bank (the "compact4" table of demod_host.cpp) make every (alignment, 4 taps)
+          an aligned ds_read_b128; four buffers of four registers rotate with the four groups of a chunk, so the buffer of a
+          group does not depend on where the ring was entered; loads run three groups ahead of the arithmetic.
+  put     a slide overwrites the oldest physical chunk: 16 v_mov_b32 (s16) or 8 v_xor_b32 with 0x80808080 (u8: the byte with
+          its top bit flipped, read as signed, is wavfile.c:61's `byte - 128`).
+
+Registers: window v[256 - NWR .. 255], then 4 temporaries and 16 coefficient registers below it; the compiler stays below those
+(`amdgpu_num_vgpr`, checked by build.py: check_asm_partition).
+"""
+import sys
+
+GEOS = {            # name: (embedded taps, window slots)
+    "WIDE": (129, 160),
+    "MID": (65, 96),
+    "FAR": (65, 112),
+}
+
+
+def q(lines):
+    return "\n".join('\t"%s\\n\\t"' % l for l in lines)
+
+
+def layout(nw, fmt):
+    nwr = nw if fmt == 16 else nw // 2          # window registers
+    wb = 256 - nwr
+    tb = wb - 4                                 # 2 temporary pairs
+    cb = tb - 16                                # 4 coefficient buffers of 4
+    return nwr, wb, tb, cb
+
+
+def jump(tag, idx):
+    return [
+        "s_getpc_b64 vcc",
+        ".L%s_pc_%%=:" % tag,
+        "s_mul_i32 %%[tmp], %%[%s], (.L%s_1_%%= - .L%s_0_%%=)" % (idx, tag, tag),
+        "s_add_u32 %%[tmp], %%[tmp], (.L%s_0_%%= - .L%s_pc_%%=)" % (tag, tag),
+        "s_add_u32 vcc_lo, vcc_lo, %[tmp]",
+        "s_addc_u32 vcc_hi, vcc_hi, 0",
+        "s_setpc_b64 vcc",
+    ]
+
+
+def fir(nw, fmt):
+    nwr, wb, tb, cb = layout(nw, fmt)
+    nch = nw // 16
+    D = 3
+
+    def load(g):                                # group g of the chunk at %[addr] (g may reach into the next chunk)
+        b = cb + 4 * (g % 4)
+        return "ds_read_b128 v[%d:%d], %%[addr] offset:%d" % (b, b + 3, 16 * g)
+
+    L = [load(g) for g in range(D)]
+    L += jump("fir", "entry")
+    for p in range(nch):
+        L += [".Lfir_%d_%%=:" % p]
+        for g in range(4):
+            L += [load(g + D), "s_waitcnt lgkmcnt(%d)" % D]
+            hb = cb + 4 * g
+
+            def src(j):                         # the raw word of slot 4g + j of physical chunk p, and the SDWA selects of (re, im)
+                s = 4 * g + j
+                if fmt == 16:
+                    return wb + 16 * p + s, "WORD_0", "WORD_1"
+                return wb + 8 * p + s // 2, "BYTE_%d" % (2 * (s & 1)), "BYTE_%d" % (2 * (s & 1) + 1)
+
+            def cvt(j):
+                r, a, b = src(j)
+                t = tb + 2 * (j & 1)
+                return ["v_cvt_f32_i32_sdwa v%d, sext(v%d) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:%s" % (t, r, a),
+                        "v_cvt_f32_i32_sdwa v%d, sext(v%d) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:%s" % (t + 1, r, b)]
+
+            def mul(j):
+                t = tb + 2 * (j & 1)
+                h = hb + 2 * (j // 2)
+                return ["v_pk_mul_f32 v[%d:%d], v[%d:%d], v[%d:%d] op_sel:[0,%d] op_sel_hi:[1,%d]" % (t, t + 1, t, t + 1, h, h + 1, j & 1, j & 1)]
+
+            def add(j):
+                t = tb + 2 * (j & 1)
+                return ["v_pk_add_f32 %%[acc], %%[acc], v[%d:%d]" % (t, t + 1)]
+
+            L += cvt(0) + cvt(1) + mul(0) + mul(1) + add(0) + cvt(2) + add(1) + cvt(3) + mul(2) + mul(3) + add(2) + add(3)
+        L += ["v_add_u32 %[addr], 64, %[addr]", "s_sub_u32 %[cnt], %[cnt], 1", "s_cbranch_scc1 .Lfir_end_%="]
+    L += ["s_branch .Lfir_0_%=", ".Lfir_end_%=:", "s_waitcnt lgkmcnt(0)"]
+    return L
+
+
+def put(nw, fmt):
+    nwr, wb, tb, cb = layout(nw, fmt)
+    nch = nw // 16
+    L = jump("put", "rot")
+    for p in range(nch):
+        L += [".Lput_%d_%%=:" % p]
+        if fmt == 16:
+            L += ["v_mov_b32 v%d, %%[g%d]" % (wb + 16 * p + s, s) for s in range(16)]
+        else:
+            L += ["v_xor_b32 v%d, 0x80808080, %%[g%d]" % (wb + 8 * p + s, s) for s in range(8)]
+        L += ["s_branch .Lput_end_%="]
+    L += [".Lput_end_%=:"]
+    return L
+
+
+def main():
+    out = ["/* GENERATED by gen_rotpk_asm.py - do not edit.  gfx950 assembly of the rotating packed register window. */",
+           "#ifndef MDEMOD_ROTPK_ASM_H", "#define MDEMOD_ROTPK_ASM_H"]
+    for name, (kt, nw) in GEOS.items():
+        for fmt in (16, 8):
+            nwr, wb, tb, cb = layout(nw, fmt)
+            tag = "%s_%d" % (name, fmt)
+            out.append("#define ROTPK_%s_LIMIT %d   /* first register the compiler may not use */" % (tag, cb))
+            out.append("#define ROTPK_%s_FIR_ASM \\\n" % tag + q(fir(nw, fmt)).replace("\n", " \\\n"))
+            out.append("#define ROTPK_%s_PUT_ASM \\\n" % tag + q(put(nw, fmt)).replace("\n", " \\\n"))
+            out.append("#define ROTPK_%s_CLOBBERS " % tag + ", ".join('"v%d"' % i for i in range(cb, wb)) + ', "v255"')
+    out.append("#endif")
+    sys.stdout.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -233,20 +233,24 @@ WIDE_KERNEL = {"c4_s16": "wide", "c4_u8": "wide", "oqpsk80k_1M": "wide", "taps97
                "far_edge_u8": "far", "defaults_1024k_f32": "mid", "oqpsk_640k_f32": "mid"}
 
 
+@pytest.mark.parametrize("generation", ["v3", "v2"])
 @pytest.mark.parametrize("name", list(WIDE_CFGS))
-def test_wide_window_batch_chained(name, gpu_device):
-    """The 129-tap / 15-samples-per-firing geometry of the register-window kernel (packed window,
-    compact coefficient table, two slides per iteration): 70 distinct streams (more than one wave,
-    every symbol phase) x chained blocks, byte-identical to the oracle, loop state included."""
+def test_wide_window_batch_chained(name, generation, gpu_device, monkeypatch):
+    """The wide / mid / far geometries (up to 129 taps, up to 30 samples per firing) on the v3 rotating packed window and on
+    the v2 moving one (packed window, compact coefficient table): 70 distinct streams (more than one wave, every symbol
+    phase) x chained blocks, byte-identical to the oracle, loop state included."""
     torch = _torch()
     cfg = WIDE_CFGS[name]
+    if generation == "v2":
+        monkeypatch.setenv("MDEMOD_KERNEL", "v2")
     rms = {8: 50.0, 16: 5000.0, 32: 0.3}[cfg.bps]
     ns, blocks = 70, [5000, 3, 9000, 1, 2047]
     streams = [synth.make_stream(8100 + i, cfg.samplerate, cfg.symrate, f0_hz=(i % 9 - 4) * 350.0, clock_ppm=(i % 7 - 3) * 15.0,
                                  esn0_db=15.0, rms=rms, oqpsk=cfg.oqpsk, fmt=cfg.bps) for i in range(ns)]
     iqs = [synth.generate_host(s, sum(blocks)) for s in streams]
     with Demodulator(cfg, ns) as d:
-        assert "v2 register window, " + WIDE_KERNEL[name] in d.kernel_name, d.kernel_name
+        want_name = ("v3 rotating packed window, " if generation == "v3" and cfg.bps != 32 else "v2 register window, ") + WIDE_KERNEL[name]
+        assert want_name in d.kernel_name, d.kernel_name
         parts = [[] for _ in range(ns)]
         pos = 0
         for b in blocks:

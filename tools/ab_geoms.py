@@ -1,0 +1,32 @@
+"""A/B of kernel generations on the geometries outside BASELINE.json's headline: wide (configs[3]), mid, far, for MDEMOD_KERNEL in
+sys.argv[1:] ("" = default).  Same tiling as bench.py's other_configs."""
+import os, subprocess, sys, json
+code = r'''
+import sys, json, torch
+sys.path.insert(0, ".")
+from meteor_demod_amd import DemodConfig, Demodulator, synth
+T, L = 393216, 16448
+cfgs = {"c4 wide 1MS/s -f64 -O8": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8),
+        "mid 1.024MS/s": DemodConfig(samplerate=1024000), "far 1.8MS/s": DemodConfig(samplerate=1800000),
+        "wide u8": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=8),
+        "c4 oqpsk 1MS/s": DemodConfig(samplerate=1000000, symrate=80000, oqpsk=True, rrc_order=64, interp_factor=8)}
+for name, cfg in cfgs.items():
+    rec = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, fmt=cfg.bps, **(dict(rms=40.0) if cfg.bps == 8 else {}))
+    buf = torch.empty((T * L, 2), dtype=torch.uint8 if cfg.bps == 8 else torch.int16, device="cuda")
+    synth.generate_device([rec], T * L, out=buf.view(1, T * L, 2))
+    x = buf.view(T, L, 2)
+    with Demodulator(cfg, T) as d:
+        soft = torch.empty((T, d.max_symbols(L), 2), dtype=torch.int8, device="cuda")
+        d.process(x, soft=soft)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3): d.process(x, soft=soft)
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 3
+        print(f"  {name:28s} {T * L / ms / 1e6:8.1f} GS/s  {ms:7.3f} ms  {d.kernel_name}", flush=True)
+    del buf, x, soft
+    torch.cuda.empty_cache()
+'''
+for k in (sys.argv[1:] or ["", "v2"]):
+    print("MDEMOD_KERNEL=%r" % k, flush=True)
+    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MDEMOD_KERNEL=k))
