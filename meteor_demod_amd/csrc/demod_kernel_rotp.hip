@@ -10,7 +10,11 @@
  * needs 516 (profiles/r02_kernels.md).
  */
 #include "rotwin_body.h"
+#ifdef ROTPK_ASM_HEADER
+#include ROTPK_ASM_HEADER        /* experimental builds (tools/build_exp_rotp.sh) */
+#else
 #include "rotpk_asm.h"
+#endif
 
 namespace {
 
@@ -24,17 +28,25 @@ static_assert(MDEMOD_RW_WIDE_NW == 160 && MDEMOD_RW_MID_NW == 96 && MDEMOD_RW_FA
 
 /* the assembly of one (geometry, format): FIR over chunks [entry, entry + cnt] of the ring, and the slide */
 template <int GEO, int FMT> struct AsmP;
+#if ROTPK_FORM == 0             /* plain f32 products and sums: the accumulator is two registers */
+#define ROTP_FIR_CALL(TEXT, CLOB)                                                                                             \
+	float ar = 0.0f, ai = 0.0f;                                                                                               \
+	asm volatile(TEXT : [ar] "+v"(ar), [ai] "+v"(ai), [addr] "+v"(addr), [cnt] "+s"(cnt), [tmp] "=&s"(tmp)                    \
+	             : [entry] "s"(entry) : "vcc", "scc", CLOB);                                                                  \
+	re = ar; im = ai;
+#else                           /* packed products and sums: the accumulator is an aligned register pair */
+#define ROTP_FIR_CALL(TEXT, CLOB)                                                                                             \
+	pair_t acc = { 0.0f, 0.0f };                                                                                              \
+	asm volatile(TEXT : [acc] "+v"(acc), [addr] "+v"(addr), [cnt] "+s"(cnt), [tmp] "=&s"(tmp)                                 \
+	             : [entry] "s"(entry) : "vcc", "scc", CLOB);                                                                  \
+	re = acc.x; im = acc.y;
+#endif
 #define ROTP_ASM(GEO, NAME, FMT)                                                                                              \
 	template <> struct AsmP<GEO, FMT> {                                                                                       \
 		__device__ static __forceinline__ void fir(uint32_t addr, int entry, int cnt, float &re, float &im)                   \
 		{                                                                                                                     \
-			pair_t acc = { 0.0f, 0.0f };                                                                                      \
 			int tmp;                                                                                                          \
-			asm volatile(ROTPK_##NAME##_##FMT##_FIR_ASM                                                                       \
-			             : [acc] "+v"(acc), [addr] "+v"(addr), [cnt] "+s"(cnt), [tmp] "=&s"(tmp)                              \
-			             : [entry] "s"(entry)                                                                                 \
-			             : "vcc", "scc", ROTPK_##NAME##_##FMT##_CLOBBERS);                                                    \
-			re = acc.x; im = acc.y;                                                                                           \
+			ROTP_FIR_CALL(ROTPK_##NAME##_##FMT##_FIR_ASM, ROTPK_##NAME##_##FMT##_CLOBBERS)                                     \
 		}                                                                                                                     \
 		__device__ static __forceinline__ void put(const uint32_t (&g)[FMT == 16 ? 16 : 8], int q);                           \
 	};
@@ -122,6 +134,9 @@ struct WinP {
 #define ROTP_KERNEL(GEO, NAME, FMT, OQ)                                                                                       \
 	__global__ void __launch_bounds__(GeoP<GEO>::BLOCK, 2) __attribute__((amdgpu_num_vgpr(ROTPK_##NAME##_##FMT##_LIMIT / 2)))  \
 	demod_kernel_rotp_##NAME##_##FMT##_##OQ(const DemodLaunch L) { rotwin_demod<WinP<GEO, FMT>, FMT, OQ, 0>(L); }
+/* configs[3] (72k QPSK in 1 MS/s, -O 8): its 109 blind symbol-clock steps compiled in, like the two LRPT settings of the std kernel */
+__global__ void __launch_bounds__(GeoP<0>::BLOCK, 2) __attribute__((amdgpu_num_vgpr(ROTPK_WIDE_16_LIMIT / 2)))
+demod_kernel_rotp_WIDE_16_0_ks109(const DemodLaunch L) { rotwin_demod<WinP<0, 16>, 16, 0, 109>(L); }
 ROTP_KERNEL(0, WIDE, 16, 0) ROTP_KERNEL(0, WIDE, 16, 1) ROTP_KERNEL(0, WIDE, 8, 0) ROTP_KERNEL(0, WIDE, 8, 1)
 ROTP_KERNEL(1, MID, 16, 0) ROTP_KERNEL(1, MID, 16, 1) ROTP_KERNEL(1, MID, 8, 0) ROTP_KERNEL(1, MID, 8, 1)
 ROTP_KERNEL(2, FAR, 16, 0) ROTP_KERNEL(2, FAR, 16, 1) ROTP_KERNEL(2, FAR, 8, 0) ROTP_KERNEL(2, FAR, 8, 1)
@@ -150,5 +165,6 @@ mdemod_launch_demod_rotp(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mi
 		{ { demod_kernel_rotp_FAR_16_0, demod_kernel_rotp_FAR_16_1 }, { demod_kernel_rotp_FAR_8_0, demod_kernel_rotp_FAR_8_1 } },
 	};
 	static const int blocks[3] = { GeoP<0>::BLOCK, GeoP<1>::BLOCK, GeoP<2>::BLOCK };
+	if (geom == 0 && fmt == 16 && !L.c.oqpsk && L.c.step_safe == 109) return launch_rotp(demod_kernel_rotp_WIDE_16_0_ks109, blocks[0], L, lds_bytes, stream);
 	return launch_rotp(table[geom][fmt == 16 ? 0 : 1][L.c.oqpsk ? 1 : 0], blocks[geom], L, lds_bytes, stream);
 }

@@ -22,7 +22,15 @@ converted at every use:
 Registers: window v[256 - NWR .. 255], then 4 temporaries and 16 coefficient registers below it; the compiler stays below those
 (`amdgpu_num_vgpr`, checked by build.py: check_asm_partition).
 """
+import os
 import sys
+
+# the tap's arithmetic after the two converts: 1 = v_pk_mul_f32 + v_pk_add_f32 (4 instructions per tap), 0 = v_mul_f32 x2 +
+# v_add_f32 x2 (6 per tap, less VALU pipe time: packed f32 ops take 6.3 cycles of a SIMD's pipe, plain ones 2.3)
+FORM = int(os.environ.get("ROTPK_FORM", "1"))
+# coefficient prefetch: 0 = one load and one s_waitcnt per group of 4 taps, three groups ahead; 1 = two loads and one s_waitcnt
+# per PAIR of groups, two groups ahead at the wait (half the s_waitcnt instructions)
+PAIRWAIT = int(os.environ.get("ROTPK_PAIRWAIT", "1"))
 
 GEOS = {            # name: (embedded taps, window slots)
     "WIDE": (129, 160),
@@ -64,12 +72,16 @@ def fir(nw, fmt):
         b = cb + 4 * (g % 4)
         return "ds_read_b128 v[%d:%d], %%[addr] offset:%d" % (b, b + 3, 16 * g)
 
-    L = [load(g) for g in range(D)]
+    L = [load(g) for g in range(2 if PAIRWAIT else D)]
     L += jump("fir", "entry")
     for p in range(nch):
         L += [".Lfir_%d_%%=:" % p]
         for g in range(4):
-            L += [load(g + D), "s_waitcnt lgkmcnt(%d)" % D]
+            if PAIRWAIT:
+                if g % 2 == 0:
+                    L += [load(g + 2), load(g + 3), "s_waitcnt lgkmcnt(2)"]
+            else:
+                L += [load(g + D), "s_waitcnt lgkmcnt(%d)" % D]
             hb = cb + 4 * g
 
             def src(j):                         # the raw word of slot 4g + j of physical chunk p, and the SDWA selects of (re, im)
@@ -87,10 +99,14 @@ def fir(nw, fmt):
             def mul(j):
                 t = tb + 2 * (j & 1)
                 h = hb + 2 * (j // 2)
+                if FORM == 0:
+                    return ["v_mul_f32 v%d, v%d, v%d" % (t, hb + j, t), "v_mul_f32 v%d, v%d, v%d" % (t + 1, hb + j, t + 1)]
                 return ["v_pk_mul_f32 v[%d:%d], v[%d:%d], v[%d:%d] op_sel:[0,%d] op_sel_hi:[1,%d]" % (t, t + 1, t, t + 1, h, h + 1, j & 1, j & 1)]
 
             def add(j):
                 t = tb + 2 * (j & 1)
+                if FORM == 0:
+                    return ["v_add_f32 %%[ar], %%[ar], v%d" % t, "v_add_f32 %%[ai], %%[ai], v%d" % (t + 1)]
                 return ["v_pk_add_f32 %%[acc], %%[acc], v[%d:%d]" % (t, t + 1)]
 
             L += cvt(0) + cvt(1) + mul(0) + mul(1) + add(0) + cvt(2) + add(1) + cvt(3) + mul(2) + mul(3) + add(2) + add(3)
@@ -116,7 +132,7 @@ def put(nw, fmt):
 
 def main():
     out = ["/* GENERATED by gen_rotpk_asm.py - do not edit.  gfx950 assembly of the rotating packed register window. */",
-           "#ifndef MDEMOD_ROTPK_ASM_H", "#define MDEMOD_ROTPK_ASM_H"]
+           "#ifndef MDEMOD_ROTPK_ASM_H", "#define MDEMOD_ROTPK_ASM_H", "#define ROTPK_FORM %d" % FORM]
     for name, (kt, nw) in GEOS.items():
         for fmt in (16, 8):
             nwr, wb, tb, cb = layout(nw, fmt)

@@ -27,6 +27,9 @@ import sys
 WB = 96          # first window register
 CB = 80          # coefficient buffers: 4 x 4 registers
 NCH = 10         # chunks of 8 slots
+# coefficient prefetch of the FIR: 0 = one load and one s_waitcnt per half-chunk, three half-chunks ahead; 1 = two loads and one
+# s_waitcnt per chunk, one chunk ahead at the wait (half the s_waitcnt instructions)
+PAIRWAIT = int(os.environ.get("ROTWIN_PAIRWAIT", "1"))
 # the FIR's tap: 0 = v_mul x2 + v_add x2; 1 = v_pk_mul_f32 + v_pk_add_f32 on (re, im) pairs (the default); 2 = v_pk_mul_f32 +
 # v_add x2; 3 = v_mul x2 + v_pk_add_f32.  2 and 3 keep their products in v[TB:TB+3] (taken from the compiler like the coefficient
 # buffers).  All four are the reference's two rounded products and two rounded sums per tap (filter.c:58-59); measured on
@@ -65,20 +68,27 @@ def fir():
     L = []
     if PK in (0, 2):
         L += ["v_mov_b32 %[ar], 0", "v_mov_b32 %[ai], 0"]
-    L += [load(h) for h in range(D)]                     # on their way before the jump (the same for every rotation)
+    L += [load(h) for h in range(2 if PAIRWAIT else D)]  # on their way before the jump (the same for every rotation)
     L += jump("fir", NCH)
     for r in range(NCH):
         L += [".Lfir_%d_%%=:" % r]
         for h in range(NH):
             c = h // 2
-            if h + D < NH:
+            if PAIRWAIT:
+                if h % 2 == 0:
+                    L += [load(x) for x in (h + 2, h + 3) if x < NH]
+            elif h + D < NH:
                 L += [load(h + D)]
             # chunk 0 = half-chunks 0 and 1: each is jumped over on its own, so that half-chunk 1's prefetch is still issued
             if h < 2:
                 L += ["s_bitcmp1_b32 %[flags], 0", "s_cbranch_scc1 .Lfir_%d_s%d_%%=" % (r, h)]
             if h == NH - 2:
                 L += ["s_bitcmp1_b32 %[flags], 1", "s_cbranch_scc1 .Lfir_%d_s9_%%=" % r]
-            L += ["s_waitcnt lgkmcnt(%d)" % min(D, NH - 1 - h)]
+            if PAIRWAIT:
+                if h % 2 == 0:
+                    L += ["s_waitcnt lgkmcnt(%d)" % (2 if h + 2 < NH else 0)]
+            else:
+                L += ["s_waitcnt lgkmcnt(%d)" % min(D, NH - 1 - h)]
             hb = CB + 4 * (h % 4)
             wq = WB + 16 * ((c + r) % NCH) + 8 * (h & 1)
             if PK == 1:

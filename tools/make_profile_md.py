@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense one tools/profile_r02.sh output directory (gpurun_out/<dir>/cX_{stats,FETCH,WRITE,sq}.md) into a profiles/*.md
+"""Condense one tools/profile_round.sh output directory (gpurun_out/<dir>/cX_{stats,FETCH,WRITE,sq}.md) into a profiles/*.md
 summary and refresh profiles/hbm_traffic.json (what bench.py reports as roofline.traffic).
 usage: make_profile_md.py gpurun_out/<dir> profiles/<name>.md <round tag> [tiles=393216] [tile_samples=16448]"""
 import json, re, sys
@@ -14,10 +14,10 @@ ROOT = Path(__file__).resolve().parent.parent
 tf = ROOT / "profiles" / "hbm_traffic.json"
 traffic = json.loads(tf.read_text()) if tf.exists() else {}
 lines = [f"# {tag}: demodulator kernels under rocprofv3 (bench.py --config X --steps 3 --warmup 1 --no-cpu-baseline --no-check, {T} tiles x {L} samples)\n",
-         "Separate passes per counter group (`tools/profile_r02.sh`): `--kernel-trace --stats`, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_*`.",
+         "Separate passes per counter group (`tools/profile_round.sh`): `--kernel-trace --stats`, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_*`.",
          "FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B: MI355X_MICROARCH.md, HBM section); WRITE_SIZE as counted.\n",
-         "| config | kernel | avg ms (stats pass) | min ms | GS/s at avg | algorithmic GB | % of 8 TB/s | FETCH x2 GB | WRITE GB | traffic / algorithmic | VALU / wave-firing | SALU | LDS | branch | wave-cycles / firing | WAIT_ANY / WAVE_CYCLES |",
-         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+         "| config | kernel | avg ms (stats pass) | min ms | GS/s at avg | algorithmic GB | % of 8 TB/s | FETCH x2 GB | WRITE GB | traffic / algorithmic | VALU / wave-firing | SALU | LDS | branch | wave-cycles / firing | WAIT_ANY / WAVE_CYCLES | WAIT_INST_ANY / WAVE_CYCLES | ACTIVE_INST_VALU / WAVE_CYCLES |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for c, (name, symrate, fs, fires) in CFG.items():
     def grab(kind):
         p = src / f"{c}_{kind}.md"
@@ -38,8 +38,9 @@ for c, (name, symrate, fs, fires) in CFG.items():
     wave_fir = T * sym_per_tile * fires / 64
     valu, salu, lds, br = (counter("sq", k) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"))
     wc, wa = counter("sq", "SQ_WAVE_CYCLES"), counter("sq", "SQ_WAIT_ANY")
+    wi, av = counter("sq2", "SQ_WAIT_INST_ANY"), counter("sq2", "SQ_ACTIVE_INST_VALU")
     lines.append(f"| {name} | `{kname[:70]}` | {avg:.3f} | {mn:.3f} | {T*L/avg/1e6:.1f} | {algo/1e9:.2f} | {algo/avg/1e6/8000*100:.2f} | {fetch_kb*2048/1e9:.2f} | {write_kb*1024/1e9:.2f} | "
-                 f"{hbm/algo:.3f} | {valu/wave_fir:.0f} | {salu/wave_fir:.0f} | {lds/wave_fir:.0f} | {br/wave_fir:.0f} | {wc*4/wave_fir:.0f} | {wa/wc:.2f} |")
+                 f"{hbm/algo:.3f} | {valu/wave_fir:.0f} | {salu/wave_fir:.0f} | {lds/wave_fir:.0f} | {br/wave_fir:.0f} | {wc*4/wave_fir:.0f} | {wa/wc:.2f} | {wi/wc:.2f} | {av/wc:.2f} |")
     traffic[f"{c}:{T}x{L}"] = {"hbm_bytes_per_launch": int(hbm), "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
                                "correction": "reads x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B: MI355X_MICROARCH.md HBM section); writes as counted; L2-miss (fabric) bytes, Infinity-Cache hits included",
                                "algorithmic_bytes_per_launch": int(algo), "kernel": kname[:90], "round": tag, "kernel_ms_under_profiler": avg,
@@ -48,7 +49,7 @@ for c, (name, symrate, fs, fires) in CFG.items():
                                "wait_any_over_wave_cycles": round(wa / wc, 3)}
 lines.append("\n(wave-firing = one firing of the symbol clock for each of the 64 streams of a wave; QPSK: one per symbol, OQPSK: two.  SQ_WAVE_CYCLES counts 4-cycle quanta.)\n")
 for c in CFG:
-    for kind in ("stats", "FETCH", "WRITE", "sq"):
+    for kind in ("stats", "FETCH", "WRITE", "sq", "sq2"):
         p = src / f"{c}_{kind}.md"
         if p.exists():
             body = "\n".join(l for l in p.read_text().splitlines() if l.startswith("|") and ("demod_kernel" in l or l.startswith("| kernel") or l.startswith("|---")))
