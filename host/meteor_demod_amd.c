@@ -303,6 +303,7 @@ main(int argc, char **argv)
 			if (!soft_all) { free(data); close_all(io, n_files); return 1; }
 			mdemod_recording_opts ro;
 			mdemod_recording_default_opts(&ro);
+			if (getenv("MDEMOD_RECORDING_DEBUG")) ro.debug = atoi(getenv("MDEMOD_RECORDING_DEBUG")) > 0 ? atoi(getenv("MDEMOD_RECORDING_DEBUG")) : 1;     /* the library reads no environment: the CLI does */
 			if (tile_samples > 0) ro.tile_samples = (uint32_t)tile_samples;
 			if (pilot_margin >= 0) ro.pilot_margin_symbols = (uint32_t)pilot_margin;
 			if (carrier_seed >= 0) ro.carrier_seed = (uint32_t)carrier_seed;

@@ -85,8 +85,15 @@ typedef struct {
 	                           wavfile.c:58-69                                        */
 	int32_t  device;        /* HIP device ordinal                                     */
 	uint32_t n_streams;     /* independent streams held by this context               */
-	uint32_t reserved;
+	uint32_t reserved;      /* 0: the library picks the kernel (what a caller passes).  MDEMOD_FLAG_* below pin a variant: the
+	                           test-suite runs every golden through all of them.  The library reads no environment variable. */
 } mdemod_params;
+
+/* mdemod_params.reserved (diagnosis and tests only; every variant produces the same bytes) */
+#define MDEMOD_FLAG_KERNEL_MASK 0x3u    /* 0 = newest generation that fits, 1 = v1 LDS ring, 2 = v2 moving register window, 3 = v3 */
+#define MDEMOD_FLAG_LAT_OFF     0x4u    /* never the wave-per-stream (latency) kernel, however few the streams */
+#define MDEMOD_FLAG_LAT_ON      0x8u    /* always, when the configuration fits it */
+#define MDEMOD_FLAG_V2_PACKED   0x10u   /* v2 std geometry: raw-sample window (3 waves per SIMD) instead of converted floats */
 
 /* Value snapshot of one stream after a call (replaces the reference's racy
  * getters polled from the UI thread, main.c:231-237,250-258). */
@@ -312,6 +319,8 @@ typedef struct {
 	                                   the pilot's carrier estimate (dead reckoning then rarely holds: repair does the work) (1) */
 	uint32_t clock_seed;            /* 0: every tile's symbol clock from its own spectral line (mdemod_estimate_clock: follows the
 	                                   Doppler on the clock, good to a tenth of the loop's own wander); 1: the pilot's omega for all (0) */
+	int32_t  debug;                 /* 0; 1: stage timings and a per-seam trace of the odd seams on stderr, 2: every seam (0) */
+	int32_t  debug_tile;            /* with debug: also trace the framing of the tiles around this index; -1 = none (-1) */
 } mdemod_recording_opts;
 
 typedef struct {

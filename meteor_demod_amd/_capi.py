@@ -21,6 +21,21 @@ MDEMOD_ERR_HIP = -3
 MDEMOD_ERR_OVERFLOW = -4
 MDEMOD_ERR_RANGE = -5
 MDEMOD_MAX_LOCK_EVENTS = 32
+MDEMOD_FLAG_KERNEL_MASK, MDEMOD_FLAG_LAT_OFF, MDEMOD_FLAG_LAT_ON, MDEMOD_FLAG_V2_PACKED = 0x3, 0x4, 0x8, 0x10
+
+
+def variant_flags_from_env() -> int:
+    """`mdemod_params.reserved` for the test and bench harness: the library itself reads no environment variable, this wrapper
+    does, so that one suite can run every kernel variant.  MDEMOD_KERNEL=v1|v2|v3, MDEMOD_LAT=0|1, MDEMOD_RW_PACKED=1."""
+    f = {"v1": 1, "v2": 2, "v3": 3}.get(_os.environ.get("MDEMOD_KERNEL", ""), 0)
+    lat = _os.environ.get("MDEMOD_LAT", "")
+    if lat == "0":
+        f |= MDEMOD_FLAG_LAT_OFF
+    elif lat not in ("", "-1"):
+        f |= MDEMOD_FLAG_LAT_ON
+    if _os.environ.get("MDEMOD_RW_PACKED", "0") not in ("", "0"):
+        f |= MDEMOD_FLAG_V2_PACKED
+    return f
 
 
 class MdemodParams(C.Structure):
@@ -64,7 +79,7 @@ class MdemodRecordingOpts(C.Structure):
     _fields_ = [("tile_samples", C.c_uint32), ("acquire_samples", C.c_uint32), ("frame_samples", C.c_uint32),
                 ("settle_samples", C.c_uint32), ("pilot_block", C.c_uint32), ("pilot_margin_symbols", C.c_uint32),
                 ("max_pilot_samples", C.c_uint64), ("match_symbols", C.c_uint32), ("repair", C.c_int32),
-                ("carrier_seed", C.c_uint32), ("clock_seed", C.c_uint32)]
+                ("carrier_seed", C.c_uint32), ("clock_seed", C.c_uint32), ("debug", C.c_int32), ("debug_tile", C.c_int32)]
 
 
 class MdemodRecordingReport(C.Structure):

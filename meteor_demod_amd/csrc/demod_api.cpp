@@ -69,11 +69,15 @@ fetch(const T *dev, uint32_t first, uint32_t count, std::vector<T> &host, hipStr
 	return MDEMOD_OK;
 }
 
-int
-env_int(const char *name, int dflt)
+/* the wave-per-stream kernel for few streams, the lane-per-stream kernels for many.  Measured r03 (tools/lat_bench.py, MS/s per
+ * stream, wave vs lane): configs[1] 3.6 vs 2.5 at 1 024 streams, 3.1 vs 2.5 at 2 048, 2.2 vs 2.5 at 4 096; configs[3] (packed
+ * window) 5.3 vs 3.7 at 1 024, 2.7 vs 3.7 at 2 048.  MDEMOD_FLAG_LAT_ON / _OFF pin the choice. */
+bool
+wants_latency_kernel(const mdemod_ctx *ctx)
 {
-	const char *v = getenv(name);
-	return (v && *v) ? atoi(v) : dflt;
+	if (!ctx->lat_ok || (ctx->params.reserved & MDEMOD_FLAG_LAT_OFF)) return false;
+	if (ctx->params.reserved & MDEMOD_FLAG_LAT_ON) return true;
+	return ctx->params.n_streams <= (ctx->tab.rw_compact4 ? 1024u : 2048u);
 }
 
 int
@@ -92,16 +96,11 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	L.ctab = ctx->d_ctab;
 	L.ctab_floats = static_cast<uint32_t>(ctx->tab.ctab.size());
 	L.tanh_lut = ctx->d_lut;
-	/* Few streams: one stream per WAVE (demod_kernel_lat.hip) instead of one per lane.  A lane runs ~0.5 M symbols/s whatever
-	 * the batch, a wave several times that, and below a few thousand streams most of the GPU idles either way.
-	 * MDEMOD_LAT=0 / 1 forces the choice (tests run every golden through both), MDEMOD_LAT_MAX_STREAMS moves the threshold. */
-	{
-		const int force = env_int("MDEMOD_LAT", -1);
-		const bool want = force >= 0 ? force != 0 : ctx->params.n_streams <= static_cast<uint32_t>(env_int("MDEMOD_LAT_MAX_STREAMS", 2048));
-		if (want && ctx->lat_ok) {
-			HIP_TRY(mdemod_launch_demod_lat(L, ctx->params.bps, ctx->d_rrc, ctx->lat_ring, ctx->lat_span, ctx->tab.use_rw ? 1 : 0, ctx->lat_lds, stream));
-			return MDEMOD_OK;
-		}
+	/* Few streams: one stream per WAVE (demod_kernel_lat.hip) instead of one per lane.  A lane runs ~0.8 M symbols/s whatever
+	 * the batch, a wave 1.5 times that, and below a few thousand streams most of the GPU idles either way. */
+	if (wants_latency_kernel(ctx)) {
+		HIP_TRY(mdemod_launch_demod_lat(L, ctx->params.bps, ctx->d_rrc, ctx->lat_ring, ctx->lat_span, ctx->tab.use_rw ? 1 : 0, ctx->lat_lds, stream));
+		return MDEMOD_OK;
 	}
 	if (ctx->tab.use_rw && ctx->use_rot)
 		HIP_TRY(mdemod_launch_demod_rot(L, ctx->params.bps, ctx->lds_bytes, stream));
@@ -110,7 +109,7 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	else if (ctx->tab.use_rw)
 		HIP_TRY((ctx->tab.rw_wide || ctx->tab.rw_mid || ctx->tab.rw_far)
 		        ? mdemod_launch_demod_rw_wide(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream)
-		                         : mdemod_launch_demod_rw_std(L, ctx->params.bps, env_int("MDEMOD_RW_PACKED", 0), ctx->lds_bytes, stream));
+		                         : mdemod_launch_demod_rw_std(L, ctx->params.bps, (ctx->params.reserved & MDEMOD_FLAG_V2_PACKED) ? 1 : 0, ctx->lds_bytes, stream));
 	else
 		HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->lds_bytes, stream));
 	return MDEMOD_OK;
@@ -187,11 +186,11 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	ctx->params = *params;
 	ctx->pipe = nullptr;
 
-	/* MDEMOD_KERNEL=v1 forces the LDS-ring kernel, =v2 the moving register window (tests cover all three generations).  The v3
+	/* MDEMOD_FLAG_KERNEL_MASK pins a generation (tests cover all three); otherwise the newest that fits.  The v3
 	 * kernels drop the range test of the NCO's turn code and wrap the NCO phase in float arithmetic (demod_device.h): both need
 	 * phase + freq < 4pi, which pll.c's own clamp gives for fmax < 2pi rad/symbol (the default is 0.3) */
-	const char *kforce = getenv("MDEMOD_KERNEL");
-	int generation = (kforce && !strcmp(kforce, "v1")) ? 0 : ((kforce && !strcmp(kforce, "v2")) ? 1 : 2);
+	const uint32_t kforce = params->reserved & MDEMOD_FLAG_KERNEL_MASK;
+	int generation = kforce == 1 ? 0 : (kforce == 2 ? 1 : 2);
 	{
 		HostTables probe;
 		int rc0 = mdemod_host_derive(*params, probe, 1);
@@ -206,11 +205,9 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	/* tunables (experiments only; defaults are the measured best) */
 	DemodConsts &c = ctx->tab.c;
 	if (!ctx->tab.use_rw) {
-		c.ring_granules = c.hpad / 4 + env_int("MDEMOD_RING_EXTRA", 8);
-		if (c.ring_granules < c.hpad / 4 + 4) c.ring_granules = c.hpad / 4 + 4;
+		c.ring_granules = c.hpad / 4 + 8;            /* v1: eight granules of slack behind the history (measured best, r01) */
 	}
-	const int waves = env_int("MDEMOD_WAVES_PER_BLOCK", 3);
-	ctx->block_threads = 64 * (waves < 1 ? 1 : (waves > 4 ? 4 : waves));      /* v1 kernel: __launch_bounds__(256) */
+	ctx->block_threads = 64 * 3;                     /* v1 kernel: three waves per block (__launch_bounds__(256); measured best, r01) */
 
 	auto lds_need = [&](int threads) {
 		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
@@ -224,8 +221,7 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 		rc = mdemod_host_derive(*params, ctx->tab, 0);
 		ctx->use_rot = false;
 		if (rc) { delete ctx; return rc; }
-		c.ring_granules = c.hpad / 4 + env_int("MDEMOD_RING_EXTRA", 8);
-		if (c.ring_granules < c.hpad / 4 + 4) c.ring_granules = c.hpad / 4 + 4;
+		c.ring_granules = c.hpad / 4 + 8;
 	}
 	while (ctx->block_threads > 64 && lds_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
 	ctx->lds_bytes = lds_need(ctx->block_threads);
@@ -261,7 +257,9 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	CREATE_TRY(dev_alloc(ctx, &ctx->d_ctab, ctx->tab.ctab.size()));
 	CREATE_TRY(dev_alloc(ctx, &ctx->d_lut, 32));
 	CREATE_TRY(dev_alloc(ctx, &ctx->d_rrc, ctx->tab.rrc.size()));
-	ctx->lat_ok = mdemod_lat_geometry(c, static_cast<double>(ctx->tab.osf) / (params->oqpsk ? 2.0 : 1.0), &ctx->lat_ring, &ctx->lat_span, &ctx->lat_lds);
+	/* like the v3 kernels, the latency kernel takes the NCO's short cuts that need fmax < 2pi (demod_device.h) */
+	ctx->lat_ok = c.pll_fmax < 6.0f &&
+	              mdemod_lat_geometry(c, static_cast<double>(ctx->tab.osf) / (params->oqpsk ? 2.0 : 1.0), &ctx->lat_ring, &ctx->lat_span, &ctx->lat_lds);
 	{
 		/* tables and the power-on state go in on a stream of their own, and only that stream is waited for: a context made while
 		   other contexts run (a second host thread, a recording's tile bank next to its serial head) must not wait for their
@@ -615,11 +613,7 @@ const char *
 mdemod_kernel_name(const mdemod_ctx *ctx)
 {
 	if (!ctx) return "";
-	{
-		const int force = env_int("MDEMOD_LAT", -1);
-		const bool want = force >= 0 ? force != 0 : ctx->params.n_streams <= static_cast<uint32_t>(env_int("MDEMOD_LAT_MAX_STREAMS", 2048));
-		if (want && ctx->lat_ok) return "demod_kernel_lat (one stream per wave: FIR farm + serial scalar stage)";
-	}
+	if (wants_latency_kernel(ctx)) return "demod_kernel_lat (one stream per wave: FIR farm + serial scalar stage)";
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
 	if (ctx->tab.rw_compact4) return ctx->tab.rw_wide ? "demod_kernel_rotp (v3 rotating packed window, wide: 129 taps)"
 	                                 : (ctx->tab.rw_mid ? "demod_kernel_rotp (v3 rotating packed window, mid: 65 taps at up to 15 samples per firing)"
@@ -629,7 +623,7 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (ctx->tab.rw_mid) return ctx->params.bps == 32 ? "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, float pairs)"
 	                                                  : "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, packed)";
 	if (ctx->use_rot) return "demod_kernel_rot (v3 rotating register window)";
-	return (ctx->params.bps != 32 && env_int("MDEMOD_RW_PACKED", 0))
+	return (ctx->params.bps != 32 && (ctx->params.reserved & MDEMOD_FLAG_V2_PACKED))
 	       ? "demod_kernel_rw (v2 register window, packed)" : "demod_kernel_rw (v2 register window, float)";
 }
 

@@ -164,7 +164,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		   arguments, lane 1 takes the cosine's */
 		const float a0 = -pll.phase;
 		const float a1 = (float)((double)a0 + MD_HALF_PI_D);
-		const float sc = md_fast_sin(lane == 1 ? a1 : a0);
+		const float sc = md_fast_sin<false>(lane == 1 ? a1 : a0);      /* |phase| < 2pi + fmax, fmax < 6: mdemod_create only picks this kernel then */
 		const float sn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), 0));
 		const float cs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), 1));
 		bool emit = true;
@@ -178,7 +178,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 			out_re = y.re * cs - y.im * sn;
 			out_im = y.re * sn + y.im * cs;
 		}
-		md_nco_advance(pll.phase, pll.freq);
+		md_nco_advance<true>(pll.phase, pll.freq);
 		if (emit) {
 			/* only the LAST symbol fired inside one input sample survives (demod.c:33-47: `*sample` and `ret` are overwritten) */
 			if (same_sample) {

@@ -80,7 +80,7 @@ ROTP_PUT16(0, WIDE) ROTP_PUT16(1, MID) ROTP_PUT16(2, FAR) ROTP_PUT8(0, WIDE) ROT
 template <int GEO, int FMT>
 struct WinP {
 	static constexpr int kTaps = GeoP<GEO>::kTaps, kBack = kTaps - 1, NW = GeoP<GEO>::NW, SLIDE = 16, AMAX = NW - kTaps,
-	                     MAXSL = GeoP<GEO>::MAXSL, BLOCK = GeoP<GEO>::BLOCK, NCH = NW / SLIDE, GD = FMT == 16 ? 16 : 8;
+	                     MAXSL = GeoP<GEO>::MAXSL, BLOCK = GeoP<GEO>::BLOCK, NCH = NW / SLIDE, GD = FMT == 16 ? 16 : 8, REGSLOTS = 0;
 	static_assert(kBack % SLIDE == 0 && NW % SLIDE == 0, "history and window are whole chunks");
 
 	/* wavfile.c:58-69 backwards: the raw sample a history value (an exactly converted input sample) came from */

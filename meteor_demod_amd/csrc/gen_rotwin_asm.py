@@ -25,11 +25,14 @@ import os
 import sys
 
 WB = 96          # first window register
-CB = 80          # coefficient buffers: 4 x 4 registers
+CB = None        # coefficient buffers: NBUF x 4 registers below the window (set below)
 NCH = 10         # chunks of 8 slots
 # coefficient prefetch of the FIR: 0 = one load and one s_waitcnt per half-chunk, three half-chunks ahead; 1 = two loads and one
 # s_waitcnt per chunk, one chunk ahead at the wait (half the s_waitcnt instructions)
 PAIRWAIT = int(os.environ.get("ROTWIN_PAIRWAIT", "1"))
+DC = int(os.environ.get("ROTWIN_DC", "1"))       # with PAIRWAIT: chunks of coefficients in flight behind the one being used (2 * (DC + 1) buffers)
+NBUF = 2 * (DC + 1) if PAIRWAIT else 4
+CB = 96 - 4 * NBUF
 # the FIR's tap: 0 = v_mul x2 + v_add x2; 1 = v_pk_mul_f32 + v_pk_add_f32 on (re, im) pairs (the default); 2 = v_pk_mul_f32 +
 # v_add x2; 3 = v_mul x2 + v_pk_add_f32.  2 and 3 keep their products in v[TB:TB+3] (taken from the compiler like the coefficient
 # buffers).  All four are the reference's two rounded products and two rounded sums per tap (filter.c:58-59); measured on
@@ -37,7 +40,7 @@ PAIRWAIT = int(os.environ.get("ROTWIN_PAIRWAIT", "1"))
 # issues one instruction per ~4.7 cycles whatever it is, and the packed form halves the FIR's instruction count while its
 # longer pipe time is paid by the other wave of the SIMD.
 PK = int(os.environ.get("ROTWIN_PK", "1"))
-TB = 76          # product temporaries of the mixed forms
+TB = CB - 4      # product temporaries of the mixed forms
 CHB = 32         # bytes of coefficients per chunk
 
 
@@ -63,12 +66,12 @@ def fir():
     """Half-chunks of 4 taps: one ds_read_b128 each, four rotating buffers of 4 registers, three half-chunks ahead."""
     NH, D = 2 * NCH, 3
     def load(h):
-        b = CB + 4 * (h % 4)
+        b = CB + 4 * (h % NBUF)
         return "ds_read_b128 v[%d:%d], %%[addr] offset:%d" % (b, b + 3, 16 * h)
     L = []
     if PK in (0, 2):
         L += ["v_mov_b32 %[ar], 0", "v_mov_b32 %[ai], 0"]
-    L += [load(h) for h in range(2 if PAIRWAIT else D)]  # on their way before the jump (the same for every rotation)
+    L += [load(h) for h in range(2 * DC if PAIRWAIT else D)]  # on their way before the jump (the same for every rotation)
     L += jump("fir", NCH)
     for r in range(NCH):
         L += [".Lfir_%d_%%=:" % r]
@@ -76,7 +79,7 @@ def fir():
             c = h // 2
             if PAIRWAIT:
                 if h % 2 == 0:
-                    L += [load(x) for x in (h + 2, h + 3) if x < NH]
+                    L += [load(x) for x in (h + 2 * DC, h + 2 * DC + 1) if x < NH]
             elif h + D < NH:
                 L += [load(h + D)]
             # chunk 0 = half-chunks 0 and 1: each is jumped over on its own, so that half-chunk 1's prefetch is still issued
@@ -86,10 +89,10 @@ def fir():
                 L += ["s_bitcmp1_b32 %[flags], 1", "s_cbranch_scc1 .Lfir_%d_s9_%%=" % r]
             if PAIRWAIT:
                 if h % 2 == 0:
-                    L += ["s_waitcnt lgkmcnt(%d)" % (2 if h + 2 < NH else 0)]
+                    L += ["s_waitcnt lgkmcnt(%d)" % min(2 * DC, max(0, NH - 2 - h))]
             else:
                 L += ["s_waitcnt lgkmcnt(%d)" % min(D, NH - 1 - h)]
-            hb = CB + 4 * (h % 4)
+            hb = CB + 4 * (h % NBUF)
             wq = WB + 16 * ((c + r) % NCH) + 8 * (h & 1)
             if PK == 1:
                 # (re, im) of a slot are an even-aligned register pair, the coefficient is broadcast with op_sel
@@ -170,7 +173,7 @@ def main():
     for kind in ("s16", "u8", "f32"):
         out.append("#define ROTWIN_PUT_%s_ASM \\\n" % kind.upper() + q(put(kind)).replace("\n", " \\\n"))
     # clobber lists
-    out.append("#define ROTWIN_COEF_CLOBBERS " + ", ".join('"v%d"' % i for i in range(TB if PK in (2, 3) else CB, CB + 16)))
+    out.append("#define ROTWIN_COEF_CLOBBERS " + ", ".join('"v%d"' % i for i in range(TB if PK in (2, 3) else CB, WB)))
     out.append("#endif")
     sys.stdout.write("\n".join(out) + "\n")
 

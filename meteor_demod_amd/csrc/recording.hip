@@ -738,6 +738,7 @@ mdemod_recording_default_opts(mdemod_recording_opts *o)
 	o->acquire_samples = o->frame_samples = o->settle_samples = 0xFFFFFFFFu;
 	o->pilot_block = 65536; o->pilot_margin_symbols = 0xFFFFFFFFu;
 	o->max_pilot_samples = 0xFFFFFFFFFFFFFFFFull; o->match_symbols = 192; o->repair = 1; o->carrier_seed = 1; o->clock_seed = 0;
+	o->debug = 0; o->debug_tile = -1;
 }
 
 namespace {
@@ -923,7 +924,7 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 	rep->exact_symbols = n_pilot_sym;
 	rep->pilot_seconds = po.seconds;
 	const auto t_tiles = std::chrono::steady_clock::now();
-	const bool dbg = getenv("MDEMOD_RECORDING_DEBUG") != nullptr;
+	const bool dbg = o.debug != 0;
 	auto mark = [&](const char *what) {
 		if (!dbg) return;
 		(void)hipStreamSynchronize(st);
@@ -1260,7 +1261,7 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 			   it were repaired for it.) */
 			const double steps = (tt - t_prev) / steps_per_nco, off_grid = std::fabs(steps - std::nearbyint(steps));
 			const bool trusted = off_grid <= 0.2 || i - i_prev > 4;
-			if (dbg && getenv("MDEMOD_RECORDING_TRACE_TILE") && std::llabs(static_cast<long long>(i) - atoll(getenv("MDEMOD_RECORDING_TRACE_TILE"))) <= 2)
+			if (dbg && o.debug_tile >= 0 && std::llabs(static_cast<long long>(i) - static_cast<long long>(o.debug_tile)) <= 2)
 				fprintf(stderr, "[recording]   trace %zu (from %zu): theta %.5f t %.3f (dt %.3f steps = %.4f nco) f %.9g res %.4f R %d t_freq %.9g t_phase %.5f locked %d pll_freq %.9g\n", i, i_prev, th, tt, tt - t_prev,
 				        steps, f_at(t_mid), res, accr, static_cast<double>(qs[i].t_freq), static_cast<double>(qs[i].t_phase), qs[i].pll_locked, static_cast<double>(qs[i].pll_freq));
 			if (dbg && (std::fabs(res) > 0.5 || !trusted)) fprintf(stderr, "[recording]   frame %zu: dead-reckoning residual %.3f rad, %.3f of a step off the symbols%s\n", i, res, off_grid, trusted ? "" : " (not chained through)");
@@ -1338,10 +1339,10 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 		for (size_t i = 1; i < T; i++) C[i] = (C[i - 1] + rot[i]) & 3;
 		bool odd = false;
 		for (size_t i = 1; i < T; i++) odd = odd || (C[i] & 1);
-		if (getenv("MDEMOD_RECORDING_DEBUG")) {
+		if (dbg) {
 			fprintf(stderr, "[recording] round %d: T=%zu tile=%u lead=%u+%u+%u\n", round, T, o.tile_samples, o.acquire_samples, o.frame_samples, o.settle_samples);
 			for (size_t i = 1; i < T; i++)
-				if (rot[i] || weak[i] || shift[i] || run[i] != 1 || getenv("MDEMOD_RECORDING_DEBUG")[0] == '2')
+				if (rot[i] || weak[i] || shift[i] || run[i] != 1 || o.debug >= 2)
 					fprintf(stderr, "[recording]   seam %zu: rot %d weak %d shift %d C %d run %d R %d cnt_pre %u cnt1 %u locked %d f0 %.6f q %.1f\n", i, rot[i], weak[i], shift[i], C[i], (int)run[i], R[i],
 					        cnt_pre[i], cnt1[i], status_body.size() > i ? status_body[i].locked : -1, fbar[i], 0.0);
 		}
@@ -1530,7 +1531,7 @@ mdemod_demodulate_recording_host(const mdemod_params *params, const mdemod_recor
                                  mdemod_recording_report *rep)
 {
 	if (!params || !iq_host || !soft_host || !rep) return MDEMOD_ERR_PARAM;
-	const bool dbg = getenv("MDEMOD_RECORDING_DEBUG") != nullptr;
+	const bool dbg = opts && opts->debug != 0;
 	const auto t_in = std::chrono::steady_clock::now();
 	auto mark = [&](const char *what) {
 		if (dbg) fprintf(stderr, "[recording host] %8.2f ms  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count() * 1e3, what);

@@ -109,6 +109,9 @@ rotwin_demod(const DemodLaunch &L)
 	typedef typename RFmt<FMT>::sample_t sample_t;
 	constexpr int kBack = W::kBack, SLIDE = W::SLIDE, AMAX = W::AMAX, BLOCK = W::BLOCK, NCH = W::NW / W::SLIDE, GPS = W::SLIDE / 4;
 	constexpr int NST = GPS * W::MAXSL;                /* granules staged ahead of the window */
+	/* per-lane loop state that is only touched once per firing lives in LDS slots [field][lane] unless the window policy has
+	 * registers to spare for it (W::REGSLOTS: bit 0 err, 1 t_prev, 2 flags, 3 sample index of the last symbol) */
+	constexpr int RS = W::REGSLOTS;
 	constexpr int PRIO = 1;                      /* the scalar stage of a firing (and the symbol clock inside it) at raised wave priority, the FIR and the slide at 0: see demod_kernel_rw.hip */
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -141,6 +144,16 @@ rotwin_demod(const DemodLaunch &L)
 	float t_phase = 0.0f, t_freq = C.t_center;
 	int dual_state = 1;
 	float r_gain = 1.0f, r_bias_re = 0.0f, r_bias_im = 0.0f, r_phase = 0.0f, r_freq = 0.0f;
+	float r_err = 1000.0f, r_tprev = 0.0f;
+	int r_flags = 0, r_lastv = -1;
+	auto ld_err = [&]() -> float { return (RS & 1) ? r_err : sl[S_ERR * 64]; };
+	auto st_err = [&](float v) { if (RS & 1) r_err = v; else sl[S_ERR * 64] = v; };
+	auto ld_tprev = [&]() -> float { return (RS & 2) ? r_tprev : sl[S_TPREV * 64]; };
+	auto st_tprev = [&](float v) { if (RS & 2) r_tprev = v; else sl[S_TPREV * 64] = v; };
+	auto ld_flags = [&]() -> int { return (RS & 4) ? r_flags : sli[S_FLAGS * 64]; };
+	auto st_flags = [&](int v) { if (RS & 4) r_flags = v; else sli[S_FLAGS * 64] = v; };
+	auto ld_lastv = [&]() -> int { return (RS & 8) ? r_lastv : sli[S_LASTV * 64]; };
+	auto st_lastv = [&](int v) { if (RS & 8) r_lastv = v; else sli[S_LASTV * 64] = v; };
 	{
 		float err = 1000.0f, t_prev = 0.0f, inph = 0.0f;
 		int fl = MDEMOD_FLAG_UPDOWN_POS | (1 << MDEMOD_FLAG_DUAL_SHIFT);
@@ -152,10 +165,10 @@ rotwin_demod(const DemodLaunch &L)
 			inph = L.st.inphase[stream];
 		}
 		dual_state = (fl >> MDEMOD_FLAG_DUAL_SHIFT) & 3;
-		sl[S_ERR * 64] = err;
-		sli[S_FLAGS * 64] = fl & 7;
-		sl[S_TPREV * 64] = t_prev; sl[S_INPHASE * 64] = inph;
-		sli[S_EVCALL * 64] = 0; sli[S_FIRSTLOCK * 64] = -1; sli[S_LASTV * 64] = -1;
+		st_err(err);
+		st_flags(fl & 7);
+		st_tprev(t_prev); sl[S_INPHASE * 64] = inph;
+		sli[S_EVCALL * 64] = 0; sli[S_FIRSTLOCK * 64] = -1; st_lastv(-1);
 	}
 
 	/* ---- window: the first kBack slots = history ([stream][kBack] float pairs), the rest = the first granules of the block ---- */
@@ -269,10 +282,10 @@ rotwin_demod(const DemodLaunch &L)
 #endif
 
 			y = md_agc(y, r_gain, r_bias_re, r_bias_im);
-			int fl = sli[S_FLAGS * 64];
+			int fl = ld_flags();
 			PllState pll;
 			pll.phase = r_phase; pll.freq = r_freq;
-			pll.err = sl[S_ERR * 64];
+			pll.err = ld_err();
 			pll.locked = fl & 1; pll.locked_once = (fl >> 1) & 1; pll.updown = (fl & 4) ? 1 : -1;
 
 			const float sn = md_fast_sin<false>(-pll.phase);
@@ -293,12 +306,12 @@ rotwin_demod(const DemodLaunch &L)
 
 			if (emit) {
 				/* demod.c:33-47: only the LAST symbol fired inside one input sample survives (see demod_kernel_rw.hip) */
-				const bool again = (v_cur == sli[S_LASTV * 64]);
-				sli[S_LASTV * 64] = v_cur;
+				const bool again = (v_cur == ld_lastv());
+				st_lastv(v_cur);
 				if (__builtin_expect(__any(again), 0)) { if (again) sym_call--; }
-				float t_prev = sl[S_TPREV * 64];
+				float t_prev = ld_tprev();
 				md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);
-				sl[S_TPREV * 64] = t_prev;
+				st_tprev(t_prev);
 			}
 			/* the clock's way to the NEXT firing starts here: a chain of ~20 dependent adds that needs nothing but the timing
 			 * update, next to the Costas update, the AGC's square root and the quantiser, which need nothing from it */
@@ -344,8 +357,8 @@ rotwin_demod(const DemodLaunch &L)
 				}
 			}
 			r_phase = pll.phase; r_freq = pll.freq;
-			sl[S_ERR * 64] = pll.err;
-			sli[S_FLAGS * 64] = (fl & 8) | (pll.locked ? 1 : 0) | (pll.locked_once ? 2 : 0) | (pll.updown > 0 ? 4 : 0);
+			st_err(pll.err);
+			st_flags((fl & 8) | (pll.locked ? 1 : 0) | (pll.locked_once ? 2 : 0) | (pll.updown > 0 ? 4 : 0));
 			if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
 			ROT_TICK(3);
 		}
@@ -356,12 +369,12 @@ rotwin_demod(const DemodLaunch &L)
 		       (unsigned long long)tacc[0], (unsigned long long)tacc[1], (unsigned long long)tacc[2], (unsigned long long)tacc[3], (unsigned long long)tacc[4]);
 #endif
 
-	if (guard == 0) sli[S_FLAGS * 64] |= 8;                          /* watchdog fired: reported as overflow */
+	if (guard == 0) st_flags(ld_flags() | 8);                        /* watchdog fired: reported as overflow */
 
 	uint32_t stream_e = stream;
 	asm volatile("" : "+v"(stream_e));
 	int8_t *soft_e = L.soft + (size_t)stream_e * L.soft_stride * 2;
-	int overflow = (sli[S_FLAGS * 64] >> 3) & 1;
+	int overflow = (ld_flags() >> 3) & 1;
 
 	/* ---- flush the ring ---- */
 	if (valid) {
@@ -381,11 +394,11 @@ rotwin_demod(const DemodLaunch &L)
 
 	/* ---- store state ---- */
 	if (valid) {
-		const int fl = sli[S_FLAGS * 64];
+		const int fl = ld_flags();
 		L.st.agc_gain[stream_e] = r_gain; L.st.agc_bias_re[stream_e] = r_bias_re; L.st.agc_bias_im[stream_e] = r_bias_im;
-		L.st.pll_phase[stream_e] = r_phase; L.st.pll_freq[stream_e] = r_freq; L.st.pll_err[stream_e] = sl[S_ERR * 64];
+		L.st.pll_phase[stream_e] = r_phase; L.st.pll_freq[stream_e] = r_freq; L.st.pll_err[stream_e] = ld_err();
 		L.st.flags[stream_e] = (fl & 7) | (dual_state << MDEMOD_FLAG_DUAL_SHIFT);
-		L.st.t_phase[stream_e] = t_phase; L.st.t_freq[stream_e] = t_freq; L.st.t_prev[stream_e] = sl[S_TPREV * 64];
+		L.st.t_phase[stream_e] = t_phase; L.st.t_freq[stream_e] = t_freq; L.st.t_prev[stream_e] = ld_tprev();
 		L.st.inphase[stream_e] = sl[S_INPHASE * 64];
 		const uint64_t nsym0 = L.st.n_symbols[stream_e];
 		const int first_lock_call = sli[S_FIRSTLOCK * 64];

@@ -57,7 +57,7 @@ class DemodConfig:
     def to_c(self, n_streams: int = 1, device: int = 0) -> MdemodParams:
         return MdemodParams(self.pll_bw, self.sym_bw, int(self.samplerate), int(self.symrate),
                             int(self.interp_factor), int(self.rrc_order), int(bool(self.oqpsk)),
-                            self.freq_max, int(self.bps), int(device), int(n_streams), 0)
+                            self.freq_max, int(self.bps), int(device), int(n_streams), _capi.variant_flags_from_env())
 
     @property
     def taps(self) -> int:

@@ -10,6 +10,8 @@ library is the one implementation, tested against the serial oracle.)
 """
 from __future__ import annotations
 
+import os as _os
+
 import numpy as np
 
 AUTO = 0xFFFFFFFF
@@ -96,7 +98,8 @@ def demodulate_recording_native(cfg, iq, tile_samples: int = 0, acquire_samples:
         raise ValueError("carrier_seed and clock_seed are 'pilot' or 'spectrum'")
     opts = _capi.MdemodRecordingOpts(int(tile_samples), int(acquire_samples), int(frame_samples), int(settle_samples),
                                      int(pilot_block), int(pilot_margin_symbols), int(max_pilot_samples), int(match_symbols),
-                                     int(bool(repair)), 1 if carrier_seed == "spectrum" else 0, 0 if clock_seed == "spectrum" else 1)
+                                     int(bool(repair)), 1 if carrier_seed == "spectrum" else 0, 0 if clock_seed == "spectrum" else 1,
+                                     int(_os.environ.get("MDEMOD_RECORDING_DEBUG", "0") or 0), int(_os.environ.get("MDEMOD_RECORDING_TRACE_TILE", "-1")))
     n = int(iq.shape[0])
     p = cfg.to_c(1, device)
     cap = int(soft_capacity) or int(n * cfg.symrate / cfg.samplerate * 1.05) + 65536   # stitched output: nominal rate + slack (checked by the callee)
