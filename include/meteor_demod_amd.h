@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MDEMOD_ABI_VERSION 2
+#define MDEMOD_ABI_VERSION 3
 
 /* Error codes (the reference surfaces none: demod_init returns void and drops
  * filter_init_rrc's status, demod.c:14). */

@@ -34,12 +34,12 @@ def test_header_symbols_are_all_exported():
 
 def test_abi_version_and_struct_layouts():
     lib = _capi.lib()
-    assert lib.mdemod_abi_version() == 2
+    assert lib.mdemod_abi_version() == 3
     assert C.sizeof(_capi.MdemodParams) == 48
     assert C.sizeof(_capi.MdemodStatus) == 56
     assert C.sizeof(_capi.MdemodLockEvent) == 16
     assert C.sizeof(_capi.MdemodStreamState) == 80
-    assert C.sizeof(_capi.MdemodRecordingOpts) == 48 and C.sizeof(_capi.MdemodRecordingReport) == 112
+    assert C.sizeof(_capi.MdemodRecordingOpts) == 56 and C.sizeof(_capi.MdemodRecordingReport) == 112
     # the C compiler agrees with the ctypes mirrors
     import subprocess, tempfile
     from conftest import ROOT
@@ -50,7 +50,7 @@ def test_abi_version_and_struct_layouts():
         (Path(td) / "s.c").write_text(src)
         subprocess.run(["gcc", "-I", str(ROOT / "include"), str(Path(td) / "s.c"), "-o", str(Path(td) / "s")], check=True)
         out = subprocess.run([str(Path(td) / "s")], capture_output=True, text=True, check=True).stdout.split()
-    assert [int(x) for x in out] == [48, 56, 16, 80, 48, 112]
+    assert [int(x) for x in out] == [48, 56, 16, 80, 56, 112]
     assert lib.mdemod_strerror(-3).decode().startswith("HIP")
 
 
