@@ -14,7 +14,9 @@
  * demodulated as one batch, one stream per file (outputs <input>.s); --tiled demodulates
  * ONE file on many GPU lanes as overlapped tiles (mdemod_demodulate_recording_host: the head
  * up to PLL lock + settling is the reference's own serial run, the rest agrees with it
- * statistically).
+ * statistically).  --devices a,b,... (default: every GPU of the node when there is more than one file) starts
+ * one worker thread and one library context per GPU: file i goes to GPU i mod G, each worker demodulates its files as its own
+ * batch (exact mode) or one after the other (--tiled) and writes its own outputs - no data crosses GPUs.
  *
  * Status line: the reference's "(%5.1f%%) Carrier: ... Symbol rate: ... Locked: ..." (main.c:249-261) from the status
  * snapshot of stream 0, at most once per -R milliseconds (default 2000 with -B, 50 without: main.c:144), "\n" separated
@@ -58,7 +60,8 @@ static const struct option longopts[] = {
 	{ "refresh-rate", 1, NULL, 'R' }, { "symrate", 1, NULL, 'r' }, { "stdout", 0, NULL, 0x00 },
 	{ "samplerate", 1, NULL, 's' }, { "bps", 1, NULL, 'S' },      { "version", 0, NULL, 'v' },
 	{ "device", 1, NULL, 0x01 },    { "tiled", 0, NULL, 0x02 },   { "tile-samples", 1, NULL, 0x03 },
-	{ "pilot-margin", 1, NULL, 0x04 }, { "carrier-seed", 1, NULL, 0x05 }, { NULL, 0, NULL, 0 }
+	{ "pilot-margin", 1, NULL, 0x04 }, { "carrier-seed", 1, NULL, 0x05 }, { "devices", 1, NULL, 0x06 }, { "plan", 0, NULL, 0x07 },
+	{ NULL, 0, NULL, 0 }
 };
 
 /* utils.c:60-86: number with optional k/M suffix, truncated to int, returned as float */
@@ -92,7 +95,9 @@ usage(const char *prog)
 	        "   -s, --samplerate <rate> Sample rate of raw input\n"
 	        "       --bps <bits>        Bits per sample of raw input (8, 16, 32)\n"
 	        "       --stdout            Write soft symbols to stdout (implies -B -q)\n"
-	        "       --device <n>        HIP device ordinal (default 0)\n"
+	        "       --device <n>        HIP device ordinal (one GPU)\n"
+	        "       --devices <a,b,..>  GPUs to spread the input files over, file i on GPU i mod G (default: all\n"
+	        "                           GPUs of the node when several files are given); --plan prints the assignment\n"
 	        "       --tiled             Each file on many lanes as overlapped tiles (fast, not bit-exact\n"
 	        "                           after the head); --tile-samples <n>, --pilot-margin <symbols>,\n"
 	        "                           --carrier-seed spectrum|pilot (default spectrum: tiles follow Doppler)\n"
@@ -170,113 +175,29 @@ now_ms(void)
 	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-int
-main(int argc, char **argv)
+
+/* What one worker (= one GPU) needs: its files and a copy of the options. */
+struct worker {
+	pthread_t   thr;
+	int         index;                   /* worker 0 prints the status line (stream 0 of ITS batch, as the reference prints its one stream) */
+	int         n_files;
+	struct stream_io *io;                /* this worker's files (a contiguous copy; the originals are not touched again) */
+	mdemod_params p;                     /* p.device, p.n_streams are this worker's */
+	int         tiled, quiet, batch, update_interval, tile_samples, pilot_margin, carrier_seed;
+	int         rc;                      /* exit code of this worker: 0 ok, 1 host error, 2 library error */
+};
+
+/* ---- --tiled: each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file ---- */
+static int
+run_tiled(struct worker *w)
 {
-	float pll_bw = MDEMOD_DEFAULT_PLL_BW, symrate = MDEMOD_DEFAULT_SYM_RATE, freq_max_delta = -1;
-	int rrc_order = MDEMOD_DEFAULT_RRC_ORDER, interp = MDEMOD_DEFAULT_INTERP;
-	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0, tiled = 0;
-	int tile_samples = 0, pilot_margin = -1, carrier_seed = -1, update_interval = -1;
-	const char *output_fname = NULL;
-	int c;
-
-	while ((c = getopt_long(argc, argv, "a:Bb:d:f:hm:o:O:qR:r:s:S:v", longopts, NULL)) != -1) {
-		switch (c) {
-		case 0x00: stdout_mode = 1; break;
-		case 0x01: device = atoi(optarg); break;
-		case 0x02: tiled = 1; break;
-		case 0x03: tile_samples = (int)human_number(optarg); break;
-		case 0x04: pilot_margin = (int)human_number(optarg); break;
-		case 0x05:
-			if (!strcmp(optarg, "spectrum")) carrier_seed = 1;
-			else if (!strcmp(optarg, "pilot")) carrier_seed = 0;
-			else { fprintf(stderr, "--carrier-seed: spectrum or pilot\n"); return 1; }
-			break;
-		case 'b': pll_bw = human_number(optarg); break;
-		case 'B': batch = 1; break;
-		case 'd': freq_max_delta = human_number(optarg); break;
-		case 'f': rrc_order = atoi(optarg); break;
-		case 'h': usage(argv[0]); return 0;
-		case 'm': if (!strcmp(optarg, "oqpsk")) oqpsk = 1; break;     /* unknown modes stay QPSK, main.c:104 */
-		case 'o': output_fname = optarg; break;
-		case 'O': interp = atoi(optarg); break;
-		case 'q': quiet = 1; break;
-		case 'R': update_interval = atoi(optarg); break;              /* main.c:116 */
-		case 'r': symrate = human_number(optarg); break;
-		case 's': samplerate = (int)human_number(optarg); break;
-		case 'S': bps = atoi(optarg); break;
-		case 'v': printf("meteor_demod_amd (MI355X) ABI %u\n", mdemod_abi_version()); return 0;
-		default: usage(argv[0]); return 1;
-		}
-	}
-	freq_max_delta = (float)(freq_max_delta * (2 * M_PI) / symrate);       /* main.c:136 */
-	if (argc - optind < 1) { usage(argv[0]); return 1; }
-	if (update_interval < 0) update_interval = batch ? 2000 : 50;                 /* main.c:144 (before batch is forced below) */
-	if (stdout_mode) { batch = 1; quiet = 1; }
-	for (int i = optind; i < argc; i++) if (!strcmp(argv[i], "-")) batch = 1;     /* stdin forces batch: main.c:157 */
-
-	const int n_files = argc - optind;
-	if (n_files > 1 && (output_fname || stdout_mode)) {
-		fprintf(stderr, "-o/--stdout need a single input file\n");
-		return 1;
-	}
-	struct stream_io *io = calloc((size_t)n_files, sizeof(*io));
-	if (!io) return 1;
-
-	for (int i = 0; i < n_files; i++) {
-		io[i].in_name = argv[optind + i];
-		io[i].in = !strcmp(io[i].in_name, "-") ? stdin : fopen(io[i].in_name, "rb");
-		if (!io[i].in) { fprintf(stderr, "Could not open input file\n"); return 1; }
-		int sr = samplerate, b = bps;
-		if (parse_wav(io[i].in, &sr, &b)) fseek(io[i].in, 0, SEEK_SET);    /* raw: main.c:164-166 */
-		if (i == 0) { samplerate = sr; bps = b; }
-		else if (sr != samplerate || b != bps) { fprintf(stderr, "all inputs of a batch must share rate and format\n"); return 1; }
-	}
-	if (samplerate < 0) {
-		fprintf(stderr, "Could not auto-detect sample rate. Please specify it with -s <samplerate>\n");
-		return 1;
-	}
-	if (!bps) { fprintf(stderr, "Could not auto-detect bits per sample, assuming 16\n"); bps = 16; }
-	/* any other sample size: the reference's reader returns 0 on the first sample (wavfile.c:71-73) and it writes an empty
-	 * output file; same here, without touching the GPU */
-	const int bps_ok = (bps == 8 || bps == 16 || bps == 32);
-	if (!bps_ok) fprintf(stderr, "%d bits per sample: nothing to demodulate (8, 16 or 32 expected)\n", bps);
-
-	for (int i = 0; i < n_files; i++) {
-		if (stdout_mode) { io[i].out = stdout; continue; }
-		if (n_files == 1 && output_fname) io[i].out_name = strdup(output_fname);
-		else if (n_files == 1) {                                           /* utils.c:8: LRPT_%Y_%m_%d-%H_%M.s */
-			char buf[64]; time_t t = time(NULL);
-			strftime(buf, sizeof(buf), "LRPT_%Y_%m_%d-%H_%M.s", localtime(&t));
-			io[i].out_name = strdup(buf);
-		} else {
-			io[i].out_name = malloc(strlen(io[i].in_name) + 3);
-			sprintf(io[i].out_name, "%s.s", io[i].in_name);
-		}
-		io[i].out = fopen(io[i].out_name, "wb");
-		if (!io[i].out) { fprintf(stderr, "Could not open output file\n"); return 1; }
-	}
-
-	if (!bps_ok) {
-		for (int i = 0; i < n_files; i++) { if (io[i].out != stdout) fclose(io[i].out); if (io[i].in != stdin) fclose(io[i].in); }
-		return 0;
-	}
-	/* file lengths for the progress figure of the status line (main.c:189-193) */
-	for (int i = 0; i < n_files; i++) {
-		if (io[i].in == stdin) continue;
-		const long here = ftell(io[i].in);
-		if (here < 0 || fseek(io[i].in, 0, SEEK_END)) continue;
-		const long end = ftell(io[i].in);
-		io[i].file_len = end > 0 ? (unsigned long)end : 0;
-		fseek(io[i].in, here, SEEK_SET);
-	}
-	/* demod_init(pll_bw, SYM_BW, samplerate, symrate, interp, order, oqpsk, freq_max): main.c:187 */
-	mdemod_params p;
-	memset(&p, 0, sizeof(p));
-	p.pll_bw = pll_bw; p.sym_bw = MDEMOD_DEFAULT_SYM_BW; p.samplerate = samplerate; p.symrate = (int)symrate;
-	p.interp_factor = interp; p.rrc_order = rrc_order; p.oqpsk = oqpsk; p.freq_max = freq_max_delta;
-	p.bps = bps; p.device = device; p.n_streams = (uint32_t)n_files;
-	if (tiled) {
+	struct stream_io *io = w->io;
+	const int n_files = w->n_files, quiet = w->quiet, bps = w->p.bps, samplerate = w->p.samplerate;
+	const float symrate = (float)w->p.symrate;
+	const int tile_samples = w->tile_samples, pilot_margin = w->pilot_margin, carrier_seed = w->carrier_seed;
+	mdemod_params p = w->p;
+	int device = w->p.device;
+	{
 		/* ---- each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file ---- */
 		const int timing = getenv("MDEMOD_CLI_TIMING") != NULL;       /* where the wall time of a --tiled run goes (stderr) */
 		pthread_t init_thr;
@@ -341,6 +262,17 @@ main(int argc, char **argv)
 		return 0;
 	}
 
+}
+
+/* ---- exact mode: this worker's files as ONE batch, one stream per file, block by block (main.c:303-316) ---- */
+static int
+run_exact(struct worker *w)
+{
+	struct stream_io *io = w->io;
+	const int n_files = w->n_files, quiet = w->quiet || w->index != 0, batch = w->batch, update_interval = w->update_interval;
+	const int bps = w->p.bps, samplerate = w->p.samplerate, interp = w->p.interp_factor, oqpsk = w->p.oqpsk;
+	const float symrate = (float)w->p.symrate;
+	mdemod_params p = w->p;
 	mdemod_ctx *ctx = NULL;
 	int rc = mdemod_create(&p, &ctx);
 	if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_create: %s\n", mdemod_strerror(rc)); close_all(io, n_files); return 2; }
@@ -411,4 +343,189 @@ main(int argc, char **argv)
 	}
 	mdemod_destroy(ctx);                                                          /* demod_deinit: main.c:273 */
 	return 0;
+}
+
+static void *
+worker_main(void *arg)
+{
+	struct worker *w = arg;
+	w->rc = w->tiled ? run_tiled(w) : run_exact(w);
+	return NULL;
+}
+
+/* "0,2,3" -> device ordinals; returns the count (0 on a malformed list) */
+static int
+parse_devices(const char *s, int *out, int cap)
+{
+	int n = 0;
+	while (*s && n < cap) {
+		char *end;
+		const long v = strtol(s, &end, 10);
+		if (end == s || v < 0) return 0;
+		out[n++] = (int)v;
+		if (*end == ',') end++;
+		else if (*end) return 0;
+		s = end;
+	}
+	return n;
+}
+
+#define MAX_DEVICES 64
+
+int
+main(int argc, char **argv)
+{
+	float pll_bw = MDEMOD_DEFAULT_PLL_BW, symrate = MDEMOD_DEFAULT_SYM_RATE, freq_max_delta = -1;
+	int rrc_order = MDEMOD_DEFAULT_RRC_ORDER, interp = MDEMOD_DEFAULT_INTERP;
+	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0, tiled = 0;
+	int tile_samples = 0, pilot_margin = -1, carrier_seed = -1, update_interval = -1;
+	const char *output_fname = NULL;
+	int devs[MAX_DEVICES], n_dev = 0, plan = 0;
+	int c;
+
+	while ((c = getopt_long(argc, argv, "a:Bb:d:f:hm:o:O:qR:r:s:S:v", longopts, NULL)) != -1) {
+		switch (c) {
+		case 0x00: stdout_mode = 1; break;
+		case 0x01: device = atoi(optarg); devs[0] = device; n_dev = 1; break;
+		case 0x06:
+			n_dev = parse_devices(optarg, devs, MAX_DEVICES);
+			if (!n_dev) { fprintf(stderr, "--devices: a comma separated list of GPU ordinals\n"); return 1; }
+			break;
+		case 0x07: plan = 1; break;
+		case 0x02: tiled = 1; break;
+		case 0x03: tile_samples = (int)human_number(optarg); break;
+		case 0x04: pilot_margin = (int)human_number(optarg); break;
+		case 0x05:
+			if (!strcmp(optarg, "spectrum")) carrier_seed = 1;
+			else if (!strcmp(optarg, "pilot")) carrier_seed = 0;
+			else { fprintf(stderr, "--carrier-seed: spectrum or pilot\n"); return 1; }
+			break;
+		case 'b': pll_bw = human_number(optarg); break;
+		case 'B': batch = 1; break;
+		case 'd': freq_max_delta = human_number(optarg); break;
+		case 'f': rrc_order = atoi(optarg); break;
+		case 'h': usage(argv[0]); return 0;
+		case 'm': if (!strcmp(optarg, "oqpsk")) oqpsk = 1; break;     /* unknown modes stay QPSK, main.c:104 */
+		case 'o': output_fname = optarg; break;
+		case 'O': interp = atoi(optarg); break;
+		case 'q': quiet = 1; break;
+		case 'R': update_interval = atoi(optarg); break;              /* main.c:116 */
+		case 'r': symrate = human_number(optarg); break;
+		case 's': samplerate = (int)human_number(optarg); break;
+		case 'S': bps = atoi(optarg); break;
+		case 'v': printf("meteor_demod_amd (MI355X) ABI %u\n", mdemod_abi_version()); return 0;
+		default: usage(argv[0]); return 1;
+		}
+	}
+	freq_max_delta = (float)(freq_max_delta * (2 * M_PI) / symrate);       /* main.c:136 */
+	if (argc - optind < 1) { usage(argv[0]); return 1; }
+	if (update_interval < 0) update_interval = batch ? 2000 : 50;                 /* main.c:144 (before batch is forced below) */
+	if (stdout_mode) { batch = 1; quiet = 1; }
+	for (int i = optind; i < argc; i++) if (!strcmp(argv[i], "-")) batch = 1;     /* stdin forces batch: main.c:157 */
+
+	const int n_files = argc - optind;
+	if (n_files > 1 && (output_fname || stdout_mode)) {
+		fprintf(stderr, "-o/--stdout need a single input file\n");
+		return 1;
+	}
+	if (plan) {
+		/* the sharding arithmetic, without touching files or GPUs: file i on the (i mod G)-th device of the list */
+		if (!n_dev) { fprintf(stderr, "--plan needs --devices\n"); return 1; }
+		const int g = n_dev > n_files ? n_files : n_dev;
+		for (int d = 0; d < g; d++) {
+			printf("device %d:", devs[d]);
+			for (int i = d; i < n_files; i += g) printf(" %s", argv[optind + i]);
+			printf("\n");
+		}
+		return 0;
+	}
+	struct stream_io *io = calloc((size_t)n_files, sizeof(*io));
+	if (!io) return 1;
+
+	for (int i = 0; i < n_files; i++) {
+		io[i].in_name = argv[optind + i];
+		io[i].in = !strcmp(io[i].in_name, "-") ? stdin : fopen(io[i].in_name, "rb");
+		if (!io[i].in) { fprintf(stderr, "Could not open input file\n"); return 1; }
+		int sr = samplerate, b = bps;
+		if (parse_wav(io[i].in, &sr, &b)) fseek(io[i].in, 0, SEEK_SET);    /* raw: main.c:164-166 */
+		if (i == 0) { samplerate = sr; bps = b; }
+		else if (sr != samplerate || b != bps) { fprintf(stderr, "all inputs of a batch must share rate and format\n"); return 1; }
+	}
+	if (samplerate < 0) {
+		fprintf(stderr, "Could not auto-detect sample rate. Please specify it with -s <samplerate>\n");
+		usage(argv[0]);                                                                /* main.c:170 */
+		return 1;
+	}
+	if (!bps) { fprintf(stderr, "Could not auto-detect bits per sample, assuming 16\n"); bps = 16; }
+	/* any other sample size: the reference's reader returns 0 on the first sample (wavfile.c:71-73) and it writes an empty
+	 * output file; same here, without touching the GPU */
+	const int bps_ok = (bps == 8 || bps == 16 || bps == 32);
+	if (!bps_ok) fprintf(stderr, "%d bits per sample: nothing to demodulate (8, 16 or 32 expected)\n", bps);
+
+	for (int i = 0; i < n_files; i++) {
+		if (stdout_mode) { io[i].out = stdout; continue; }
+		if (n_files == 1 && output_fname) io[i].out_name = strdup(output_fname);
+		else if (n_files == 1) {                                           /* utils.c:8: LRPT_%Y_%m_%d-%H_%M.s */
+			char buf[64]; time_t t = time(NULL);
+			strftime(buf, sizeof(buf), "LRPT_%Y_%m_%d-%H_%M.s", localtime(&t));
+			io[i].out_name = strdup(buf);
+		} else {
+			io[i].out_name = malloc(strlen(io[i].in_name) + 3);
+			sprintf(io[i].out_name, "%s.s", io[i].in_name);
+		}
+		io[i].out = fopen(io[i].out_name, "wb");
+		if (!io[i].out) { fprintf(stderr, "Could not open output file\n"); return 1; }
+	}
+
+	if (!quiet)                                                                        /* main.c:200 */
+		for (int i = 0; i < n_files; i++) printf("Input: %s, output: %s\n", io[i].in_name, stdout_mode ? "(stdout)" : io[i].out_name);
+	if (!bps_ok) {
+		for (int i = 0; i < n_files; i++) { if (io[i].out != stdout) fclose(io[i].out); if (io[i].in != stdin) fclose(io[i].in); }
+		return 0;
+	}
+	/* file lengths for the progress figure of the status line (main.c:189-193) */
+	for (int i = 0; i < n_files; i++) {
+		if (io[i].in == stdin) continue;
+		const long here = ftell(io[i].in);
+		if (here < 0 || fseek(io[i].in, 0, SEEK_END)) continue;
+		const long end = ftell(io[i].in);
+		io[i].file_len = end > 0 ? (unsigned long)end : 0;
+		fseek(io[i].in, here, SEEK_SET);
+	}
+	/* demod_init(pll_bw, SYM_BW, samplerate, symrate, interp, order, oqpsk, freq_max): main.c:187 */
+	mdemod_params p;
+	memset(&p, 0, sizeof(p));
+	p.pll_bw = pll_bw; p.sym_bw = MDEMOD_DEFAULT_SYM_BW; p.samplerate = samplerate; p.symrate = (int)symrate;
+	p.interp_factor = interp; p.rrc_order = rrc_order; p.oqpsk = oqpsk; p.freq_max = freq_max_delta;
+	p.bps = bps; p.device = device; p.n_streams = (uint32_t)n_files;
+	/* ---- one worker per GPU: file i on GPU i mod G (streams shard, nothing crosses GPUs) ---- */
+	if (n_dev == 0) {
+		int have = mdemod_device_count();
+		if (n_files < 2 || have < 2) { devs[0] = device; n_dev = 1; }
+		else for (n_dev = 0; n_dev < have && n_dev < MAX_DEVICES; n_dev++) devs[n_dev] = n_dev;
+	}
+	if (n_dev > n_files) n_dev = n_files;
+	struct worker *ws = calloc((size_t)n_dev, sizeof(*ws));
+	if (!ws) return 1;
+	for (int d = 0; d < n_dev; d++) {
+		struct worker *w = &ws[d];
+		w->index = d; w->p = p; w->p.device = devs[d];
+		w->tiled = tiled; w->quiet = quiet; w->batch = batch; w->update_interval = update_interval;
+		w->tile_samples = tile_samples; w->pilot_margin = pilot_margin; w->carrier_seed = carrier_seed;
+		for (int i = d; i < n_files; i += n_dev) w->n_files++;
+		w->io = calloc((size_t)w->n_files, sizeof(*w->io));
+		if (!w->io) return 1;
+		for (int i = d, k = 0; i < n_files; i += n_dev, k++) w->io[k] = io[i];
+		w->p.n_streams = (uint32_t)w->n_files;
+	}
+	if (n_dev == 1) {
+		worker_main(&ws[0]);
+	} else {
+		for (int d = 0; d < n_dev; d++)
+			if (pthread_create(&ws[d].thr, NULL, worker_main, &ws[d])) { fprintf(stderr, "could not start the worker of device %d\n", devs[d]); return 1; }
+		for (int d = 0; d < n_dev; d++) pthread_join(ws[d].thr, NULL);
+	}
+	int rc_all = 0;
+	for (int d = 0; d < n_dev; d++) if (ws[d].rc > rc_all) rc_all = ws[d].rc;
+	return rc_all;
 }

@@ -141,6 +141,8 @@ const char *mdemod_strerror(int code);
 /* Optional: brings up the HIP runtime on `device` (0.1-0.2 s in a new process) - e.g. from a second thread while the host
  * reads its input file.  Every other entry does this by itself when it has not happened yet. */
 int  mdemod_init_device(int device);
+/* GPUs this process sees (hipGetDeviceCount); 0 when there is none or the runtime cannot start. */
+int  mdemod_device_count(void);
 
 /* Replaces demod_init (demod.c:8-15).  Derives loop constants, RRC taps and the
  * tanh LUT on the host with the reference's exact mixed float/double

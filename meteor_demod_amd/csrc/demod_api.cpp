@@ -141,6 +141,13 @@ mdemod_init_device(int device)
 	return hipFree(nullptr) == hipSuccess ? MDEMOD_OK : MDEMOD_ERR_HIP;     /* forces the context */
 }
 
+int
+mdemod_device_count(void)
+{
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 const char *
 mdemod_strerror(int code)
 {

@@ -49,6 +49,60 @@ def test_cli_batch_of_files_equals_one_by_one(manifest, tmp_path, gpu_device):
         assert Path(str(p) + ".s").read_bytes() == load_npz(n)["out"].tobytes()
 
 
+def test_cli_spreads_files_over_devices(manifest, tmp_path, gpu_device):
+    """--devices a,b,...: one worker thread and one library context per listed GPU, file i on the (i mod G)-th of them, every
+    worker its own batch and its own outputs (streams shard, nothing crosses GPUs).  Two workers on THIS box's one
+    GPU exercise all of it (threads, contexts side by side); with two GPUs the same on both.  Outputs = the reference binary's."""
+    from meteor_demod_amd import _capi
+    names = ["file_wav_s16", "file_never_locks", "file_wav_s16", "file_never_locks", "file_wav_s16"]
+    paths = []
+    for k, n in enumerate(names):
+        p = tmp_path / f"{k}_{n}.wav"
+        p.write_bytes(file_case_bytes(manifest["file_cases"][n]))
+        paths.append(p)
+    lists = ["0,0"] + (["0,1"] if _capi.lib().mdemod_device_count() >= 2 else [])
+    for devs in lists:
+        for extra in ([], ["--tiled"]):
+            for p in paths:
+                Path(str(p) + ".s").unlink(missing_ok=True)
+            r = subprocess.run([str(CLI), "-q", "--devices", devs, *extra, *map(str, paths)], capture_output=True, text=True, cwd=tmp_path)
+            assert r.returncode == 0, r.stderr
+            for n, p in zip(names, paths):
+                got = Path(str(p) + ".s").read_bytes()
+                if not extra:
+                    assert got == load_npz(n)["out"].tobytes(), (devs, n)
+                else:                            # tiled: same length and lock gate (short files: the head is most of them)
+                    assert len(got) == len(load_npz(n)["out"].tobytes()), (devs, n)
+
+
+def test_cli_status_line_and_banner(manifest, tmp_path, gpu_device):
+    """Without -q: `Input: ..., output: ...` (main.c:200), `Demodulator initialized` (main.c:219) and, with -B -R 0, one status
+    line per block (main.c:249-261); the last one carries the final carrier and symbol-rate words of the oracle's run."""
+    import re
+    import oracle_py as O
+    from meteor_demod_amd import DemodConfig
+    meta = manifest["file_cases"]["file_wav_s16"]
+    data = file_case_bytes(meta)
+    inp, out = tmp_path / "in.wav", tmp_path / "out.s"
+    inp.write_bytes(data)
+    r = subprocess.run([str(CLI), "-B", "-R", "0", "-o", str(out), *meta["cli_args"], str(inp)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert f"Input: {inp}, output: {out}" in r.stdout and "Demodulator initialized" in r.stdout
+    lines = re.findall(r"\(\s*([\d.]+)%\) Carrier:\s*([+-][\d.]+) Hz, Symbol rate: ([\d.]+) Hz, Locked: (Yes|No)", r.stdout)
+    assert lines, r.stdout
+    cfg = DemodConfig(**meta["cfg"])
+    payload = data[44:]
+    n = len(payload) // 32768 * 32768 // 4
+    iq = np.frombuffer(payload[: n * 4], dtype=np.int16).reshape(-1, 2)
+    ost = O.OracleStream(cfg)
+    ost.run(iq)
+    freq_hz = float(ost.state.pll_freq) * cfg.symrate / (2 * np.pi)
+    rate_hz = float(ost.state.t_freq) * cfg.samplerate * cfg.interp_factor / (2 * np.pi)
+    pct, carrier, rate, locked = lines[-1]
+    assert abs(float(carrier) - freq_hz) < 0.06 and abs(float(rate) - rate_hz) < 0.06, (lines[-1], freq_hz, rate_hz)
+    assert (locked == "Yes") == bool(ost.state.locked) and float(pct) > 99.0
+
+
 def test_cli_stdout_mode_and_errors(manifest, tmp_path, gpu_device):
     meta = manifest["file_cases"]["file_wav_s16"]
     inp = tmp_path / "in.wav"

@@ -185,6 +185,19 @@ def test_period_wrap_in_float_arithmetic_proof_holds_on_the_host():
     assert "checked 16777216 floats" in out and "mismatches 0" in out, out
 
 
+def test_cli_device_plan_is_round_robin():
+    """host/meteor_demod_amd.c --devices a,b,c --plan: the sharding arithmetic of the C host without files or GPUs - file i on the
+    (i mod G)-th device of the list, never more workers than files."""
+    import subprocess
+    cli = ROOT / "meteor_demod_amd" / "lib" / "meteor_demod_amd"
+    r = subprocess.run([str(cli), "--devices", "0,2,5", "--plan", "a", "b", "c", "d", "e", "f", "g"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == ["device 0: a d g", "device 2: b e", "device 5: c f"]
+    r = subprocess.run([str(cli), "--devices", "3,1", "--plan", "only"], capture_output=True, text=True)
+    assert r.stdout.splitlines() == ["device 3: only"]
+    assert subprocess.run([str(cli), "--devices", "0,x", "--plan", "a"], capture_output=True).returncode == 1
+
+
 def test_rotating_window_register_partition():
     """demod_kernel_rot.hip hands v[ROTWIN_LIMIT..255] to hand-written assembly and keeps hipcc below with `amdgpu_num_vgpr`,
     whose unit is an observed property of the compiler (two registers on gfx90a+), not a documented one: check the emitted
