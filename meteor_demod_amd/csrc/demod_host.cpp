@@ -66,11 +66,10 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	if (p.interp_factor < 1 || p.interp_factor > 64) return MDEMOD_ERR_PARAM;
 	if (p.rrc_order < 1 || p.rrc_order > 256) return MDEMOD_ERR_PARAM;
 	if (p.samplerate <= 0 || p.symrate <= 0) return MDEMOD_ERR_PARAM;
-	/* Fewer than one input sample per symbol: the reference fires more than once inside its per-sample loop and
-	 * returns only the LAST symbol of each sample (demod.c:33-47, 62-90: `ret` and `*sample` are overwritten), an
-	 * artefact these kernels do not reproduce (they emit every firing).  Refused instead of silently different;
-	 * 0.1 % margin for the symbol clock's own +-2^-12 range (timing.c:84). */
-	if (static_cast<double>(p.samplerate) < static_cast<double>(p.symrate) * 1.001) return MDEMOD_ERR_PARAM;
+	/* Fewer than one input sample per symbol is fine: the reference then fires more than once inside its per-sample loop and keeps
+	 * only the LAST symbol of each sample (demod.c:33-47, 62-90: `ret` and `*sample` are overwritten), and so do the kernels
+	 * (goldens one_per_symbol, sub_sample, sub_sample_oqpsk).  Below a quarter of a sample per firing nothing has been tested. */
+	if (static_cast<double>(p.samplerate) * (p.oqpsk ? 2.0 : 1.0) < static_cast<double>(p.symrate) * 0.25) return MDEMOD_ERR_PARAM;
 	if (p.bps != 8 && p.bps != 16 && p.bps != 32) return MDEMOD_ERR_PARAM;
 
 	DemodConsts &c = out.c;

@@ -342,7 +342,6 @@ orc_push(orc_stream *st, float re, float im, orc_cf *out)
 			pll_update(c, s, y.re, y.im);
 			*out = y;
 			produced = 1;
-			s->n_symbols++;
 		} else {
 			if (!(s->t_phase >= (float)s->dual_state * PI_F)) continue;   /* timing.c:50 */
 			const int which = s->dual_state;
@@ -364,10 +363,13 @@ orc_push(orc_stream *st, float re, float im, orc_cf *out)
 				timing_update(c, s, quad);
 				pll_update(c, s, s->inphase, quad);
 				produced = 1;
-				s->n_symbols++;
 			}
 		}
 	}
+	/* symbols are counted as the caller sees them: one per input sample that returns one (demod.c:33-47, 62-90 overwrite `*sample`
+	 * and `ret` when the clock fires twice inside a sample: the earlier symbol is gone, and pll.c's lock flags are read by
+	 * main.c:312 against this count) */
+	if (produced) s->n_symbols++;
 	return produced;
 }
 

@@ -103,6 +103,14 @@ CASES = [
     Case("odd_cfg", DemodConfig(samplerate=144000, symrate=72000, rrc_order=17, interp_factor=3, bps=16),
          [Segment(100000, dict(f0_hz=-50.0, esn0_db=25.0))],
          note="non-default -f 17 -O 3 at 2 samples/symbol (generic kernel path)", seed=6001),
+    # --- at most one input sample per symbol: the reference's per-sample loop fires more than once per sample and keeps only the
+    #     LAST symbol of each (demod.c:33-47, 62-90: `*sample` and `ret` are overwritten) -------------------------------------
+    Case("one_per_symbol", DemodConfig(samplerate=72000), [Segment(60000, dict(f0_hz=100.0, esn0_db=20.0))],
+         note="-s 72000 at 72k symbols/s: exactly one sample per symbol, two firings inside one sample whenever the clock runs fast", seed=7001),
+    Case("sub_sample", DemodConfig(samplerate=60000), [Segment(50000, dict(f0_hz=-150.0, esn0_db=20.0))],
+         note="-s 60000 at 72k symbols/s: 0.83 samples per symbol, every sixth sample holds two firings: only the last survives", seed=7002),
+    Case("sub_sample_oqpsk", DemodConfig(samplerate=64000, symrate=80000, oqpsk=True, interp_factor=4), [Segment(50000, dict(f0_hz=60.0, esn0_db=20.0))],
+         note="OQPSK 80k in 64 kS/s -O 4: 0.4 samples per firing", seed=7003),
 ]
 
 BY_NAME = {c.name: c for c in CASES}
