@@ -102,9 +102,9 @@ def test_product_constants_equal_oracle_constants():
 
 def test_bad_parameters_are_rejected():
     lib = _capi.lib()
-    # samplerate 72000 at 72k symbols/s: < 1 sample per symbol, where the reference returns only the last symbol of a sample
-    for bad in (dict(interp_factor=0), dict(rrc_order=0), dict(samplerate=0), dict(symrate=-1), dict(bps=12), dict(samplerate=72000),
-                dict(samplerate=60000)):
+    # samplerate 17000 at 72k symbols/s: less than a quarter of a sample per symbol (down to there the reference's
+    # keep-the-last-symbol-of-a-sample rule is what the kernels do: goldens one_per_symbol, sub_sample*)
+    for bad in (dict(interp_factor=0), dict(rrc_order=0), dict(samplerate=0), dict(symrate=-1), dict(bps=12), dict(samplerate=17000)):
         cfg = DemodConfig(samplerate=230000)
         for k, v in bad.items():
             setattr(cfg, k, v)
