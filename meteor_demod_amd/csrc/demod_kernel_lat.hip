@@ -123,8 +123,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 	const int k_safe = KSAFE ? KSAFE : C.step_safe;
 	const float f_hi = C.step_fmax;
 	const uint32_t magic = C.interp_magic;
-	const uint64_t guard64 = 4ull * (uint64_t)(n + hpad) * (uint64_t)interp + 4096ull;
-	uint32_t guard = guard64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)guard64;
+	uint64_t guard = 4ull * (uint64_t)(n + hpad) * (uint64_t)interp + 4096ull;     /* 64 bits: the careful path spends one per interpolated step, and 2^30 samples x 64 steps do not fit 32 */
 	const int n_chunks = min(kMaxChunks, (span + 63) / 64 + 1);
 	int since_emit = 1 << 28;                /* interpolated steps since the last emitted symbol (same-sample rule below) */
 

@@ -590,8 +590,8 @@ demod_kernel_rw(const DemodLaunch L)
 						int8_t *soft_out = L.soft + (size_t)stream * L.soft_stride * 2;
 						if (sym_call <= L.soft_cap) {
 							const uint4 a = stage[0], b = stage[G::BLOCK], c = stage[2 * G::BLOCK], d = stage[3 * G::BLOCK];
-							uint4 *dst = reinterpret_cast<uint4 *>(soft_out + 2 * (size_t)(sym_call - 32));
-							dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+							int8_t *dst = soft_out + 2 * (size_t)(sym_call - 32);       /* memcpy: buffer and pitch need not be 16-byte aligned */
+							__builtin_memcpy(dst, &a, 16); __builtin_memcpy(dst + 16, &b, 16); __builtin_memcpy(dst + 32, &c, 16); __builtin_memcpy(dst + 48, &d, 16);
 						} else {
 							fl |= 8;
 							for (uint32_t i = 0; i < 32 && sym_call - 32 + i < L.soft_cap; i++)
@@ -659,7 +659,7 @@ demod_kernel_rw(const DemodLaunch L)
 	if (valid && MDEMOD_RW_STAGE == 2) {
 		const uint32_t r = sym_call & 31u, sb = sym_call - r;              /* symbols still in the ring: complete groups as 16 bytes, the rest singly */
 		for (uint32_t g = 0; g < (r >> 3); g++) {
-			if (sb + 8 * g + 8 <= L.soft_cap) *reinterpret_cast<uint4 *>(soft_e + 2 * (size_t)(sb + 8 * g)) = stage[g * G::BLOCK];
+			if (sb + 8 * g + 8 <= L.soft_cap) { const uint4 qv = stage[g * G::BLOCK]; __builtin_memcpy(soft_e + 2 * (size_t)(sb + 8 * g), &qv, 16); }
 			else for (uint32_t i = 0; i < 8; i++) {
 				if (sb + 8 * g + i < L.soft_cap) *reinterpret_cast<uint16_t *>(soft_e + 2 * (size_t)(sb + 8 * g + i)) = reinterpret_cast<const uint16_t *>(stage + g * G::BLOCK)[i];
 				else overflow = 1;

@@ -493,8 +493,8 @@ rot_group(uint4 v, int k)
 	return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-/* One block per (tile, slice): the tile's kept symbols go to their place in the output, 16 bytes per thread and step (rows
- * start 16-byte aligned; the destination is only 2-byte aligned, which global stores take).  gridDim.y slices share a tile. */
+/* One block per (tile, slice): the tile's kept symbols go to their place in the output, 16 bytes per thread and step (neither
+ * side need be more than 2-byte aligned: a seam fix starts a row one symbol in).  gridDim.y slices share a tile. */
 __global__ void
 assemble_kernel(const TileCopy *tiles, int8_t *out)
 {
@@ -506,9 +506,10 @@ assemble_kernel(const TileCopy *tiles, int8_t *out)
 	}
 	if (t.head) dst += 2;
 	const uint32_t groups = t.keep / 8;
-	const uint4 *src16 = reinterpret_cast<const uint4 *>(t.src);
 	for (uint32_t g = blockIdx.y * blockDim.x + threadIdx.x; g < groups; g += gridDim.y * blockDim.x) {
-		const uint4 v = rot_group(src16[g], t.rot);
+		uint4 raw;
+		__builtin_memcpy(&raw, t.src + 16 * (size_t)g, 16);             /* a seam fix starts a row one symbol in: 2-byte aligned */
+		const uint4 v = rot_group(raw, t.rot);
 		__builtin_memcpy(dst + 16 * (size_t)g, &v, 16);
 	}
 	if (blockIdx.y == 0)
@@ -945,6 +946,7 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 		o.tile_samples = std::max<uint32_t>(4096, (static_cast<uint32_t>(b_sym * osf) + 63) / 64 * 64);
 		if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
 	}
+	else o.tile_samples = (o.tile_samples + 7) / 8 * 8;       /* a user's tile: whole groups of 8 samples, so that the rows of the bank's buffers (pitch = samples + 8 symbols) start 16-byte aligned for the assembly kernel's 16-byte reads */
 	rep->tile_samples = o.tile_samples;
 	const uint64_t B = o.tile_samples, A = o.acquire_samples, KP = o.frame_samples, WS = o.settle_samples;
 	const size_t T = static_cast<size_t>((n_samples - P + B - 1) / B);
@@ -982,6 +984,7 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 	   length, and 131 072 windows of 65 536 samples are 100 GB of reads over the three passes */
 	const int nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(
 	                     std::min(std::min(262144.0, 20536.0 * osf), std::max(5000.0 * osf, static_cast<double>(B))))));
+	const float min_quality = 8.0f;                   /* spectral line over the band's mean: below this a window has no line to speak of */
 	std::vector<uint64_t> wstart(T);
 	for (size_t i = 0; i < T; i++) {
 		const double c = i == 0 ? static_cast<double>(P) : 0.5 * (static_cast<double>(i == 1 ? P : q[i - 1]) + static_cast<double>(q[i]));
@@ -994,7 +997,6 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 		TRY(upload(mem, wstart, &d_starts, st));
 		TRY(mem.alloc(&d_freq, T)); TRY(mem.alloc(&d_qual, T)); TRY(mem.alloc(&d_chirp, T));
 		std::vector<float> fh(T), qh(T), chirp(T, 0.0f);
-		const float min_quality = 8.0f;
 		for (int pass = 0; pass < 3; pass++) {
 			/* pass 0: plain; passes 1, 2: with the local slope taken out of the window (a Doppler ramp smears the line) */
 			if (pass) {
@@ -1051,58 +1053,59 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 			}
 		}
 		mark("carrier lines");
-		if (o.clock_seed == 0 && n_samples >= 4096) {
-			/* ---- symbol clock of every tile (a pass moves the clock with the carrier: 20 ppm and more between the pilot and the far
-			   end; the loop's integrator needs 8 000 symbols per e-fold to make that up).  The clock is smooth, so its windows are
-			   the estimator's longest (2^18 samples: 5e-8 of the rate), side by side over the tiled part, whatever the tile length;
-			   every tile reads a straight line through the estimates around it. ---- */
-			uint32_t wc = 4096;
-			while (wc * 2 <= std::min<uint64_t>(n_samples, 1u << 18)) wc *= 2;
-			const uint64_t first = std::min<uint64_t>(s0[1], n_samples - wc);
-			std::vector<uint64_t> cst;
-			for (uint64_t a = first; ; a += wc) {
-				if (a + wc >= n_samples) { cst.push_back(n_samples - wc); break; }
-				cst.push_back(a);
-			}
-			const size_t Tc = cst.size();
-			std::vector<float> cf(Tc), cc(Tc);
-			std::vector<double> cx(Tc);
-			for (size_t j = 0; j < Tc; j++) {
-				cx[j] = static_cast<double>(cst[j]) + 0.5 * wc;
-				cf[j] = static_cast<float>(interp_at(centre, fbar, std::min(std::max(cx[j], centre.front()), centre.back())));     /* OQPSK: where its two lines are */
-				cc[j] = static_cast<float>(interp_at(centre, slope, std::min(std::max(cx[j], centre.front()), centre.back())));
-			}
-			uint64_t *d_cst; float *d_cf, *d_cc, *d_tfq, *d_cq;
-			TRY(upload(mem, cst, &d_cst, st)); TRY(upload(mem, cf, &d_cf, st)); TRY(upload(mem, cc, &d_cc, st));
-			TRY(mem.alloc(&d_tfq, Tc)); TRY(mem.alloc(&d_cq, Tc));
-			TRY(mdemod_estimate_clock(params, iq_dev, n_samples, d_cst, d_cf, d_cc, static_cast<uint32_t>(Tc), wc, d_tfq, d_cq, st));
-			std::vector<float> th(Tc), cq(Tc);
-			HTRY(hipMemcpyAsync(th.data(), d_tfq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
-			HTRY(hipMemcpyAsync(cq.data(), d_cq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
-			HTRY(hipStreamSynchronize(st));
-			size_t lo = 0, hi = 0, weak = 0;
-			const double span = 2.5 * wc;                            /* five windows: the clock moves by < 1e-6 of the rate per second */
-			for (size_t i = 0; i < T; i++) {
-				const double t = static_cast<double>(s0[i]);
-				while (lo + 1 < Tc && cx[lo] < t - span) lo++;
-				while (hi + 1 < Tc && cx[hi + 1] <= t + span) hi++;
-				double sw = 0, sx = 0, sy = 0, sxx = 0, sxy = 0;
-				for (size_t j = lo; j <= hi; j++) {
-					if (cq[j] < min_quality) continue;
-					const double x = cx[j] - t, y = static_cast<double>(th[j]) - static_cast<double>(seed.t_freq);
-					sw += 1; sx += x; sy += y; sxx += x * x; sxy += x * y;
-				}
-				if (sw < 1) { weak++; continue; }                       /* no line anywhere near: the pilot's omega stays */
-				const double det = sw * sxx - sx * sx;
-				const double at_t = (sw >= 3 && det > 1e-6 * sw * sxx) ? (sy * sxx - sx * sxy) / det : sy / sw;
-				const double lim = static_cast<double>(consts[6]);   /* timing.c:80-86 keeps the loop within this of its centre */
-				tclk[i] = static_cast<double>(consts[5]) + std::max(-lim, std::min(lim, static_cast<double>(seed.t_freq) + at_t - static_cast<double>(consts[5])));
-			}
-			rep->weak_clock_tiles = static_cast<uint32_t>(weak);
-			if (dbg) fprintf(stderr, "[recording] clock seeds from %zu windows of %u: pilot %.9g, tiles %.9g .. %.9g (weak %zu)\n", Tc, wc, static_cast<double>(seed.t_freq), tclk[T > 1 ? 1 : 0], tclk[T - 1], weak);
-		}
 	} else {
 		for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
+	}
+	/* (with carrier_seed = 0 the OQPSK line pair is looked for around the pilot's carrier word, with no chirp taken out) */
+	if (o.clock_seed == 0 && T > 1 && n_samples >= 4096) {
+		/* ---- symbol clock of every tile (a pass moves the clock with the carrier: 20 ppm and more between the pilot and the far
+		   end; the loop's integrator needs 8 000 symbols per e-fold to make that up).  The clock is smooth, so its windows are
+		   the estimator's longest (2^18 samples: 5e-8 of the rate), side by side over the tiled part, whatever the tile length;
+		   every tile reads a straight line through the estimates around it. ---- */
+		uint32_t wc = 4096;
+		while (wc * 2 <= std::min<uint64_t>(n_samples, 1u << 18)) wc *= 2;
+		const uint64_t first = std::min<uint64_t>(s0[1], n_samples - wc);
+		std::vector<uint64_t> cst;
+		for (uint64_t a = first; ; a += wc) {
+			if (a + wc >= n_samples) { cst.push_back(n_samples - wc); break; }
+			cst.push_back(a);
+		}
+		const size_t Tc = cst.size();
+		std::vector<float> cf(Tc), cc(Tc);
+		std::vector<double> cx(Tc);
+		for (size_t j = 0; j < Tc; j++) {
+			cx[j] = static_cast<double>(cst[j]) + 0.5 * wc;
+			cf[j] = static_cast<float>(interp_at(centre, fbar, std::min(std::max(cx[j], centre.front()), centre.back())));     /* OQPSK: where its two lines are */
+			cc[j] = static_cast<float>(interp_at(centre, slope, std::min(std::max(cx[j], centre.front()), centre.back())));
+		}
+		uint64_t *d_cst; float *d_cf, *d_cc, *d_tfq, *d_cq;
+		TRY(upload(mem, cst, &d_cst, st)); TRY(upload(mem, cf, &d_cf, st)); TRY(upload(mem, cc, &d_cc, st));
+		TRY(mem.alloc(&d_tfq, Tc)); TRY(mem.alloc(&d_cq, Tc));
+		TRY(mdemod_estimate_clock(params, iq_dev, n_samples, d_cst, d_cf, d_cc, static_cast<uint32_t>(Tc), wc, d_tfq, d_cq, st));
+		std::vector<float> th(Tc), cq(Tc);
+		HTRY(hipMemcpyAsync(th.data(), d_tfq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipMemcpyAsync(cq.data(), d_cq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
+		HTRY(hipStreamSynchronize(st));
+		size_t lo = 0, hi = 0, weak = 0;
+		const double span = 2.5 * wc;                            /* five windows: the clock moves by < 1e-6 of the rate per second */
+		for (size_t i = 0; i < T; i++) {
+			const double t = static_cast<double>(s0[i]);
+			while (lo + 1 < Tc && cx[lo] < t - span) lo++;
+			while (hi + 1 < Tc && cx[hi + 1] <= t + span) hi++;
+			double sw = 0, sx = 0, sy = 0, sxx = 0, sxy = 0;
+			for (size_t j = lo; j <= hi; j++) {
+				if (cq[j] < min_quality) continue;
+				const double x = cx[j] - t, y = static_cast<double>(th[j]) - static_cast<double>(seed.t_freq);
+				sw += 1; sx += x; sy += y; sxx += x * x; sxy += x * y;
+			}
+			if (sw < 1) { weak++; continue; }                       /* no line anywhere near: the pilot's omega stays */
+			const double det = sw * sxx - sx * sx;
+			const double at_t = (sw >= 3 && det > 1e-6 * sw * sxx) ? (sy * sxx - sx * sxy) / det : sy / sw;
+			const double lim = static_cast<double>(consts[6]);   /* timing.c:80-86 keeps the loop within this of its centre */
+			tclk[i] = static_cast<double>(consts[5]) + std::max(-lim, std::min(lim, static_cast<double>(seed.t_freq) + at_t - static_cast<double>(consts[5])));
+		}
+		rep->weak_clock_tiles = static_cast<uint32_t>(weak);
+		if (dbg) fprintf(stderr, "[recording] clock seeds from %zu windows of %u: pilot %.9g, tiles %.9g .. %.9g (weak %zu)\n", Tc, wc, static_cast<double>(seed.t_freq), tclk[T > 1 ? 1 : 0], tclk[T - 1], weak);
 	}
 	mark("carrier estimates");
 	auto f_at = [&](double t) { return interp_at(centre, fbar, t); };
@@ -1398,10 +1401,20 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 		std::vector<size_t> preds;
 		for (size_t i = 1; i < T; i++)
 			if (run[i] && (out_rot[i] & 1) && !(out_rot[i - 1] & 1) && (i + 1 >= T || !(out_rot[i + 1] & 1)) && !merged[i - 1] && len[i] > 0) { merged[i] = 1; preds.push_back(i - 1); }
+		const uint64_t cap_fix = mdemod_max_symbols(bank.c, 2 * B);
+		int8_t *soft_fix = nullptr;
 		if (!preds.empty()) {
-			const uint64_t cap_fix = mdemod_max_symbols(bank.c, 2 * B);
-			int8_t *soft_fix;
-			TRY(mem.alloc(&soft_fix, T * cap_fix * 2));
+			/* rows are indexed by stream (the bank's launches have one pitch for all): rows up to the last stream that runs
+			   are enough.  No room for them: the tiles stay as they are, a quarter turn off, and are REPORTED (rotation_jumps,
+			   below) - better than failing a recording whose every other symbol is done. */
+			const size_t rows = preds.back() + 1;
+			if (mem.alloc(&soft_fix, rows * cap_fix * 2) != MDEMOD_OK) {
+				for (size_t j : preds) merged[j + 1] = 0;
+				preds.clear();
+				soft_fix = nullptr;
+			}
+		}
+		if (!preds.empty()) {
 			TRY(mdemod_copy_state(bank.c, saved.c, st));
 			std::vector<int32_t> qt(T, 0);
 			std::vector<uint64_t> c_stl(T, 0), c_body(T, 0), c_post(T, 0), o_post(T, 0);

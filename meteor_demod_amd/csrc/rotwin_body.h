@@ -341,11 +341,13 @@ rotwin_demod(const DemodLaunch &L)
 					if (__builtin_expect(sym_call <= L.soft_cap, 1)) {
 						/* one 16-byte group in flight at a time: four would not fit next to the live registers of the wide geometry
 						 * and spill (once per 32 symbols: the three extra LDS round trips do not show) */
-						uint4 *dst = reinterpret_cast<uint4 *>(soft_out + 2 * (size_t)(sym_call - 32));
+						/* memcpy, not a uint4 lvalue: the caller's buffer and pitch need not be 16-byte aligned (the hardware's
+						 * unaligned access mode takes the same global_store_dwordx4 either way) */
+						int8_t *dst = soft_out + 2 * (size_t)(sym_call - 32);
 #pragma unroll
 						for (int g4 = 0; g4 < 4; g4++) {
 							const uint4 qv = stage[g4 * BLOCK];
-							dst[g4] = qv;
+							__builtin_memcpy(dst + 16 * g4, &qv, 16);
 							asm volatile("" ::: "memory");
 						}
 					} else {
@@ -380,7 +382,7 @@ rotwin_demod(const DemodLaunch &L)
 	if (valid) {
 		const uint32_t r = sym_call & 31u, sb = sym_call - r;
 		for (uint32_t g = 0; g < (r >> 3); g++) {
-			if (sb + 8 * g + 8 <= L.soft_cap) *reinterpret_cast<uint4 *>(soft_e + 2 * (size_t)(sb + 8 * g)) = stage[g * BLOCK];
+			if (sb + 8 * g + 8 <= L.soft_cap) { const uint4 qv = stage[g * BLOCK]; __builtin_memcpy(soft_e + 2 * (size_t)(sb + 8 * g), &qv, 16); }
 			else for (uint32_t i = 0; i < 8; i++) {
 				if (sb + 8 * g + i < L.soft_cap) *reinterpret_cast<uint16_t *>(soft_e + 2 * (size_t)(sb + 8 * g + i)) = reinterpret_cast<const uint16_t *>(stage + g * BLOCK)[i];
 				else overflow = 1;
