@@ -7,6 +7,7 @@
 
 #include <stdint.h>
 #include "../../include/meteor_demod_amd.h"
+#include "mdemod_internal_api.h"
 
 #define MDEMOD_WAVE            64
 #define MDEMOD_GRANULE_SAMPLES 4      /* ring granule = 4 consecutive IQ samples */

@@ -35,7 +35,7 @@
 #include <thread>
 #include <vector>
 
-#include "meteor_demod_amd.h"
+#include "mdemod_internal_api.h"
 
 namespace {
 
