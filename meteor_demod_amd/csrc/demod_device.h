@@ -115,9 +115,9 @@ md_cabsf(float re, float im)
 	return (float)md_sqrt_sumsq(s);
 }
 
-/* dsp/agc.c:13-25 */
+/* dsp/agc.c:13-20: bias tracking and scaling (what the rest of the symbol needs) */
 __device__ __forceinline__ cf32
-md_agc(cf32 x, float &gain, float &bias_re, float &bias_im)
+md_agc_apply(cf32 x, float gain, float &bias_re, float &bias_im)
 {
 	const float keep = 1.0f - 0.001f;
 	bias_re = bias_re * keep + 0.001f * x.re;
@@ -126,9 +126,24 @@ md_agc(cf32 x, float &gain, float &bias_re, float &bias_im)
 	x.im = x.im - bias_im;
 	x.re = x.re * gain;
 	x.im = x.im * gain;
-	const float mag = md_cabsf(x.re, x.im);
+	return x;
+}
+
+/* dsp/agc.c:21-24: the gain for the NEXT symbol from the magnitude of this one */
+__device__ __forceinline__ void
+md_agc_gain(cf32 scaled, float &gain)
+{
+	const float mag = md_cabsf(scaled.re, scaled.im);
 	gain = gain + 0.0001f * (190.0f - mag);
 	gain = (0.0f > gain) ? 0.0f : gain;
+}
+
+/* dsp/agc.c:13-25 */
+__device__ __forceinline__ cf32
+md_agc(cf32 x, float &gain, float &bias_re, float &bias_im)
+{
+	x = md_agc_apply(x, gain, bias_re, bias_im);
+	md_agc_gain(x, gain);
 	return x;
 }
 
