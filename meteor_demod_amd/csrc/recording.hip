@@ -877,248 +877,44 @@ run_pilot(const mdemod_params *params, const mdemod_recording_opts &o, const voi
 	return MDEMOD_OK;
 }
 
-/* The entry proper.  `need(upto)`, when given, returns once samples [0, upto) of iq_dev are there: the host-buffer entry copies
- * the recording in behind the serial head. */
-static int
-demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_opts *opts_in,
-                          const void *iq_dev, uint64_t n_samples,
-                          int8_t *soft_dev, uint64_t soft_cap_symbols,
-                          mdemod_recording_report *rep, void *hip_stream, const std::function<void(uint64_t)> *need)
-{
-	if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
-	if (params->samplerate <= 0 || params->symrate <= 0) return MDEMOD_ERR_PARAM;
+/* The entry proper: one object per call, one method per stage of DESIGN.md 3.1 (they used to be one 635-line function).  `need(upto)`,
+ * when given, returns once samples [0, upto) of iq_dev are there: the host-buffer entry copies the recording in behind the serial
+ * head. */
+struct Stitcher {
+	/* the call */
+	const mdemod_params *params; const mdemod_recording_opts *opts_in; const void *iq_dev; uint64_t n_samples;
+	int8_t *soft_dev; uint64_t soft_cap_symbols; mdemod_recording_report *rep; hipStream_t st; const std::function<void(uint64_t)> *need;
 	mdemod_recording_opts o;
-	if (opts_in) o = *opts_in; else mdemod_recording_default_opts(&o);
-	const double osf = static_cast<double>(params->samplerate) / static_cast<double>(params->symrate);
-	const double symrate = params->symrate, fs = params->samplerate;
-	const int nco = params->oqpsk ? 2 : 1;
-	if (o.acquire_samples == 0xFFFFFFFFu) o.acquire_samples = static_cast<uint32_t>(2000 * osf);
-	if (o.frame_samples == 0xFFFFFFFFu) o.frame_samples = static_cast<uint32_t>(1500 * osf);
-	if (o.settle_samples == 0xFFFFFFFFu) o.settle_samples = static_cast<uint32_t>(24000 * osf);
-	/* symbols between the reference's first lock and the hand-over: the tiles right after it are seeded with a model of the serial
-	   loop's remaining convergence, which holds once the lock is this old (measured: the first tiles lose 5 % of their +-1 LSB
-	   agreement with 10 000 symbols less; OQPSK's loop, at twice the bandwidth, wanders more and wants 30 000) */
-	if (o.pilot_margin_symbols == 0xFFFFFFFFu) o.pilot_margin_symbols = (o.clock_seed || !o.carrier_seed) ? (params->oqpsk ? 30000 : 20000)      /* tiles that start from the pilot's own omega / carrier word: those need longer */
-		                                                                                 : (params->oqpsk ? 20000 : 15000);
-	if (o.max_pilot_samples == 0xFFFFFFFFFFFFFFFFull) o.max_pilot_samples = static_cast<uint64_t>(1.5e6 * osf);
-	if (!o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
-	hipStream_t st = static_cast<hipStream_t>(hip_stream);
-	memset(rep, 0, sizeof(*rep));
-	rep->first_lock_symbol = -1;
-	const int K = static_cast<int>(std::max<uint32_t>(o.match_symbols, 32));     /* fewer symbols cannot tell 4 rotations x 3 shifts apart at 12 dB */
+	double osf = 0, symrate = 0, fs = 0; int nco = 1, K = 32, interp = 1; bool dbg = false;
+	std::chrono::steady_clock::time_point t_tiles;
+	/* the serial head */
+	PilotOut po; mdemod_stream_state seed; uint64_t P = 0, n_pilot_sym = 0;
+	/* the plan: tile i emits [E_i, E_i + len_i), its stream starts at s0_i and runs acq_i + frm_i + stl_i samples before that */
+	uint64_t B = 0, A = 0, KP = 0, WS = 0; size_t T = 0;
+	std::vector<uint64_t> E, len, s0, acq, frm, stl, q;
+	mdemod_params bp; Ctx bank, saved; DevMem mem; float consts[8]; double fmax = 0, tau_pll = 0;
+	/* per-tile estimates */
+	std::vector<double> tclk, centre, fbar, slope; int nfft = 0; float min_quality = 8.0f; std::vector<uint64_t> wstart; double f_pilot_target = 0;
+	/* seeds */
+	std::vector<float> f0, tf, gains; std::vector<int32_t> ud; float *d_f0 = nullptr, *d_tf = nullptr, *d_gain = nullptr; int32_t *d_ud = nullptr;
+	/* the bank's buffers and what the launches leave in them */
+	uint64_t tail_samples = 0, cap_lead = 0, cap = 0, cap_post = 0; int8_t *soft_pre = nullptr, *soft1 = nullptr, *soft_post = nullptr; int32_t *d_rot = nullptr;
+	std::vector<uint32_t> cnt_tmp, cnt_pre, cnt1, cnt_post; std::vector<mdemod_status> status_body; std::vector<int32_t> R, shift, rot, weak;
+	std::vector<uint64_t> stl_off, ends, post_len;
+	/* rotations: taken out of the state before settling, left for the output, expected by the second round */
+	std::vector<char> run, jump_at, merged; std::vector<int32_t> state_rot, out_rot, expect; bool second_round = false;
+	std::vector<const int8_t *> src_of;
 
-	auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
-		return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-	};
-	/* ---- pilot ---- */
-	PilotOut po;
-	TRY(run_pilot(params, o, iq_dev, n_samples, soft_dev, soft_cap_symbols, st, need, po));
-	const mdemod_stream_state seed = po.seed;
-	const std::vector<PilotBlock> &pilot_blocks = po.blocks;
-	const uint64_t nsym = po.nsym, pos = po.P;
-	const uint64_t P = pos;
-	if (need) (*need)(n_samples);                          /* everything after the head reads all over the recording */
-	rep->pilot_samples = P; rep->pilot_symbols = seed.n_symbols;
-	rep->pilot_locked = seed.pll_locked; rep->first_lock_symbol = seed.first_lock_symbol;
-	rep->samples_demodulated = P;
-	const uint64_t n_pilot_sym = nsym;
-	rep->exact_symbols = n_pilot_sym;
-	rep->pilot_seconds = po.seconds;
-	const auto t_tiles = std::chrono::steady_clock::now();
-	const bool dbg = o.debug != 0;
-	auto mark = [&](const char *what) {
+	void mark(const char *what)
+	{
 		if (!dbg) return;
 		(void)hipStreamSynchronize(st);
-		fprintf(stderr, "[recording] %8.2f ms  %s\n", seconds_since(t_tiles) * 1e3, what);
-	};
-
-	/* ---- plan: tile i emits [E_i, E_i + len_i); its stream starts `lead` samples early -------------------------- */
-	if (P >= n_samples) { rep->n_symbols = n_pilot_sym; return MDEMOD_OK; }
-	if (o.tile_samples == 0) {
-		/* as short as fills the lanes (latency of a small recording is the samples ONE lane runs: lead + tile), as long as the
-		   lead stays a small part of the work once the GPU is full; kept off powers of two (lanes read at base + l * tile) */
-		const double rest_sym = static_cast<double>(n_samples - P) / osf;
-		/* Up to ~1000 tiles run one per WAVE (latency kernel, 1.9x a lane's rate with a SIMD to itself): a recording of up to
-		   1000 x 41 072 symbols is cut into that many; a longer one into tiles for one residency round of the lane kernels
-		   (131 072 lanes, with slack). */
-		const double b_sym = rest_sym / 1000.0 <= 41072.0 ? std::max(8192.0, rest_sym / 1000.0)
-		                                                   : std::min(41072.0, std::max(8192.0, rest_sym / 126976.0));
-		o.tile_samples = std::max<uint32_t>(4096, (static_cast<uint32_t>(b_sym * osf) + 63) / 64 * 64);
-		if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
+		fprintf(stderr, "[recording] %8.2f ms  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tiles).count() * 1e3, what);
 	}
-	else o.tile_samples = (o.tile_samples + 7) / 8 * 8;       /* a user's tile: whole groups of 8 samples, so that the rows of the bank's buffers (pitch = samples + 8 symbols) start 16-byte aligned for the assembly kernel's 16-byte reads */
-	rep->tile_samples = o.tile_samples;
-	const uint64_t B = o.tile_samples, A = o.acquire_samples, KP = o.frame_samples, WS = o.settle_samples;
-	const size_t T = static_cast<size_t>((n_samples - P + B - 1) / B);
-	rep->n_tiles = static_cast<uint32_t>(T);
-	std::vector<uint64_t> E(T), len(T), s0(T), acq(T), frm(T), stl(T), q(T);
-	for (size_t i = 0; i < T; i++) {
-		E[i] = P + i * B; len[i] = std::min<uint64_t>(B, n_samples - E[i]);
-		if (i == 0) { s0[i] = q[i] = E[i]; acq[i] = frm[i] = stl[i] = 0; continue; }     /* tile 0: the pilot's exact continuation */
-		const uint64_t lead = std::min<uint64_t>(A + KP + WS, E[i]);
-		s0[i] = E[i] - lead;
-		acq[i] = std::min<uint64_t>(A, lead); frm[i] = std::min<uint64_t>(KP, lead - acq[i]); stl[i] = lead - acq[i] - frm[i];
-		q[i] = s0[i] + acq[i] + frm[i];
-	}
-
-	mdemod_params bp = *params; bp.n_streams = static_cast<uint32_t>(T);
-	Ctx bank, saved;
-	mark("plan");
-	TRY(mdemod_create(&bp, &bank.c));
-	mark("bank created");
-	DevMem mem;
-	float consts[8];
-	TRY(mdemod_get_loop_constants(bank.c, consts));
-	const double pll_alpha = consts[0], pll_beta = consts[1], fmax = consts[2];
-	const double tau_pll = pll_beta > 0 ? pll_alpha / pll_beta : 0.0;     /* slow pole of the (overdamped) carrier loop, in NCO steps: pll.c:133-140 */
-	const int interp = params->interp_factor;
-
-	const std::vector<float> &seed_hist = po.hist;
-
-	/* ---- carrier of every tile: window i is centred on the span its frame is dead-reckoned over, [q_{i-1}, q_i] ---------------- */
-	std::vector<double> tclk(T, static_cast<double>(seed.t_freq));   /* symbol clock seeds, rad per interpolated step */
-	std::vector<double> centre(T), fbar(T), slope(T, 0.0);         /* rad per NCO step at centre[i]; slope in rad per NCO step per sample */
-	/* about 20 000 symbols per window (65 536 samples at 72k in 230 kS/s, 262 144 at 1 MS/s): the frames are dead-reckoned over a
-	   tile, the estimate has to be good to a fraction of a radian over that many symbols */
-	/* ... but no longer than a tile needs: the error of the estimate falls with the window^1.5 and is multiplied by the tile
-	   length, and 131 072 windows of 65 536 samples are 100 GB of reads over the three passes */
-	const int nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(
-	                     std::min(std::min(262144.0, 20536.0 * osf), std::max(5000.0 * osf, static_cast<double>(B))))));
-	const float min_quality = 8.0f;                   /* spectral line over the band's mean: below this a window has no line to speak of */
-	std::vector<uint64_t> wstart(T);
-	for (size_t i = 0; i < T; i++) {
-		const double c = i == 0 ? static_cast<double>(P) : 0.5 * (static_cast<double>(i == 1 ? P : q[i - 1]) + static_cast<double>(q[i]));
-		const double w0 = std::max(0.0, std::min(c - nfft / 2, static_cast<double>(n_samples) - nfft));
-		wstart[i] = static_cast<uint64_t>(w0);
-		centre[i] = static_cast<double>(wstart[i]) + nfft / 2;
-	}
-	if (o.carrier_seed == 1 && T > 1) {
-		uint64_t *d_starts; float *d_freq, *d_qual, *d_chirp;
-		TRY(upload(mem, wstart, &d_starts, st));
-		TRY(mem.alloc(&d_freq, T)); TRY(mem.alloc(&d_qual, T)); TRY(mem.alloc(&d_chirp, T));
-		std::vector<float> fh(T), qh(T), chirp(T, 0.0f);
-		for (int pass = 0; pass < 3; pass++) {
-			/* pass 0: plain; passes 1, 2: with the local slope taken out of the window (a Doppler ramp smears the line) */
-			if (pass) {
-				for (size_t i = 0; i < T; i++) {      /* robust local slope: median of up to five neighbouring finite differences */
-					double v[5]; int m = 0;
-					for (size_t j = i >= 2 ? i - 2 : 0; j <= std::min(T - 1, i + 2); j++) v[m++] = slope[j];
-					std::sort(v, v + m);
-					chirp[i] = static_cast<float>(v[m / 2]);
-				}
-				bool any = false;
-				for (size_t i = 0; i < T; i++) any = any || std::fabs(chirp[i]) * nfft > 2e-6;      /* less than a tenth of a bin across the window: nothing to take out */
-				if (!any) break;
-				HTRY(hipMemcpyAsync(d_chirp, chirp.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
-				HTRY(hipStreamSynchronize(st));
-			}
-			TRY(mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, d_starts, pass ? d_chirp : nullptr, static_cast<uint32_t>(T),
-			                                  static_cast<uint32_t>(nfft), d_freq, d_qual, st));
-			HTRY(hipMemcpyAsync(fh.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
-			HTRY(hipMemcpyAsync(qh.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
-			HTRY(hipStreamSynchronize(st));
-			/* tiles without a clear line (fade, interference) take their good neighbours' estimate, interpolated over time;
-			   with no good tile at all, the pilot's frequency */
-			std::vector<size_t> good;
-			for (size_t i = 0; i < T; i++) if (qh[i] >= min_quality) good.push_back(i);
-			rep->weak_carrier_tiles = static_cast<uint32_t>(T - good.size());
-			if (good.empty()) {
-				for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
-			} else {
-				std::vector<double> gx, gv;
-				for (size_t g : good) { gx.push_back(centre[g]); gv.push_back(fh[g]); }
-				for (size_t i = 0; i < T; i++)
-					fbar[i] = qh[i] >= min_quality ? static_cast<double>(fh[i]) : interp_at(gx, gv, std::min(std::max(centre[i], gx.front()), gx.back()));
-			}
-			/* one estimate far off the line through its neighbours (a spur, a burst: 1 in 1e5 windows) would put every later tile
-			   in the wrong frame: the carrier is smooth, the neighbours decide */
-			if (T >= 5) {
-				std::vector<double> fixed = fbar;
-				for (size_t i = 1; i + 1 < T; i++) {
-					const double w = (centre[i] - centre[i - 1]) / (centre[i + 1] - centre[i - 1]);
-					const double pred = fbar[i - 1] + (fbar[i + 1] - fbar[i - 1]) * w;
-					if (std::fabs(fbar[i] - pred) > 6e-6 / nco) {
-						/* which of the three is the odd one?  the one whose own neighbours agree with each other without it */
-						const size_t a = i >= 2 ? i - 2 : i - 1, b = std::min(T - 1, i + 2);
-						const double wa = (centre[i] - centre[a]) / (centre[b] - centre[a]);
-						const double pred2 = fbar[a] + (fbar[b] - fbar[a]) * wa;
-						if (std::fabs(pred - pred2) < std::fabs(fbar[i] - pred2)) fixed[i] = pred;
-					}
-				}
-				fbar = fixed;
-			}
-			for (size_t i = 0; i < T; i++) {
-				const size_t lo = i ? i - 1 : 0, hi = std::min(T - 1, i + 1);
-				slope[i] = centre[hi] > centre[lo] ? (fbar[hi] - fbar[lo]) / (centre[hi] - centre[lo]) : 0.0;
-			}
-		}
-		mark("carrier lines");
-	} else {
-		for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
-	}
-	/* (with carrier_seed = 0 the OQPSK line pair is looked for around the pilot's carrier word, with no chirp taken out) */
-	if (o.clock_seed == 0 && T > 1 && n_samples >= 4096) {
-		/* ---- symbol clock of every tile (a pass moves the clock with the carrier: 20 ppm and more between the pilot and the far
-		   end; the loop's integrator needs 8 000 symbols per e-fold to make that up).  The clock is smooth, so its windows are
-		   the estimator's longest (2^18 samples: 5e-8 of the rate), side by side over the tiled part, whatever the tile length;
-		   every tile reads a straight line through the estimates around it. ---- */
-		uint32_t wc = 4096;
-		while (wc * 2 <= std::min<uint64_t>(n_samples, 1u << 18)) wc *= 2;
-		const uint64_t first = std::min<uint64_t>(s0[1], n_samples - wc);
-		std::vector<uint64_t> cst;
-		for (uint64_t a = first; ; a += wc) {
-			if (a + wc >= n_samples) { cst.push_back(n_samples - wc); break; }
-			cst.push_back(a);
-		}
-		const size_t Tc = cst.size();
-		std::vector<float> cf(Tc), cc(Tc);
-		std::vector<double> cx(Tc);
-		for (size_t j = 0; j < Tc; j++) {
-			cx[j] = static_cast<double>(cst[j]) + 0.5 * wc;
-			cf[j] = static_cast<float>(interp_at(centre, fbar, std::min(std::max(cx[j], centre.front()), centre.back())));     /* OQPSK: where its two lines are */
-			cc[j] = static_cast<float>(interp_at(centre, slope, std::min(std::max(cx[j], centre.front()), centre.back())));
-		}
-		uint64_t *d_cst; float *d_cf, *d_cc, *d_tfq, *d_cq;
-		TRY(upload(mem, cst, &d_cst, st)); TRY(upload(mem, cf, &d_cf, st)); TRY(upload(mem, cc, &d_cc, st));
-		TRY(mem.alloc(&d_tfq, Tc)); TRY(mem.alloc(&d_cq, Tc));
-		TRY(mdemod_estimate_clock(params, iq_dev, n_samples, d_cst, d_cf, d_cc, static_cast<uint32_t>(Tc), wc, d_tfq, d_cq, st));
-		std::vector<float> th(Tc), cq(Tc);
-		HTRY(hipMemcpyAsync(th.data(), d_tfq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
-		HTRY(hipMemcpyAsync(cq.data(), d_cq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
-		HTRY(hipStreamSynchronize(st));
-		size_t lo = 0, hi = 0, weak = 0;
-		const double span = 2.5 * wc;                            /* five windows: the clock moves by < 1e-6 of the rate per second */
-		for (size_t i = 0; i < T; i++) {
-			const double t = static_cast<double>(s0[i]);
-			while (lo + 1 < Tc && cx[lo] < t - span) lo++;
-			while (hi + 1 < Tc && cx[hi + 1] <= t + span) hi++;
-			double sw = 0, sx = 0, sy = 0, sxx = 0, sxy = 0;
-			for (size_t j = lo; j <= hi; j++) {
-				if (cq[j] < min_quality) continue;
-				const double x = cx[j] - t, y = static_cast<double>(th[j]) - static_cast<double>(seed.t_freq);
-				sw += 1; sx += x; sy += y; sxx += x * x; sxy += x * y;
-			}
-			if (sw < 1) { weak++; continue; }                       /* no line anywhere near: the pilot's omega stays */
-			const double det = sw * sxx - sx * sx;
-			const double at_t = (sw >= 3 && det > 1e-6 * sw * sxx) ? (sy * sxx - sx * sxy) / det : sy / sw;
-			const double lim = static_cast<double>(consts[6]);   /* timing.c:80-86 keeps the loop within this of its centre */
-			tclk[i] = static_cast<double>(consts[5]) + std::max(-lim, std::min(lim, static_cast<double>(seed.t_freq) + at_t - static_cast<double>(consts[5])));
-		}
-		rep->weak_clock_tiles = static_cast<uint32_t>(weak);
-		if (dbg) fprintf(stderr, "[recording] clock seeds from %zu windows of %u: pilot %.9g, tiles %.9g .. %.9g (weak %zu)\n", Tc, wc, static_cast<double>(seed.t_freq), tclk[T > 1 ? 1 : 0], tclk[T - 1], weak);
-	}
-	mark("carrier estimates");
-	auto f_at = [&](double t) { return interp_at(centre, fbar, t); };
-	/* The carrier loop is heavily overdamped: its frequency word follows a moving carrier with the lag slope * tau (pll.c:115
-	   integrates beta * e, the phase term alpha * e does the tracking), and right after the pilot's hand-over the serial run is
-	   still converging with the same time constant.  A tile settles for less than tau, so it is seeded with the frequency the
-	   SERIAL loop has at that point, not with the carrier: estimate - lag + what is left of the pilot's own offset. */
-	const double f_pilot_target = f_at(static_cast<double>(P)) - (T > 1 ? slope[0] * osf / nco * tau_pll : 0.0);
-	/* a lock the reference declares far from the carrier (its OQPSK loop does on about half of all recordings with an offset, and
-	   never leaves it) is reported: the tiles demodulate the signal, the reference from there on does not */
-	if (o.carrier_seed == 1 && T > 1 && seed.pll_locked && rep->weak_carrier_tiles < T / 2 &&
-	    std::fabs(static_cast<double>(seed.pll_freq) - f_pilot_target) > 2 * kPi * 100.0 / (symrate * nco)) rep->pilot_locked = 2;
-	auto f_seed = [&](size_t i, double t) {
+	double f_at(double t) const { return interp_at(centre, fbar, t); }
+	/* the carrier word the SERIAL loop has at sample t of tile i's lead (see seed_tiles) */
+	double f_seed(size_t i, double t) const
+	{
 		const double lag = slope[i] * osf / nco * tau_pll;
 		/* before the hand-over (a lead that starts inside the pilot) the serial run was further away still: same exponential, back to
 		   where the pilot's margin began at most, and by no more than one time constant (OQPSK's loop has a quarter of QPSK's: 74x
@@ -1127,17 +923,9 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 		const double gone = tau_pll > 0 ? std::exp(-std::max(back, (t - static_cast<double>(P)) / osf * nco / tau_pll)) : 0.0;
 		const double f = f_at(t) - lag + (o.carrier_seed == 1 ? (static_cast<double>(seed.pll_freq) - f_pilot_target) * gone : 0.0);
 		return std::max(-fmax, std::min(fmax, f));
-	};
-
-	/* ---- seeds ------------------------------------------------------------------------------------------------ */
-	TRY(mdemod_set_state_all(bank.c, &seed, st));
-	TRY(mdemod_set_state(bank.c, 0, &seed, st));
-	TRY(mdemod_set_history(bank.c, 0, seed_hist.data(), st));
-	std::vector<float> f0(T), tf(T, seed.t_freq), gains(T, seed.agc_gain); std::vector<int32_t> ud(T);
-	for (size_t i = 1; i < T; i++) tf[i] = static_cast<float>(tclk[i]);
-	float *d_f0, *d_tf, *d_gain; int32_t *d_ud;
-	TRY(mem.alloc(&d_f0, T)); TRY(mem.alloc(&d_tf, T)); TRY(mem.alloc(&d_gain, T)); TRY(mem.alloc(&d_ud, T));
-	auto put_carrier_seeds = [&](bool at_acquired) -> int {
+	}
+	int put_carrier_seeds(bool at_acquired)
+	{
 		for (size_t i = 0; i < T; i++) {
 			f0[i] = i == 0 ? seed.pll_freq : static_cast<float>(f_seed(i, static_cast<double>(s0[i] + (at_acquired ? acq[i] : 0))));
 			ud[i] = i == 0 ? seed.pll_updown : (slope[i] >= 0 ? 1 : -1);
@@ -1146,68 +934,13 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 		HTRY(hipMemcpyAsync(d_ud, ud.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
 		HTRY(hipStreamSynchronize(st));
 		return mdemod_set_carrier_seeds(bank.c, d_f0, d_ud, st);
-	};
-	/* the reference's AGC moves by 1e-4 * 190 / gain of itself per symbol (agc.c:13-25): with s16-scale input (gain ~ 0.03) it is
-	   there within a few symbols whatever it starts from; only a slow one (float input around +-1: tens of thousands of symbols)
-	   needs a seed per tile, and only then is the recording read once more for its power */
-	const bool slow_agc = 6.0 * static_cast<double>(seed.agc_gain) / (1e-4 * 190.0) > 0.25 * static_cast<double>(A) / osf;
-	if (T > 1 && !slow_agc) {
-		HTRY(hipMemcpyAsync(d_gain, gains.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
-		HTRY(hipMemcpyAsync(d_tf, tf.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
-		HTRY(hipStreamSynchronize(st));
-		TRY(put_carrier_seeds(false));
 	}
-	if (T > 1 && slow_agc) {
-		/* AGC gain seeds: g* = c / sqrt(sample power), c fitted on the pilot's last blocks, then the reference's AGC in closed
-		   form over the tiles' powers (agc.c:13-25) */
-		const size_t nb = std::min<size_t>(10, pilot_blocks.size());
-		const size_t b0 = pilot_blocks.size() - nb;
-		std::vector<uint64_t> ws; std::vector<uint32_t> wl;
-		for (size_t j = b0; j < pilot_blocks.size(); j++) { ws.push_back(pilot_blocks[j].start); wl.push_back(pilot_blocks[j].len); }
-		for (size_t i = 0; i < T; i++) { ws.push_back(E[i]); wl.push_back(static_cast<uint32_t>(len[i])); }
-		uint64_t *d_ws; uint32_t *d_wl; float *d_wp;
-		TRY(upload(mem, ws, &d_ws, st));
-		TRY(upload(mem, wl, &d_wl, st));
-		TRY(mem.alloc(&d_wp, ws.size()));
-		HTRY(hipStreamSynchronize(st));
-		const dim3 grid(static_cast<unsigned>(ws.size()));
-		switch (params->bps) {
-		case 16: hipLaunchKernelGGL(window_power_kernel<16>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
-		case 8:  hipLaunchKernelGGL(window_power_kernel<8>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
-		default: hipLaunchKernelGGL(window_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
-		}
-		HTRY(hipGetLastError());
-		std::vector<float> wp(ws.size());
-		HTRY(hipMemcpyAsync(wp.data(), d_wp, wp.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-		HTRY(hipStreamSynchronize(st));
-		std::vector<double> blk_gain(nb), blk_power(nb), blk_syms(nb);
-		for (size_t j = 0; j < nb; j++) {
-			const PilotBlock &pb = pilot_blocks[b0 + j];
-			const uint64_t before = (b0 + j) ? pilot_blocks[b0 + j - 1].symbols_after : 0;
-			blk_gain[j] = pb.gain_after; blk_power[j] = wp[j]; blk_syms[j] = static_cast<double>(pb.symbols_after - before);
-		}
-		const double c = nb ? fit_agc_calibration(blk_gain, blk_power, blk_syms) : 0.0;
-		/* gE[k]: the serial run's gain at E_k; stream i starts its lead before E_i and takes the gain of the boundary at or
-		   before its start */
-		std::vector<double> gE(T + 1);
-		gE[0] = seed.agc_gain;
-		for (size_t k = 0; k < T; k++) gE[k + 1] = agc_step(gE[k], c, wp[nb + k], static_cast<double>(len[k]) * symrate / fs);
-		for (size_t i = 1; i < T; i++) {
-			const size_t back = static_cast<size_t>((E[i] - s0[i] + B - 1) / B);
-			gains[i] = static_cast<float>(gE[i > back ? i - back : 0]);
-		}
-		HTRY(hipMemcpyAsync(d_gain, gains.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
-		HTRY(hipMemcpyAsync(d_tf, tf.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
-		HTRY(hipStreamSynchronize(st));
-		TRY(mdemod_set_gain_seeds(bank.c, d_gain, st));
-		TRY(put_carrier_seeds(false));
-	}
-
 	/* ---- launches ------------------------------------------------------------------------------------------- */
 	/* discard: the streams run and their state advances, nothing is written (capacity 0; the kernels then raise the overflow flag,
 	   which means nothing here) - acquisition, frame and most of the settling are only run for their end state */
-	auto launch = [&](const std::vector<uint64_t> &off, const std::vector<uint64_t> &cnt, int8_t *soft, uint64_t stride,
-	                  std::vector<uint32_t> &produced, std::vector<mdemod_status> *status_out = nullptr, bool discard = false) -> int {
+	int launch(const std::vector<uint64_t> &off, const std::vector<uint64_t> &cnt, int8_t *soft, uint64_t stride,
+	                  std::vector<uint32_t> &produced, std::vector<mdemod_status> *status_out = nullptr, bool discard = false)
+	{
 		std::vector<uint32_t> c32(cnt.begin(), cnt.end());
 		uint64_t *d_off; uint32_t *d_cnt;
 		TRY(upload(mem, off, &d_off, st));
@@ -1217,312 +950,663 @@ demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_op
 		else TRY(counts_of(bank.c, static_cast<uint32_t>(T), produced, st, status_out));
 		for (uint64_t c : cnt) rep->samples_demodulated += c;
 		return MDEMOD_OK;
-	};
-	mark("seeds");
-	/* of the lead only the last symbols are kept: what the seam check compares with the predecessor's tail */
-	const uint64_t tail_samples = static_cast<uint64_t>((K + 24) * osf * 1.05) + 16;
-	const uint64_t cap_lead = std::max<uint64_t>(8, mdemod_max_symbols(bank.c, tail_samples));
-	const uint64_t cap = mdemod_max_symbols(bank.c, B);
-	int8_t *soft_pre, *soft1;
-	TRY(mem.alloc(&soft_pre, T * cap_lead * 2));
-	TRY(mem.alloc(&soft1, T * cap * 2));
-	mark("output buffers allocated");
-	std::vector<uint32_t> cnt_tmp, cnt_pre(T, 0), cnt1(T, 0);
-	std::vector<mdemod_status> status_body;
-	std::vector<int32_t> R(T, 0);
-	std::vector<mdemod_stream_state> qs(T);
-	if (T > 1) {
-		/* acquire, then the two integrators back on their seeds (the gain keeps what it found) */
-		TRY(launch(s0, acq, soft_pre, cap_lead, cnt_tmp, nullptr, true));
-		mark("acquire");
-		TRY(put_carrier_seeds(true));
-		TRY(mdemod_set_clock_seeds(bank.c, d_tf, st));
-		std::vector<uint64_t> off(T);
-		for (size_t i = 0; i < T; i++) off[i] = s0[i] + acq[i];
-		TRY(launch(off, frm, soft_pre, cap_lead, cnt_tmp, nullptr, true));
-		mark("frame");
-
-		/* ---- frames by dead reckoning along the chain pilot -> tile 1 -> tile 2 ... ---------------------------------- */
-		TRY(mdemod_get_states(bank.c, 0, static_cast<uint32_t>(T), qs.data(), st));
-		double th_prev = seed.pll_phase, t_prev = last_nco_time(seed, static_cast<double>(P), interp, params->oqpsk);
-		size_t i_prev = 0;                                     /* the chain's last trusted link */
-		int32_t acc_prev = 0; double res2 = 0.0; size_t hung = 0;
-		for (size_t i = 1; i < T; i++) {
-			const double th = qs[i].pll_phase, tt = last_nco_time(qs[i], static_cast<double>(q[i]), interp, params->oqpsk);
-			const double t_mid = 0.5 * (t_prev + tt) / interp;
-			double res;
-			/* NCO steps between the two: the symbol period of THIS stretch of the recording (a pass moves the clock: 50 ppm over a
-			   41 072-symbol tile would be two steps with the pilot's period) */
-			const double steps_per_nco = 2 * kPi / (0.5 * (tclk[i_prev] + tclk[i])) / nco;
-			const int32_t accr = (acc_prev + frame_between(th_prev, t_prev, th, tt, f_at(t_mid), steps_per_nco, &res)) & 3;
-			R[i] = accr; res2 += res * res;
-			/* Two streams that are on the symbols are a whole number of steps apart (seen: +-0.02).  One in 1e5 tiles is still hung
-			   up between two symbols after acquire + frame (the Mueller-Mueller detector's unstable equilibrium): its own phase
-			   says little (best guess kept: the seam check will see), and the chain must not go through it - its successor is
-			   reckoned from the last stream that was on the symbols.  (Found on the 6.5 G-sample recording: tile 121 764 was
-			   0.44 of a step off, both its links had a residual of -0.7 rad, one rounded the wrong way and 5 184 tiles behind
-			   it were repaired for it.) */
-			const double steps = (tt - t_prev) / steps_per_nco, off_grid = std::fabs(steps - std::nearbyint(steps));
-			const bool trusted = off_grid <= 0.2 || i - i_prev > 4;
-			if (dbg && o.debug_tile >= 0 && std::llabs(static_cast<long long>(i) - static_cast<long long>(o.debug_tile)) <= 2)
-				fprintf(stderr, "[recording]   trace %zu (from %zu): theta %.5f t %.3f (dt %.3f steps = %.4f nco) f %.9g res %.4f R %d t_freq %.9g t_phase %.5f locked %d pll_freq %.9g\n", i, i_prev, th, tt, tt - t_prev,
-				        steps, f_at(t_mid), res, accr, static_cast<double>(qs[i].t_freq), static_cast<double>(qs[i].t_phase), qs[i].pll_locked, static_cast<double>(qs[i].pll_freq));
-			if (dbg && (std::fabs(res) > 0.5 || !trusted)) fprintf(stderr, "[recording]   frame %zu: dead-reckoning residual %.3f rad, %.3f of a step off the symbols%s\n", i, res, off_grid, trusted ? "" : " (not chained through)");
-			if (trusted) { th_prev = th; t_prev = tt; i_prev = i; acc_prev = accr; } else hung++;
-		}
-		if (dbg) fprintf(stderr, "[recording] %zu tiles not on the symbols when their frame was taken\n", hung);
-		rep->frame_residual_rms = static_cast<float>(std::sqrt(res2 / static_cast<double>(T - 1)));
-		/* checkpoint of the bank before any rotation: what a repair starts from */
-		if (o.repair) {
-			TRY(mdemod_create(&bp, &saved.c));
-			TRY(mdemod_copy_state(saved.c, bank.c, st));
-		}
-		mark("frames dead-reckoned, checkpoint");
-	}
-	int32_t *d_rot;
-	TRY(mem.alloc(&d_rot, T));
-	std::vector<int32_t> shift(T, 0), rot(T, 0), weak(T, 0);
-	std::vector<uint64_t> stl_off(T);
-	for (size_t i = 0; i < T; i++) stl_off[i] = q[i];
-	const uint64_t post = 4096;                               /* OQPSK: look-ahead into the next tile for the seam check */
-	int8_t *soft_post = nullptr; uint64_t cap_post = 0;
-	std::vector<uint32_t> cnt_post(T, 0);
-	std::vector<uint64_t> ends(T), post_len(T);
-	for (size_t i = 0; i < T; i++) { ends[i] = E[i] + len[i]; post_len[i] = std::min<uint64_t>(post, n_samples - ends[i]); }
-	if (params->oqpsk) {
-		cap_post = std::max<uint64_t>(8, mdemod_max_symbols(bank.c, post));
-		TRY(mem.alloc(&soft_post, T * cap_post * 2));
 	}
 
-	/* settle + body (+ OQPSK look-ahead) of the streams in `run` (all of them the first time), then every seam again */
-	std::vector<char> run(T, 1);
-	std::vector<int32_t> state_rot = R;                    /* output rotation taken out of each stream's state before it settles */
-	std::vector<int32_t> out_rot(T, 0), expect(T, 0);     /* rotation left for the output; what the second round should find */
-	std::vector<char> jump_at(T, 0);                       /* seams that still show a rotation after the repair */
-	bool second_round = false;
-	for (int round = 0; round < 2; round++) {
-		std::vector<int32_t> qt(T);
-		for (size_t i = 0; i < T; i++) qt[i] = run[i] ? (4 - state_rot[i]) & 3 : 0;
-		HTRY(hipMemcpyAsync(d_rot, qt.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
-		HTRY(hipStreamSynchronize(st));
-		TRY(mdemod_rotate_carrier(bank.c, d_rot, st));
-		auto masked = [&](const std::vector<uint64_t> &c) { std::vector<uint64_t> m(T); for (size_t i = 0; i < T; i++) m[i] = run[i] ? c[i] : 0; return m; };
-		std::vector<mdemod_status> stat;
-		{
-			std::vector<uint64_t> stl_a(T), stl_b(T), off_b(T);
-			for (size_t i = 0; i < T; i++) { stl_b[i] = std::min<uint64_t>(stl[i], tail_samples); stl_a[i] = stl[i] - stl_b[i]; off_b[i] = q[i] + stl_a[i]; }
-			TRY(launch(stl_off, masked(stl_a), soft_pre, cap_lead, cnt_tmp, nullptr, true));
-			TRY(launch(off_b, masked(stl_b), soft_pre, cap_lead, cnt_tmp));
+	/* pilot: the reference's own serial run of the head (run_pilot) */
+	int run_head()
+	{
+		if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
+		if (params->samplerate <= 0 || params->symrate <= 0) return MDEMOD_ERR_PARAM;
+		if (opts_in) o = *opts_in; else mdemod_recording_default_opts(&o);
+		osf = static_cast<double>(params->samplerate) / static_cast<double>(params->symrate);
+		symrate = params->symrate; fs = params->samplerate;
+		nco = params->oqpsk ? 2 : 1;
+		if (o.acquire_samples == 0xFFFFFFFFu) o.acquire_samples = static_cast<uint32_t>(2000 * osf);
+		if (o.frame_samples == 0xFFFFFFFFu) o.frame_samples = static_cast<uint32_t>(1500 * osf);
+		if (o.settle_samples == 0xFFFFFFFFu) o.settle_samples = static_cast<uint32_t>(24000 * osf);
+		/* symbols between the reference's first lock and the hand-over: the tiles right after it are seeded with a model of the serial
+		   loop's remaining convergence, which holds once the lock is this old (measured: the first tiles lose 5 % of their +-1 LSB
+		   agreement with 10 000 symbols less; OQPSK's loop, at twice the bandwidth, wanders more and wants 30 000) */
+		if (o.pilot_margin_symbols == 0xFFFFFFFFu) o.pilot_margin_symbols = (o.clock_seed || !o.carrier_seed) ? (params->oqpsk ? 30000 : 20000)      /* tiles that start from the pilot's own omega / carrier word: those need longer */
+			                                                                                 : (params->oqpsk ? 20000 : 15000);
+		if (o.max_pilot_samples == 0xFFFFFFFFFFFFFFFFull) o.max_pilot_samples = static_cast<uint64_t>(1.5e6 * osf);
+		if (!o.pilot_block || !o.match_symbols) return MDEMOD_ERR_PARAM;
+		memset(rep, 0, sizeof(*rep));
+		rep->first_lock_symbol = -1;
+		K = static_cast<int>(std::max<uint32_t>(o.match_symbols, 32));     /* fewer symbols cannot tell 4 rotations x 3 shifts apart at 12 dB */
+
+		/* ---- pilot ---- */
+		TRY(run_pilot(params, o, iq_dev, n_samples, soft_dev, soft_cap_symbols, st, need, po));
+		seed = po.seed;
+		const uint64_t nsym = po.nsym;
+		P = po.P;
+		if (need) (*need)(n_samples);                          /* everything after the head reads all over the recording */
+		rep->pilot_samples = P; rep->pilot_symbols = seed.n_symbols;
+		rep->pilot_locked = seed.pll_locked; rep->first_lock_symbol = seed.first_lock_symbol;
+		rep->samples_demodulated = P;
+		n_pilot_sym = nsym;
+		rep->exact_symbols = n_pilot_sym;
+		rep->pilot_seconds = po.seconds;
+		t_tiles = std::chrono::steady_clock::now();
+		dbg = o.debug != 0;
+		return MDEMOD_OK;
+	}
+
+	/* tile grid behind the head */
+	int plan_tiles()
+	{
+		/* ---- plan: tile i emits [E_i, E_i + len_i); its stream starts `lead` samples early -------------------------- */
+		if (P >= n_samples) { rep->n_symbols = n_pilot_sym; T = 0; return MDEMOD_OK; }
+		if (o.tile_samples == 0) {
+			/* as short as fills the lanes (latency of a small recording is the samples ONE lane runs: lead + tile), as long as the
+			   lead stays a small part of the work once the GPU is full; kept off powers of two (lanes read at base + l * tile) */
+			const double rest_sym = static_cast<double>(n_samples - P) / osf;
+			/* Up to ~1000 tiles run one per WAVE (latency kernel, 1.9x a lane's rate with a SIMD to itself): a recording of up to
+			   1000 x 41 072 symbols is cut into that many; a longer one into tiles for one residency round of the lane kernels
+			   (131 072 lanes, with slack). */
+			const double b_sym = rest_sym / 1000.0 <= 41072.0 ? std::max(8192.0, rest_sym / 1000.0)
+			                                                   : std::min(41072.0, std::max(8192.0, rest_sym / 126976.0));
+			o.tile_samples = std::max<uint32_t>(4096, (static_cast<uint32_t>(b_sym * osf) + 63) / 64 * 64);
+			if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
 		}
-		mark("settle");
-		for (size_t i = 0; i < T; i++) if (run[i]) cnt_pre[i] = cnt_tmp[i];
-		TRY(launch(E, masked(len), soft1, cap, cnt_tmp, &stat));
-		mark("body");
-		if (status_body.empty()) status_body = stat;
-		for (size_t i = 0; i < T; i++) if (run[i]) { cnt1[i] = cnt_tmp[i]; status_body[i] = stat[i]; }
-		if (params->oqpsk) {
-			TRY(launch(ends, masked(post_len), soft_post, cap_post, cnt_tmp));
-			for (size_t i = 0; i < T; i++) if (run[i]) cnt_post[i] = cnt_tmp[i];
+		else o.tile_samples = (o.tile_samples + 7) / 8 * 8;       /* a user's tile: whole groups of 8 samples, so that the rows of the bank's buffers (pitch = samples + 8 symbols) start 16-byte aligned for the assembly kernel's 16-byte reads */
+		rep->tile_samples = o.tile_samples;
+		B = o.tile_samples; A = o.acquire_samples; KP = o.frame_samples; WS = o.settle_samples;
+		T = static_cast<size_t>((n_samples - P + B - 1) / B);
+		rep->n_tiles = static_cast<uint32_t>(T);
+		E.assign(T, 0); len.assign(T, 0); s0.assign(T, 0); acq.assign(T, 0); frm.assign(T, 0); stl.assign(T, 0); q.assign(T, 0);
+		for (size_t i = 0; i < T; i++) {
+			E[i] = P + i * B; len[i] = std::min<uint64_t>(B, n_samples - E[i]);
+			if (i == 0) { s0[i] = q[i] = E[i]; acq[i] = frm[i] = stl[i] = 0; continue; }     /* tile 0: the pilot's exact continuation */
+			const uint64_t lead = std::min<uint64_t>(A + KP + WS, E[i]);
+			s0[i] = E[i] - lead;
+			acq[i] = std::min<uint64_t>(A, lead); frm[i] = std::min<uint64_t>(KP, lead - acq[i]); stl[i] = lead - acq[i] - frm[i];
+			q[i] = s0[i] + acq[i] + frm[i];
 		}
 
-		/* ---- seams: tile i's settled tail against its predecessor's body tail (tile 1: against tile 0 = the serial run) ---- */
-		std::vector<TailPair> pairs(T > 1 ? T - 1 : 0);
-		for (size_t i = 1; i < T; i++) {
-			TailPair &p = pairs[i - 1];
-			p.a = soft1 + (i - 1) * cap * 2; p.a_cnt = cnt1[i - 1];
-			p.b = soft_pre + i * cap_lead * 2; p.b_cnt = cnt_pre[i];
-			p.b_rot = 0; p.force_weak = stl[i] == 0;
+		bp = *params; bp.n_streams = static_cast<uint32_t>(T);
+		mark("plan");
+		TRY(mdemod_create(&bp, &bank.c));
+		mark("bank created");
+		TRY(mdemod_get_loop_constants(bank.c, consts));
+		const double pll_alpha = consts[0], pll_beta = consts[1];
+		fmax = consts[2];
+		tau_pll = pll_beta > 0 ? pll_alpha / pll_beta : 0.0;     /* slow pole of the (overdamped) carrier loop, in NCO steps: pll.c:133-140 */
+		interp = params->interp_factor;
+		return MDEMOD_OK;
+	}
+
+	/* 4th-power line of every tile, de-chirped (mdemod_estimate_carrier_chirp) */
+	int estimate_carriers()
+	{
+		/* ---- carrier of every tile: window i is centred on the span its frame is dead-reckoned over, [q_{i-1}, q_i] ---------------- */
+		tclk.assign(T, static_cast<double>(seed.t_freq));   /* symbol clock seeds, rad per interpolated step */
+		centre.assign(T, 0.0); fbar.assign(T, 0.0); slope.assign(T, 0.0);         /* rad per NCO step at centre[i]; slope in rad per NCO step per sample */
+		/* about 20 000 symbols per window (65 536 samples at 72k in 230 kS/s, 262 144 at 1 MS/s): the frames are dead-reckoned over a
+		   tile, the estimate has to be good to a fraction of a radian over that many symbols */
+		/* ... but no longer than a tile needs: the error of the estimate falls with the window^1.5 and is multiplied by the tile
+		   length, and 131 072 windows of 65 536 samples are 100 GB of reads over the three passes */
+		nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(
+		                     std::min(std::min(262144.0, 20536.0 * osf), std::max(5000.0 * osf, static_cast<double>(B))))));
+		min_quality = 8.0f;                   /* spectral line over the band's mean: below this a window has no line to speak of */
+		wstart.assign(T, 0);
+		for (size_t i = 0; i < T; i++) {
+			const double c = i == 0 ? static_cast<double>(P) : 0.5 * (static_cast<double>(i == 1 ? P : q[i - 1]) + static_cast<double>(q[i]));
+			const double w0 = std::max(0.0, std::min(c - nfft / 2, static_cast<double>(n_samples) - nfft));
+			wstart[i] = static_cast<uint64_t>(w0);
+			centre[i] = static_cast<double>(wstart[i]) + nfft / 2;
 		}
-		std::vector<int32_t> sh, ro, we;
-		TRY(run_match(mem, pairs, K, sh, ro, we, st, params->oqpsk ? 1 : 0));
-		mark("seams");
-		for (size_t i = 1; i < T; i++) { shift[i] = params->oqpsk ? 0 : sh[i - 1]; rot[i] = we[i - 1] ? 0 : (ro[i - 1] & 3); weak[i] = we[i - 1]; }
-		/* rotation each stream's output still needs to sit in the serial run's frame: b * j^rot matches a, summed along the chain */
-		std::vector<int32_t> C(T, 0);
-		for (size_t i = 1; i < T; i++) C[i] = (C[i - 1] + rot[i]) & 3;
-		bool odd = false;
-		for (size_t i = 1; i < T; i++) odd = odd || (C[i] & 1);
-		if (dbg) {
-			fprintf(stderr, "[recording] round %d: T=%zu tile=%u lead=%u+%u+%u\n", round, T, o.tile_samples, o.acquire_samples, o.frame_samples, o.settle_samples);
-			for (size_t i = 1; i < T; i++)
-				if (rot[i] || weak[i] || shift[i] || run[i] != 1 || o.debug >= 2)
-					fprintf(stderr, "[recording]   seam %zu: rot %d weak %d shift %d C %d run %d R %d cnt_pre %u cnt1 %u locked %d f0 %.6f q %.1f\n", i, rot[i], weak[i], shift[i], C[i], (int)run[i], R[i],
-					        cnt_pre[i], cnt1[i], status_body.size() > i ? status_body[i].locked : -1, fbar[i], 0.0);
-		}
-		if (round == 0) {
-			for (size_t i = 1; i < T; i++) rep->frame_misses += rot[i] ? 1 : 0;
-			out_rot = C;
-			if (!odd) break;
-			size_t n_odd = 0;
-			for (size_t i = 1; i < T; i++) n_odd += (C[i] & 1);
-			/* A repair is one more settle + body for the lanes concerned - as long as for all of them.  It pays when dead reckoning
-			   failed broadly; one odd tile in 10^5 (its decisions are exact once the output is turned, only its soft values sit on
-			   the other rail's timing noise: 2 % of them off by more than an LSB) does not move the result by 1e-6. */
-			/* OQPSK has no such choice: a tile a quarter turn off pairs its rails one symbol apart (demod.c:66-76), which turning
-			   the output cannot undo */
-			if (!o.repair || !saved.c || (!params->oqpsk && n_odd * 200 < T)) {
-				for (size_t i = 1; i < T; i++) rep->rotation_jumps += (!o.repair && (rot[i] & 1)) ? 1 : 0;
-				rep->odd_tiles_kept = static_cast<uint32_t>(n_odd);
-				break;
+		if (o.carrier_seed == 1 && T > 1) {
+			uint64_t *d_starts; float *d_freq, *d_qual, *d_chirp;
+			TRY(upload(mem, wstart, &d_starts, st));
+			TRY(mem.alloc(&d_freq, T)); TRY(mem.alloc(&d_qual, T)); TRY(mem.alloc(&d_chirp, T));
+			std::vector<float> fh(T), qh(T), chirp(T, 0.0f);
+			for (int pass = 0; pass < 3; pass++) {
+				/* pass 0: plain; passes 1, 2: with the local slope taken out of the window (a Doppler ramp smears the line) */
+				if (pass) {
+					for (size_t i = 0; i < T; i++) {      /* robust local slope: median of up to five neighbouring finite differences */
+						double v[5]; int m = 0;
+						for (size_t j = i >= 2 ? i - 2 : 0; j <= std::min(T - 1, i + 2); j++) v[m++] = slope[j];
+						std::sort(v, v + m);
+						chirp[i] = static_cast<float>(v[m / 2]);
+					}
+					bool any = false;
+					for (size_t i = 0; i < T; i++) any = any || std::fabs(chirp[i]) * nfft > 2e-6;      /* less than a tenth of a bin across the window: nothing to take out */
+					if (!any) break;
+					HTRY(hipMemcpyAsync(d_chirp, chirp.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+					HTRY(hipStreamSynchronize(st));
+				}
+				TRY(mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, d_starts, pass ? d_chirp : nullptr, static_cast<uint32_t>(T),
+				                                  static_cast<uint32_t>(nfft), d_freq, d_qual, st));
+				HTRY(hipMemcpyAsync(fh.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
+				HTRY(hipMemcpyAsync(qh.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
+				HTRY(hipStreamSynchronize(st));
+				/* tiles without a clear line (fade, interference) take their good neighbours' estimate, interpolated over time;
+				   with no good tile at all, the pilot's frequency */
+				std::vector<size_t> good;
+				for (size_t i = 0; i < T; i++) if (qh[i] >= min_quality) good.push_back(i);
+				rep->weak_carrier_tiles = static_cast<uint32_t>(T - good.size());
+				if (good.empty()) {
+					for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
+				} else {
+					std::vector<double> gx, gv;
+					for (size_t g : good) { gx.push_back(centre[g]); gv.push_back(fh[g]); }
+					for (size_t i = 0; i < T; i++)
+						fbar[i] = qh[i] >= min_quality ? static_cast<double>(fh[i]) : interp_at(gx, gv, std::min(std::max(centre[i], gx.front()), gx.back()));
+				}
+				/* one estimate far off the line through its neighbours (a spur, a burst: 1 in 1e5 windows) would put every later tile
+				   in the wrong frame: the carrier is smooth, the neighbours decide */
+				if (T >= 5) {
+					std::vector<double> fixed = fbar;
+					for (size_t i = 1; i + 1 < T; i++) {
+						const double w = (centre[i] - centre[i - 1]) / (centre[i + 1] - centre[i - 1]);
+						const double pred = fbar[i - 1] + (fbar[i + 1] - fbar[i - 1]) * w;
+						if (std::fabs(fbar[i] - pred) > 6e-6 / nco) {
+							/* which of the three is the odd one?  the one whose own neighbours agree with each other without it */
+							const size_t a = i >= 2 ? i - 2 : i - 1, b = std::min(T - 1, i + 2);
+							const double wa = (centre[i] - centre[a]) / (centre[b] - centre[a]);
+							const double pred2 = fbar[a] + (fbar[b] - fbar[a]) * wa;
+							if (std::fabs(pred - pred2) < std::fabs(fbar[i] - pred2)) fixed[i] = pred;
+						}
+					}
+					fbar = fixed;
+				}
+				for (size_t i = 0; i < T; i++) {
+					const size_t lo = i ? i - 1 : 0, hi = std::min(T - 1, i + 1);
+					slope[i] = centre[hi] > centre[lo] ? (fbar[hi] - fbar[lo]) / (centre[hi] - centre[lo]) : 0.0;
+				}
 			}
-			/* repair: a stream an odd number of quarter turns off has settled on the other rail's noise (timing.c:65-66).  It
-			   starts again from the checkpoint with the measured rotation taken out of its state; streams that are 0 or 180
-			   degrees off keep their run (180 degrees is exact on the output).  The checkpoint restores every stream, the ones
-			   that keep their run are simply not launched again. */
-			TRY(mdemod_copy_state(bank.c, saved.c, st));
-			for (size_t i = 0; i < T; i++) {
-				run[i] = (C[i] & 1) ? 1 : 0;
-				if (run[i]) { state_rot[i] = (R[i] + C[i]) & 3; expect[i] = 0; rep->repaired_tiles++; }
-				else expect[i] = C[i];
-			}
+			mark("carrier lines");
 		} else {
-			out_rot = C;
-			second_round = true;
-			/* what the second round was not expected to find.  A re-run tile that sits half a turn off on BOTH its seams is no jump:
-			   its output is turned (exact) and continuous with its neighbours */
-			std::vector<int32_t> D(T);
-			for (size_t i = 0; i < T; i++) D[i] = (C[i] - expect[i]) & 3;
-			for (size_t i = 1; i < T; i++) {
-				if (D[i] == D[i - 1]) continue;
-				if (!((D[i] - D[i - 1]) & 1) && (i + 1 >= T || D[i + 1] == D[i - 1])) { i++; continue; }
-				jump_at[i] = 1;
-			}
+			for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
 		}
+		return MDEMOD_OK;
 	}
 
-	/* ---- tiles the repair did not cure --------------------------------------------------------------------------------------
-	   A stream that slips a quarter turn on its way in one run and not in the other (seen on OQPSK at low resolution / under a
-	   ramp: 2 of 260 soak recordings) comes out odd again, the other way round, when it is re-run with its state turned.  Its
-	   samples are then demodulated by its PREDECESSOR instead: that stream runs again from the checkpoint through its own tile
-	   (the same bytes as before) and on through the next one - no seam, no rotation to get wrong. ---- */
-	std::vector<char> merged(T, 0);                         /* tile i is the second half of stream i-1's long run */
-	std::vector<const int8_t *> src_of(T, nullptr);
-	if (second_round && saved.c) {
-		std::vector<size_t> preds;
-		for (size_t i = 1; i < T; i++)
-			if (run[i] && (out_rot[i] & 1) && !(out_rot[i - 1] & 1) && (i + 1 >= T || !(out_rot[i + 1] & 1)) && !merged[i - 1] && len[i] > 0) { merged[i] = 1; preds.push_back(i - 1); }
-		const uint64_t cap_fix = mdemod_max_symbols(bank.c, 2 * B);
-		int8_t *soft_fix = nullptr;
-		if (!preds.empty()) {
-			/* rows are indexed by stream (the bank's launches have one pitch for all): rows up to the last stream that runs
-			   are enough.  No room for them: the tiles stay as they are, a quarter turn off, and are REPORTED (rotation_jumps,
-			   below) - better than failing a recording whose every other symbol is done. */
-			const size_t rows = preds.back() + 1;
-			if (mem.alloc(&soft_fix, rows * cap_fix * 2) != MDEMOD_OK) {
-				for (size_t j : preds) merged[j + 1] = 0;
-				preds.clear();
-				soft_fix = nullptr;
+	/* symbol-rate line around every tile (mdemod_estimate_clock); the pilot's hand-over target */
+	int estimate_clocks()
+	{
+		/* (with carrier_seed = 0 the OQPSK line pair is looked for around the pilot's carrier word, with no chirp taken out) */
+		if (o.clock_seed == 0 && T > 1 && n_samples >= 4096) {
+			/* ---- symbol clock of every tile (a pass moves the clock with the carrier: 20 ppm and more between the pilot and the far
+			   end; the loop's integrator needs 8 000 symbols per e-fold to make that up).  The clock is smooth, so its windows are
+			   the estimator's longest (2^18 samples: 5e-8 of the rate), side by side over the tiled part, whatever the tile length;
+			   every tile reads a straight line through the estimates around it. ---- */
+			uint32_t wc = 4096;
+			while (wc * 2 <= std::min<uint64_t>(n_samples, 1u << 18)) wc *= 2;
+			const uint64_t first = std::min<uint64_t>(s0[1], n_samples - wc);
+			std::vector<uint64_t> cst;
+			for (uint64_t a = first; ; a += wc) {
+				if (a + wc >= n_samples) { cst.push_back(n_samples - wc); break; }
+				cst.push_back(a);
 			}
+			const size_t Tc = cst.size();
+			std::vector<float> cf(Tc), cc(Tc);
+			std::vector<double> cx(Tc);
+			for (size_t j = 0; j < Tc; j++) {
+				cx[j] = static_cast<double>(cst[j]) + 0.5 * wc;
+				cf[j] = static_cast<float>(interp_at(centre, fbar, std::min(std::max(cx[j], centre.front()), centre.back())));     /* OQPSK: where its two lines are */
+				cc[j] = static_cast<float>(interp_at(centre, slope, std::min(std::max(cx[j], centre.front()), centre.back())));
+			}
+			uint64_t *d_cst; float *d_cf, *d_cc, *d_tfq, *d_cq;
+			TRY(upload(mem, cst, &d_cst, st)); TRY(upload(mem, cf, &d_cf, st)); TRY(upload(mem, cc, &d_cc, st));
+			TRY(mem.alloc(&d_tfq, Tc)); TRY(mem.alloc(&d_cq, Tc));
+			TRY(mdemod_estimate_clock(params, iq_dev, n_samples, d_cst, d_cf, d_cc, static_cast<uint32_t>(Tc), wc, d_tfq, d_cq, st));
+			std::vector<float> th(Tc), cq(Tc);
+			HTRY(hipMemcpyAsync(th.data(), d_tfq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
+			HTRY(hipMemcpyAsync(cq.data(), d_cq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
+			HTRY(hipStreamSynchronize(st));
+			size_t lo = 0, hi = 0, weak = 0;
+			const double span = 2.5 * wc;                            /* five windows: the clock moves by < 1e-6 of the rate per second */
+			for (size_t i = 0; i < T; i++) {
+				const double t = static_cast<double>(s0[i]);
+				while (lo + 1 < Tc && cx[lo] < t - span) lo++;
+				while (hi + 1 < Tc && cx[hi + 1] <= t + span) hi++;
+				double sw = 0, sx = 0, sy = 0, sxx = 0, sxy = 0;
+				for (size_t j = lo; j <= hi; j++) {
+					if (cq[j] < min_quality) continue;
+					const double x = cx[j] - t, y = static_cast<double>(th[j]) - static_cast<double>(seed.t_freq);
+					sw += 1; sx += x; sy += y; sxx += x * x; sxy += x * y;
+				}
+				if (sw < 1) { weak++; continue; }                       /* no line anywhere near: the pilot's omega stays */
+				const double det = sw * sxx - sx * sx;
+				const double at_t = (sw >= 3 && det > 1e-6 * sw * sxx) ? (sy * sxx - sx * sxy) / det : sy / sw;
+				const double lim = static_cast<double>(consts[6]);   /* timing.c:80-86 keeps the loop within this of its centre */
+				tclk[i] = static_cast<double>(consts[5]) + std::max(-lim, std::min(lim, static_cast<double>(seed.t_freq) + at_t - static_cast<double>(consts[5])));
+			}
+			rep->weak_clock_tiles = static_cast<uint32_t>(weak);
+			if (dbg) fprintf(stderr, "[recording] clock seeds from %zu windows of %u: pilot %.9g, tiles %.9g .. %.9g (weak %zu)\n", Tc, wc, static_cast<double>(seed.t_freq), tclk[T > 1 ? 1 : 0], tclk[T - 1], weak);
 		}
-		if (!preds.empty()) {
-			TRY(mdemod_copy_state(bank.c, saved.c, st));
-			std::vector<int32_t> qt(T, 0);
-			std::vector<uint64_t> c_stl(T, 0), c_body(T, 0), c_post(T, 0), o_post(T, 0);
-			for (size_t j : preds) { qt[j] = (4 - state_rot[j]) & 3; c_stl[j] = stl[j]; c_body[j] = len[j] + len[j + 1]; o_post[j] = ends[j + 1]; c_post[j] = post_len[j + 1]; }
+		mark("carrier estimates");
+		/* The carrier loop is heavily overdamped: its frequency word follows a moving carrier with the lag slope * tau (pll.c:115
+		   integrates beta * e, the phase term alpha * e does the tracking), and right after the pilot's hand-over the serial run is
+		   still converging with the same time constant.  A tile settles for less than tau, so it is seeded with the frequency the
+		   SERIAL loop has at that point, not with the carrier: estimate - lag + what is left of the pilot's own offset. */
+		f_pilot_target = f_at(static_cast<double>(P)) - (T > 1 ? slope[0] * osf / nco * tau_pll : 0.0);
+		/* a lock the reference declares far from the carrier (its OQPSK loop does on about half of all recordings with an offset, and
+		   never leaves it) is reported: the tiles demodulate the signal, the reference from there on does not */
+		if (o.carrier_seed == 1 && T > 1 && seed.pll_locked && rep->weak_carrier_tiles < T / 2 &&
+		    std::fabs(static_cast<double>(seed.pll_freq) - f_pilot_target) > 2 * kPi * 100.0 / (symrate * nco)) rep->pilot_locked = 2;
+		return MDEMOD_OK;
+	}
+
+	/* loop state, gains and carrier words of every stream */
+	int seed_tiles()
+	{
+		/* ---- seeds ------------------------------------------------------------------------------------------------ */
+		TRY(mdemod_set_state_all(bank.c, &seed, st));
+		TRY(mdemod_set_state(bank.c, 0, &seed, st));
+		TRY(mdemod_set_history(bank.c, 0, po.hist.data(), st));
+		f0.assign(T, 0.0f); tf.assign(T, seed.t_freq); gains.assign(T, seed.agc_gain); ud.assign(T, 0);
+		for (size_t i = 1; i < T; i++) tf[i] = static_cast<float>(tclk[i]);
+		TRY(mem.alloc(&d_f0, T)); TRY(mem.alloc(&d_tf, T)); TRY(mem.alloc(&d_gain, T)); TRY(mem.alloc(&d_ud, T));
+		/* the reference's AGC moves by 1e-4 * 190 / gain of itself per symbol (agc.c:13-25): with s16-scale input (gain ~ 0.03) it is
+		   there within a few symbols whatever it starts from; only a slow one (float input around +-1: tens of thousands of symbols)
+		   needs a seed per tile, and only then is the recording read once more for its power */
+		const bool slow_agc = 6.0 * static_cast<double>(seed.agc_gain) / (1e-4 * 190.0) > 0.25 * static_cast<double>(A) / osf;
+		if (T > 1 && !slow_agc) {
+			HTRY(hipMemcpyAsync(d_gain, gains.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+			HTRY(hipMemcpyAsync(d_tf, tf.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+			HTRY(hipStreamSynchronize(st));
+			TRY(put_carrier_seeds(false));
+		}
+		if (T > 1 && slow_agc) {
+			/* AGC gain seeds: g* = c / sqrt(sample power), c fitted on the pilot's last blocks, then the reference's AGC in closed
+			   form over the tiles' powers (agc.c:13-25) */
+			const size_t nb = std::min<size_t>(10, po.blocks.size());
+			const size_t b0 = po.blocks.size() - nb;
+			std::vector<uint64_t> ws; std::vector<uint32_t> wl;
+			for (size_t j = b0; j < po.blocks.size(); j++) { ws.push_back(po.blocks[j].start); wl.push_back(po.blocks[j].len); }
+			for (size_t i = 0; i < T; i++) { ws.push_back(E[i]); wl.push_back(static_cast<uint32_t>(len[i])); }
+			uint64_t *d_ws; uint32_t *d_wl; float *d_wp;
+			TRY(upload(mem, ws, &d_ws, st));
+			TRY(upload(mem, wl, &d_wl, st));
+			TRY(mem.alloc(&d_wp, ws.size()));
+			HTRY(hipStreamSynchronize(st));
+			const dim3 grid(static_cast<unsigned>(ws.size()));
+			switch (params->bps) {
+			case 16: hipLaunchKernelGGL(window_power_kernel<16>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
+			case 8:  hipLaunchKernelGGL(window_power_kernel<8>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
+			default: hipLaunchKernelGGL(window_power_kernel<32>, grid, dim3(256), 0, st, iq_dev, d_ws, d_wl, d_wp); break;
+			}
+			HTRY(hipGetLastError());
+			std::vector<float> wp(ws.size());
+			HTRY(hipMemcpyAsync(wp.data(), d_wp, wp.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+			HTRY(hipStreamSynchronize(st));
+			std::vector<double> blk_gain(nb), blk_power(nb), blk_syms(nb);
+			for (size_t j = 0; j < nb; j++) {
+				const PilotBlock &pb = po.blocks[b0 + j];
+				const uint64_t before = (b0 + j) ? po.blocks[b0 + j - 1].symbols_after : 0;
+				blk_gain[j] = pb.gain_after; blk_power[j] = wp[j]; blk_syms[j] = static_cast<double>(pb.symbols_after - before);
+			}
+			const double c = nb ? fit_agc_calibration(blk_gain, blk_power, blk_syms) : 0.0;
+			/* gE[k]: the serial run's gain at E_k; stream i starts its lead before E_i and takes the gain of the boundary at or
+			   before its start */
+			std::vector<double> gE(T + 1);
+			gE[0] = seed.agc_gain;
+			for (size_t k = 0; k < T; k++) gE[k + 1] = agc_step(gE[k], c, wp[nb + k], static_cast<double>(len[k]) * symrate / fs);
+			for (size_t i = 1; i < T; i++) {
+				const size_t back = static_cast<size_t>((E[i] - s0[i] + B - 1) / B);
+				gains[i] = static_cast<float>(gE[i > back ? i - back : 0]);
+			}
+			HTRY(hipMemcpyAsync(d_gain, gains.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+			HTRY(hipMemcpyAsync(d_tf, tf.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+			HTRY(hipStreamSynchronize(st));
+			TRY(mdemod_set_gain_seeds(bank.c, d_gain, st));
+			TRY(put_carrier_seeds(false));
+		}
+		return MDEMOD_OK;
+	}
+
+	/* acquire, re-seed the integrators, frame by dead reckoning, checkpoint */
+	int acquire_and_frame()
+	{
+		mark("seeds");
+		/* of the lead only the last symbols are kept: what the seam check compares with the predecessor's tail */
+		tail_samples = static_cast<uint64_t>((K + 24) * osf * 1.05) + 16;
+		cap_lead = std::max<uint64_t>(8, mdemod_max_symbols(bank.c, tail_samples));
+		cap = mdemod_max_symbols(bank.c, B);
+		TRY(mem.alloc(&soft_pre, T * cap_lead * 2));
+		TRY(mem.alloc(&soft1, T * cap * 2));
+		mark("output buffers allocated");
+		cnt_tmp.clear(); cnt_pre.assign(T, 0); cnt1.assign(T, 0);
+		status_body.clear();
+		R.assign(T, 0);
+		if (T > 1) {
+			/* acquire, then the two integrators back on their seeds (the gain keeps what it found) */
+			TRY(launch(s0, acq, soft_pre, cap_lead, cnt_tmp, nullptr, true));
+			mark("acquire");
+			TRY(put_carrier_seeds(true));
+			TRY(mdemod_set_clock_seeds(bank.c, d_tf, st));
+			std::vector<uint64_t> off(T);
+			for (size_t i = 0; i < T; i++) off[i] = s0[i] + acq[i];
+			TRY(launch(off, frm, soft_pre, cap_lead, cnt_tmp, nullptr, true));
+			mark("frame");
+
+			/* ---- frames by dead reckoning along the chain pilot -> tile 1 -> tile 2 ... ---------------------------------- */
+			std::vector<mdemod_stream_state> qs(T);
+			TRY(mdemod_get_states(bank.c, 0, static_cast<uint32_t>(T), qs.data(), st));
+			double th_prev = seed.pll_phase, t_prev = last_nco_time(seed, static_cast<double>(P), interp, params->oqpsk);
+			size_t i_prev = 0;                                     /* the chain's last trusted link */
+			int32_t acc_prev = 0; double res2 = 0.0; size_t hung = 0;
+			for (size_t i = 1; i < T; i++) {
+				const double th = qs[i].pll_phase, tt = last_nco_time(qs[i], static_cast<double>(q[i]), interp, params->oqpsk);
+				const double t_mid = 0.5 * (t_prev + tt) / interp;
+				double res;
+				/* NCO steps between the two: the symbol period of THIS stretch of the recording (a pass moves the clock: 50 ppm over a
+				   41 072-symbol tile would be two steps with the pilot's period) */
+				const double steps_per_nco = 2 * kPi / (0.5 * (tclk[i_prev] + tclk[i])) / nco;
+				const int32_t accr = (acc_prev + frame_between(th_prev, t_prev, th, tt, f_at(t_mid), steps_per_nco, &res)) & 3;
+				R[i] = accr; res2 += res * res;
+				/* Two streams that are on the symbols are a whole number of steps apart (seen: +-0.02).  One in 1e5 tiles is still hung
+				   up between two symbols after acquire + frame (the Mueller-Mueller detector's unstable equilibrium): its own phase
+				   says little (best guess kept: the seam check will see), and the chain must not go through it - its successor is
+				   reckoned from the last stream that was on the symbols.  (Found on the 6.5 G-sample recording: tile 121 764 was
+				   0.44 of a step off, both its links had a residual of -0.7 rad, one rounded the wrong way and 5 184 tiles behind
+				   it were repaired for it.) */
+				const double steps = (tt - t_prev) / steps_per_nco, off_grid = std::fabs(steps - std::nearbyint(steps));
+				const bool trusted = off_grid <= 0.2 || i - i_prev > 4;
+				if (dbg && o.debug_tile >= 0 && std::llabs(static_cast<long long>(i) - static_cast<long long>(o.debug_tile)) <= 2)
+					fprintf(stderr, "[recording]   trace %zu (from %zu): theta %.5f t %.3f (dt %.3f steps = %.4f nco) f %.9g res %.4f R %d t_freq %.9g t_phase %.5f locked %d pll_freq %.9g\n", i, i_prev, th, tt, tt - t_prev,
+					        steps, f_at(t_mid), res, accr, static_cast<double>(qs[i].t_freq), static_cast<double>(qs[i].t_phase), qs[i].pll_locked, static_cast<double>(qs[i].pll_freq));
+				if (dbg && (std::fabs(res) > 0.5 || !trusted)) fprintf(stderr, "[recording]   frame %zu: dead-reckoning residual %.3f rad, %.3f of a step off the symbols%s\n", i, res, off_grid, trusted ? "" : " (not chained through)");
+				if (trusted) { th_prev = th; t_prev = tt; i_prev = i; acc_prev = accr; } else hung++;
+			}
+			if (dbg) fprintf(stderr, "[recording] %zu tiles not on the symbols when their frame was taken\n", hung);
+			rep->frame_residual_rms = static_cast<float>(std::sqrt(res2 / static_cast<double>(T - 1)));
+			/* checkpoint of the bank before any rotation: what a repair starts from */
+			if (o.repair) {
+				TRY(mdemod_create(&bp, &saved.c));
+				TRY(mdemod_copy_state(saved.c, bank.c, st));
+			}
+			mark("frames dead-reckoned, checkpoint");
+		}
+		TRY(mem.alloc(&d_rot, T));
+		shift.assign(T, 0); rot.assign(T, 0); weak.assign(T, 0);
+		stl_off.assign(T, 0);
+		for (size_t i = 0; i < T; i++) stl_off[i] = q[i];
+		const uint64_t post = 4096;                               /* OQPSK: look-ahead into the next tile for the seam check */
+		soft_post = nullptr; cap_post = 0;
+		cnt_post.assign(T, 0);
+		ends.assign(T, 0); post_len.assign(T, 0);
+		for (size_t i = 0; i < T; i++) { ends[i] = E[i] + len[i]; post_len[i] = std::min<uint64_t>(post, n_samples - ends[i]); }
+		if (params->oqpsk) {
+			cap_post = std::max<uint64_t>(8, mdemod_max_symbols(bank.c, post));
+			TRY(mem.alloc(&soft_post, T * cap_post * 2));
+		}
+		return MDEMOD_OK;
+	}
+
+	/* settle + body (+ OQPSK look-ahead), every seam, one repair round for odd tiles */
+	int settle_body_seams()
+	{
+		/* settle + body (+ OQPSK look-ahead) of the streams in `run` (all of them the first time), then every seam again */
+		run.assign(T, 1);
+		state_rot = R;                    /* output rotation taken out of each stream's state before it settles */
+		out_rot.assign(T, 0); expect.assign(T, 0);     /* rotation left for the output; what the second round should find */
+		jump_at.assign(T, 0);                       /* seams that still show a rotation after the repair */
+		second_round = false;
+		for (int round = 0; round < 2; round++) {
+			std::vector<int32_t> qt(T);
+			for (size_t i = 0; i < T; i++) qt[i] = run[i] ? (4 - state_rot[i]) & 3 : 0;
 			HTRY(hipMemcpyAsync(d_rot, qt.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
 			HTRY(hipStreamSynchronize(st));
 			TRY(mdemod_rotate_carrier(bank.c, d_rot, st));
-			std::vector<uint32_t> cnt_fix;
-			TRY(launch(stl_off, c_stl, soft_pre, cap_lead, cnt_tmp, nullptr, true));
-			TRY(launch(E, c_body, soft_fix, cap_fix, cnt_fix));
-			if (params->oqpsk) {
-				TRY(launch(o_post, c_post, soft_post, cap_post, cnt_tmp));
-				for (size_t j : preds) cnt_post[j] = cnt_tmp[j];
+			auto masked = [&](const std::vector<uint64_t> &c) { std::vector<uint64_t> m(T); for (size_t i = 0; i < T; i++) m[i] = run[i] ? c[i] : 0; return m; };
+			std::vector<mdemod_status> stat;
+			{
+				std::vector<uint64_t> stl_a(T), stl_b(T), off_b(T);
+				for (size_t i = 0; i < T; i++) { stl_b[i] = std::min<uint64_t>(stl[i], tail_samples); stl_a[i] = stl[i] - stl_b[i]; off_b[i] = q[i] + stl_a[i]; }
+				TRY(launch(stl_off, masked(stl_a), soft_pre, cap_lead, cnt_tmp, nullptr, true));
+				TRY(launch(off_b, masked(stl_b), soft_pre, cap_lead, cnt_tmp));
 			}
-			/* the seam behind the long run: its tail against the next tile's settled tail */
-			std::vector<TailPair> pairs;
-			std::vector<size_t> at;
-			for (size_t j : preds) {
-				const size_t i = j + 1;
-				src_of[j] = soft_fix + j * cap_fix * 2; cnt1[j] = cnt_fix[j]; cnt1[i] = 0;
-				out_rot[i] = out_rot[j]; shift[i] = 0; weak[i] = 0; jump_at[i] = 0;
-				rep->repaired_tiles++;
-				if (i + 1 < T) {
-					TailPair p;
-					p.a = src_of[j]; p.a_cnt = cnt1[j]; p.b = soft_pre + (i + 1) * cap_lead * 2; p.b_cnt = cnt_pre[i + 1]; p.b_rot = 0; p.force_weak = stl[i + 1] == 0;
-					pairs.push_back(p); at.push_back(i + 1);
-				}
+			mark("settle");
+			for (size_t i = 0; i < T; i++) if (run[i]) cnt_pre[i] = cnt_tmp[i];
+			TRY(launch(E, masked(len), soft1, cap, cnt_tmp, &stat));
+			mark("body");
+			if (status_body.empty()) status_body = stat;
+			for (size_t i = 0; i < T; i++) if (run[i]) { cnt1[i] = cnt_tmp[i]; status_body[i] = stat[i]; }
+			if (params->oqpsk) {
+				TRY(launch(ends, masked(post_len), soft_post, cap_post, cnt_tmp));
+				for (size_t i = 0; i < T; i++) if (run[i]) cnt_post[i] = cnt_tmp[i];
+			}
+
+			/* ---- seams: tile i's settled tail against its predecessor's body tail (tile 1: against tile 0 = the serial run) ---- */
+			std::vector<TailPair> pairs(T > 1 ? T - 1 : 0);
+			for (size_t i = 1; i < T; i++) {
+				TailPair &p = pairs[i - 1];
+				p.a = soft1 + (i - 1) * cap * 2; p.a_cnt = cnt1[i - 1];
+				p.b = soft_pre + i * cap_lead * 2; p.b_cnt = cnt_pre[i];
+				p.b_rot = 0; p.force_weak = stl[i] == 0;
 			}
 			std::vector<int32_t> sh, ro, we;
 			TRY(run_match(mem, pairs, K, sh, ro, we, st, params->oqpsk ? 1 : 0));
-			for (size_t k = 0; k < at.size(); k++) {
-				const size_t n = at[k];
-				if (!params->oqpsk) shift[n] = sh[k];
-				weak[n] = we[k];
-				/* measured: tile n needs ro[k] quarter turns against the long run; it was given out_rot[n] against the chain */
-				jump_at[n] = (!we[k] && ((out_rot[n - 1] + ro[k] - out_rot[n]) & 3)) ? 1 : 0;
+			mark("seams");
+			for (size_t i = 1; i < T; i++) { shift[i] = params->oqpsk ? 0 : sh[i - 1]; rot[i] = we[i - 1] ? 0 : (ro[i - 1] & 3); weak[i] = we[i - 1]; }
+			/* rotation each stream's output still needs to sit in the serial run's frame: b * j^rot matches a, summed along the chain */
+			std::vector<int32_t> C(T, 0);
+			for (size_t i = 1; i < T; i++) C[i] = (C[i - 1] + rot[i]) & 3;
+			bool odd = false;
+			for (size_t i = 1; i < T; i++) odd = odd || (C[i] & 1);
+			if (dbg) {
+				fprintf(stderr, "[recording] round %d: T=%zu tile=%u lead=%u+%u+%u\n", round, T, o.tile_samples, o.acquire_samples, o.frame_samples, o.settle_samples);
+				for (size_t i = 1; i < T; i++)
+					if (rot[i] || weak[i] || shift[i] || run[i] != 1 || o.debug >= 2)
+						fprintf(stderr, "[recording]   seam %zu: rot %d weak %d shift %d C %d run %d R %d cnt_pre %u cnt1 %u locked %d f0 %.6f q %.1f\n", i, rot[i], weak[i], shift[i], C[i], (int)run[i], R[i],
+						        cnt_pre[i], cnt1[i], status_body.size() > i ? status_body[i].locked : -1, fbar[i], 0.0);
 			}
-			if (dbg) fprintf(stderr, "[recording] %zu tiles handed to their predecessors' streams\n", preds.size());
-			mark("merged");
+			if (round == 0) {
+				for (size_t i = 1; i < T; i++) rep->frame_misses += rot[i] ? 1 : 0;
+				out_rot = C;
+				if (!odd) break;
+				size_t n_odd = 0;
+				for (size_t i = 1; i < T; i++) n_odd += (C[i] & 1);
+				/* A repair is one more settle + body for the lanes concerned - as long as for all of them.  It pays when dead reckoning
+				   failed broadly; one odd tile in 10^5 (its decisions are exact once the output is turned, only its soft values sit on
+				   the other rail's timing noise: 2 % of them off by more than an LSB) does not move the result by 1e-6. */
+				/* OQPSK has no such choice: a tile a quarter turn off pairs its rails one symbol apart (demod.c:66-76), which turning
+				   the output cannot undo */
+				if (!o.repair || !saved.c || (!params->oqpsk && n_odd * 200 < T)) {
+					for (size_t i = 1; i < T; i++) rep->rotation_jumps += (!o.repair && (rot[i] & 1)) ? 1 : 0;
+					rep->odd_tiles_kept = static_cast<uint32_t>(n_odd);
+					break;
+				}
+				/* repair: a stream an odd number of quarter turns off has settled on the other rail's noise (timing.c:65-66).  It
+				   starts again from the checkpoint with the measured rotation taken out of its state; streams that are 0 or 180
+				   degrees off keep their run (180 degrees is exact on the output).  The checkpoint restores every stream, the ones
+				   that keep their run are simply not launched again. */
+				TRY(mdemod_copy_state(bank.c, saved.c, st));
+				for (size_t i = 0; i < T; i++) {
+					run[i] = (C[i] & 1) ? 1 : 0;
+					if (run[i]) { state_rot[i] = (R[i] + C[i]) & 3; expect[i] = 0; rep->repaired_tiles++; }
+					else expect[i] = C[i];
+				}
+			} else {
+				out_rot = C;
+				second_round = true;
+				/* what the second round was not expected to find.  A re-run tile that sits half a turn off on BOTH its seams is no jump:
+				   its output is turned (exact) and continuous with its neighbours */
+				std::vector<int32_t> D(T);
+				for (size_t i = 0; i < T; i++) D[i] = (C[i] - expect[i]) & 3;
+				for (size_t i = 1; i < T; i++) {
+					if (D[i] == D[i - 1]) continue;
+					if (!((D[i] - D[i - 1]) & 1) && (i + 1 >= T || D[i + 1] == D[i - 1])) { i++; continue; }
+					jump_at[i] = 1;
+				}
+			}
 		}
+		return MDEMOD_OK;
 	}
-	for (size_t i = 1; i < T; i++) rep->rotation_jumps += jump_at[i];
-	if (params->oqpsk && T > 1) {
-		/* rails come from firings half a symbol apart: the one-symbol disagreement is looked for on heads, tile i-1's
-		   look-ahead past its end against tile i's body (both start on the same sample) */
-		std::vector<TailPair> heads(T - 1);
-		for (size_t i = 1; i < T; i++) {
-			const size_t pr = merged[i - 1] ? i - 2 : i - 1;       /* the stream that ran up to this tile's first sample */
-			heads[i - 1].a = soft_post + pr * cap_post * 2;     heads[i - 1].a_cnt = cnt_post[pr];
-			heads[i - 1].b = soft1 + i * cap * 2;               heads[i - 1].b_cnt = cnt1[i];
-			heads[i - 1].b_rot = 0; heads[i - 1].force_weak = merged[i] ? 1 : 0;
-		}
-		std::vector<int32_t> sh2, r2, w2;
-		TRY(run_match(mem, heads, K, sh2, r2, w2, st, 2));
-		for (size_t i = 1; i < T; i++) { if (merged[i]) continue; shift[i] = w2[i - 1] ? 0 : -sh2[i - 1]; if (w2[i - 1]) weak[i] = 1; }
-	}
-	const std::vector<int32_t> &Rtot = out_rot;
-	for (size_t i = 0; i < T; i++) rep->weak_seams += weak[i];
 
-	/* ---- concatenate: pilot ++ tiles, with the seam fixes and what rotation is left on the output ---- */
-	std::vector<TileCopy> copies(T);
-	for (size_t i = 0; i < T; i++) {
-		copies[i].src = src_of[i] ? src_of[i] : soft1 + i * cap * 2; copies[i].rot = Rtot[i]; copies[i].keep = cnt1[i];
-		copies[i].head = nullptr; copies[i].head_rot = 0;
-		if (i && shift[i] == -1) {
-			/* the symbol straddling the seam is missing on both sides: take it from tile i's own settled run (its last symbol
-			   before the body; OQPSK: from the predecessor's look-ahead) */
-			const size_t pr = merged[i - 1] ? i - 2 : i - 1;
-			if (params->oqpsk) { if (cnt_post[pr] > 0) { copies[i].head = soft_post + pr * cap_post * 2; copies[i].head_rot = Rtot[pr]; } }
-			else if (cnt_pre[i] > 0) { copies[i].head = soft_pre + (i * cap_lead + cnt_pre[i] - 1) * 2; copies[i].head_rot = Rtot[i]; }
+	/* tiles the repair did not cure run as the tail of their predecessors' streams */
+	int hand_over_uncured()
+	{
+		/* ---- tiles the repair did not cure --------------------------------------------------------------------------------------
+		   A stream that slips a quarter turn on its way in one run and not in the other (seen on OQPSK at low resolution / under a
+		   ramp: 2 of 260 soak recordings) comes out odd again, the other way round, when it is re-run with its state turned.  Its
+		   samples are then demodulated by its PREDECESSOR instead: that stream runs again from the checkpoint through its own tile
+		   (the same bytes as before) and on through the next one - no seam, no rotation to get wrong. ---- */
+		merged.assign(T, 0);                         /* tile i is the second half of stream i-1's long run */
+		src_of.assign(T, nullptr);
+		if (second_round && saved.c) {
+			std::vector<size_t> preds;
+			for (size_t i = 1; i < T; i++)
+				if (run[i] && (out_rot[i] & 1) && !(out_rot[i - 1] & 1) && (i + 1 >= T || !(out_rot[i + 1] & 1)) && !merged[i - 1] && len[i] > 0) { merged[i] = 1; preds.push_back(i - 1); }
+			const uint64_t cap_fix = mdemod_max_symbols(bank.c, 2 * B);
+			int8_t *soft_fix = nullptr;
+			if (!preds.empty()) {
+				/* rows are indexed by stream (the bank's launches have one pitch for all): rows up to the last stream that runs
+				   are enough.  No room for them: the tiles stay as they are, a quarter turn off, and are REPORTED (rotation_jumps,
+				   below) - better than failing a recording whose every other symbol is done. */
+				const size_t rows = preds.back() + 1;
+				if (mem.alloc(&soft_fix, rows * cap_fix * 2) != MDEMOD_OK) {
+					for (size_t j : preds) merged[j + 1] = 0;
+					preds.clear();
+					soft_fix = nullptr;
+				}
+			}
+			if (!preds.empty()) {
+				TRY(mdemod_copy_state(bank.c, saved.c, st));
+				std::vector<int32_t> qt(T, 0);
+				std::vector<uint64_t> c_stl(T, 0), c_body(T, 0), c_post(T, 0), o_post(T, 0);
+				for (size_t j : preds) { qt[j] = (4 - state_rot[j]) & 3; c_stl[j] = stl[j]; c_body[j] = len[j] + len[j + 1]; o_post[j] = ends[j + 1]; c_post[j] = post_len[j + 1]; }
+				HTRY(hipMemcpyAsync(d_rot, qt.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+				HTRY(hipStreamSynchronize(st));
+				TRY(mdemod_rotate_carrier(bank.c, d_rot, st));
+				std::vector<uint32_t> cnt_fix;
+				TRY(launch(stl_off, c_stl, soft_pre, cap_lead, cnt_tmp, nullptr, true));
+				TRY(launch(E, c_body, soft_fix, cap_fix, cnt_fix));
+				if (params->oqpsk) {
+					TRY(launch(o_post, c_post, soft_post, cap_post, cnt_tmp));
+					for (size_t j : preds) cnt_post[j] = cnt_tmp[j];
+				}
+				/* the seam behind the long run: its tail against the next tile's settled tail */
+				std::vector<TailPair> pairs;
+				std::vector<size_t> at;
+				for (size_t j : preds) {
+					const size_t i = j + 1;
+					src_of[j] = soft_fix + j * cap_fix * 2; cnt1[j] = cnt_fix[j]; cnt1[i] = 0;
+					out_rot[i] = out_rot[j]; shift[i] = 0; weak[i] = 0; jump_at[i] = 0;
+					rep->repaired_tiles++;
+					if (i + 1 < T) {
+						TailPair p;
+						p.a = src_of[j]; p.a_cnt = cnt1[j]; p.b = soft_pre + (i + 1) * cap_lead * 2; p.b_cnt = cnt_pre[i + 1]; p.b_rot = 0; p.force_weak = stl[i + 1] == 0;
+						pairs.push_back(p); at.push_back(i + 1);
+					}
+				}
+				std::vector<int32_t> sh, ro, we;
+				TRY(run_match(mem, pairs, K, sh, ro, we, st, params->oqpsk ? 1 : 0));
+				for (size_t k = 0; k < at.size(); k++) {
+					const size_t n = at[k];
+					if (!params->oqpsk) shift[n] = sh[k];
+					weak[n] = we[k];
+					/* measured: tile n needs ro[k] quarter turns against the long run; it was given out_rot[n] against the chain */
+					jump_at[n] = (!we[k] && ((out_rot[n - 1] + ro[k] - out_rot[n]) & 3)) ? 1 : 0;
+				}
+				if (dbg) fprintf(stderr, "[recording] %zu tiles handed to their predecessors' streams\n", preds.size());
+				mark("merged");
+			}
 		}
+		for (size_t i = 1; i < T; i++) rep->rotation_jumps += jump_at[i];
+		if (params->oqpsk && T > 1) {
+			/* rails come from firings half a symbol apart: the one-symbol disagreement is looked for on heads, tile i-1's
+			   look-ahead past its end against tile i's body (both start on the same sample) */
+			std::vector<TailPair> heads(T - 1);
+			for (size_t i = 1; i < T; i++) {
+				const size_t pr = merged[i - 1] ? i - 2 : i - 1;       /* the stream that ran up to this tile's first sample */
+				heads[i - 1].a = soft_post + pr * cap_post * 2;     heads[i - 1].a_cnt = cnt_post[pr];
+				heads[i - 1].b = soft1 + i * cap * 2;               heads[i - 1].b_cnt = cnt1[i];
+				heads[i - 1].b_rot = 0; heads[i - 1].force_weak = merged[i] ? 1 : 0;
+			}
+			std::vector<int32_t> sh2, r2, w2;
+			TRY(run_match(mem, heads, K, sh2, r2, w2, st, 2));
+			for (size_t i = 1; i < T; i++) { if (merged[i]) continue; shift[i] = w2[i - 1] ? 0 : -sh2[i - 1]; if (w2[i - 1]) weak[i] = 1; }
+		}
+		for (size_t i = 0; i < T; i++) rep->weak_seams += weak[i];
+		return MDEMOD_OK;
 	}
-	uint64_t out_pos = n_pilot_sym;
-	for (size_t i = 0; i < T; i++) {
-		const size_t nx = (i + 1 < T && merged[i + 1]) ? i + 2 : i + 1;      /* (a merged tile is part of this one's run) */
-		const uint32_t drop = (!merged[i] && nx < T && shift[nx] == 1) ? 1 : 0;      /* the successor emits this tile's last symbol too */
-		copies[i].keep = copies[i].keep > drop ? copies[i].keep - drop : 0;
-		if (shift[i] == -1 && !copies[i].head) shift[i] = 0;
-		copies[i].dst = out_pos;
-		out_pos += copies[i].keep + (copies[i].head ? 1 : 0);
-		if (shift[i]) rep->seam_fixes++;
-		if (i == 0) rep->exact_symbols = out_pos;
-	}
-	if (out_pos > soft_cap_symbols) return MDEMOD_ERR_OVERFLOW;
-	if (rep->first_lock_symbol < 0) {
-		/* The pilot never locked (a recording that starts before the signal does): the lock gate (main.c:308-315) opens
-		   at the first tile whose stream reports a first lock - inside its emitted body, or before it (then the whole
-		   body counts).  Approximate to the tiles' own acquisition, which is faster than the serial sweep. */
+
+	/* concatenate pilot ++ tiles with the seam fixes */
+	int assemble()
+	{
+		/* ---- concatenate: pilot ++ tiles, with the seam fixes and what rotation is left on the output ---- */
+		std::vector<TileCopy> copies(T);
 		for (size_t i = 0; i < T; i++) {
-			const int64_t fl = status_body[i].first_lock_symbol;
-			if (fl < 0) continue;
-			const uint64_t n_start = status_body[i].n_symbols - cnt1[i];
-			const uint64_t inside = static_cast<uint64_t>(fl) > n_start ? static_cast<uint64_t>(fl) - n_start : 0;
-			rep->first_lock_symbol = static_cast<int64_t>(copies[i].dst + std::min<uint64_t>(inside, copies[i].keep));
-			break;
+			copies[i].src = src_of[i] ? src_of[i] : soft1 + i * cap * 2; copies[i].rot = out_rot[i]; copies[i].keep = cnt1[i];
+			copies[i].head = nullptr; copies[i].head_rot = 0;
+			if (i && shift[i] == -1) {
+				/* the symbol straddling the seam is missing on both sides: take it from tile i's own settled run (its last symbol
+				   before the body; OQPSK: from the predecessor's look-ahead) */
+				const size_t pr = merged[i - 1] ? i - 2 : i - 1;
+				if (params->oqpsk) { if (cnt_post[pr] > 0) { copies[i].head = soft_post + pr * cap_post * 2; copies[i].head_rot = out_rot[pr]; } }
+				else if (cnt_pre[i] > 0) { copies[i].head = soft_pre + (i * cap_lead + cnt_pre[i] - 1) * 2; copies[i].head_rot = out_rot[i]; }
+			}
 		}
+		uint64_t out_pos = n_pilot_sym;
+		for (size_t i = 0; i < T; i++) {
+			const size_t nx = (i + 1 < T && merged[i + 1]) ? i + 2 : i + 1;      /* (a merged tile is part of this one's run) */
+			const uint32_t drop = (!merged[i] && nx < T && shift[nx] == 1) ? 1 : 0;      /* the successor emits this tile's last symbol too */
+			copies[i].keep = copies[i].keep > drop ? copies[i].keep - drop : 0;
+			if (shift[i] == -1 && !copies[i].head) shift[i] = 0;
+			copies[i].dst = out_pos;
+			out_pos += copies[i].keep + (copies[i].head ? 1 : 0);
+			if (shift[i]) rep->seam_fixes++;
+			if (i == 0) rep->exact_symbols = out_pos;
+		}
+		if (out_pos > soft_cap_symbols) return MDEMOD_ERR_OVERFLOW;
+		if (rep->first_lock_symbol < 0) {
+			/* The pilot never locked (a recording that starts before the signal does): the lock gate (main.c:308-315) opens
+			   at the first tile whose stream reports a first lock - inside its emitted body, or before it (then the whole
+			   body counts).  Approximate to the tiles' own acquisition, which is faster than the serial sweep. */
+			for (size_t i = 0; i < T; i++) {
+				const int64_t fl = status_body[i].first_lock_symbol;
+				if (fl < 0) continue;
+				const uint64_t n_start = status_body[i].n_symbols - cnt1[i];
+				const uint64_t inside = static_cast<uint64_t>(fl) > n_start ? static_cast<uint64_t>(fl) - n_start : 0;
+				rep->first_lock_symbol = static_cast<int64_t>(copies[i].dst + std::min<uint64_t>(inside, copies[i].keep));
+				break;
+			}
+		}
+		TileCopy *d_copies;
+		TRY(upload(mem, copies, &d_copies, st));
+		/* few tiles: several blocks per tile, so that the copy still fills the GPU */
+		const unsigned slices = static_cast<unsigned>(std::min<uint64_t>(64, std::max<uint64_t>(1, 4096 / T)));
+		hipLaunchKernelGGL(assemble_kernel, dim3(static_cast<unsigned>(T), slices), dim3(256), 0, st, d_copies, soft_dev);
+		HTRY(hipGetLastError());
+		HTRY(hipStreamSynchronize(st));
+		mark("assembled");
+		rep->n_symbols = out_pos;
+		rep->tiles_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tiles).count();
+		return MDEMOD_OK;
 	}
-	TileCopy *d_copies;
-	TRY(upload(mem, copies, &d_copies, st));
-	/* few tiles: several blocks per tile, so that the copy still fills the GPU */
-	const unsigned slices = static_cast<unsigned>(std::min<uint64_t>(64, std::max<uint64_t>(1, 4096 / T)));
-	hipLaunchKernelGGL(assemble_kernel, dim3(static_cast<unsigned>(T), slices), dim3(256), 0, st, d_copies, soft_dev);
-	HTRY(hipGetLastError());
-	HTRY(hipStreamSynchronize(st));
-	mark("assembled");
-	rep->n_symbols = out_pos;
-	rep->tiles_seconds = seconds_since(t_tiles);
-	return MDEMOD_OK;
+
+	int run_all()
+	{
+		TRY(run_head());
+		TRY(plan_tiles());
+		if (T == 0) return MDEMOD_OK;                        /* the head was the whole recording */
+		TRY(estimate_carriers());
+		TRY(estimate_clocks());
+		TRY(seed_tiles());
+		TRY(acquire_and_frame());
+		TRY(settle_body_seams());
+		TRY(hand_over_uncured());
+		return assemble();
+	}
+};
+
+static int
+demodulate_recording_impl(const mdemod_params *params, const mdemod_recording_opts *opts_in,
+                          const void *iq_dev, uint64_t n_samples,
+                          int8_t *soft_dev, uint64_t soft_cap_symbols,
+                          mdemod_recording_report *rep, void *hip_stream, const std::function<void(uint64_t)> *need)
+{
+	if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
+	if (params->samplerate <= 0 || params->symrate <= 0) return MDEMOD_ERR_PARAM;
+	Stitcher s;
+	s.params = params; s.opts_in = opts_in; s.iq_dev = iq_dev; s.n_samples = n_samples; s.soft_dev = soft_dev;
+	s.soft_cap_symbols = soft_cap_symbols; s.rep = rep; s.st = static_cast<hipStream_t>(hip_stream); s.need = need;
+	return s.run_all();
 }
 
 extern "C" int
