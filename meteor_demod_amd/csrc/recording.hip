@@ -1057,10 +1057,15 @@ struct Stitcher {
 			centre[i] = static_cast<double>(wstart[i]) + nfft / 2;
 		}
 		if (o.carrier_seed == 1 && T > 1) {
-			uint64_t *d_starts; float *d_freq, *d_qual, *d_chirp;
+			uint64_t *d_starts, *d_starts_sel; float *d_freq, *d_qual, *d_chirp;
 			TRY(upload(mem, wstart, &d_starts, st));
-			TRY(mem.alloc(&d_freq, T)); TRY(mem.alloc(&d_qual, T)); TRY(mem.alloc(&d_chirp, T));
-			std::vector<float> fh(T), qh(T), chirp(T, 0.0f);
+			TRY(mem.alloc(&d_freq, T)); TRY(mem.alloc(&d_qual, T)); TRY(mem.alloc(&d_chirp, T)); TRY(mem.alloc(&d_starts_sel, T));
+			std::vector<float> fh(T), qh(T), chirp(T, 0.0f), fsel(T), qsel(T), csel(T);
+			std::vector<uint64_t> wsel(T); std::vector<size_t> sel;
+			/* a ramp that moves the line by less than a tenth of a bin across the window smears nothing (the Hann window's main lobe is
+			   four bins wide): such a window keeps the estimate it has.  Without a Doppler ramp the local slopes are the estimates' own
+			   noise, a few hundredths of a bin, and the plain pass is the only one. */
+			const double bin = (fs / nfft / 4.0) * 2 * kPi / (symrate * nco);
 			for (int pass = 0; pass < 3; pass++) {
 				/* pass 0: plain; passes 1, 2: with the local slope taken out of the window (a Doppler ramp smears the line) */
 				if (pass) {
@@ -1070,17 +1075,27 @@ struct Stitcher {
 						std::sort(v, v + m);
 						chirp[i] = static_cast<float>(v[m / 2]);
 					}
-					bool any = false;
-					for (size_t i = 0; i < T; i++) any = any || std::fabs(chirp[i]) * nfft > 2e-6;      /* less than a tenth of a bin across the window: nothing to take out */
-					if (!any) break;
-					HTRY(hipMemcpyAsync(d_chirp, chirp.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
+					sel.clear();
+					for (size_t i = 0; i < T; i++) if (std::fabs(chirp[i]) * nfft > 0.1 * bin) sel.push_back(i);
+					if (sel.empty()) break;
+					for (size_t k = 0; k < sel.size(); k++) { wsel[k] = wstart[sel[k]]; csel[k] = chirp[sel[k]]; }
+					HTRY(hipMemcpyAsync(d_chirp, csel.data(), sel.size() * sizeof(float), hipMemcpyHostToDevice, st));
+					HTRY(hipMemcpyAsync(d_starts_sel, wsel.data(), sel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+					HTRY(hipStreamSynchronize(st));
+					TRY(mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, d_starts_sel, d_chirp, static_cast<uint32_t>(sel.size()),
+					                                  static_cast<uint32_t>(nfft), d_freq, d_qual, st));
+					HTRY(hipMemcpyAsync(fsel.data(), d_freq, sel.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+					HTRY(hipMemcpyAsync(qsel.data(), d_qual, sel.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+					HTRY(hipStreamSynchronize(st));
+					for (size_t k = 0; k < sel.size(); k++) { fh[sel[k]] = fsel[k]; qh[sel[k]] = qsel[k]; }
+				} else {
+					TRY(mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, d_starts, nullptr, static_cast<uint32_t>(T),
+					                                  static_cast<uint32_t>(nfft), d_freq, d_qual, st));
+					HTRY(hipMemcpyAsync(fh.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
+					HTRY(hipMemcpyAsync(qh.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
 					HTRY(hipStreamSynchronize(st));
 				}
-				TRY(mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, d_starts, pass ? d_chirp : nullptr, static_cast<uint32_t>(T),
-				                                  static_cast<uint32_t>(nfft), d_freq, d_qual, st));
-				HTRY(hipMemcpyAsync(fh.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
-				HTRY(hipMemcpyAsync(qh.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
-				HTRY(hipStreamSynchronize(st));
+				if (dbg) fprintf(stderr, "[recording] carrier pass %d: %zu of %zu windows\n", pass, pass ? sel.size() : T, T);
 				/* tiles without a clear line (fade, interference) take their good neighbours' estimate, interpolated over time;
 				   with no good tile at all, the pilot's frequency */
 				std::vector<size_t> good;
