@@ -20,7 +20,9 @@
  *
  * Status line: the reference's "(%5.1f%%) Carrier: ... Symbol rate: ... Locked: ..." (main.c:249-261) from the status
  * snapshot of stream 0, at most once per -R milliseconds (default 2000 with -B, 50 without: main.c:144), "\n" separated
- * with -B and redrawn in place otherwise.  Not reproduced (out of scope): the ncurses TUI.
+ * with -B and redrawn in place otherwise.  On a terminal, without -B / -q / --tiled, the full-screen display of the reference
+ * (tui.c; main.c:197,224-245) is drawn instead: host/tui.c, built in when ncurses is there (as the reference's ENABLE_TUI).
+ * Unlike the reference it is not started when stdin or stdout is not a terminal, unless --tui asks for it.
  * Known deviation: if the final flush would read past the 1024-byte ring (ring_idx >
  * 512, where the reference reads out of bounds) only the bytes inside the ring are
  * written.
@@ -33,8 +35,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "meteor_demod_amd.h"
+#ifdef MDEMOD_TUI
+#include "tui.h"
+#endif
 
 #define FILE_BUFFER_SIZE 32768          /* wavfile.c:6 */
 #define RINGSIZE 512                    /* main.c:20   */
@@ -61,6 +67,7 @@ static const struct option longopts[] = {
 	{ "samplerate", 1, NULL, 's' }, { "bps", 1, NULL, 'S' },      { "version", 0, NULL, 'v' },
 	{ "device", 1, NULL, 0x01 },    { "tiled", 0, NULL, 0x02 },   { "tile-samples", 1, NULL, 0x03 },
 	{ "pilot-margin", 1, NULL, 0x04 }, { "carrier-seed", 1, NULL, 0x05 }, { "devices", 1, NULL, 0x06 }, { "plan", 0, NULL, 0x07 },
+	{ "tui-selftest", 0, NULL, 0x08 }, { "tui", 0, NULL, 0x09 },
 	{ NULL, 0, NULL, 0 }
 };
 
@@ -83,7 +90,8 @@ usage(const char *prog)
 {
 	fprintf(stderr,
 	        "Usage: %s [options] file_in [file_in ...]\n"
-	        "   -B, --batch             Do not redraw a status line\n"
+	        "   -B, --batch             No full-screen display, status lines one below the other\n"
+	        "       --tui               Full-screen display even when stdin / stdout are not a terminal\n"
 	        "   -b, --pll-bw <bw>       PLL bandwidth (default: 1)\n"
 	        "   -d, --freq-delta <hz>   Max carrier deviation in Hz (default: +-3.5 kHz at 72 ksym/s)\n"
 	        "   -f, --fir-order <ord>   RRC filter order (default: 32)\n"
@@ -176,6 +184,42 @@ now_ms(void)
 }
 
 
+/* main.c:150: messages go to stdout, or into the display's log pane while that is up */
+static int (*say)(const char *, ...) = printf;
+
+#ifdef MDEMOD_TUI
+/* --tui-selftest: the display's formatting helpers as text, and - on a terminal - one frame of made-up values (no GPU call) */
+static int
+tui_selftest(int force)
+{
+	int8_t sym[2 * RINGSIZE];
+	unsigned lcg = 12345;
+	for (int k = 0; k < RINGSIZE; k++) {
+		lcg = lcg * 1664525u + 1013904223u;
+		sym[2 * k] = (int8_t)(((lcg >> 8) & 1 ? 90 : -90) + (int)((lcg >> 16) % 21) - 10);
+		sym[2 * k + 1] = (int8_t)(((lcg >> 9) & 1 ? 90 : -90) + (int)((lcg >> 24) % 21) - 10);
+	}
+	if ((force || (isatty(STDIN_FILENO) && isatty(STDOUT_FILENO))) && tui_open(50) == 0) {
+		const struct tui_frame f = { 1234.5, 72000.1, 0.031, 1, 60ul << 20, 110ul << 20, 920000, 23456789ul, sym, RINGSIZE };
+		tui_log("Input: %s, output: %s\n", "selftest.wav", "selftest.s");
+		tui_log("Demodulator initialized\n");
+		tui_draw(&f);
+		tui_log("Demodulation complete\n");
+		tui_log("Press any key to exit...\n");
+		tui_wait_key();
+		tui_close();
+	}
+	const unsigned long sizes[] = { 0, 999, 1000, 1001, 12345, 123456, 23456789ul, 4000000000ul };
+	for (unsigned i = 0; i < sizeof(sizes) / sizeof(sizes[0]); i++) { char b[16]; tui_fmt_size(sizes[i], b); printf("size %lu -> [%sB]\n", sizes[i], b); }
+	const unsigned long secs[] = { 0, 59, 3725, 356400, 360000 };
+	for (unsigned i = 0; i < sizeof(secs) / sizeof(secs[0]); i++) { char b[16]; tui_fmt_clock(secs[i], b); printf("clock %lu -> %s\n", secs[i], b); }
+	unsigned char hits[9 * 19];
+	tui_constellation(sym, RINGSIZE, 9, 19, hits);
+	for (int r = 0; r < 9; r++) { printf("plot |"); for (int c = 0; c < 19; c++) putchar(tui_glyph(hits[r * 19 + c])); printf("|\n"); }
+	return 0;
+}
+#endif
+
 /* What one worker (= one GPU) needs: its files and a copy of the options. */
 struct worker {
 	pthread_t   thr;
@@ -184,6 +228,7 @@ struct worker {
 	struct stream_io *io;                /* this worker's files (a contiguous copy; the originals are not touched again) */
 	mdemod_params p;                     /* p.device, p.n_streams are this worker's */
 	int         tiled, quiet, batch, update_interval, tile_samples, pilot_margin, carrier_seed;
+	int         tui;                     /* worker 0 only: the full-screen display is up */
 	int         rc;                      /* exit code of this worker: 0 ok, 1 host error, 2 library error */
 };
 
@@ -276,8 +321,8 @@ run_exact(struct worker *w)
 	mdemod_ctx *ctx = NULL;
 	int rc = mdemod_create(&p, &ctx);
 	if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_create: %s\n", mdemod_strerror(rc)); close_all(io, n_files); return 2; }
-	if (!quiet) printf("Demodulator initialized\n");                                 /* main.c:219 */
-	if (!quiet && n_files < 64 && io[0].file_len > (64ul << 20))
+	if (!quiet) say("Demodulator initialized\n");                                    /* main.c:219 */
+	if (!quiet && !w->tui && n_files < 64 && io[0].file_len > (64ul << 20))
 		fprintf(stderr, "note: %d file%s demodulated exactly = %d serial stream%s, one GPU wavefront each (a few MS/s); --tiled puts a long "
 		        "recording on many lanes (50x faster, same symbols, soft values within +-1 LSB of these on 99.6-99.9 %%)\n",
 		        n_files, n_files == 1 ? "" : "s", n_files, n_files == 1 ? "" : "s");
@@ -297,6 +342,10 @@ run_exact(struct worker *w)
 	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) return 1;
 
 	double last_status = -1e18;
+#ifdef MDEMOD_TUI
+	int8_t shown[2 * RINGSIZE];                 /* the latest symbols of stream 0 for the constellation (main.c:238 shows its ring) */
+	unsigned n_shown = 0;
+#endif
 	for (;;) {
 		int active = 0;
 		for (int i = 0; i < n_files; i++) {
@@ -318,19 +367,34 @@ run_exact(struct worker *w)
 		if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_get_status: %s\n", mdemod_strerror(rc)); close_all(io, n_files); return 2; }
 		for (int i = 0; i < n_files; i++)
 			write_gated(&io[i], outp[i], n_out[i], st[i].first_lock_symbol);
+#ifdef MDEMOD_TUI
+		if (w->tui && n_out[0]) {
+			n_shown = n_out[0] < RINGSIZE ? n_out[0] : RINGSIZE;
+			memcpy(shown, outp[0] + 2 * (size_t)(n_out[0] - n_shown), 2 * (size_t)n_shown);
+		}
+#endif
 		if (!quiet && now_ms() - last_status >= update_interval) {
 			/* main.c:249-261: status line from the snapshot of stream 0, at most once per refresh period */
 			last_status = now_ms();
 			const double freq_hz = st[0].pll_freq * symrate / (2 * M_PI) * (oqpsk ? 2 : 1);
 			const double rate_hz = st[0].omega * ((double)samplerate * interp) / (2 * M_PI);
 			const long pos = io[0].in != stdin ? ftell(io[0].in) : 0;
+#ifdef MDEMOD_TUI
+			if (w->tui) {
+				/* main.c:224-239: the display instead of the line; q ends the run after this block (the reference's `done = 1`) */
+				const struct tui_frame f = { freq_hz, rate_hz, st[0].gain, st[0].locked, pos > 0 ? (unsigned long)pos : 0, io[0].file_len,
+				                             (unsigned)(2 * (size_t)samplerate * (size_t)bps / 8), io[0].bytes_out, shown, n_shown };
+				if (tui_draw(&f)) for (int i = 0; i < n_files; i++) io[i].eof = 1;
+				continue;
+			}
+#endif
 			printf(batch ? "\n" : "\033[1K\r");
 			printf("(%5.1f%%) Carrier: %+7.1f Hz, Symbol rate: %.1f Hz, Locked: %s",
 			       io[0].file_len && pos > 0 ? 100.0 * (double)pos / (double)io[0].file_len : 0.0, freq_hz, rate_hz, st[0].locked ? "Yes" : "No");
 			fflush(stdout);
 		}
 	}
-	if (!quiet) printf("\n");
+	if (!quiet && !w->tui) printf("\n");
 
 	for (int i = 0; i < n_files; i++) {
 		/* main.c:321: fwrite(ring, ring_idx, 2, f) */
@@ -342,6 +406,15 @@ run_exact(struct worker *w)
 		if (io[i].in != stdin) fclose(io[i].in);
 	}
 	mdemod_destroy(ctx);                                                          /* demod_deinit: main.c:273 */
+#ifdef MDEMOD_TUI
+	if (w->tui) {                                                                 /* main.c:241-244 */
+		say("Demodulation complete\n");
+		say("Press any key to exit...\n");
+		tui_wait_key();
+		tui_close();
+		say = printf;
+	}
+#endif
 	return 0;
 }
 
@@ -380,7 +453,7 @@ main(int argc, char **argv)
 	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0, tiled = 0;
 	int tile_samples = 0, pilot_margin = -1, carrier_seed = -1, update_interval = -1;
 	const char *output_fname = NULL;
-	int devs[MAX_DEVICES], n_dev = 0, plan = 0;
+	int devs[MAX_DEVICES], n_dev = 0, plan = 0, force_tui = 0;
 	int c;
 
 	while ((c = getopt_long(argc, argv, "a:Bb:d:f:hm:o:O:qR:r:s:S:v", longopts, NULL)) != -1) {
@@ -392,6 +465,13 @@ main(int argc, char **argv)
 			if (!n_dev) { fprintf(stderr, "--devices: a comma separated list of GPU ordinals\n"); return 1; }
 			break;
 		case 0x07: plan = 1; break;
+		case 0x09: force_tui = 1; break;
+		case 0x08:
+#ifdef MDEMOD_TUI
+			return tui_selftest(force_tui);
+#else
+			fprintf(stderr, "built without ncurses\n"); return 1;
+#endif
 		case 0x02: tiled = 1; break;
 		case 0x03: tile_samples = (int)human_number(optarg); break;
 		case 0x04: pilot_margin = (int)human_number(optarg); break;
@@ -477,8 +557,17 @@ main(int argc, char **argv)
 		if (!io[i].out) { fprintf(stderr, "Could not open output file\n"); return 1; }
 	}
 
+	int use_tui = 0;
+#ifdef MDEMOD_TUI
+	/* main.c:197: the display unless -B (or a mode that forces it); here also only when both ends are a terminal, or with --tui
+	   (the reference draws into whatever stdout is) */
+	if (!batch && !quiet && !tiled && bps_ok && (force_tui || (isatty(STDIN_FILENO) && isatty(STDOUT_FILENO))) && tui_open(update_interval) == 0) {
+		use_tui = 1;
+		say = tui_log;
+	}
+#endif
 	if (!quiet)                                                                        /* main.c:200 */
-		for (int i = 0; i < n_files; i++) printf("Input: %s, output: %s\n", io[i].in_name, stdout_mode ? "(stdout)" : io[i].out_name);
+		for (int i = 0; i < n_files; i++) say("Input: %s, output: %s\n", io[i].in_name, stdout_mode ? "(stdout)" : io[i].out_name);
 	if (!bps_ok) {
 		for (int i = 0; i < n_files; i++) { if (io[i].out != stdout) fclose(io[i].out); if (io[i].in != stdin) fclose(io[i].in); }
 		return 0;
@@ -512,6 +601,7 @@ main(int argc, char **argv)
 		w->index = d; w->p = p; w->p.device = devs[d];
 		w->tiled = tiled; w->quiet = quiet; w->batch = batch; w->update_interval = update_interval;
 		w->tile_samples = tile_samples; w->pilot_margin = pilot_margin; w->carrier_seed = carrier_seed;
+		w->tui = use_tui && d == 0;
 		for (int i = d; i < n_files; i += n_dev) w->n_files++;
 		w->io = calloc((size_t)w->n_files, sizeof(*w->io));
 		if (!w->io) return 1;

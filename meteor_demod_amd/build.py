@@ -128,10 +128,16 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
     host_src = ROOT / "host" / "meteor_demod_amd.c"
     if host_src.exists():
         exe = LIB / "meteor_demod_amd"
-        if force or _stale(exe, [host_src, ROOT / "include" / "meteor_demod_amd.h", so]):
+        tui_src = [ROOT / "host" / "tui.c", ROOT / "host" / "tui.h"]
+        if force or _stale(exe, [host_src, ROOT / "include" / "meteor_demod_amd.h", so, *tui_src]):
             cc = shutil.which("gcc") or shutil.which("cc")
-            _run([cc, "-std=gnu11", "-O2", "-Wall", "-pthread", f"-I{ROOT / 'include'}", str(host_src), "-o", str(exe),
-                  f"-L{LIB}", "-lmeteor_demod_amd", f"-Wl,-rpath,$ORIGIN", "-lm"])
+            # the full-screen display needs ncurses (as the reference's ENABLE_TUI does); linked statically so that the binary
+            # that travels to another box of this image needs nothing beyond libc there
+            tui = []
+            if Path("/usr/include/curses.h").exists():
+                tui = ["-DMDEMOD_TUI", str(tui_src[0]), "-l:libncurses.a", "-l:libtinfo.a"]
+            _run([cc, "-std=gnu11", "-O2", "-Wall", "-pthread", f"-I{ROOT / 'include'}", f"-I{ROOT / 'host'}", str(host_src), *tui[:2], "-o", str(exe),
+                  f"-L{LIB}", "-lmeteor_demod_amd", f"-Wl,-rpath,$ORIGIN", "-lm", *tui[2:]])
         out["cli"] = exe
     return out
 

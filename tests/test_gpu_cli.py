@@ -103,6 +103,53 @@ def test_cli_status_line_and_banner(manifest, tmp_path, gpu_device):
     assert (locked == "Yes") == bool(ost.state.locked) and float(pct) > 99.0
 
 
+def test_cli_full_screen_display(manifest, tmp_path, gpu_device):
+    """On a terminal and without -B the reference draws its ncurses display (main.c:197,224-245); so does the C host: panes with the
+    final loop words, `Demodulation complete`, a key to leave - and the same output file as with -B."""
+    import re
+    from ptyrun import run_on_pipes
+    meta = manifest["file_cases"]["file_wav_s16"]
+    inp, out = tmp_path / "in.wav", tmp_path / "out.s"
+    inp.write_bytes(file_case_bytes(meta))
+    rc, screen, err = run_on_pipes([str(CLI), "--tui", "-R", "0", "-o", str(out), *meta["cli_args"], str(inp)], cols=300, timeout=120)      # wide: the paths of the Input line must not wrap
+    if "PLL status" not in screen:
+        r = subprocess.run([str(CLI), "--tui-selftest"], stdin=subprocess.DEVNULL, capture_output=True, text=True)
+        if "built without ncurses" in r.stderr:
+            pytest.skip("no ncurses in this image")
+    assert rc == 0, (err, screen[-2000:])
+    for piece in (f"Input: {inp}, output: {out}", "Demodulator initialized", "PLL status: ", "Carrier freq", "Data in", "(100.0%)", "Data out",
+                  "Demodulation complete", "Press any key to exit..."):
+        assert piece in screen, (piece, screen[-3000:])
+    assert out.read_bytes() == load_npz("file_wav_s16")["out"].tobytes()
+    # the last PLL pane: the words the status line test pins (test_cli_status_line_and_banner), to the display's one decimal
+    words = re.findall(r"([+-]\d+\.\d) Hz\s+(\d+\.\d) Hz", screen)
+    assert words, screen[-3000:]
+    r = subprocess.run([str(CLI), "-B", "-R", "0", "-o", str(tmp_path / "b.s"), *meta["cli_args"], str(inp)], capture_output=True, text=True)
+    last = re.findall(r"Carrier:\s*([+-][\d.]+) Hz, Symbol rate: ([\d.]+) Hz", r.stdout)[-1]
+    assert abs(float(words[-1][0]) - float(last[0])) < 0.11 and abs(float(words[-1][1]) - float(last[1])) < 0.11, (words[-1], last)
+
+
+def test_cli_full_screen_display_q_ends_the_run(tmp_path, gpu_device):
+    """q: the run stops after the block in flight (the reference's `done = 1`, main.c:226-229) and what was demodulated is on disk."""
+    from ptyrun import run_on_pipes
+    import torch
+    from meteor_demod_amd import synth
+    from golden_cases import wav_header
+    n = 1 << 24                                   # 16 blocks of 4 MiB
+    st = synth.make_stream(1000, 230000, 72000, f0_hz=300.0, clock_ppm=0.0)
+    iq = synth.generate_device([st], n)[0].cpu().numpy()
+    inp, out = tmp_path / "long.wav", tmp_path / "long.s"
+    with open(inp, "wb") as f:
+        f.write(wav_header(230000, 16, iq.nbytes)); f.write(iq.tobytes())
+    rc, screen, err = run_on_pipes([str(CLI), "--tui", "-R", "0", "-o", str(out), str(inp)], script=((b"Data out", b"q"), (b"Press any key", b"x")), timeout=180)
+    if "PLL status" not in screen:
+        pytest.skip("no ncurses in this image")
+    assert rc == 0, err
+    assert "Demodulation complete" in screen
+    full = int(n * 72000 / 230000) * 2
+    assert 0 < out.stat().st_size < 0.9 * full, (out.stat().st_size, full)
+
+
 def test_cli_stdout_mode_and_errors(manifest, tmp_path, gpu_device):
     meta = manifest["file_cases"]["file_wav_s16"]
     inp = tmp_path / "in.wav"

@@ -230,3 +230,66 @@ def test_carrier_window_rounding_is_host_logic():
     assert used(80000, 72000, 100_000) == 32768             # 1.1 samples per symbol: decimation by 2 still keeps the band
     assert used(73000, 72000, 100_000) == 16384             # barely oversampled: no decimation, 16384 points
     assert lib.mdemod_carrier_window_samples(None, 4096) == 0
+
+
+# ---- the C host's full-screen display (host/tui.c; the reference's tui.c) ----------------------------------------------
+
+# what the reference's own humanize() / seconds_to_str() (utils.c:22-57) print for these values (recorded from a scratch build of
+# utils.c in this container)
+TUI_FORMATS = """size 0 -> [0  B]
+size 999 -> [999  B]
+size 1000 -> [1000  B]
+size 1001 -> [1.00 kB]
+size 12345 -> [12.3 kB]
+size 123456 -> [123 kB]
+size 23456789 -> [23.5 MB]
+size 4000000000 -> [4.00 GB]
+clock 0 -> 00:00:00
+clock 59 -> 00:00:59
+clock 3725 -> 01:02:05
+clock 356400 -> 99:00:00
+clock 360000 -> 00:00:00
+"""
+
+
+def _cli():
+    from meteor_demod_amd import build
+    exe = build.LIB / "meteor_demod_amd"
+    if not exe.exists():
+        pytest.skip("C host not built")
+    return exe
+
+
+def test_tui_formats_are_the_references():
+    import subprocess
+    r = subprocess.run([str(_cli()), "--tui-selftest"], stdin=subprocess.DEVNULL, capture_output=True, text=True)
+    if "built without ncurses" in r.stderr:
+        pytest.skip("no ncurses in this image")
+    assert r.returncode == 0
+    assert r.stdout.startswith(TUI_FORMATS), r.stdout
+    plot = [l[6:-1] for l in r.stdout.splitlines() if l.startswith("plot |")]
+    assert len(plot) == 9 and all(len(l) == 19 for l in plot)
+    # four clusters at (+-90, +-90): columns 9 +- 90*19/255 = 3 / 15, rows 4 -+ 90*9/255 = 1 / 7 (and their neighbours: +-10 of noise)
+    for r_, c_ in ((1, 3), (1, 15), (7, 3), (7, 15)):
+        assert plot[r_][c_] == "#", plot
+    assert all(ch == " " for ch in plot[4]) and all(l[9] == " " for l in plot)     # nothing on the axes
+
+
+@pytest.mark.parametrize("how", ["terminal", "pipes"])
+def test_tui_draws_its_panes(how):
+    """No GPU call: --tui-selftest draws one frame of made-up values when stdin and stdout are a terminal, or anywhere with --tui."""
+    from ptyrun import run_in_pty, run_on_pipes
+    if how == "terminal":
+        try:
+            rc, screen, err = run_in_pty([str(_cli()), "--tui-selftest"])
+        except OSError as e:
+            pytest.skip(f"no pseudo-terminals here: {e}")
+    else:
+        rc, screen, err = run_on_pipes([str(_cli()), "--tui", "--tui-selftest"])
+    if "built without ncurses" in err:
+        pytest.skip("no ncurses in this image")
+    assert rc == 0, err
+    for piece in ("Input: selftest.wav, output: selftest.s", "Demodulator initialized", "PLL status: Locked", "Carrier freq", "+1234.5 Hz",
+                  "72000.1 Hz", "0.031", "Data in", "00:01:08/00:02:05 (54.5%)", "Data out", "23.5 MB", "Demodulation complete",
+                  "Press any key to exit..."):
+        assert piece in screen, (piece, screen)
