@@ -134,13 +134,17 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	const bool mid_ok = wide_ok && c.taps <= 65;
 	/* far: the short filter at 2 MS/s-class rates: up to 30 samples per firing, two 16-slot slides per iteration */
 	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= 30.0 && p.bps != 32;
+	/* hybrid: float input with 66..129 taps (a float window of 160 slots is 320 registers: the older half stays in registers, the
+	 * newer half lives in LDS: demod_kernel_rot.hip, WinH) */
+	const bool hyb_ok = generation >= 2 && !std_ok && per_firing <= 15.0 && p.bps == 32 && c.taps > 65 && c.taps <= 129;
 	const bool allow_rw = generation >= 1;
-	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok);
+	out.rw_hyb = hyb_ok;
+	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok);
 	out.rw_mid = out.use_rw && !std_ok && mid_ok;
 	out.rw_far = out.use_rw && far_ok;
-	out.rw_wide = out.use_rw && !std_ok && !mid_ok && !far_ok;
+	out.rw_wide = out.use_rw && !std_ok && !mid_ok && !far_ok && !hyb_ok;
 	c.chunk_granules = 2;
-	if (out.use_rw && !out.rw_wide && !out.rw_mid && !out.rw_far) {
+	if (out.use_rw && !out.rw_wide && !out.rw_mid && !out.rw_far && !out.rw_hyb) {
 		/* v2: 80-slot register window, filter embedded as 65 taps (leading zeros), 16 alignments */
 		const int kTaps = 65, NW = 80, AL = NW - kTaps + 1;
 		c.hpad = kTaps - 1;
@@ -158,21 +162,22 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		return MDEMOD_OK;
 	}
 	out.rw_compact4 = generation >= 2 && (out.rw_wide || out.rw_mid || out.rw_far) && p.bps != 32;
-	if (out.rw_compact4) {
+	if (out.rw_compact4 || out.rw_hyb) {
 		/* v3 packed rotating window: per bank the padded sequence P = AMAX zeros ++ taps ++ AMAX zeros, stored FOUR times:
 		 * copy (bank, k)[i] = P[i + k].  A lane at alignment a reads P[(AMAX - a) + s] for slot s, i.e. copy ((AMAX - a) & 3) at the
 		 * 16-byte aligned index ((AMAX - a) & ~3) + s: every group of four taps is one ds_read_b128.  The FIR's prefetch runs up
 		 * to six groups (24 floats) past the last tap it uses: rows carry that much padding. */
-		const int kTaps = out.rw_wide ? 129 : 65;
+		const int kTaps = (out.rw_wide || out.rw_hyb) ? 129 : 65;
 		const int NW = out.rw_mid ? MDEMOD_RW_MID_NW : (out.rw_far ? MDEMOD_RW_FAR_NW : MDEMOD_RW_WIDE_NW), AMAX = NW - kTaps;
 		const int LP = kTaps + 2 * AMAX;
 		c.hpad = kTaps - 1;
 		c.win_granules = NW / 4;
 		c.ring_granules = 0;
 		c.ctab_row_floats = LP;
-		c.ctab_row_stride = (LP + 3 + 24 + 3) / 4 * 4;                    /* whole 16-byte groups ...            */
+		/* (the hybrid window reads exactly the NW slots of its alignment, no prefetch past them, and has no LDS to spare) */
+		c.ctab_row_stride = (LP + 3 + (out.rw_hyb ? 0 : 24 + 3)) / 4 * 4; /* whole 16-byte groups ...            */
 		if ((c.ctab_row_stride / 4) % 2 == 0) c.ctab_row_stride += 4;    /* ... an odd number of them           */
-		out.ctab.assign(static_cast<size_t>(4) * banks * c.ctab_row_stride + 32, 0.0f);
+		out.ctab.assign(static_cast<size_t>(4) * banks * c.ctab_row_stride + (out.rw_hyb ? 0 : 32), 0.0f);
 		const int lead = kTaps - c.taps;
 		for (unsigned b = 0; b < banks; b++) {
 			std::vector<float> P(static_cast<size_t>(LP) + 4, 0.0f);

@@ -80,7 +80,8 @@ ROTP_PUT16(0, WIDE) ROTP_PUT16(1, MID) ROTP_PUT16(2, FAR) ROTP_PUT8(0, WIDE) ROT
 template <int GEO, int FMT>
 struct WinP {
 	static constexpr int kTaps = GeoP<GEO>::kTaps, kBack = kTaps - 1, NW = GeoP<GEO>::NW, SLIDE = 16, AMAX = NW - kTaps,
-	                     MAXSL = GeoP<GEO>::MAXSL, BLOCK = GeoP<GEO>::BLOCK, NCH = NW / SLIDE, GD = FMT == 16 ? 16 : 8, REGSLOTS = 0;
+	                     MAXSL = GeoP<GEO>::MAXSL, BLOCK = GeoP<GEO>::BLOCK, NCH = NW / SLIDE, GD = FMT == 16 ? 16 : 8, REGSLOTS = 0, ROTN = NCH, RING = 32;
+	__device__ __forceinline__ void setup(uint32_t) {}
 	static_assert(kBack % SLIDE == 0 && NW % SLIDE == 0, "history and window are whole chunks");
 
 	/* wavfile.c:58-69 backwards: the raw sample a history value (an exactly converted input sample) came from */
@@ -109,6 +110,7 @@ struct WinP {
 			for (int j = 0; j < GD / 4; j++) g[i * (GD / 4) + j] = gr[i].w[j];
 		AsmP<GEO, FMT>::put(g, q);
 	}
+	__device__ static __forceinline__ void put_init(const RGran<FMT> (&gr)[4], int q) { put(gr, q); }
 	__device__ static __forceinline__ void fir(uint32_t ctab_addr, int a, int bank, const DemodConsts &C, int rot, float &re, float &im)
 	{
 		/* compact4 table: per bank the taps padded with AMAX zeros either side, four copies shifted by 0..3 floats: the lane at

@@ -3,11 +3,15 @@
  * window, std geometry; demod_kernel_rotp.hip: packed raw window, wide / mid / far geometries).
  *
  * One lane = one stream, the reference's serial recurrence bit for bit (citations in demod_device.h).  The FIR window lives in
- * registers that belong to hand-written assembly and never moves: a window policy class W supplies
- *     W::put_history(hist, valid, q)   SLIDE history samples (float pairs) -> physical chunk q
- *     W::put(granules, q)              SLIDE raw input samples             -> physical chunk q  (the slide)
- *     W::fir(ctab_addr, a, bank, C, rot, re, im)      filter.c:46-65 for a lane whose taps start `a` slots into the window
- * and the geometry (kTaps, kBack, NW, SLIDE, AMAX, MAXSL, BLOCK).  Everything else - symbol clock, AGC, NCO, loops, lock
+ * registers that belong to hand-written assembly and never moves: a window policy class W (one object per lane; the register
+ * windows have no members, the hybrid one keeps its LDS address) supplies
+ *     setup(lds_addr)                  the LDS behind the body's own (0 bytes unless the policy asks the host for more)
+ *     put_history(hist, valid, c)      SLIDE history samples (float pairs) -> chunk c of the window at rotation 0
+ *     put_init(granules, c)            SLIDE raw input samples             -> chunk c of the window at rotation 0
+ *     put(granules, q)                 the slide: SLIDE raw input samples become the newest chunk, chunk q (the oldest) goes
+ *     fir(ctab_addr, a, bank, C, rot, re, im)      filter.c:46-65 for a lane whose taps start `a` slots into the window
+ * and the geometry (kTaps, kBack, NW, SLIDE, AMAX, MAXSL, BLOCK, ROTN: rotations before the window is where it started,
+ * RING: symbols of the per-lane output ring).  Everything else - symbol clock, AGC, NCO, loops, lock
  * detector, output ring, state and history hand-over - is here, compiled for the registers the policy leaves to hipcc.
  */
 #ifndef MDEMOD_ROTWIN_BODY_H
@@ -109,6 +113,8 @@ rotwin_demod(const DemodLaunch &L)
 	typedef typename RFmt<FMT>::sample_t sample_t;
 	constexpr int kBack = W::kBack, SLIDE = W::SLIDE, AMAX = W::AMAX, BLOCK = W::BLOCK, NCH = W::NW / W::SLIDE, GPS = W::SLIDE / 4;
 	constexpr int NST = GPS * W::MAXSL;                /* granules staged ahead of the window */
+	constexpr int ROTN = W::ROTN, RING = W::RING, RGR = RING / 8;      /* output ring: RGR groups of 8 symbols (16 bytes) per lane */
+	static_assert(RING == 32 || RING == 16, "output ring");
 	/* per-lane loop state that is only touched once per firing lives in LDS slots [field][lane] unless the window policy has
 	 * registers to spare for it (W::REGSLOTS: bit 0 err, 1 t_prev, 2 flags, 3 sample index of the last symbol) */
 	constexpr int RS = W::REGSLOTS;
@@ -123,6 +129,8 @@ rotwin_demod(const DemodLaunch &L)
 	int *sli = reinterpret_cast<int *>(sl);
 	uint4 *stage = reinterpret_cast<uint4 *>(lut + 32 + (BLOCK / 64) * (S_COUNT * 64)) + threadIdx.x;
 	const uint32_t ctab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
+	W win;
+	win.setup(ctab_addr + (uint32_t)(reinterpret_cast<unsigned char *>(stage - threadIdx.x + BLOCK * RGR) - lds));
 
 	const DemodConsts &C = L.c;
 	const uint32_t stream = blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,13 +183,13 @@ rotwin_demod(const DemodLaunch &L)
 	{
 		const float2 *hist = reinterpret_cast<const float2 *>(L.st.hist) + (size_t)(valid ? stream : 0) * kBack;
 #pragma unroll 1
-		for (int c = 0; c < kBack / SLIDE; c++) W::put_history(hist + c * SLIDE, valid, __builtin_amdgcn_readfirstlane(c));
+		for (int c = 0; c < kBack / SLIDE; c++) win.put_history(hist + c * SLIDE, valid, __builtin_amdgcn_readfirstlane(c));
 #pragma unroll 1
 		for (int c = 0; c < NCH - kBack / SLIDE; c++) {
 			RGran<FMT> g[GPS];
 #pragma unroll
 			for (int i = 0; i < GPS; i++) g[i] = rot_fetch<FMT>(src, SLIDE * c + 4 * i, n);
-			W::put(g, __builtin_amdgcn_readfirstlane(kBack / SLIDE + c));
+			win.put_init(g, __builtin_amdgcn_readfirstlane(kBack / SLIDE + c));
 		}
 	}
 	int g_load = (W::NW - kBack) / 4;                      /* next block granule to fetch (wave-uniform) */
@@ -250,8 +258,8 @@ rotwin_demod(const DemodLaunch &L)
 				RGran<FMT> g[GPS];
 #pragma unroll
 				for (int i = 0; i < GPS; i++) g[i] = stg[i];
-				W::put(g, __builtin_amdgcn_readfirstlane(rot));
-				rot = __builtin_amdgcn_readfirstlane((rot == NCH - 1) ? 0 : rot + 1);       /* wave-uniform: keep them in SGPRs */
+				win.put(g, __builtin_amdgcn_readfirstlane(rot));
+				rot = __builtin_amdgcn_readfirstlane((rot == ROTN - 1) ? 0 : rot + 1);      /* wave-uniform: keep them in SGPRs */
 				base = __builtin_amdgcn_readfirstlane(base + SLIDE);
 #pragma unroll
 				for (int i = 0; i + GPS < NST; i++) stg[i] = stg[i + GPS];
@@ -274,7 +282,7 @@ rotwin_demod(const DemodLaunch &L)
 			fired = false;
 			const int bank = interp - 1 - fire_sub;                     /* filter.c:52 */
 			cf32 y;
-			W::fir(ctab_addr, a, bank, C, __builtin_amdgcn_readfirstlane(rot), y.re, y.im);
+			win.fir(ctab_addr, a, bank, C, __builtin_amdgcn_readfirstlane(rot), y.re, y.im);
 			if (PRIO) __builtin_amdgcn_s_setprio(2);
 			ROT_TICK(2);
 #ifdef ROT_EXP_TIMING
@@ -332,28 +340,28 @@ rotwin_demod(const DemodLaunch &L)
 					}
 				}
 				const uint32_t sym = (uint32_t)(md_quantise(out_re) & 0xFF) | ((uint32_t)(md_quantise(out_im) & 0xFF) << 8);
-				/* 32-symbol ring per lane in LDS, [16-byte group][thread]; every 32 symbols one full 64-byte run goes out */
-				const uint32_t k = sym_call & 31u;
+				/* RING-symbol ring per lane in LDS, [16-byte group][thread]; every RING symbols one full run (64 bytes for 32) goes out */
+				const uint32_t k = sym_call & (uint32_t)(RING - 1);
 				reinterpret_cast<uint16_t *>(stage + (k >> 3) * BLOCK)[k & 7u] = (uint16_t)sym;
 				sym_call++;
-				if (__builtin_expect((sym_call & 31u) == 0, 0)) {
+				if (__builtin_expect((sym_call & (uint32_t)(RING - 1)) == 0, 0)) {
 					int8_t *soft_out = L.soft + (size_t)stream * L.soft_stride * 2;
 					if (__builtin_expect(sym_call <= L.soft_cap, 1)) {
 						/* one 16-byte group in flight at a time: four would not fit next to the live registers of the wide geometry
 						 * and spill (once per 32 symbols: the three extra LDS round trips do not show) */
 						/* memcpy, not a uint4 lvalue: the caller's buffer and pitch need not be 16-byte aligned (the hardware's
 						 * unaligned access mode takes the same global_store_dwordx4 either way) */
-						int8_t *dst = soft_out + 2 * (size_t)(sym_call - 32);
+						int8_t *dst = soft_out + 2 * (size_t)(sym_call - RING);
 #pragma unroll
-						for (int g4 = 0; g4 < 4; g4++) {
+						for (int g4 = 0; g4 < RGR; g4++) {
 							const uint4 qv = stage[g4 * BLOCK];
 							__builtin_memcpy(dst + 16 * g4, &qv, 16);
 							asm volatile("" ::: "memory");
 						}
 					} else {
 						fl |= 8;
-						for (uint32_t i = 0; i < 32 && sym_call - 32 + i < L.soft_cap; i++)
-							*reinterpret_cast<uint16_t *>(soft_out + 2 * (size_t)(sym_call - 32 + i)) =
+						for (uint32_t i = 0; i < (uint32_t)RING && sym_call - RING + i < L.soft_cap; i++)
+							*reinterpret_cast<uint16_t *>(soft_out + 2 * (size_t)(sym_call - RING + i)) =
 							    reinterpret_cast<const uint16_t *>(stage + (i >> 3) * BLOCK)[i & 7u];
 					}
 				}
@@ -380,7 +388,7 @@ rotwin_demod(const DemodLaunch &L)
 
 	/* ---- flush the ring ---- */
 	if (valid) {
-		const uint32_t r = sym_call & 31u, sb = sym_call - r;
+		const uint32_t r = sym_call & (uint32_t)(RING - 1), sb = sym_call - r;
 		for (uint32_t g = 0; g < (r >> 3); g++) {
 			if (sb + 8 * g + 8 <= L.soft_cap) { const uint4 qv = stage[g * BLOCK]; __builtin_memcpy(soft_e + 2 * (size_t)(sb + 8 * g), &qv, 16); }
 			else for (uint32_t i = 0; i < 8; i++) {

@@ -227,10 +227,15 @@ WIDE_CFGS = {
     "far_edge_u8": DemodConfig(samplerate=2150000, rrc_order=20, interp_factor=3, bps=8), # 29.9 samples per symbol
     "defaults_1024k_f32": DemodConfig(samplerate=1024000, bps=32),                        # float input: mid geometry with a float-pair window
     "oqpsk_640k_f32": DemodConfig(samplerate=640000, symrate=80000, oqpsk=True, rrc_order=24, interp_factor=4, bps=32),
+    "c4_f32": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),      # float input, 129 taps: hybrid window (registers + LDS)
+    "oqpsk80k_1M_f32": DemodConfig(samplerate=1000000, symrate=80000, oqpsk=True, rrc_order=64, interp_factor=8, bps=32),
+    "taps97_230k_f32": DemodConfig(samplerate=230000, rrc_order=48, interp_factor=5, bps=32),   # the long filter at the LRPT rate: 3.2 samples per firing
+    "taps129_O12_f32": DemodConfig(samplerate=900000, rrc_order=64, interp_factor=12, bps=32),  # a table that leaves LDS for two waves per block only
 }
 WIDE_KERNEL = {"c4_s16": "wide", "c4_u8": "wide", "oqpsk80k_1M": "wide", "taps97_os6": "wide", "edge_15_per_symbol": "wide",
                "taps65_slow_clock": "mid", "defaults_1024k": "mid", "defaults_1024k_oqpsk_u8": "mid", "defaults_2048k": "far",
-               "far_edge_u8": "far", "defaults_1024k_f32": "mid", "oqpsk_640k_f32": "mid"}
+               "far_edge_u8": "far", "defaults_1024k_f32": "mid", "oqpsk_640k_f32": "mid",
+               "c4_f32": "hybrid", "oqpsk80k_1M_f32": "hybrid", "taps97_230k_f32": "hybrid", "taps129_O12_f32": "hybrid"}
 
 
 @pytest.mark.parametrize("generation", ["v3", "v2"])
@@ -250,6 +255,8 @@ def test_wide_window_batch_chained(name, generation, gpu_device, monkeypatch):
     iqs = [synth.generate_host(s, sum(blocks)) for s in streams]
     with Demodulator(cfg, ns) as d:
         want_name = ("v3 rotating packed window, " if generation == "v3" and cfg.bps != 32 else "v2 register window, ") + WIDE_KERNEL[name]
+        if WIDE_KERNEL[name] == "hybrid":
+            want_name = "v3 hybrid window" if generation == "v3" else "v1 LDS ring"
         assert want_name in d.kernel_name, d.kernel_name
         parts = [[] for _ in range(ns)]
         pos = 0
