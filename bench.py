@@ -299,7 +299,7 @@ def other_configs(skip: str, T: int, L: int, local: int) -> dict:
              "x2": (DemodConfig(samplerate=1800000), "not in BASELINE.json: QPSK 72k, 1.8 MS/s s16, default RRC order 32, oversamp 5"),
              "x3": (DemodConfig(samplerate=1024000, bps=32), "not in BASELINE.json: QPSK 72k, 1.024 MS/s f32, default RRC order 32, oversamp 5"),
              "x4": (DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),
-                    "not in BASELINE.json: QPSK 72k, 1 MS/s f32, RRC order 64, oversamp 8 (a geometry still on the v1 ring kernel)")}
+                    "not in BASELINE.json: QPSK 72k, 1 MS/s f32, RRC order 64, oversamp 8 (v3 hybrid window since r03; v1 ring kernel before)")}
     for tag in ("c3", "c4", "x1", "x2", "x3", "x4"):
         if tag == skip:
             continue

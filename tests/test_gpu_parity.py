@@ -681,10 +681,13 @@ def _check_cfg_against_oracle(cfg):
         assert all(s.overflow == 0 for s in d.status())
 
 
-def test_float_input_ring_kernel_ignores_stale_lds(gpu_device, monkeypatch):
-    """Float input on the LDS-ring kernel: ring slots outside a lane's window are multiplied by zero coefficients, so they
-    must never hold stale NaN bits (0 * NaN = NaN).  A first context fills the CUs' LDS with NaN samples."""
+@pytest.mark.parametrize("kernel", ["v1", ""], ids=["ring", "hybrid"])
+def test_float_input_ring_kernel_ignores_stale_lds(kernel, gpu_device, monkeypatch):
+    """Float input with window slots in LDS (the v1 ring kernel; the newer half of the v3 hybrid window): slots outside a lane's
+    taps are multiplied by zero coefficients, so they must never hold stale NaN bits (0 * NaN = NaN).  A first context fills the
+    CUs' LDS with NaN samples."""
     torch = _torch()
+    monkeypatch.setenv("MDEMOD_KERNEL", kernel)
     cfg = DemodConfig(samplerate=1072367, pll_bw=5.0, symrate=72000, interp_factor=4, rrc_order=33, oqpsk=True, bps=32)
     with Demodulator(cfg, 8192) as poison:
         poison.process(torch.full((8192, 600, 2), float("nan"), dtype=torch.float32, device="cuda"))
@@ -692,7 +695,7 @@ def test_float_input_ring_kernel_ignores_stale_lds(gpu_device, monkeypatch):
     streams = [synth.make_stream(40 + i, cfg.samplerate, cfg.symrate, f0_hz=300.0, esn0_db=15.0, rms=0.7, oqpsk=True, fmt=32) for i in range(6)]
     iqs = [synth.generate_host(s, 9051) for s in streams]
     with Demodulator(cfg, 29) as d:
-        assert "ring" in d.kernel_name
+        assert ("ring" if kernel == "v1" else "hybrid") in d.kernel_name, d.kernel_name
         got = [[] for _ in range(29)]
         for lo, hi in ((0, 1000), (1000, 9051)):
             soft = d.process(torch.from_numpy(np.stack([iqs[i % 6][lo:hi] for i in range(29)])).cuda())
