@@ -450,7 +450,7 @@ def main() -> None:
 
     # counters cannot be collected inside a timed run: traffic and the instruction mix are READ from the tracked rocprofv3 profile
     # of this exact command (profiles/hbm_traffic.json, written by tools/make_profile_md.py), keyed by configuration and shape
-    traffic = valu_per_firing = prof_round = None
+    traffic = valu_per_firing = prof_round = simd_busy = None
     tfile = ROOT / "profiles" / "hbm_traffic.json"
     if tfile.exists():
         try:
@@ -459,6 +459,7 @@ def main() -> None:
             if key in rec_t:
                 traffic = rec_t[key]["hbm_bytes_per_launch"]
                 valu_per_firing = rec_t[key].get("valu_per_wave_firing")
+                simd_busy = rec_t[key].get("simd_valu_busy_frac")
                 prof_round = rec_t[key].get("round")
         except Exception:
             traffic = None
@@ -487,6 +488,8 @@ def main() -> None:
                      "valu": {"achieved_top_s": round(valu_tops, 2), "peak_top_s": VALU_PEAK_TOPS, "frac": round(valu_tops / VALU_PEAK_TOPS, 4),
                               "algorithmic_unfused_flops_per_sample": round(flops_per_sample, 1),
                               "valu_instructions_per_wave_firing": valu_per_firing,
+                              # share of a SIMD's 4-cycle issue quanta that carry a VALU instruction (2 waves x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)
+                              "simd_valu_busy_frac": simd_busy,
                               "valu_instructions_source": f"profiles/hbm_traffic.json (round {prof_round}, SQ_INSTS_VALU)" if valu_per_firing else None},
                      "kernel": d.kernel_name,
                      "kernel_ms": round(kernel_ms, 3),

@@ -46,7 +46,9 @@ for c, (name, symrate, fs, fires) in CFG.items():
                                "algorithmic_bytes_per_launch": int(algo), "kernel": kname[:90], "round": tag, "kernel_ms_under_profiler": avg,
                                "valu_per_wave_firing": round(valu / wave_fir, 1), "salu_per_wave_firing": round(salu / wave_fir, 1),
                                "lds_per_wave_firing": round(lds / wave_fir, 1), "wave_cycles_per_firing": round(wc * 4 / wave_fir, 0),
-                               "wait_any_over_wave_cycles": round(wa / wc, 3)}
+                               "wait_any_over_wave_cycles": round(wa / wc, 3),
+                               # two waves share a SIMD: the share of the SIMD's 4-cycle issue quanta that carry a VALU instruction
+                               "simd_valu_busy_frac": round(2 * av / wc, 3)}
 lines.append("\n(wave-firing = one firing of the symbol clock for each of the 64 streams of a wave; QPSK: one per symbol, OQPSK: two.  SQ_WAVE_CYCLES counts 4-cycle quanta.)\n")
 for c in CFG:
     for kind in ("stats", "FETCH", "WRITE", "sq", "sq2"):
