@@ -111,6 +111,19 @@ def test_many_short_tiles_regime_agrees_with_the_serial_reference(gpu_device):
     assert a["hard_decisions_equal"] >= 0.9999 and a["within_1lsb"] >= 0.9965 and a["worst_window"] >= 0.96, a
 
 
+def test_float_recording_with_the_long_filter_on_the_hybrid_window(gpu_device):
+    """configs[3] with float input (1 MS/s, -f 64 -O 8, f32 around +-0.3): head on the latency kernel, > 2 048 tiles on the v3
+    hybrid window (registers + LDS), the float recording's slow AGC seeded per tile - against the untiled serial oracle."""
+    cfg = DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32)
+    st = synth.make_stream(1000, 1000000, 72000, f0_hz=1200.0, clock_ppm=-3.5, rms=0.3, fmt=32)
+    iq = synth.generate_device([st], 1 << 25)[0]
+    out, serial, rep, a = _run(cfg, iq, tile_samples=6144)
+    assert rep.n_tiles > 2048 and rep.pilot_locked == 1, rep.n_tiles
+    assert rep.weak_seams == 0 and rep.rotation_jumps == 0
+    assert a["len_stitched"] == a["len_serial"]
+    assert a["hard_decisions_equal"] >= 0.9999 and a["within_1lsb"] >= 0.995, a
+
+
 def test_long_recording_on_many_lanes_agrees_with_the_serial_reference(gpu_device):
     """16 M samples (70 s of signal) at -700 Hz (the reference sweeps up first: it needs 0.66 M symbols to lock)."""
     st = synth.make_stream(99, 230000, 72000, f0_hz=-700.0, clock_ppm=-20.0, esn0_db=12.0)
