@@ -21,6 +21,7 @@
 
 static struct {
 	int     up;
+	SCREEN *term;
 	WINDOW *title, *plot, *pll, *in, *out, *log;
 	int     plot_rows, plot_cols;
 } scr;
@@ -118,7 +119,10 @@ tui_open(int refresh_ms)
 {
 	(void)refresh_ms;
 	if (scr.up) return 0;
-	if (!initscr()) return 1;
+	/* newterm, not initscr: an unknown or missing TERM makes initscr() exit the program; here the caller falls back to status lines */
+	scr.term = newterm(NULL, stdout, stdin);
+	if (!scr.term) return 1;
+	set_term(scr.term);
 	cbreak();
 	noecho();
 	curs_set(0);
@@ -135,6 +139,8 @@ tui_close(void)
 	if (!scr.up) return;
 	drop(&scr.title); drop(&scr.plot); drop(&scr.pll); drop(&scr.in); drop(&scr.out); drop(&scr.log);
 	endwin();
+	if (scr.term) delscreen(scr.term);
+	scr.term = NULL;
 	scr.up = 0;
 }
 
