@@ -58,6 +58,7 @@ def check_rot_partition() -> list[str]:
     import re
     import tempfile
     limit = int(re.search(r"#define ROTWIN_LIMIT (\d+)", (CSRC / "rotwin_asm.h").read_text()).group(1))
+    alimit = int(re.search(r"#define ROTWIN_AB (\d+)", (CSRC / "rotwin_asm.h").read_text()).group(1))
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / "rot.s"
         _run([_hipcc(), *COMMON, *ROT_FLAGS, "-x", "hip", "--offload-device-only", "-S", str(CSRC / "demod_kernel_rot.hip"), "-o", str(out)])
@@ -72,7 +73,8 @@ def check_rot_partition() -> list[str]:
                 if not t or t[0] in ";." or t.endswith(":"):
                     continue
                 regs = [int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", t)] + [int(m.group(2)) for m in re.finditer(r"\bv\[(\d+):(\d+)\]", t)]
-                if any(r >= limit for r in regs):
+                aregs = [int(m.group(1)) for m in re.finditer(r"\ba(\d+)\b", t)] + [int(m.group(2)) for m in re.finditer(r"\ba\[(\d+):(\d+)\]", t)]
+                if any(r >= limit for r in regs) or any(r >= alimit for r in aregs):      # (the AccVGPR half of the hybrid window)
                     bad.append(f"{n}: {t}")
     return bad
 

@@ -28,7 +28,7 @@ struct mdemod_ctx {
 	float        *d_ctab;
 	float        *d_lut;
 	float        *d_rrc;       /* plain polyphase table [bank][taps] (filter.c:18-22) for the latency kernel */
-	int           hyb_block;   /* hybrid window (tab.rw_hyb): threads per block, as many waves as fit the LDS next to the table (192, 128 or 64) */
+	int           hyb_block;   /* hybrid window (tab.rw_hyb): threads per block */
 	bool          use_rot;     /* std geometry on the v3 rotating-window kernel (demod_kernel_rot.hip) instead of v2 */
 	bool          lat_ok;      /* the latency kernel (one stream per wave) fits this configuration */
 	int           lat_ring, lat_span;
@@ -220,19 +220,8 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	}
 	ctx->block_threads = 64 * 3;                     /* v1 kernel: three waves per block (__launch_bounds__(256); measured best, r01) */
 
-	auto hyb_need = [&](int threads) {
-		return (ctx->tab.ctab.size() + 32) * sizeof(float) + static_cast<size_t>(threads / 64) * (MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float) + MDEMOD_RW_HYB_WAVE_LDS)
-		       + static_cast<size_t>(threads) * MDEMOD_RW_HYB_RING * 2;
-	};
-	if (ctx->tab.rw_hyb) {
-		for (int t = 192; t >= 64 && !ctx->hyb_block; t -= 64) if (hyb_need(t) <= 160 * 1024) ctx->hyb_block = t;
-		if (!ctx->hyb_block) {                          /* -O beyond 37: the table alone is too large: the v1 ring kernel */
-			rc = mdemod_host_derive(*params, ctx->tab, 0);
-			if (rc) { delete ctx; return rc; }
-		}
-	}
+	if (ctx->tab.rw_hyb) ctx->hyb_block = MDEMOD_RW_BLOCK;
 	auto lds_need = [&](int threads) {
-		if (ctx->tab.rw_hyb) return hyb_need(ctx->hyb_block);
 		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
 		       (ctx->tab.use_rw ? static_cast<size_t>((ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
 		                          + static_cast<size_t>(ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) * 64     /* soft-symbol staging: a 32-symbol ring (4 x 16 B) per thread */
@@ -638,7 +627,7 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (!ctx) return "";
 	if (wants_latency_kernel(ctx)) return "demod_kernel_lat (one stream per wave: FIR farm + serial scalar stage)";
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
-	if (ctx->tab.rw_hyb) return "demod_kernel_roth (v3 hybrid window: float input, 129 taps, 80 slots in registers + 80 in LDS)";
+	if (ctx->tab.rw_hyb) return "demod_kernel_roth (v3 hybrid window: float input, 129 taps, 80 slots in VGPRs + 80 in AccVGPRs)";
 	if (ctx->tab.rw_compact4) return ctx->tab.rw_wide ? "demod_kernel_rotp (v3 rotating packed window, wide: 129 taps)"
 	                                 : (ctx->tab.rw_mid ? "demod_kernel_rotp (v3 rotating packed window, mid: 65 taps at up to 15 samples per firing)"
 	                                                    : "demod_kernel_rotp (v3 rotating packed window, far: 65 taps at up to 30 samples per firing)");

@@ -134,8 +134,8 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	const bool mid_ok = wide_ok && c.taps <= 65;
 	/* far: the short filter at 2 MS/s-class rates: up to 30 samples per firing, two 16-slot slides per iteration */
 	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= 30.0 && p.bps != 32;
-	/* hybrid: float input with 66..129 taps (a float window of 160 slots is 320 registers: the older half stays in registers, the
-	 * newer half lives in LDS: demod_kernel_rot.hip, WinH) */
+	/* hybrid: float input with 66..129 taps (a float window of 160 slots is 320 registers: the older half in VGPRs, the newer half
+	 * in AccVGPRs, one wave per SIMD: demod_kernel_rot.hip, WinH) */
 	const bool hyb_ok = generation >= 2 && !std_ok && per_firing <= 15.0 && p.bps == 32 && c.taps > 65 && c.taps <= 129;
 	const bool allow_rw = generation >= 1;
 	out.rw_hyb = hyb_ok;
@@ -174,7 +174,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		c.win_granules = NW / 4;
 		c.ring_granules = 0;
 		c.ctab_row_floats = LP;
-		/* (the hybrid window reads exactly the NW slots of its alignment, no prefetch past them, and has no LDS to spare) */
+		/* (the hybrid window reads exactly the NW slots of its alignment, no prefetch past them) */
 		c.ctab_row_stride = (LP + 3 + (out.rw_hyb ? 0 : 24 + 3)) / 4 * 4; /* whole 16-byte groups ...            */
 		if ((c.ctab_row_stride / 4) % 2 == 0) c.ctab_row_stride += 4;    /* ... an odd number of them           */
 		out.ctab.assign(static_cast<size_t>(4) * banks * c.ctab_row_stride + (out.rw_hyb ? 0 : 32), 0.0f);

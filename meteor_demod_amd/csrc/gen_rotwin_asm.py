@@ -159,6 +159,77 @@ def put(kind):
     return L
 
 
+# ---- the AccVGPR half of the hybrid window (float input, 66..129 taps: demod_kernel_rot.hip, WinA) ------------------------
+# A wave that has its SIMD to itself (one wave per SIMD: 512 registers per lane) owns 256 AccVGPRs next to its 256 VGPRs.
+# VALU instructions cannot read them, v_accvgpr_read_b32 / v_accvgpr_write_b32 move one register each way.  The NEWER 80 slots of
+# the 160-slot window live in a[96:255], ten physical chunks of 8 slots like the VGPR half, rotating with it.
+AB = 96          # first AccVGPR of the window: a[96:255] (hipcc hands out AccVGPRs from a0 up when it spills into them; build.py checks
+                 # that compiler-generated code stays below this, as it does for the VGPRs)
+
+
+def fir_acc():
+    """filter.c:46-65 continued over the AccVGPR half: logical chunk c of rotation r is physical chunk (c + r) mod 10.  Per tap two
+    v_accvgpr_read_b32 into a VGPR pair, then the same v_pk_mul_f32 + v_pk_add_f32 as the VGPR half.  %[addr] points at the
+    coefficient of the half's first slot; the sum leaves after logical chunk %[last] (6..9: the chunk of the wave's last tap)."""
+    NH = 2 * NCH
+    # v80..v91: three coefficient buffers of four (a half-chunk each, loaded two half-chunks ahead); v[92:93], v[94:95]: the two
+    # pairs a tap's samples are read into
+    def load(h):
+        b = CB + 4 * (h % 3)
+        return "ds_read_b128 v[%d:%d], %%[addr] offset:%d" % (b, b + 3, 16 * h)
+    L = [load(h) for h in range(2)]
+    L += jump("fira", NCH)
+    for r in range(NCH):
+        L += [".Lfira_%d_%%=:" % r]
+        for h in range(NH):
+            c = h // 2
+            if h + 2 < NH:
+                L += [load(h + 2)]
+            L += ["s_waitcnt lgkmcnt(%d)" % min(2, NH - 1 - h)]
+            hb = CB + 4 * (h % 3)
+            aq = AB + 16 * ((c + r) % NCH) + 8 * (h & 1)
+            def rd(j):
+                t = CB + 12 + 2 * (j & 1)
+                return ["v_accvgpr_read_b32 v%d, a%d" % (t, aq + 2 * j), "v_accvgpr_read_b32 v%d, a%d" % (t + 1, aq + 2 * j + 1)]
+            def mul(j):
+                t = CB + 12 + 2 * (j & 1)
+                return ["v_pk_mul_f32 v[%d:%d], v[%d:%d], v[%d:%d] op_sel:[0,%d] op_sel_hi:[1,%d]" % (t, t + 1, t, t + 1, hb + 2 * (j // 2), hb + 2 * (j // 2) + 1, j & 1, j & 1)]
+            def add(j):
+                t = CB + 12 + 2 * (j & 1)
+                return ["v_pk_add_f32 %%[acc], %%[acc], v[%d:%d]" % (t, t + 1)]
+            # oldest tap first; a tap's product is not the instruction before its sum, a pair is read while the other one is summed
+            L += rd(0) + rd(1) + mul(0) + mul(1) + add(0) + rd(2) + add(1) + rd(3) + mul(2) + mul(3) + add(2) + add(3)
+            if h % 2 == 1 and 6 <= c < NCH - 1:
+                L += ["s_cmp_eq_u32 %%[last], %d" % c, "s_cbranch_scc1 .Lfira_end_%="]
+        L += ["s_branch .Lfira_end_%="]
+    L += [".Lfira_end_%=:", "s_waitcnt lgkmcnt(0)"]
+    return L
+
+
+def migrate():
+    """The slide of the hybrid window at rotation %[rot]: AccVGPR chunk q (the oldest of the newer half) moves into VGPR chunk q
+    (whose samples leave the window), the 8 new samples (16 floats f0..f15) take its place."""
+    L = jump("mig", NCH)
+    for r in range(NCH):
+        L += [".Lmig_%d_%%=:" % r]
+        L += ["v_accvgpr_read_b32 v%d, a%d" % (WB + 16 * r + k, AB + 16 * r + k) for k in range(16)]
+        L += ["v_accvgpr_write_b32 a%d, %%[f%d]" % (AB + 16 * r + k, k) for k in range(16)]
+        L += ["s_branch .Lmig_end_%="]
+    L += [".Lmig_end_%=:"]
+    return L
+
+
+def put_acc():
+    """16 ready floats into AccVGPR chunk %[rot] (history and the first samples at kernel start)."""
+    L = jump("puta", NCH)
+    for r in range(NCH):
+        L += [".Lputa_%d_%%=:" % r]
+        L += ["v_accvgpr_write_b32 a%d, %%[f%d]" % (AB + 16 * r + k, k) for k in range(16)]
+        L += ["s_branch .Lputa_end_%="]
+    L += [".Lputa_end_%=:"]
+    return L
+
+
 def main():
     out = []
     out.append("/* GENERATED by gen_rotwin_asm.py - do not edit.  gfx950 assembly of the rotating register window. */")
@@ -168,10 +239,15 @@ def main():
     out.append("#define ROTWIN_CB %d" % CB)
     out.append("#define ROTWIN_LIMIT %d   /* first register the compiler may not use */" % (TB if PK in (2, 3) else CB))
     out.append("#define ROTWIN_NCH %d" % NCH)
+    out.append("#define ROTWIN_AB %d   /* first AccVGPR of the hybrid window's newer half */" % AB)
     out.append("#define ROTWIN_PK %d" % PK)
     out.append("#define ROTWIN_FIR_ASM \\\n" + q(fir()).replace("\n", " \\\n"))
     for kind in ("s16", "u8", "f32"):
         out.append("#define ROTWIN_PUT_%s_ASM \\\n" % kind.upper() + q(put(kind)).replace("\n", " \\\n"))
+    out.append("#define ROTWIN_FIR_ACC_ASM \\\n" + q(fir_acc()).replace("\n", " \\\n"))
+    out.append("#define ROTWIN_MIGRATE_ASM \\\n" + q(migrate()).replace("\n", " \\\n"))
+    out.append("#define ROTWIN_PUT_ACC_ASM \\\n" + q(put_acc()).replace("\n", " \\\n"))
+    out.append("#define ROTWIN_ACC_CLOBBERS " + ", ".join('"a%d"' % i for i in range(AB, AB + 16 * NCH)))
     # clobber lists
     out.append("#define ROTWIN_COEF_CLOBBERS " + ", ".join('"v%d"' % i for i in range(TB if PK in (2, 3) else CB, WB)))
     out.append("#endif")

@@ -227,10 +227,10 @@ WIDE_CFGS = {
     "far_edge_u8": DemodConfig(samplerate=2150000, rrc_order=20, interp_factor=3, bps=8), # 29.9 samples per symbol
     "defaults_1024k_f32": DemodConfig(samplerate=1024000, bps=32),                        # float input: mid geometry with a float-pair window
     "oqpsk_640k_f32": DemodConfig(samplerate=640000, symrate=80000, oqpsk=True, rrc_order=24, interp_factor=4, bps=32),
-    "c4_f32": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),      # float input, 129 taps: hybrid window (registers + LDS)
+    "c4_f32": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),      # float input, 129 taps: hybrid window (VGPRs + AccVGPRs)
     "oqpsk80k_1M_f32": DemodConfig(samplerate=1000000, symrate=80000, oqpsk=True, rrc_order=64, interp_factor=8, bps=32),
     "taps97_230k_f32": DemodConfig(samplerate=230000, rrc_order=48, interp_factor=5, bps=32),   # the long filter at the LRPT rate: 3.2 samples per firing
-    "taps129_O12_f32": DemodConfig(samplerate=900000, rrc_order=64, interp_factor=12, bps=32),  # a table that leaves LDS for two waves per block only
+    "taps129_O12_f32": DemodConfig(samplerate=900000, rrc_order=64, interp_factor=12, bps=32),
 }
 WIDE_KERNEL = {"c4_s16": "wide", "c4_u8": "wide", "oqpsk80k_1M": "wide", "taps97_os6": "wide", "edge_15_per_symbol": "wide",
                "taps65_slow_clock": "mid", "defaults_1024k": "mid", "defaults_1024k_oqpsk_u8": "mid", "defaults_2048k": "far",
@@ -683,9 +683,9 @@ def _check_cfg_against_oracle(cfg):
 
 @pytest.mark.parametrize("kernel", ["v1", ""], ids=["ring", "hybrid"])
 def test_float_input_ring_kernel_ignores_stale_lds(kernel, gpu_device, monkeypatch):
-    """Float input with window slots in LDS (the v1 ring kernel; the newer half of the v3 hybrid window): slots outside a lane's
-    taps are multiplied by zero coefficients, so they must never hold stale NaN bits (0 * NaN = NaN).  A first context fills the
-    CUs' LDS with NaN samples."""
+    """Float input with window slots outside a lane's taps (the v1 ring kernel's LDS ring; the v3 hybrid window's registers): they are
+    multiplied by zero coefficients, so they must never hold stale NaN bits (0 * NaN = NaN).  A first context fills the CUs' LDS
+    and registers with NaN samples."""
     torch = _torch()
     monkeypatch.setenv("MDEMOD_KERNEL", kernel)
     cfg = DemodConfig(samplerate=1072367, pll_bw=5.0, symrate=72000, interp_factor=4, rrc_order=33, oqpsk=True, bps=32)
