@@ -13,7 +13,7 @@ CFG = {"c1": ("configs[1] QPSK 72k, 230 kS/s, -f 32 -O 5", 72000, 230000, 1), "c
 ROOT = Path(__file__).resolve().parent.parent
 tf = ROOT / "profiles" / "hbm_traffic.json"
 traffic = json.loads(tf.read_text()) if tf.exists() else {}
-lines = [f"# {tag}: demodulator kernels under rocprofv3 (bench.py --config X --steps 3 --warmup 1 --no-cpu-baseline --no-check, {T} tiles x {L} samples)\n",
+lines = [f"# {tag}: demodulator kernels under rocprofv3 (bench.py --config X --steps 10 --warmup 2 --no-cpu-baseline --no-check, {T} tiles x {L} samples)\n",
          "Separate passes per counter group (`tools/profile_round.sh`): `--kernel-trace --stats`, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_*`.",
          "FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B: MI355X_MICROARCH.md, HBM section); WRITE_SIZE as counted.\n",
          "| config | kernel | avg ms (stats pass) | min ms | GS/s at avg | algorithmic GB | % of 8 TB/s | FETCH x2 GB | WRITE GB | traffic / algorithmic | VALU / wave-firing | SALU | LDS | branch | wave-cycles / firing | WAIT_ANY / WAVE_CYCLES | WAIT_INST_ANY / WAVE_CYCLES | ACTIVE_INST_VALU / WAVE_CYCLES |",

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r03}; mkdir -p $O
 CFGS=${2:-"c1 c3 c4"}
 for c in $CFGS; do
-  B="python3 bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-check"
+  B="python3 bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline --no-check"
   rocprofv3 --kernel-trace --stats -d $O/${c}_stats -o x -- $B > $O/${c}_stats.log 2>&1
   rocprofv3 --pmc FETCH_SIZE -d $O/${c}_FETCH -o x -- $B > $O/${c}_F.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $O/${c}_WRITE -o x -- $B > $O/${c}_W.log 2>&1
