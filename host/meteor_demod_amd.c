@@ -46,6 +46,7 @@
 #define RINGSIZE 512                    /* main.c:20   */
 #define BLOCK_BUFFERS 128               /* 4 MiB of input per stream per GPU call (files) */
 #define PIPE_BUFFERS  8                 /* 256 KiB when reading a pipe: ~0.3 s of a live 230 kS/s s16 stream */
+#define MAX_JOBS 16                     /* --tiled: files of one GPU in flight at once, at most */
 
 struct stream_io {
 	const char *in_name;
@@ -67,7 +68,7 @@ static const struct option longopts[] = {
 	{ "samplerate", 1, NULL, 's' }, { "bps", 1, NULL, 'S' },      { "version", 0, NULL, 'v' },
 	{ "device", 1, NULL, 0x01 },    { "tiled", 0, NULL, 0x02 },   { "tile-samples", 1, NULL, 0x03 },
 	{ "pilot-margin", 1, NULL, 0x04 }, { "carrier-seed", 1, NULL, 0x05 }, { "devices", 1, NULL, 0x06 }, { "plan", 0, NULL, 0x07 },
-	{ "tui-selftest", 0, NULL, 0x08 }, { "tui", 0, NULL, 0x09 },
+	{ "tui-selftest", 0, NULL, 0x08 }, { "tui", 0, NULL, 0x09 }, { "jobs", 1, NULL, 0x0a },
 	{ NULL, 0, NULL, 0 }
 };
 
@@ -108,7 +109,9 @@ usage(const char *prog)
 	        "                           GPUs of the node when several files are given); --plan prints the assignment\n"
 	        "       --tiled             Each file on many lanes as overlapped tiles (fast, not bit-exact\n"
 	        "                           after the head); --tile-samples <n>, --pilot-margin <symbols>,\n"
-	        "                           --carrier-seed spectrum|pilot (default spectrum: tiles follow Doppler)\n"
+	        "                           --carrier-seed spectrum|pilot (default spectrum: tiles follow Doppler);\n"
+	        "                           --jobs <n>: files of one GPU in flight at once (default 1: reading one file\n"
+	        "                           overlaps demodulating another, the serial heads do not overlap yet)\n"
 	        "   -h, --help   -v, --version\n", prog);
 }
 
@@ -229,84 +232,132 @@ struct worker {
 	mdemod_params p;                     /* p.device, p.n_streams are this worker's */
 	int         tiled, quiet, batch, update_interval, tile_samples, pilot_margin, carrier_seed;
 	int         tui;                     /* worker 0 only: the full-screen display is up */
+	int         jobs;                    /* --tiled: files of this worker in flight at once */
 	int         rc;                      /* exit code of this worker: 0 ok, 1 host error, 2 library error */
 };
 
-/* ---- --tiled: each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file ---- */
+/* ---- --tiled: each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file.  The
+ * serial head of a recording keeps one wavefront busy for ~0.1 s and its file takes as long to read: up to `jobs` files of a worker
+ * are in flight at once, each on a host thread of its own (the library calls are independent: own contexts, own streams).
+ * Measured on page-cached files (tools/cli_jobs_time.py, 8 x 2^25 samples): 1.64 s with one job, 1.48 s with four - the file reads
+ * overlap, the heads of concurrent host-buffer calls do not yet (each reports 0.38 s instead of 0.09: the calls' hipMalloc / hipFree
+ * and pageable copies synchronise the device), so the default stays 1. ---- */
+struct tiled_pool {
+	struct worker  *w;
+	pthread_mutex_t lock;
+	int             next;                /* next file of the worker nobody has taken */
+	int             rc;                  /* worst exit code so far */
+};
+
 static int
-run_tiled(struct worker *w)
+tiled_one_file(struct worker *w, int f)
 {
 	struct stream_io *io = w->io;
-	const int n_files = w->n_files, quiet = w->quiet, bps = w->p.bps, samplerate = w->p.samplerate;
+	const int quiet = w->quiet, bps = w->p.bps, samplerate = w->p.samplerate;
 	const float symrate = (float)w->p.symrate;
 	const int tile_samples = w->tile_samples, pilot_margin = w->pilot_margin, carrier_seed = w->carrier_seed;
 	mdemod_params p = w->p;
-	int device = w->p.device;
-	{
-		/* ---- each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file ---- */
-		const int timing = getenv("MDEMOD_CLI_TIMING") != NULL;       /* where the wall time of a --tiled run goes (stderr) */
-		pthread_t init_thr;
-		const int init_started = pthread_create(&init_thr, NULL, init_device_thread, &device) == 0;
-		for (int f = 0; f < n_files; f++) {
-			const double t_begin = now_ms();
-			size_t cap_bytes = 1u << 26, len = 0;
-			if (io[f].file_len + 2 * FILE_BUFFER_SIZE > cap_bytes) cap_bytes = io[f].file_len + 2 * FILE_BUFFER_SIZE;   /* a regular file: one allocation, no copies */
-			unsigned char *data = malloc(cap_bytes);
-			for (;;) {
-				if (len + FILE_BUFFER_SIZE > cap_bytes) {
-					unsigned char *grown = realloc(data, cap_bytes * 2);
-					if (!grown) { free(data); data = NULL; break; }
-					data = grown; cap_bytes *= 2;
-				}
-				if (!data) break;
-				if (fread(data + len, FILE_BUFFER_SIZE, 1, io[f].in) != 1) break;
-				len += FILE_BUFFER_SIZE;
-			}
-			if (!data) { fprintf(stderr, "out of memory reading %s\n", io[f].in_name); close_all(io, n_files); return 1; }
-			const uint64_t n_samples = len / (2 * (size_t)bps / 8);
-			const uint64_t cap_sym = (uint64_t)((double)n_samples * symrate / samplerate * 1.02) + 4096;
-			int8_t *soft_all = malloc(cap_sym * 2);
-			if (!soft_all) { free(data); close_all(io, n_files); return 1; }
-			mdemod_recording_opts ro;
-			mdemod_recording_default_opts(&ro);
-			if (getenv("MDEMOD_RECORDING_DEBUG")) ro.debug = atoi(getenv("MDEMOD_RECORDING_DEBUG")) > 0 ? atoi(getenv("MDEMOD_RECORDING_DEBUG")) : 1;     /* the library reads no environment: the CLI does */
-			if (tile_samples > 0) ro.tile_samples = (uint32_t)tile_samples;
-			if (pilot_margin >= 0) ro.pilot_margin_symbols = (uint32_t)pilot_margin;
-			if (carrier_seed >= 0) ro.carrier_seed = (uint32_t)carrier_seed;
-			mdemod_recording_report rr;
-			const double t_read = now_ms();
-			if (f == 0 && init_started) pthread_join(init_thr, NULL);
-			int rc2 = mdemod_demodulate_recording_host(&p, &ro, data, n_samples, soft_all, cap_sym, &rr);
-			const double t_lib = now_ms();
-			if (rc2 != MDEMOD_OK) {
-				fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2));
-				free(data); free(soft_all); close_all(io, n_files);
-				return 2;
-			}
-			if (rr.pilot_locked == 2)
-				fprintf(stderr, "%s: note: the reference's PLL reports lock far from this signal's carrier (a false lock, common with "
-				        "-m oqpsk): the exact mode would write what it produces from there on; --tiled demodulates the signal\n", io[f].in_name);
-			if (!quiet)
-				fprintf(stderr, "%s: %llu samples: %llu serial (pilot) + %u tiles, %llu symbols, first lock at symbol %lld, %u seam fixes, "
-				        "%u weak seams, %u rotation jumps, %u tiles without a carrier line, %.2f s\n", io[f].in_name, (unsigned long long)n_samples,
-				        (unsigned long long)rr.pilot_samples, rr.n_tiles, (unsigned long long)rr.n_symbols, (long long)rr.first_lock_symbol,
-				        rr.seam_fixes, rr.weak_seams, rr.rotation_jumps, rr.weak_carrier_tiles, rr.pilot_seconds + rr.tiles_seconds);
-			for (uint64_t k = 0; k < rr.n_symbols; k += 1u << 20)
-				write_gated(&io[f], soft_all + 2 * k, (uint32_t)((rr.n_symbols - k < (1u << 20)) ? rr.n_symbols - k : (1u << 20)), rr.first_lock_symbol);
-			size_t tail = 2 * (size_t)io[f].ring_idx;                       /* main.c:321 */
-			if (tail > sizeof(io[f].ring)) tail = sizeof(io[f].ring);
-			fwrite(io[f].ring, 1, tail, io[f].out);
-			if (io[f].out != stdout) fclose(io[f].out);
-			if (io[f].in != stdin) fclose(io[f].in);
-			io[f].out = NULL; io[f].in = NULL;
-			free(data); free(soft_all);
-			if (timing)
-				fprintf(stderr, "%s: read %.0f ms, library call %.0f ms (pilot %.0f + tiles %.0f on the device), write %.0f ms\n", io[f].in_name,
-				        t_read - t_begin, t_lib - t_read, rr.pilot_seconds * 1e3, rr.tiles_seconds * 1e3, now_ms() - t_lib);
+	const int timing = getenv("MDEMOD_CLI_TIMING") != NULL;       /* where the wall time of a --tiled run goes (stderr) */
+	const double t_begin = now_ms();
+	size_t cap_bytes = 1u << 26, len = 0;
+	if (io[f].file_len + 2 * FILE_BUFFER_SIZE > cap_bytes) cap_bytes = io[f].file_len + 2 * FILE_BUFFER_SIZE;   /* a regular file: one allocation, no copies */
+	unsigned char *data = malloc(cap_bytes);
+	for (;;) {
+		if (len + FILE_BUFFER_SIZE > cap_bytes) {
+			unsigned char *grown = realloc(data, cap_bytes * 2);
+			if (!grown) { free(data); data = NULL; break; }
+			data = grown; cap_bytes *= 2;
 		}
-		return 0;
+		if (!data) break;
+		if (fread(data + len, FILE_BUFFER_SIZE, 1, io[f].in) != 1) break;
+		len += FILE_BUFFER_SIZE;
 	}
+	if (!data) { fprintf(stderr, "out of memory reading %s\n", io[f].in_name); return 1; }
+	const uint64_t n_samples = len / (2 * (size_t)bps / 8);
+	const uint64_t cap_sym = (uint64_t)((double)n_samples * symrate / samplerate * 1.02) + 4096;
+	int8_t *soft_all = malloc(cap_sym * 2);
+	if (!soft_all) { free(data); return 1; }
+	mdemod_recording_opts ro;
+	mdemod_recording_default_opts(&ro);
+	if (getenv("MDEMOD_RECORDING_DEBUG")) ro.debug = atoi(getenv("MDEMOD_RECORDING_DEBUG")) > 0 ? atoi(getenv("MDEMOD_RECORDING_DEBUG")) : 1;     /* the library reads no environment: the CLI does */
+	if (tile_samples > 0) ro.tile_samples = (uint32_t)tile_samples;
+	if (pilot_margin >= 0) ro.pilot_margin_symbols = (uint32_t)pilot_margin;
+	if (carrier_seed >= 0) ro.carrier_seed = (uint32_t)carrier_seed;
+	mdemod_recording_report rr;
+	const double t_read = now_ms();
+	int rc2 = mdemod_demodulate_recording_host(&p, &ro, data, n_samples, soft_all, cap_sym, &rr);
+	const double t_lib = now_ms();
+	if (rc2 != MDEMOD_OK) {
+		fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2));
+		free(data); free(soft_all);
+		return 2;
+	}
+	if (rr.pilot_locked == 2)
+		fprintf(stderr, "%s: note: the reference's PLL reports lock far from this signal's carrier (a false lock, common with "
+		        "-m oqpsk): the exact mode would write what it produces from there on; --tiled demodulates the signal\n", io[f].in_name);
+	if (!quiet)
+		fprintf(stderr, "%s: %llu samples: %llu serial (pilot) + %u tiles, %llu symbols, first lock at symbol %lld, %u seam fixes, "
+		        "%u weak seams, %u rotation jumps, %u tiles without a carrier line, %.2f s\n", io[f].in_name, (unsigned long long)n_samples,
+		        (unsigned long long)rr.pilot_samples, rr.n_tiles, (unsigned long long)rr.n_symbols, (long long)rr.first_lock_symbol,
+		        rr.seam_fixes, rr.weak_seams, rr.rotation_jumps, rr.weak_carrier_tiles, rr.pilot_seconds + rr.tiles_seconds);
+	for (uint64_t k = 0; k < rr.n_symbols; k += 1u << 20)
+		write_gated(&io[f], soft_all + 2 * k, (uint32_t)((rr.n_symbols - k < (1u << 20)) ? rr.n_symbols - k : (1u << 20)), rr.first_lock_symbol);
+	size_t tail = 2 * (size_t)io[f].ring_idx;                       /* main.c:321 */
+	if (tail > sizeof(io[f].ring)) tail = sizeof(io[f].ring);
+	fwrite(io[f].ring, 1, tail, io[f].out);
+	if (io[f].out != stdout) fclose(io[f].out);
+	if (io[f].in != stdin) fclose(io[f].in);
+	io[f].out = NULL; io[f].in = NULL;
+	free(data); free(soft_all);
+	if (timing)
+		fprintf(stderr, "%s: read %.0f ms, library call %.0f ms (pilot %.0f + tiles %.0f on the device), write %.0f ms\n", io[f].in_name,
+		        t_read - t_begin, t_lib - t_read, rr.pilot_seconds * 1e3, rr.tiles_seconds * 1e3, now_ms() - t_lib);
+	return 0;
+}
 
+static void *
+tiled_job(void *arg)
+{
+	struct tiled_pool *pool = arg;
+	for (;;) {
+		pthread_mutex_lock(&pool->lock);
+		const int f = pool->next < pool->w->n_files && pool->rc == 0 ? pool->next++ : -1;
+		pthread_mutex_unlock(&pool->lock);
+		if (f < 0) return NULL;
+		const int rc = tiled_one_file(pool->w, f);
+		if (rc) {
+			pthread_mutex_lock(&pool->lock);
+			if (rc > pool->rc) pool->rc = rc;
+			pthread_mutex_unlock(&pool->lock);
+		}
+	}
+}
+
+static int
+run_tiled(struct worker *w)
+{
+	int device = w->p.device;
+	/* the HIP runtime comes up (0.1-0.2 s) on a thread of its own while the first file is read */
+	pthread_t init_thr;
+	const int init_started = pthread_create(&init_thr, NULL, init_device_thread, &device) == 0;
+	struct tiled_pool pool = { w, PTHREAD_MUTEX_INITIALIZER, 0, 0 };
+	int jobs = w->jobs < 1 ? 1 : w->jobs;
+	if (jobs > w->n_files) jobs = w->n_files;
+	if (jobs > MAX_JOBS) jobs = MAX_JOBS;
+	for (int i = 0; i < w->n_files; i++) if (w->io[i].in == stdin || w->io[i].out == stdout) jobs = 1;
+	if (jobs == 1) {
+		tiled_job(&pool);
+		if (init_started) pthread_join(init_thr, NULL);
+	} else {
+		pthread_t thr[MAX_JOBS];
+		int started = 0;
+		for (; started < jobs; started++) if (pthread_create(&thr[started], NULL, tiled_job, &pool)) break;
+		if (!started) tiled_job(&pool);
+		for (int i = 0; i < started; i++) pthread_join(thr[i], NULL);
+		if (init_started) pthread_join(init_thr, NULL);
+	}
+	if (pool.rc) close_all(w->io, w->n_files);
+	return pool.rc;
 }
 
 /* ---- exact mode: this worker's files as ONE batch, one stream per file, block by block (main.c:303-316) ---- */
@@ -453,7 +504,7 @@ main(int argc, char **argv)
 	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0, tiled = 0;
 	int tile_samples = 0, pilot_margin = -1, carrier_seed = -1, update_interval = -1;
 	const char *output_fname = NULL;
-	int devs[MAX_DEVICES], n_dev = 0, plan = 0, force_tui = 0;
+	int devs[MAX_DEVICES], n_dev = 0, plan = 0, force_tui = 0, jobs = 1;
 	int c;
 
 	while ((c = getopt_long(argc, argv, "a:Bb:d:f:hm:o:O:qR:r:s:S:v", longopts, NULL)) != -1) {
@@ -466,6 +517,7 @@ main(int argc, char **argv)
 			break;
 		case 0x07: plan = 1; break;
 		case 0x09: force_tui = 1; break;
+		case 0x0a: jobs = atoi(optarg); if (jobs < 1) { fprintf(stderr, "--jobs: a positive number\n"); return 1; } break;
 		case 0x08:
 #ifdef MDEMOD_TUI
 			return tui_selftest(force_tui);
@@ -602,6 +654,7 @@ main(int argc, char **argv)
 		w->tiled = tiled; w->quiet = quiet; w->batch = batch; w->update_interval = update_interval;
 		w->tile_samples = tile_samples; w->pilot_margin = pilot_margin; w->carrier_seed = carrier_seed;
 		w->tui = use_tui && d == 0;
+		w->jobs = jobs;
 		for (int i = d; i < n_files; i += n_dev) w->n_files++;
 		w->io = calloc((size_t)w->n_files, sizeof(*w->io));
 		if (!w->io) return 1;

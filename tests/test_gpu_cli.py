@@ -213,6 +213,17 @@ def test_cli_tiled_mode_single_file(tmp_path, gpu_device):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert Path(str(inp) + ".s").read_bytes() == out.read_bytes() == Path(str(inp2) + ".s").read_bytes()
+    # ... with several of them in flight at once (--jobs) or one after the other: the same files
+    more = [tmp_path / f"m{i}.wav" for i in range(5)]
+    for m in more:
+        m.write_bytes(inp.read_bytes())
+    for jobs in ("3", "1"):
+        r = subprocess.run([str(CLI), "-q", "--tiled", "--jobs", jobs, "--tile-samples", "32768", "--pilot-margin", "100k", *map(str, more)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for m in more:
+            assert Path(str(m) + ".s").read_bytes() == out.read_bytes(), (jobs, m)
+            Path(str(m) + ".s").unlink()
     # OQPSK works too (state rotation pass): same length as the serial file, hard decisions equal
     cfg_o = DemodConfig(samplerate=230000, symrate=80000, oqpsk=True)
     iq_o = synth.generate_host(synth.make_stream(22, 230000, 80000, f0_hz=250.0, esn0_db=14.0, oqpsk=True), n)
