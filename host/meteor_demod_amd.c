@@ -110,8 +110,8 @@ usage(const char *prog)
 	        "       --tiled             Each file on many lanes as overlapped tiles (fast, not bit-exact\n"
 	        "                           after the head); --tile-samples <n>, --pilot-margin <symbols>,\n"
 	        "                           --carrier-seed spectrum|pilot (default spectrum: tiles follow Doppler);\n"
-	        "                           --jobs <n>: files of one GPU in flight at once (default 1: reading one file\n"
-	        "                           overlaps demodulating another, the serial heads do not overlap yet)\n"
+	        "                           --jobs <n>: files of one GPU in flight at once (default 4: their serial heads\n"
+	        "                           and file reads overlap)\n"
 	        "   -h, --help   -v, --version\n", prog);
 }
 
@@ -239,9 +239,9 @@ struct worker {
 /* ---- --tiled: each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file.  The
  * serial head of a recording keeps one wavefront busy for ~0.1 s and its file takes as long to read: up to `jobs` files of a worker
  * are in flight at once, each on a host thread of its own (the library calls are independent: own contexts, own streams).
- * Measured on page-cached files (tools/cli_jobs_time.py, 8 x 2^25 samples): 1.64 s with one job, 1.48 s with four - the file reads
- * overlap, the heads of concurrent host-buffer calls do not yet (each reports 0.38 s instead of 0.09: the calls' hipMalloc / hipFree
- * and pageable copies synchronise the device), so the default stays 1. ---- */
+ * Measured on page-cached files (tools/cli_jobs_time.py, 8 x 2^25 samples, 0.45 s of it process and runtime start): 1.66 s with one
+ * job, 1.25 with two, 1.13 with four (the default), 1.15 with eight - the heads and the file reads overlap, the tile phases (each
+ * fills the GPU) do not. ---- */
 struct tiled_pool {
 	struct worker  *w;
 	pthread_mutex_t lock;
@@ -504,7 +504,7 @@ main(int argc, char **argv)
 	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0, tiled = 0;
 	int tile_samples = 0, pilot_margin = -1, carrier_seed = -1, update_interval = -1;
 	const char *output_fname = NULL;
-	int devs[MAX_DEVICES], n_dev = 0, plan = 0, force_tui = 0, jobs = 1;
+	int devs[MAX_DEVICES], n_dev = 0, plan = 0, force_tui = 0, jobs = 4;
 	int c;
 
 	while ((c = getopt_long(argc, argv, "a:Bb:d:f:hm:o:O:qR:r:s:S:v", longopts, NULL)) != -1) {

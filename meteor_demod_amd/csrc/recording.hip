@@ -1682,12 +1682,19 @@ mdemod_demodulate_recording_host(const mdemod_params *params, const mdemod_recor
 	const std::function<void(uint64_t)> need = [&](uint64_t upto) {
 		while (there.load() < std::min(upto, n_samples)) std::this_thread::sleep_for(std::chrono::microseconds(50));
 	};
-	const int rc = demodulate_recording_impl(params, opts, d_iq, n_samples, d_soft, soft_cap_symbols, rep, nullptr, &need);
+	/* a stream of this call's own: on the null stream the calls of several host threads (the C host's --jobs) would run one
+	   kernel after the other, serial heads included */
+	struct OwnStream { hipStream_t s = nullptr; ~OwnStream() { if (s) (void)hipStreamDestroy(s); } } own;
+	HTRY(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking));
+	const int rc = demodulate_recording_impl(params, opts, d_iq, n_samples, d_soft, soft_cap_symbols, rep, own.s, &need);
 	if (copier.t.joinable()) copier.t.join();
 	mark("demodulated");
 	if (copy_failed.load()) return MDEMOD_ERR_HIP;
 	TRY(rc);
-	if (rep->n_symbols) HTRY(hipMemcpy(soft_host, d_soft, static_cast<size_t>(rep->n_symbols) * 2, hipMemcpyDeviceToHost));
+	if (rep->n_symbols) {
+		HTRY(hipMemcpyAsync(soft_host, d_soft, static_cast<size_t>(rep->n_symbols) * 2, hipMemcpyDeviceToHost, own.s));
+		HTRY(hipStreamSynchronize(own.s));
+	}
 	mark("symbols copied out");
 	return MDEMOD_OK;
 }
