@@ -138,8 +138,8 @@ typedef struct {
 
 uint32_t mdemod_abi_version(void);
 const char *mdemod_strerror(int code);
-/* Optional: brings up the HIP runtime on `device` (0.1-0.2 s in a new process) - e.g. from a second thread while the host
- * reads its input file.  Every other entry does this by itself when it has not happened yet. */
+/* Optional: brings up the HIP runtime on `device` and loads the library's code objects (0.1-0.2 s in a new process) - e.g. from
+ * a second thread while the host reads its input file.  Every other entry does this by itself when it has not happened yet. */
 int  mdemod_init_device(int device);
 /* GPUs this process sees (hipGetDeviceCount); 0 when there is none or the runtime cannot start. */
 int  mdemod_device_count(void);

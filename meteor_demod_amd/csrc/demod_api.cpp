@@ -141,7 +141,13 @@ int
 mdemod_init_device(int device)
 {
 	if (hipSetDevice(device) != hipSuccess) return MDEMOD_ERR_HIP;
-	return hipFree(nullptr) == hipSuccess ? MDEMOD_OK : MDEMOD_ERR_HIP;     /* forces the context */
+	if (hipFree(nullptr) != hipSuccess) return MDEMOD_ERR_HIP;             /* forces the context */
+	/* ... and the code objects (loaded at the first launch of a process), on a stream of its own */
+	hipStream_t s = nullptr;
+	if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return MDEMOD_ERR_HIP;
+	const bool ok = mdemod_launch_warm(s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+	(void)hipStreamDestroy(s);
+	return ok ? MDEMOD_OK : MDEMOD_ERR_HIP;
 }
 
 int

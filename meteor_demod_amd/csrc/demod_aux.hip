@@ -145,6 +145,17 @@ selftest_turncode_kernel(unsigned long long *mismatch)
 
 } /* namespace */
 
+/* An empty launch: the first launch of a process loads the library's code objects (tens of milliseconds for the generated
+ * assembly kernels); mdemod_init_device does it off the critical path of the first demodulation. */
+namespace { __global__ void warm_kernel() {} }
+
+hipError_t
+mdemod_launch_warm(hipStream_t stream)
+{
+	hipLaunchKernelGGL(warm_kernel, dim3(1), dim3(64), 0, stream);
+	return hipGetLastError();
+}
+
 hipError_t
 mdemod_launch_selftest_turncode(unsigned long long *mismatch_dev, hipStream_t stream)
 {

@@ -94,6 +94,7 @@ hipError_t mdemod_launch_demod_rotp(const DemodLaunch &L, int fmt, int geom /* 0
 hipError_t mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mid, 2 far */, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_lat(const DemodLaunch &L, int fmt, const float *rrc_dev, int ring_size, int span, int float_history, size_t lds_bytes, hipStream_t stream);
 bool mdemod_lat_geometry(const DemodConsts &c, double samples_per_firing, int *ring_size, int *span, size_t *lds_bytes);
+hipError_t mdemod_launch_warm(hipStream_t stream);   /* empty kernel: loads the code objects */
 hipError_t mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int float_history, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_seed(const DemodStateSoA &st, const DemodConsts &c, const mdemod_stream_state &v, int32_t flags, int fmt,
                               int float_history, uint32_t n_streams, hipStream_t stream);
