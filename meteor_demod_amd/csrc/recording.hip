@@ -893,8 +893,11 @@ struct Stitcher {
 	uint64_t B = 0, A = 0, KP = 0, WS = 0; size_t T = 0;
 	std::vector<uint64_t> E, len, s0, acq, frm, stl, q;
 	mdemod_params bp; Ctx bank, saved; DevMem mem; float consts[8]; double fmax = 0, tau_pll = 0;
-	/* per-tile estimates */
-	std::vector<double> tclk, centre, fbar, slope; int nfft = 0; float min_quality = 8.0f; std::vector<uint64_t> wstart; double f_pilot_target = 0;
+	/* estimates: carrier (centre, fbar, slope) and clock lines (ge_*) on grids of their own, taken while the head runs; per tile
+	   the clock seed and the carrier's local slope */
+	std::vector<double> tclk, centre, fbar, slope, slope_tile; int nfft = 0; float min_quality = 8.0f; std::vector<uint64_t> wstart; double f_pilot_target = 0;
+	std::vector<double> ge_cx; std::vector<float> ge_th, ge_cq; uint32_t ge_wc = 0; bool ge_no_carrier = true, ge_clock_deferred = false;
+	struct EstThread { std::thread t; int rc = MDEMOD_OK; ~EstThread() { if (t.joinable()) t.join(); } } est;
 	/* seeds */
 	std::vector<float> f0, tf, gains; std::vector<int32_t> ud; float *d_f0 = nullptr, *d_tf = nullptr, *d_gain = nullptr; int32_t *d_ud = nullptr;
 	/* the bank's buffers and what the launches leave in them */
@@ -915,7 +918,7 @@ struct Stitcher {
 	/* the carrier word the SERIAL loop has at sample t of tile i's lead (see seed_tiles) */
 	double f_seed(size_t i, double t) const
 	{
-		const double lag = slope[i] * osf / nco * tau_pll;
+		const double lag = slope_tile[i] * osf / nco * tau_pll;
 		/* before the hand-over (a lead that starts inside the pilot) the serial run was further away still: same exponential, back to
 		   where the pilot's margin began at most, and by no more than one time constant (OQPSK's loop has a quarter of QPSK's: 74x
 		   the pilot's offset is not a seed) */
@@ -928,7 +931,7 @@ struct Stitcher {
 	{
 		for (size_t i = 0; i < T; i++) {
 			f0[i] = i == 0 ? seed.pll_freq : static_cast<float>(f_seed(i, static_cast<double>(s0[i] + (at_acquired ? acq[i] : 0))));
-			ud[i] = i == 0 ? seed.pll_updown : (slope[i] >= 0 ? 1 : -1);
+			ud[i] = i == 0 ? seed.pll_updown : (slope_tile[i] >= 0 ? 1 : -1);
 		}
 		HTRY(hipMemcpyAsync(d_f0, f0.data(), T * sizeof(float), hipMemcpyHostToDevice, st));
 		HTRY(hipMemcpyAsync(d_ud, ud.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -952,8 +955,8 @@ struct Stitcher {
 		return MDEMOD_OK;
 	}
 
-	/* pilot: the reference's own serial run of the head (run_pilot) */
-	int run_head()
+	/* options and the constants everything else derives from */
+	int prepare()
 	{
 		if (!params || !iq_dev || !soft_dev || !rep) return MDEMOD_ERR_PARAM;
 		if (params->samplerate <= 0 || params->symrate <= 0) return MDEMOD_ERR_PARAM;
@@ -974,7 +977,14 @@ struct Stitcher {
 		memset(rep, 0, sizeof(*rep));
 		rep->first_lock_symbol = -1;
 		K = static_cast<int>(std::max<uint32_t>(o.match_symbols, 32));     /* fewer symbols cannot tell 4 rotations x 3 shifts apart at 12 dB */
+		dbg = o.debug != 0;
+		min_quality = 8.0f;                   /* spectral line over the band's mean: below this a window has no line to speak of */
+		return MDEMOD_OK;
+	}
 
+	/* pilot: the reference's own serial run of the head (run_pilot) */
+	int run_head()
+	{
 		/* ---- pilot ---- */
 		TRY(run_pilot(params, o, iq_dev, n_samples, soft_dev, soft_cap_symbols, st, need, po));
 		seed = po.seed;
@@ -988,7 +998,6 @@ struct Stitcher {
 		rep->exact_symbols = n_pilot_sym;
 		rep->pilot_seconds = po.seconds;
 		t_tiles = std::chrono::steady_clock::now();
-		dbg = o.debug != 0;
 		return MDEMOD_OK;
 	}
 
@@ -1036,32 +1045,80 @@ struct Stitcher {
 		return MDEMOD_OK;
 	}
 
-	/* 4th-power line of every tile, de-chirped (mdemod_estimate_carrier_chirp) */
-	int estimate_carriers()
+	/* ---- symbol-rate line (a pass moves the clock with the carrier: 20 ppm and more between the head and the far end; the loop's
+	   integrator needs 8 000 symbols per e-fold to make that up).  The clock is smooth: every tile reads a straight line through
+	   the estimates around it (estimate_clocks).  OQPSK's line pair sits at twice the carrier +- the rate: it is looked for around
+	   the carrier curve, or - without one - around `carrier_word` (the head's). ---- */
+	int clock_lines(hipStream_t es, DevMem &emem, float carrier_word)
 	{
-		/* ---- carrier of every tile: window i is centred on the span its frame is dead-reckoned over, [q_{i-1}, q_i] ---------------- */
-		tclk.assign(T, static_cast<double>(seed.t_freq));   /* symbol clock seeds, rad per interpolated step */
-		centre.assign(T, 0.0); fbar.assign(T, 0.0); slope.assign(T, 0.0);         /* rad per NCO step at centre[i]; slope in rad per NCO step per sample */
-		/* about 20 000 symbols per window (65 536 samples at 72k in 230 kS/s, 262 144 at 1 MS/s): the frames are dead-reckoned over a
-		   tile, the estimate has to be good to a fraction of a radian over that many symbols */
-		/* ... but no longer than a tile needs: the error of the estimate falls with the window^1.5 and is multiplied by the tile
-		   length, and 131 072 windows of 65 536 samples are 100 GB of reads over the three passes */
-		nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(
-		                     std::min(std::min(262144.0, 20536.0 * osf), std::max(5000.0 * osf, static_cast<double>(B))))));
-		min_quality = 8.0f;                   /* spectral line over the band's mean: below this a window has no line to speak of */
-		wstart.assign(T, 0);
-		for (size_t i = 0; i < T; i++) {
-			const double c = i == 0 ? static_cast<double>(P) : 0.5 * (static_cast<double>(i == 1 ? P : q[i - 1]) + static_cast<double>(q[i]));
-			const double w0 = std::max(0.0, std::min(c - nfft / 2, static_cast<double>(n_samples) - nfft));
-			wstart[i] = static_cast<uint64_t>(w0);
-			centre[i] = static_cast<double>(wstart[i]) + nfft / 2;
+		if (o.clock_seed == 0 && n_samples >= 4096) {
+			uint32_t wc = 4096;
+			while (wc * 2 <= std::min<uint64_t>(n_samples, 1u << 18)) wc *= 2;
+			std::vector<uint64_t> cst;
+			for (uint64_t a = 0; ; a += wc) {
+				if (a + wc >= n_samples) { cst.push_back(n_samples - wc); break; }
+				cst.push_back(a);
+			}
+			const size_t Tc = cst.size();
+			const bool curve = o.carrier_seed == 1 && !ge_no_carrier;
+			std::vector<float> cf(Tc, carrier_word), cc(Tc, 0.0f);
+			ge_cx.assign(Tc, 0.0);
+			for (size_t k = 0; k < Tc; k++) {
+				ge_cx[k] = static_cast<double>(cst[k]) + 0.5 * wc;
+				if (curve) {
+					cf[k] = static_cast<float>(interp_at(centre, fbar, std::min(std::max(ge_cx[k], centre.front()), centre.back())));     /* OQPSK: where its two lines are */
+					cc[k] = static_cast<float>(interp_at(centre, slope, std::min(std::max(ge_cx[k], centre.front()), centre.back())));
+				}
+			}
+			uint64_t *d_cst; float *d_cf, *d_cc, *d_tfq, *d_cq;
+			TRY(upload(emem, cst, &d_cst, es)); TRY(upload(emem, cf, &d_cf, es)); TRY(upload(emem, cc, &d_cc, es));
+			TRY(emem.alloc(&d_tfq, Tc)); TRY(emem.alloc(&d_cq, Tc));
+			TRY(mdemod_estimate_clock(params, iq_dev, n_samples, d_cst, d_cf, d_cc, static_cast<uint32_t>(Tc), wc, d_tfq, d_cq, es));
+			ge_th.assign(Tc, 0.0f); ge_cq.assign(Tc, 0.0f);
+			HTRY(hipMemcpyAsync(ge_th.data(), d_tfq, Tc * sizeof(float), hipMemcpyDeviceToHost, es));
+			HTRY(hipMemcpyAsync(ge_cq.data(), d_cq, Tc * sizeof(float), hipMemcpyDeviceToHost, es));
+			HTRY(hipStreamSynchronize(es));
+			ge_wc = wc;
 		}
-		if (o.carrier_seed == 1 && T > 1) {
+		return MDEMOD_OK;
+	}
+
+	/* ---- carrier and symbol clock of the recording, on grids of their own (nothing here needs the head: this runs on a second
+	 * host thread and stream while the head does) ------------------------------------------------------------------------------
+	 * carrier: 4th-power line (mdemod_estimate_carrier_chirp) of windows side by side over the whole recording, about 20 000
+	 * symbols each (65 536 samples at 72k in 230 kS/s, 262 144 at 1 MS/s): the frames are dead-reckoned from tile to tile with the
+	 * carrier read off this curve, which has to be good to a fraction of a radian over a tile.  clock: symbol-rate line
+	 * (mdemod_estimate_clock) of the estimator's longest windows (2^18 samples: 5e-8 of the rate), side by side as well. */
+	int estimate_grid()
+	{
+		if (hipSetDevice(params->device) != hipSuccess) return MDEMOD_ERR_HIP;
+		struct OwnStream { hipStream_t s = nullptr; ~OwnStream() { if (s) (void)hipStreamDestroy(s); } } own;
+		{
+			int least = 0, greatest = 0;                          /* behind the head's launches in the queues */
+			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+			HTRY(hipStreamCreateWithPriority(&own.s, hipStreamNonBlocking, least));
+		}
+		hipStream_t es = own.s;
+		DevMem emem;
+		if (need) (*need)(n_samples);                          /* the host-buffer entry is still copying the recording in */
+		nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(std::min(262144.0, 20536.0 * osf))));
+		const uint64_t W = static_cast<uint64_t>(nfft);
+		wstart.clear();
+		if (n_samples <= W) wstart.push_back(0);
+		else {
+			for (uint64_t a = 0; a + W <= n_samples; a += W) wstart.push_back(a);
+			if (wstart.back() + W < n_samples) wstart.push_back(n_samples - W);      /* the tail: one more window, flush with the end */
+		}
+		const size_t G = wstart.size();
+		centre.assign(G, 0.0); fbar.assign(G, 0.0); slope.assign(G, 0.0);         /* rad per NCO step at centre[i]; slope in rad per NCO step per sample */
+		for (size_t i = 0; i < G; i++) centre[i] = static_cast<double>(wstart[i]) + nfft / 2;
+		ge_no_carrier = true;
+		if (o.carrier_seed == 1 && n_samples >= 4096) {
 			uint64_t *d_starts, *d_starts_sel; float *d_freq, *d_qual, *d_chirp;
-			TRY(upload(mem, wstart, &d_starts, st));
-			TRY(mem.alloc(&d_freq, T)); TRY(mem.alloc(&d_qual, T)); TRY(mem.alloc(&d_chirp, T)); TRY(mem.alloc(&d_starts_sel, T));
-			std::vector<float> fh(T), qh(T), chirp(T, 0.0f), fsel(T), qsel(T), csel(T);
-			std::vector<uint64_t> wsel(T); std::vector<size_t> sel;
+			TRY(upload(emem, wstart, &d_starts, es));
+			TRY(emem.alloc(&d_freq, G)); TRY(emem.alloc(&d_qual, G)); TRY(emem.alloc(&d_chirp, G)); TRY(emem.alloc(&d_starts_sel, G));
+			std::vector<float> fh(G), qh(G), chirp(G, 0.0f), fsel(G), qsel(G), csel(G);
+			std::vector<uint64_t> wsel(G); std::vector<size_t> sel;
 			/* a ramp that moves the line by less than a tenth of a bin across the window smears nothing (the Hann window's main lobe is
 			   four bins wide): such a window keeps the estimate it has.  Without a Doppler ramp the local slopes are the estimates' own
 			   noise, a few hundredths of a bin, and the plain pass is the only one. */
@@ -1069,56 +1126,56 @@ struct Stitcher {
 			for (int pass = 0; pass < 3; pass++) {
 				/* pass 0: plain; passes 1, 2: with the local slope taken out of the window (a Doppler ramp smears the line) */
 				if (pass) {
-					for (size_t i = 0; i < T; i++) {      /* robust local slope: median of up to five neighbouring finite differences */
+					for (size_t i = 0; i < G; i++) {      /* robust local slope: median of up to five neighbouring finite differences */
 						double v[5]; int m = 0;
-						for (size_t j = i >= 2 ? i - 2 : 0; j <= std::min(T - 1, i + 2); j++) v[m++] = slope[j];
+						for (size_t k = i >= 2 ? i - 2 : 0; k <= std::min(G - 1, i + 2); k++) v[m++] = slope[k];
 						std::sort(v, v + m);
 						chirp[i] = static_cast<float>(v[m / 2]);
 					}
 					sel.clear();
-					for (size_t i = 0; i < T; i++) if (std::fabs(chirp[i]) * nfft > 0.1 * bin) sel.push_back(i);
+					for (size_t i = 0; i < G; i++) if (std::fabs(chirp[i]) * nfft > 0.1 * bin) sel.push_back(i);
 					if (sel.empty()) break;
 					for (size_t k = 0; k < sel.size(); k++) { wsel[k] = wstart[sel[k]]; csel[k] = chirp[sel[k]]; }
-					HTRY(hipMemcpyAsync(d_chirp, csel.data(), sel.size() * sizeof(float), hipMemcpyHostToDevice, st));
-					HTRY(hipMemcpyAsync(d_starts_sel, wsel.data(), sel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-					HTRY(hipStreamSynchronize(st));
+					HTRY(hipMemcpyAsync(d_chirp, csel.data(), sel.size() * sizeof(float), hipMemcpyHostToDevice, es));
+					HTRY(hipMemcpyAsync(d_starts_sel, wsel.data(), sel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, es));
+					HTRY(hipStreamSynchronize(es));
 					TRY(mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, d_starts_sel, d_chirp, static_cast<uint32_t>(sel.size()),
-					                                  static_cast<uint32_t>(nfft), d_freq, d_qual, st));
-					HTRY(hipMemcpyAsync(fsel.data(), d_freq, sel.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-					HTRY(hipMemcpyAsync(qsel.data(), d_qual, sel.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-					HTRY(hipStreamSynchronize(st));
+					                                  static_cast<uint32_t>(nfft), d_freq, d_qual, es));
+					HTRY(hipMemcpyAsync(fsel.data(), d_freq, sel.size() * sizeof(float), hipMemcpyDeviceToHost, es));
+					HTRY(hipMemcpyAsync(qsel.data(), d_qual, sel.size() * sizeof(float), hipMemcpyDeviceToHost, es));
+					HTRY(hipStreamSynchronize(es));
 					for (size_t k = 0; k < sel.size(); k++) { fh[sel[k]] = fsel[k]; qh[sel[k]] = qsel[k]; }
 				} else {
-					TRY(mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, d_starts, nullptr, static_cast<uint32_t>(T),
-					                                  static_cast<uint32_t>(nfft), d_freq, d_qual, st));
-					HTRY(hipMemcpyAsync(fh.data(), d_freq, T * sizeof(float), hipMemcpyDeviceToHost, st));
-					HTRY(hipMemcpyAsync(qh.data(), d_qual, T * sizeof(float), hipMemcpyDeviceToHost, st));
-					HTRY(hipStreamSynchronize(st));
+					TRY(mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, d_starts, nullptr, static_cast<uint32_t>(G),
+					                                  static_cast<uint32_t>(nfft), d_freq, d_qual, es));
+					HTRY(hipMemcpyAsync(fh.data(), d_freq, G * sizeof(float), hipMemcpyDeviceToHost, es));
+					HTRY(hipMemcpyAsync(qh.data(), d_qual, G * sizeof(float), hipMemcpyDeviceToHost, es));
+					HTRY(hipStreamSynchronize(es));
 				}
-				if (dbg) fprintf(stderr, "[recording] carrier pass %d: %zu of %zu windows\n", pass, pass ? sel.size() : T, T);
-				/* tiles without a clear line (fade, interference) take their good neighbours' estimate, interpolated over time;
-				   with no good tile at all, the pilot's frequency */
+				if (dbg) fprintf(stderr, "[recording] carrier pass %d: %zu of %zu windows of %d\n", pass, pass ? sel.size() : G, G, nfft);
+				/* windows without a clear line (fade, interference) take their good neighbours' estimate, interpolated over time;
+				   with no good window at all, the pilot's frequency (put in once the head is through) */
 				std::vector<size_t> good;
-				for (size_t i = 0; i < T; i++) if (qh[i] >= min_quality) good.push_back(i);
-				rep->weak_carrier_tiles = static_cast<uint32_t>(T - good.size());
-				if (good.empty()) {
-					for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
-				} else {
+				for (size_t i = 0; i < G; i++) if (qh[i] >= min_quality) good.push_back(i);
+				rep->weak_carrier_tiles = static_cast<uint32_t>(G - good.size());
+				ge_no_carrier = good.empty();
+				if (good.empty()) break;
+				{
 					std::vector<double> gx, gv;
 					for (size_t g : good) { gx.push_back(centre[g]); gv.push_back(fh[g]); }
-					for (size_t i = 0; i < T; i++)
+					for (size_t i = 0; i < G; i++)
 						fbar[i] = qh[i] >= min_quality ? static_cast<double>(fh[i]) : interp_at(gx, gv, std::min(std::max(centre[i], gx.front()), gx.back()));
 				}
 				/* one estimate far off the line through its neighbours (a spur, a burst: 1 in 1e5 windows) would put every later tile
 				   in the wrong frame: the carrier is smooth, the neighbours decide */
-				if (T >= 5) {
+				if (G >= 5) {
 					std::vector<double> fixed = fbar;
-					for (size_t i = 1; i + 1 < T; i++) {
+					for (size_t i = 1; i + 1 < G; i++) {
 						const double w = (centre[i] - centre[i - 1]) / (centre[i + 1] - centre[i - 1]);
 						const double pred = fbar[i - 1] + (fbar[i + 1] - fbar[i - 1]) * w;
 						if (std::fabs(fbar[i] - pred) > 6e-6 / nco) {
 							/* which of the three is the odd one?  the one whose own neighbours agree with each other without it */
-							const size_t a = i >= 2 ? i - 2 : i - 1, b = std::min(T - 1, i + 2);
+							const size_t a = i >= 2 ? i - 2 : i - 1, b = std::min(G - 1, i + 2);
 							const double wa = (centre[i] - centre[a]) / (centre[b] - centre[a]);
 							const double pred2 = fbar[a] + (fbar[b] - fbar[a]) * wa;
 							if (std::fabs(pred - pred2) < std::fabs(fbar[i] - pred2)) fixed[i] = pred;
@@ -1126,51 +1183,47 @@ struct Stitcher {
 					}
 					fbar = fixed;
 				}
-				for (size_t i = 0; i < T; i++) {
-					const size_t lo = i ? i - 1 : 0, hi = std::min(T - 1, i + 1);
+				for (size_t i = 0; i < G; i++) {
+					const size_t lo = i ? i - 1 : 0, hi = std::min(G - 1, i + 1);
 					slope[i] = centre[hi] > centre[lo] ? (fbar[hi] - fbar[lo]) / (centre[hi] - centre[lo]) : 0.0;
 				}
 			}
-			mark("carrier lines");
-		} else {
-			for (size_t i = 0; i < T; i++) fbar[i] = seed.pll_freq;
 		}
+		/* the symbol-rate lines, unless they have to wait for the head's carrier word (OQPSK without a carrier curve) */
+		ge_cx.clear(); ge_th.clear(); ge_cq.clear(); ge_wc = 0;
+		ge_clock_deferred = params->oqpsk && (o.carrier_seed != 1 || ge_no_carrier);
+		if (!ge_clock_deferred) TRY(clock_lines(es, emem, 0.0f));
 		return MDEMOD_OK;
 	}
 
-	/* symbol-rate line around every tile (mdemod_estimate_clock); the pilot's hand-over target */
+	/* the carrier curve as the tiles read it: joined with the estimator thread; without a line anywhere, the head's own word */
+	int estimate_carriers()
+	{
+		if (est.t.joinable()) est.t.join();
+		TRY(est.rc);
+		mark("estimates joined");
+		if (o.carrier_seed != 1 || ge_no_carrier) {
+			centre.assign(2, 0.0); centre[1] = static_cast<double>(std::max<uint64_t>(n_samples, 1));
+			fbar.assign(2, static_cast<double>(seed.pll_freq)); slope.assign(2, 0.0);
+		}
+		/* the carrier's local slope where tile i is dead-reckoned: over [q_{i-1}, q_i] */
+		slope_tile.assign(T, 0.0);
+		for (size_t i = 0; i < T; i++) {
+			const double c = i == 0 ? static_cast<double>(P) : 0.5 * (static_cast<double>(i == 1 ? P : q[i - 1]) + static_cast<double>(q[i]));
+			slope_tile[i] = interp_at(centre, slope, std::min(std::max(c, centre.front()), centre.back()));
+		}
+		mark("carrier lines");
+		return MDEMOD_OK;
+	}
+
+	/* every tile's clock seed: a straight line through the clock estimates around it; the pilot's hand-over target */
 	int estimate_clocks()
 	{
-		/* (with carrier_seed = 0 the OQPSK line pair is looked for around the pilot's carrier word, with no chirp taken out) */
-		if (o.clock_seed == 0 && T > 1 && n_samples >= 4096) {
-			/* ---- symbol clock of every tile (a pass moves the clock with the carrier: 20 ppm and more between the pilot and the far
-			   end; the loop's integrator needs 8 000 symbols per e-fold to make that up).  The clock is smooth, so its windows are
-			   the estimator's longest (2^18 samples: 5e-8 of the rate), side by side over the tiled part, whatever the tile length;
-			   every tile reads a straight line through the estimates around it. ---- */
-			uint32_t wc = 4096;
-			while (wc * 2 <= std::min<uint64_t>(n_samples, 1u << 18)) wc *= 2;
-			const uint64_t first = std::min<uint64_t>(s0[1], n_samples - wc);
-			std::vector<uint64_t> cst;
-			for (uint64_t a = first; ; a += wc) {
-				if (a + wc >= n_samples) { cst.push_back(n_samples - wc); break; }
-				cst.push_back(a);
-			}
-			const size_t Tc = cst.size();
-			std::vector<float> cf(Tc), cc(Tc);
-			std::vector<double> cx(Tc);
-			for (size_t j = 0; j < Tc; j++) {
-				cx[j] = static_cast<double>(cst[j]) + 0.5 * wc;
-				cf[j] = static_cast<float>(interp_at(centre, fbar, std::min(std::max(cx[j], centre.front()), centre.back())));     /* OQPSK: where its two lines are */
-				cc[j] = static_cast<float>(interp_at(centre, slope, std::min(std::max(cx[j], centre.front()), centre.back())));
-			}
-			uint64_t *d_cst; float *d_cf, *d_cc, *d_tfq, *d_cq;
-			TRY(upload(mem, cst, &d_cst, st)); TRY(upload(mem, cf, &d_cf, st)); TRY(upload(mem, cc, &d_cc, st));
-			TRY(mem.alloc(&d_tfq, Tc)); TRY(mem.alloc(&d_cq, Tc));
-			TRY(mdemod_estimate_clock(params, iq_dev, n_samples, d_cst, d_cf, d_cc, static_cast<uint32_t>(Tc), wc, d_tfq, d_cq, st));
-			std::vector<float> th(Tc), cq(Tc);
-			HTRY(hipMemcpyAsync(th.data(), d_tfq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
-			HTRY(hipMemcpyAsync(cq.data(), d_cq, Tc * sizeof(float), hipMemcpyDeviceToHost, st));
-			HTRY(hipStreamSynchronize(st));
+		tclk.assign(T, static_cast<double>(seed.t_freq));   /* symbol clock seeds, rad per interpolated step */
+		if (ge_clock_deferred && T > 1) TRY(clock_lines(st, mem, seed.pll_freq));
+		if (o.clock_seed == 0 && T > 1 && ge_wc) {
+			const std::vector<double> &cx = ge_cx; const std::vector<float> &th = ge_th, &cq = ge_cq;
+			const size_t Tc = cx.size(); const uint32_t wc = ge_wc;
 			size_t lo = 0, hi = 0, weak = 0;
 			const double span = 2.5 * wc;                            /* five windows: the clock moves by < 1e-6 of the rate per second */
 			for (size_t i = 0; i < T; i++) {
@@ -1197,10 +1250,10 @@ struct Stitcher {
 		   integrates beta * e, the phase term alpha * e does the tracking), and right after the pilot's hand-over the serial run is
 		   still converging with the same time constant.  A tile settles for less than tau, so it is seeded with the frequency the
 		   SERIAL loop has at that point, not with the carrier: estimate - lag + what is left of the pilot's own offset. */
-		f_pilot_target = f_at(static_cast<double>(P)) - (T > 1 ? slope[0] * osf / nco * tau_pll : 0.0);
+		f_pilot_target = f_at(static_cast<double>(P)) - (T > 1 ? slope_tile[0] * osf / nco * tau_pll : 0.0);
 		/* a lock the reference declares far from the carrier (its OQPSK loop does on about half of all recordings with an offset, and
 		   never leaves it) is reported: the tiles demodulate the signal, the reference from there on does not */
-		if (o.carrier_seed == 1 && T > 1 && seed.pll_locked && rep->weak_carrier_tiles < T / 2 &&
+		if (o.carrier_seed == 1 && T > 1 && seed.pll_locked && !ge_no_carrier && rep->weak_carrier_tiles < centre.size() / 2 &&
 		    std::fabs(static_cast<double>(seed.pll_freq) - f_pilot_target) > 2 * kPi * 100.0 / (symrate * nco)) rep->pilot_locked = 2;
 		return MDEMOD_OK;
 	}
@@ -1408,7 +1461,7 @@ struct Stitcher {
 				for (size_t i = 1; i < T; i++)
 					if (rot[i] || weak[i] || shift[i] || run[i] != 1 || o.debug >= 2)
 						fprintf(stderr, "[recording]   seam %zu: rot %d weak %d shift %d C %d run %d R %d cnt_pre %u cnt1 %u locked %d f0 %.6f q %.1f\n", i, rot[i], weak[i], shift[i], C[i], (int)run[i], R[i],
-						        cnt_pre[i], cnt1[i], status_body.size() > i ? status_body[i].locked : -1, fbar[i], 0.0);
+						        cnt_pre[i], cnt1[i], status_body.size() > i ? status_body[i].locked : -1, f_at(static_cast<double>(E[i])), 0.0);
 			}
 			if (round == 0) {
 				for (size_t i = 1; i < T; i++) rep->frame_misses += rot[i] ? 1 : 0;
@@ -1597,6 +1650,8 @@ struct Stitcher {
 
 	int run_all()
 	{
+		TRY(prepare());
+		est.t = std::thread([this]() { est.rc = estimate_grid(); });        /* joined by estimate_carriers, or by ~EstThread on an early return */
 		TRY(run_head());
 		TRY(plan_tiles());
 		if (T == 0) return MDEMOD_OK;                        /* the head was the whole recording */
