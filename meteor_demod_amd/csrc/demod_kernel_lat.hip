@@ -62,9 +62,6 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 	typedef LFmt<FMT> F;
 	typedef typename F::sample_t sample_t;
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	/* a stream per wave is a serial chain: whatever else shares its SIMD (the stitcher's estimators run next to the serial head)
-	   issues behind it */
-	__builtin_amdgcn_s_setprio(3);
 	const DemodConsts &C = L.c;
 	const int lane = threadIdx.x;
 	const uint32_t stream = blockIdx.x;
