@@ -1651,7 +1651,11 @@ struct Stitcher {
 	int run_all()
 	{
 		TRY(prepare());
-		est.t = std::thread([this]() { est.rc = estimate_grid(); });        /* joined by estimate_carriers, or by ~EstThread on an early return */
+		try {
+			est.t = std::thread([this]() { est.rc = estimate_grid(); });    /* joined by estimate_carriers, or by ~EstThread on an early return */
+		} catch (...) {
+			est.rc = estimate_grid();                                       /* no thread to be had: before the head, then */
+		}
 		TRY(run_head());
 		TRY(plan_tiles());
 		if (T == 0) return MDEMOD_OK;                        /* the head was the whole recording */
