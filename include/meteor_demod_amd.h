@@ -228,8 +228,10 @@ int  mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs,
 /* ONE recording on many lanes.  The reference runs a recording as one serial recurrence (main.c:303-316);
  * here only its head runs serially (the "pilot": from the reference's power-on state until the carrier loop has locked and
  * settled - those symbols ARE the reference's symbols, lock gate included), the rest as tiles, one lane each:
- *   acquire   every tile starts (acquire + frame + settle) samples early from the pilot's loop state, its own carrier
- *             estimate (4th-power spectrum, de-chirped) and gain estimate;
+ *   estimates the carrier (4th-power spectrum, de-chirped) and the symbol clock (symbol-rate line) along the whole recording, on
+ *             windows side by side: taken on a host thread and a stream of the call's own while the head runs;
+ *   acquire   every tile starts (acquire + frame + settle) samples early from the pilot's loop state, the carrier and clock
+ *             read off those curves at its position and its gain estimate;
  *   re-seed   after `acquire_samples` the two loop integrators (pll.c:115 freq, timing.c:84 freq) are put back on their
  *             seeds: the acquisition transient kicks them and they need 8-16 k symbols to come back on their own;
  *   frame     a Costas loop locks on one of four rotations.  After `frame_samples` more the rotation of every tile relative
@@ -243,7 +245,8 @@ int  mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs,
  *             output, odd quarter turns by one more settle + body pass from the saved post-acquisition state) and the
  *             one-symbol duplicate / gap at the seam.
  * Tile 0 is the exact continuation of the pilot.  iq_dev: n_samples IQ samples in the format of params->bps, in device
- * memory; soft_dev: device buffer for soft_cap_symbols int8 pairs.  params->n_streams is ignored.  Synchronous on hip_stream. */
+ * memory; soft_dev: device buffer for soft_cap_symbols int8 pairs.  params->n_streams is ignored.  Synchronous on hip_stream (the
+ * estimates run on one more stream and host thread, both gone when the call returns). */
 typedef struct {
 	uint32_t tile_samples;          /* body samples per tile; 0 = automatic: 8 192 ... 41 072 symbols worth: ~1000 tiles (one per
 	                                   wave: latency kernel) while that fits, else as short as keeps them within 131 072 lanes */
@@ -280,7 +283,7 @@ typedef struct {
 	                                   max_pilot_samples (the head does not hand over on such a lock while it has patience left: the
 	                                   reference's OQPSK loop and any float recording's first seconds produce them).  From there on the
 	                                   reference's output is not a demodulation of this signal, the tiles' is: the two cannot agree */
-	uint32_t weak_carrier_tiles;    /* carrier_seed=1: tiles without a clear spectral line, seeded from their neighbours */
+	uint32_t weak_carrier_tiles;    /* carrier_seed=1: carrier windows (~20 000 symbols each, side by side) without a clear spectral line: the curve is interpolated across them */
 	double   pilot_seconds;         /* wall time of the serial head                          */
 	double   tiles_seconds;         /* wall time of everything after it                      */
 	uint32_t frame_misses;          /* seams where dead reckoning put the tile in another rotation than the correlation found */
