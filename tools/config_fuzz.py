@@ -1,6 +1,6 @@
 """Soak test: random -f/-O/-r/-s/-b/-d/-m/--bps combinations (every kernel geometry gets selected), several streams,
 chained ragged blocks, GPU vs oracle byte for byte incl. final loop state.  Usage: config_fuzz.py [n_configs] [seed]"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np, torch
 import oracle_py as O
@@ -24,6 +24,9 @@ for ci in range(n_cfg):
                       pll_bw=float(rng.choice([0.01, 0.5, 1.0, 2.0, 5.0, 100.0, 3000.0])),
                       freq_max=float(rng.choice([-1.0, 0.0, 0.001, 0.05, 0.3, 1.5])),
                       bps=int(rng.choice([8, 16, 16, 16, 32])))
+    if os.environ.get("FUZZ_HYB"):          # float input with 66..129 taps only: the v3 hybrid window (VGPRs + AccVGPRs)
+        cfg = DemodConfig(samplerate=cfg.samplerate, symrate=cfg.symrate, oqpsk=cfg.oqpsk, rrc_order=int(rng.choice([33, 40, 48, 63, 64])),
+                          interp_factor=int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 16])), pll_bw=cfg.pll_bw, freq_max=cfg.freq_max, bps=32)
     # the reference divides 0/0 when an RRC tap falls on t = 1/(4*alpha): undefined there, skip
     if cfg.samplerate * (2 if cfg.oqpsk else 1) < cfg.symrate * 0.25:
         continue            # less than a quarter of a sample per firing: refused by mdemod_create (untested region)
@@ -33,7 +36,7 @@ for ci in range(n_cfg):
             continue
     except Exception:
         continue
-    ns = int(rng.integers(1, 70))
+    ns = int(rng.integers(1, 70)) if not os.environ.get("FUZZ_HYB") else int(rng.choice([1, 63, 64, 65, 255, 256, 257, 300, 513]))
     blocks = [int(rng.choice([0, 1, 7, 64, 129, 1000, 4097, 9000])) for _ in range(int(rng.integers(1, 4)))]
     blocks.append(int(rng.integers(2000, 12000)))
     total = sum(blocks)
