@@ -641,7 +641,9 @@ main(int argc, char **argv)
 	p.bps = bps; p.device = device; p.n_streams = (uint32_t)n_files;
 	/* ---- one worker per GPU: file i on GPU i mod G (streams shard, nothing crosses GPUs) ---- */
 	if (n_dev == 0) {
-		int have = mdemod_device_count();
+		/* (one file: one GPU, and no question to the HIP runtime before its input is being read - the runtime takes 50-100 ms to
+		   come up, which --tiled hides behind the file read) */
+		const int have = n_files < 2 ? 1 : mdemod_device_count();
 		if (n_files < 2 || have < 2) { devs[0] = device; n_dev = 1; }
 		else for (n_dev = 0; n_dev < have && n_dev < MAX_DEVICES; n_dev++) devs[n_dev] = n_dev;
 	}
