@@ -134,9 +134,10 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	const bool mid_ok = wide_ok && c.taps <= 65;
 	/* far: the short filter at 2 MS/s-class rates: up to 30 samples per firing, two 16-slot slides per iteration */
 	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= 30.0 && p.bps != 32;
-	/* hybrid: float input with 66..129 taps (a float window of 160 slots is 320 registers: the older half in VGPRs, the newer half
-	 * in AccVGPRs, one wave per SIMD: demod_kernel_rot.hip, WinH) */
-	const bool hyb_ok = generation >= 2 && !std_ok && per_firing <= 15.0 && p.bps == 32 && c.taps > 65 && c.taps <= 129;
+	/* hybrid: float input outside the std geometry, up to 129 taps at up to 15 samples per firing (a float window of 160 slots is 320
+	 * registers: the older 80 slots in VGPRs, the newer ones in AccVGPRs, one wave per SIMD: demod_kernel_rot.hip, WinH; with up to 65
+	 * taps - rw_mid as well - the window has 96 slots) */
+	const bool hyb_ok = generation >= 2 && !std_ok && per_firing <= 15.0 && p.bps == 32 && c.taps <= 129;
 	const bool allow_rw = generation >= 1;
 	out.rw_hyb = hyb_ok;
 	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok);
@@ -167,7 +168,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		 * copy (bank, k)[i] = P[i + k].  A lane at alignment a reads P[(AMAX - a) + s] for slot s, i.e. copy ((AMAX - a) & 3) at the
 		 * 16-byte aligned index ((AMAX - a) & ~3) + s: every group of four taps is one ds_read_b128.  The FIR's prefetch runs up
 		 * to six groups (24 floats) past the last tap it uses: rows carry that much padding. */
-		const int kTaps = (out.rw_wide || out.rw_hyb) ? 129 : 65;
+		const int kTaps = (out.rw_wide || (out.rw_hyb && !out.rw_mid)) ? 129 : 65;
 		const int NW = out.rw_mid ? MDEMOD_RW_MID_NW : (out.rw_far ? MDEMOD_RW_FAR_NW : MDEMOD_RW_WIDE_NW), AMAX = NW - kTaps;
 		const int LP = kTaps + 2 * AMAX;
 		c.hpad = kTaps - 1;

@@ -167,27 +167,29 @@ AB = 96          # first AccVGPR of the window: a[96:255] (hipcc hands out AccVG
                  # that compiler-generated code stays below this, as it does for the VGPRs)
 
 
-def fir_acc():
-    """filter.c:46-65 continued over the AccVGPR half: logical chunk c of rotation r is physical chunk (c + r) mod 10.  Per tap two
+def fir_acc(NA, tag):
+    """filter.c:46-65 continued over the AccVGPR part (NA chunks): logical chunk c of rotation r is physical chunk (c + r) mod NA.  Per tap two
     v_accvgpr_read_b32 into a VGPR pair, then the same v_pk_mul_f32 + v_pk_add_f32 as the VGPR half.  %[addr] points at the
-    coefficient of the half's first slot; the sum leaves after logical chunk %[last] (6..9: the chunk of the wave's last tap)."""
-    NH = 2 * NCH
+    coefficient of the part's first slot; the sum leaves after logical chunk %[last] (the chunk of the wave's last tap; the first
+    `lo` chunks are inside every lane's taps and carry no test)."""
+    NH = 2 * NA
+    lo = 6 if NA == NCH else 0
     # v80..v91: three coefficient buffers of four (a half-chunk each, loaded two half-chunks ahead); v[92:93], v[94:95]: the two
     # pairs a tap's samples are read into
     def load(h):
         b = CB + 4 * (h % 3)
         return "ds_read_b128 v[%d:%d], %%[addr] offset:%d" % (b, b + 3, 16 * h)
     L = [load(h) for h in range(2)]
-    L += jump("fira", NCH)
-    for r in range(NCH):
-        L += [".Lfira_%d_%%=:" % r]
+    L += jump(tag, NA)
+    for r in range(NA):
+        L += [".L%s_%d_%%=:" % (tag, r)]
         for h in range(NH):
             c = h // 2
             if h + 2 < NH:
                 L += [load(h + 2)]
             L += ["s_waitcnt lgkmcnt(%d)" % min(2, NH - 1 - h)]
             hb = CB + 4 * (h % 3)
-            aq = AB + 16 * ((c + r) % NCH) + 8 * (h & 1)
+            aq = AB + 16 * ((c + r) % NA) + 8 * (h & 1)
             def rd(j):
                 t = CB + 12 + 2 * (j & 1)
                 return ["v_accvgpr_read_b32 v%d, a%d" % (t, aq + 2 * j), "v_accvgpr_read_b32 v%d, a%d" % (t + 1, aq + 2 * j + 1)]
@@ -199,34 +201,36 @@ def fir_acc():
                 return ["v_pk_add_f32 %%[acc], %%[acc], v[%d:%d]" % (t, t + 1)]
             # oldest tap first; a tap's product is not the instruction before its sum, a pair is read while the other one is summed
             L += rd(0) + rd(1) + mul(0) + mul(1) + add(0) + rd(2) + add(1) + rd(3) + mul(2) + mul(3) + add(2) + add(3)
-            if h % 2 == 1 and 6 <= c < NCH - 1:
-                L += ["s_cmp_eq_u32 %%[last], %d" % c, "s_cbranch_scc1 .Lfira_end_%="]
-        L += ["s_branch .Lfira_end_%="]
-    L += [".Lfira_end_%=:", "s_waitcnt lgkmcnt(0)"]
+            if h % 2 == 1 and lo <= c < NA - 1:
+                L += ["s_cmp_eq_u32 %%[last], %d" % c, "s_cbranch_scc1 .L%s_end_%%=" % tag]
+        L += ["s_branch .L%s_end_%%=" % tag]
+    L += [".L%s_end_%%=:" % tag, "s_waitcnt lgkmcnt(0)"]
     return L
 
 
-def migrate():
-    """The slide of the hybrid window at rotation %[rot]: AccVGPR chunk q (the oldest of the newer half) moves into VGPR chunk q
-    (whose samples leave the window), the 8 new samples (16 floats f0..f15) take its place."""
-    L = jump("mig", NCH)
+def migrate(NA, tag):
+    """The slide of the hybrid window at rotation %[rot] of the VGPR ring: AccVGPR chunk q mod NA (the oldest of the newer part; NA
+    divides the ten VGPR chunks, so the two rings stay in step) moves into VGPR chunk q (whose samples leave the window), the 8 new
+    samples (16 floats f0..f15) take its place."""
+    assert NCH % NA == 0
+    L = jump(tag, NCH)
     for r in range(NCH):
-        L += [".Lmig_%d_%%=:" % r]
-        L += ["v_accvgpr_read_b32 v%d, a%d" % (WB + 16 * r + k, AB + 16 * r + k) for k in range(16)]
-        L += ["v_accvgpr_write_b32 a%d, %%[f%d]" % (AB + 16 * r + k, k) for k in range(16)]
-        L += ["s_branch .Lmig_end_%="]
-    L += [".Lmig_end_%=:"]
+        L += [".L%s_%d_%%=:" % (tag, r)]
+        L += ["v_accvgpr_read_b32 v%d, a%d" % (WB + 16 * r + k, AB + 16 * (r % NA) + k) for k in range(16)]
+        L += ["v_accvgpr_write_b32 a%d, %%[f%d]" % (AB + 16 * (r % NA) + k, k) for k in range(16)]
+        L += ["s_branch .L%s_end_%%=" % tag]
+    L += [".L%s_end_%%=:" % tag]
     return L
 
 
-def put_acc():
+def put_acc(NA, tag):
     """16 ready floats into AccVGPR chunk %[rot] (history and the first samples at kernel start)."""
-    L = jump("puta", NCH)
-    for r in range(NCH):
-        L += [".Lputa_%d_%%=:" % r]
+    L = jump(tag, NA)
+    for r in range(NA):
+        L += [".L%s_%d_%%=:" % (tag, r)]
         L += ["v_accvgpr_write_b32 a%d, %%[f%d]" % (AB + 16 * r + k, k) for k in range(16)]
-        L += ["s_branch .Lputa_end_%="]
-    L += [".Lputa_end_%=:"]
+        L += ["s_branch .L%s_end_%%=" % tag]
+    L += [".L%s_end_%%=:" % tag]
     return L
 
 
@@ -244,9 +248,11 @@ def main():
     out.append("#define ROTWIN_FIR_ASM \\\n" + q(fir()).replace("\n", " \\\n"))
     for kind in ("s16", "u8", "f32"):
         out.append("#define ROTWIN_PUT_%s_ASM \\\n" % kind.upper() + q(put(kind)).replace("\n", " \\\n"))
-    out.append("#define ROTWIN_FIR_ACC_ASM \\\n" + q(fir_acc()).replace("\n", " \\\n"))
-    out.append("#define ROTWIN_MIGRATE_ASM \\\n" + q(migrate()).replace("\n", " \\\n"))
-    out.append("#define ROTWIN_PUT_ACC_ASM \\\n" + q(put_acc()).replace("\n", " \\\n"))
+    # ten AccVGPR chunks: 160-slot window (129 taps); two: 96-slot window (65 taps at up to 15 samples per firing)
+    for NA, sfx in ((NCH, ""), (2, "2")):
+        out.append("#define ROTWIN_FIR_ACC%s_ASM \\\n" % sfx + q(fir_acc(NA, "fira" + sfx)).replace("\n", " \\\n"))
+        out.append("#define ROTWIN_MIGRATE%s_ASM \\\n" % sfx + q(migrate(NA, "mig" + sfx)).replace("\n", " \\\n"))
+        out.append("#define ROTWIN_PUT_ACC%s_ASM \\\n" % sfx + q(put_acc(NA, "puta" + sfx)).replace("\n", " \\\n"))
     out.append("#define ROTWIN_ACC_CLOBBERS " + ", ".join('"a%d"' % i for i in range(AB, AB + 16 * NCH)))
     # clobber lists
     out.append("#define ROTWIN_COEF_CLOBBERS " + ", ".join('"v%d"' % i for i in range(TB if PK in (2, 3) else CB, WB)))

@@ -225,7 +225,7 @@ WIDE_CFGS = {
     "defaults_1024k_oqpsk_u8": DemodConfig(samplerate=1024000, oqpsk=True, bps=8),
     "defaults_2048k": DemodConfig(samplerate=2048000),                                    # 28.4 samples per symbol: far geometry
     "far_edge_u8": DemodConfig(samplerate=2150000, rrc_order=20, interp_factor=3, bps=8), # 29.9 samples per symbol
-    "defaults_1024k_f32": DemodConfig(samplerate=1024000, bps=32),                        # float input: mid geometry with a float-pair window
+    "defaults_1024k_f32": DemodConfig(samplerate=1024000, bps=32),                        # float input: hybrid window (v3), float-pair window (v2)
     "oqpsk_640k_f32": DemodConfig(samplerate=640000, symrate=80000, oqpsk=True, rrc_order=24, interp_factor=4, bps=32),
     "c4_f32": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),      # float input, 129 taps: hybrid window (VGPRs + AccVGPRs)
     "oqpsk80k_1M_f32": DemodConfig(samplerate=1000000, symrate=80000, oqpsk=True, rrc_order=64, interp_factor=8, bps=32),
@@ -256,7 +256,9 @@ def test_wide_window_batch_chained(name, generation, gpu_device, monkeypatch):
     with Demodulator(cfg, ns) as d:
         want_name = ("v3 rotating packed window, " if generation == "v3" and cfg.bps != 32 else "v2 register window, ") + WIDE_KERNEL[name]
         if WIDE_KERNEL[name] == "hybrid":
-            want_name = "v3 hybrid window" if generation == "v3" else "v1 LDS ring"
+            want_name = "v3 hybrid window: float input, 129 taps" if generation == "v3" else "v1 LDS ring"
+        elif cfg.bps == 32 and generation == "v3":
+            want_name = "v3 hybrid window, mid"           # float input with up to 65 taps: the 96-slot window
         assert want_name in d.kernel_name, d.kernel_name
         parts = [[] for _ in range(ns)]
         pos = 0

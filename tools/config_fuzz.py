@@ -25,7 +25,7 @@ for ci in range(n_cfg):
                       freq_max=float(rng.choice([-1.0, 0.0, 0.001, 0.05, 0.3, 1.5])),
                       bps=int(rng.choice([8, 16, 16, 16, 32])))
     if os.environ.get("FUZZ_HYB"):          # float input with 66..129 taps only: the v3 hybrid window (VGPRs + AccVGPRs)
-        cfg = DemodConfig(samplerate=cfg.samplerate, symrate=cfg.symrate, oqpsk=cfg.oqpsk, rrc_order=int(rng.choice([33, 40, 48, 63, 64])),
+        cfg = DemodConfig(samplerate=cfg.samplerate, symrate=cfg.symrate, oqpsk=cfg.oqpsk, rrc_order=int(rng.choice([8, 16, 24, 32, 33, 40, 48, 63, 64])),
                           interp_factor=int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 16])), pll_bw=cfg.pll_bw, freq_max=cfg.freq_max, bps=32)
     # the reference divides 0/0 when an RRC tap falls on t = 1/(4*alpha): undefined there, skip
     if cfg.samplerate * (2 if cfg.oqpsk else 1) < cfg.symrate * 0.25:
