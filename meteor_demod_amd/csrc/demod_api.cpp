@@ -633,7 +633,7 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (!ctx) return "";
 	if (wants_latency_kernel(ctx)) return "demod_kernel_lat (one stream per wave: FIR farm + serial scalar stage)";
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
-	if (ctx->tab.rw_hyb) return ctx->tab.rw_mid ? "demod_kernel_roth (v3 hybrid window, mid: float input, 65 taps at up to 15 samples per firing, 80 slots in VGPRs + 16 in AccVGPRs)"
+	if (ctx->tab.rw_hyb) return ctx->tab.rw_mid ? "demod_kernel_roth (v3 hybrid window, mid: float input, 65 taps at up to 30 samples per firing, 80 slots in VGPRs + 16 in AccVGPRs)"
 	                                            : "demod_kernel_roth (v3 hybrid window: float input, 129 taps, 80 slots in VGPRs + 80 in AccVGPRs)";
 	if (ctx->tab.rw_compact4) return ctx->tab.rw_wide ? "demod_kernel_rotp (v3 rotating packed window, wide: 129 taps)"
 	                                 : (ctx->tab.rw_mid ? "demod_kernel_rotp (v3 rotating packed window, mid: 65 taps at up to 15 samples per firing)"

@@ -134,14 +134,14 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	const bool mid_ok = wide_ok && c.taps <= 65;
 	/* far: the short filter at 2 MS/s-class rates: up to 30 samples per firing, two 16-slot slides per iteration */
 	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= 30.0 && p.bps != 32;
-	/* hybrid: float input outside the std geometry, up to 129 taps at up to 15 samples per firing (a float window of 160 slots is 320
+	/* hybrid: float input outside the std geometry, up to 129 taps at up to 15 samples per firing or up to 65 taps at up to 30 (a float window of 160 slots is 320
 	 * registers: the older 80 slots in VGPRs, the newer ones in AccVGPRs, one wave per SIMD: demod_kernel_rot.hip, WinH; with up to 65
 	 * taps - rw_mid as well - the window has 96 slots) */
-	const bool hyb_ok = generation >= 2 && !std_ok && per_firing <= 15.0 && p.bps == 32 && c.taps <= 129;
+	const bool hyb_ok = generation >= 2 && !std_ok && p.bps == 32 && ((per_firing <= 15.0 && c.taps <= 129) || (per_firing <= 30.0 && c.taps <= 65));
 	const bool allow_rw = generation >= 1;
 	out.rw_hyb = hyb_ok;
 	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok);
-	out.rw_mid = out.use_rw && !std_ok && mid_ok;
+	out.rw_mid = out.use_rw && !std_ok && (mid_ok || (hyb_ok && c.taps <= 65));
 	out.rw_far = out.use_rw && far_ok;
 	out.rw_wide = out.use_rw && !std_ok && !mid_ok && !far_ok && !hyb_ok;
 	c.chunk_granules = 2;

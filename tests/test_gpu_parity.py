@@ -231,11 +231,12 @@ WIDE_CFGS = {
     "oqpsk80k_1M_f32": DemodConfig(samplerate=1000000, symrate=80000, oqpsk=True, rrc_order=64, interp_factor=8, bps=32),
     "taps97_230k_f32": DemodConfig(samplerate=230000, rrc_order=48, interp_factor=5, bps=32),   # the long filter at the LRPT rate: 3.2 samples per firing
     "taps129_O12_f32": DemodConfig(samplerate=900000, rrc_order=64, interp_factor=12, bps=32),
+    "defaults_2048k_f32": DemodConfig(samplerate=2048000, bps=32),                          # 28.4 samples per symbol, float input
 }
 WIDE_KERNEL = {"c4_s16": "wide", "c4_u8": "wide", "oqpsk80k_1M": "wide", "taps97_os6": "wide", "edge_15_per_symbol": "wide",
                "taps65_slow_clock": "mid", "defaults_1024k": "mid", "defaults_1024k_oqpsk_u8": "mid", "defaults_2048k": "far",
                "far_edge_u8": "far", "defaults_1024k_f32": "mid", "oqpsk_640k_f32": "mid",
-               "c4_f32": "hybrid", "oqpsk80k_1M_f32": "hybrid", "taps97_230k_f32": "hybrid", "taps129_O12_f32": "hybrid"}
+               "c4_f32": "hybrid", "oqpsk80k_1M_f32": "hybrid", "taps97_230k_f32": "hybrid", "taps129_O12_f32": "hybrid", "defaults_2048k_f32": "far-f32"}
 
 
 @pytest.mark.parametrize("generation", ["v3", "v2"])
@@ -257,6 +258,8 @@ def test_wide_window_batch_chained(name, generation, gpu_device, monkeypatch):
         want_name = ("v3 rotating packed window, " if generation == "v3" and cfg.bps != 32 else "v2 register window, ") + WIDE_KERNEL[name]
         if WIDE_KERNEL[name] == "hybrid":
             want_name = "v3 hybrid window: float input, 129 taps" if generation == "v3" else "v1 LDS ring"
+        elif WIDE_KERNEL[name] == "far-f32":
+            want_name = "v3 hybrid window, mid" if generation == "v3" else "v1 LDS ring"
         elif cfg.bps == 32 and generation == "v3":
             want_name = "v3 hybrid window, mid"           # float input with up to 65 taps: the 96-slot window
         assert want_name in d.kernel_name, d.kernel_name
