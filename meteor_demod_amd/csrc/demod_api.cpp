@@ -635,9 +635,9 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
 	if (ctx->tab.rw_hyb) return ctx->tab.rw_mid ? "demod_kernel_roth (v3 hybrid window, mid: float input, 65 taps at up to 30 samples per firing, 80 slots in VGPRs + 16 in AccVGPRs)"
 	                                            : "demod_kernel_roth (v3 hybrid window: float input, 129 taps, 80 slots in VGPRs + 80 in AccVGPRs)";
-	if (ctx->tab.rw_compact4) return ctx->tab.rw_wide ? "demod_kernel_rotp (v3 rotating packed window, wide: 129 taps)"
+	if (ctx->tab.rw_compact4) return ctx->tab.rw_wide ? "demod_kernel_rotp (v3 rotating packed window, wide: 129 taps at up to 30 samples per firing)"
 	                                 : (ctx->tab.rw_mid ? "demod_kernel_rotp (v3 rotating packed window, mid: 65 taps at up to 15 samples per firing)"
-	                                                    : "demod_kernel_rotp (v3 rotating packed window, far: 65 taps at up to 30 samples per firing)");
+	                                                    : "demod_kernel_rotp (v3 rotating packed window, far: 65 taps at up to 46 samples per firing)");
 	if (ctx->tab.rw_wide) return "demod_kernel_rw (v2 register window, wide: 129 taps, packed)";
 	if (ctx->tab.rw_far) return "demod_kernel_rw (v2 register window, far: 65 taps at up to 30 samples per firing, packed)";
 	if (ctx->tab.rw_mid) return ctx->params.bps == 32 ? "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, float pairs)"

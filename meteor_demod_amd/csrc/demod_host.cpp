@@ -132,15 +132,18 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	/* mid: the short filter at a high sample rate (e.g. the default -f 32 at 1.024 MS/s): same lane spread as wide, but
 	 * a 96-slot window instead of 160 */
 	const bool mid_ok = wide_ok && c.taps <= 65;
-	/* far: the short filter at 2 MS/s-class rates: up to 30 samples per firing, two 16-slot slides per iteration */
-	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= 30.0 && p.bps != 32;
+	/* far: the short filter at 2-3 MS/s-class rates: up to 30 (v3: 46) samples per firing, two 16-slot slides per iteration */
+	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= (generation >= 2 ? 46.0 : 30.0) && p.bps != 32;   /* (v3: 47 alignments, as many loop iterations per firing as it takes; v2's window moves twice per iteration at most) */
 	/* hybrid: float input outside the std geometry, up to 129 taps at up to 15 samples per firing or up to 65 taps at up to 30 (a float window of 160 slots is 320
 	 * registers: the older 80 slots in VGPRs, the newer ones in AccVGPRs, one wave per SIMD: demod_kernel_rot.hip, WinH; with up to 65
 	 * taps - rw_mid as well - the window has 96 slots) */
-	const bool hyb_ok = generation >= 2 && !std_ok && p.bps == 32 && ((per_firing <= 15.0 && c.taps <= 129) || (per_firing <= 30.0 && c.taps <= 65));
+	const bool hyb_ok = generation >= 2 && !std_ok && p.bps == 32 && per_firing <= 30.0 && c.taps <= 129;
+	/* the long filter at 15..30 samples per firing (s16 / u8): the wide window has the 31 alignments for it and slides once per
+	 * loop iteration, so such a firing takes two iterations */
+	const bool wide_far_ok = generation >= 2 && !std_ok && !wide_ok && !far_ok && per_firing <= 30.0 && c.taps <= 129 && p.bps != 32;
 	const bool allow_rw = generation >= 1;
 	out.rw_hyb = hyb_ok;
-	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok);
+	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok || wide_far_ok);
 	out.rw_mid = out.use_rw && !std_ok && (mid_ok || (hyb_ok && c.taps <= 65));
 	out.rw_far = out.use_rw && far_ok;
 	out.rw_wide = out.use_rw && !std_ok && !mid_ok && !far_ok && !hyb_ok;

@@ -232,17 +232,22 @@ WIDE_CFGS = {
     "taps97_230k_f32": DemodConfig(samplerate=230000, rrc_order=48, interp_factor=5, bps=32),   # the long filter at the LRPT rate: 3.2 samples per firing
     "taps129_O12_f32": DemodConfig(samplerate=900000, rrc_order=64, interp_factor=12, bps=32),
     "defaults_2048k_f32": DemodConfig(samplerate=2048000, bps=32),                          # 28.4 samples per symbol, float input
+    "taps129_2048k_f32": DemodConfig(samplerate=2048000, rrc_order=64, interp_factor=4, bps=32),   # ... with the long filter
+    "taps129_2048k": DemodConfig(samplerate=2048000, rrc_order=64, interp_factor=4),              # the long filter at 28.4 samples per symbol, s16
+    "taps97_1800k_u8": DemodConfig(samplerate=1800000, rrc_order=48, interp_factor=3, bps=8),
+    "defaults_3200k": DemodConfig(samplerate=3200000),                                            # RTL-SDR's top rate: 44.4 samples per symbol
+    "defaults_2400k_u8": DemodConfig(samplerate=2400000, bps=8),
 }
 WIDE_KERNEL = {"c4_s16": "wide", "c4_u8": "wide", "oqpsk80k_1M": "wide", "taps97_os6": "wide", "edge_15_per_symbol": "wide",
                "taps65_slow_clock": "mid", "defaults_1024k": "mid", "defaults_1024k_oqpsk_u8": "mid", "defaults_2048k": "far",
                "far_edge_u8": "far", "defaults_1024k_f32": "mid", "oqpsk_640k_f32": "mid",
-               "c4_f32": "hybrid", "oqpsk80k_1M_f32": "hybrid", "taps97_230k_f32": "hybrid", "taps129_O12_f32": "hybrid", "defaults_2048k_f32": "far-f32"}
+               "c4_f32": "hybrid", "oqpsk80k_1M_f32": "hybrid", "taps97_230k_f32": "hybrid", "taps129_O12_f32": "hybrid", "defaults_2048k_f32": "far-f32", "taps129_2048k_f32": "hybrid", "taps129_2048k": "wide-far", "taps97_1800k_u8": "wide-far", "defaults_3200k": "far-far", "defaults_2400k_u8": "far-far"}
 
 
 @pytest.mark.parametrize("generation", ["v3", "v2"])
 @pytest.mark.parametrize("name", list(WIDE_CFGS))
 def test_wide_window_batch_chained(name, generation, gpu_device, monkeypatch):
-    """The wide / mid / far geometries (up to 129 taps, up to 30 samples per firing) on the v3 rotating packed window and on
+    """The wide / mid / far / hybrid geometries (up to 129 taps at up to 30 samples per firing, up to 65 at up to 46) on the v3 rotating packed window and on
     the v2 moving one (packed window, compact coefficient table): 70 distinct streams (more than one wave, every symbol
     phase) x chained blocks, byte-identical to the oracle, loop state included."""
     torch = _torch()
@@ -258,6 +263,10 @@ def test_wide_window_batch_chained(name, generation, gpu_device, monkeypatch):
         want_name = ("v3 rotating packed window, " if generation == "v3" and cfg.bps != 32 else "v2 register window, ") + WIDE_KERNEL[name]
         if WIDE_KERNEL[name] == "hybrid":
             want_name = "v3 hybrid window: float input, 129 taps" if generation == "v3" else "v1 LDS ring"
+        elif WIDE_KERNEL[name] == "wide-far":
+            want_name = "v3 rotating packed window, wide" if generation == "v3" else "v1 LDS ring"
+        elif WIDE_KERNEL[name] == "far-far":
+            want_name = "v3 rotating packed window, far" if generation == "v3" else "v1 LDS ring"
         elif WIDE_KERNEL[name] == "far-f32":
             want_name = "v3 hybrid window, mid" if generation == "v3" else "v1 LDS ring"
         elif cfg.bps == 32 and generation == "v3":
