@@ -124,6 +124,21 @@ def test_float_recording_with_the_long_filter_on_the_hybrid_window(gpu_device):
     assert a["hard_decisions_equal"] >= 0.9999 and a["within_1lsb"] >= 0.995, a
 
 
+@pytest.mark.parametrize("cfg,rms,fmt", [(DemodConfig(samplerate=2048000, rrc_order=64, interp_factor=4), 500.0, 16),
+                                         (DemodConfig(samplerate=2048000, bps=32), 0.3, 32)], ids=["s16-129taps", "f32-65taps"])
+def test_recording_at_two_megasamples(cfg, rms, fmt, gpu_device):
+    """28.4 samples per symbol (twice what a window slides per loop iteration): head on the latency kernel, > 2 048 tiles on the wide
+    packed window (s16, 129 taps) / the 96-slot hybrid window (float input) - against the untiled serial oracle.  (Amplitudes at
+    which the reference's own AGC is stable at this rate: agc.c:13-25 overshoots through zero once |y| * 1e-4 reaches 1.)"""
+    st = synth.make_stream(1000, cfg.samplerate, cfg.symrate, f0_hz=600.0, clock_ppm=-3.5, rms=rms, fmt=fmt)
+    iq = synth.generate_device([st], 1 << 26)[0]
+    out, serial, rep, a = _run(cfg, iq, tile_samples=20480)
+    assert rep.n_tiles > 2048 and rep.pilot_locked == 1, rep.n_tiles
+    assert rep.weak_seams == 0 and rep.rotation_jumps == 0
+    assert a["len_stitched"] == a["len_serial"]
+    assert a["hard_decisions_equal"] >= 0.9999 and a["within_1lsb"] >= 0.997, a
+
+
 def test_long_recording_on_many_lanes_agrees_with_the_serial_reference(gpu_device):
     """16 M samples (70 s of signal) at -700 Hz (the reference sweeps up first: it needs 0.66 M symbols to lock)."""
     st = synth.make_stream(99, 230000, 72000, f0_hz=-700.0, clock_ppm=-20.0, esn0_db=12.0)
