@@ -143,6 +143,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	const bool wide_far_ok = generation >= 2 && !std_ok && !wide_ok && !far_ok && per_firing <= 30.0 && c.taps <= 129 && p.bps != 32;
 	const bool allow_rw = generation >= 1;
 	out.rw_hyb = hyb_ok;
+	out.rw_std_compact = false;
 	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok || wide_far_ok);
 	out.rw_mid = out.use_rw && !std_ok && (mid_ok || (hyb_ok && c.taps <= 65));
 	out.rw_far = out.use_rw && far_ok;
@@ -156,8 +157,28 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		c.ring_granules = 0;
 		c.ctab_row_floats = NW;
 		c.ctab_row_stride = NW + 4;                       /* 21 x 16 B: rows 16-byte aligned for ds_read_b128, odd => consecutive rows on distinct 16-byte slots */
-		out.ctab.assign(static_cast<size_t>(AL) * banks * c.ctab_row_stride, 0.0f);
 		const int lead = kTaps - c.taps;
+		/* sixteen rows per bank are 5.4 KB: past -O 18 (100 KB) the v3 kernel takes the compact4 layout of the other geometries instead
+		 * (four shifted copies of the padded taps per bank, 1.6 KB: demod_kernel_rot.hip, WinF<.., COMPACT>) - two more instructions
+		 * per firing for the row address, and -O 29 .. 80 stay off the v1 ring kernel */
+		out.rw_std_compact = generation >= 2 && static_cast<size_t>(AL) * banks * c.ctab_row_stride * sizeof(float) > 100 * 1024;
+		if (out.rw_std_compact) {
+			const int AMAX = NW - kTaps, LP = kTaps + 2 * AMAX;
+			c.ctab_row_floats = LP;
+			c.ctab_row_stride = (LP + 3) / 4 * 4;
+			if ((c.ctab_row_stride / 4) % 2 == 0) c.ctab_row_stride += 4;
+			out.ctab.assign(static_cast<size_t>(4) * banks * c.ctab_row_stride, 0.0f);
+			for (unsigned b = 0; b < banks; b++) {
+				std::vector<float> P(static_cast<size_t>(LP) + 4, 0.0f);
+				for (int k = 0; k < c.taps; k++) P[AMAX + lead + k] = out.rrc[b * taps + k];
+				for (int k = 0; k < 4; k++) {
+					float *row = &out.ctab[(static_cast<size_t>(b) * 4 + k) * c.ctab_row_stride];
+					for (int i = 0; i < LP; i++) row[i] = P[i + k];
+				}
+			}
+			return MDEMOD_OK;
+		}
+		out.ctab.assign(static_cast<size_t>(AL) * banks * c.ctab_row_stride, 0.0f);
 		for (int a = 0; a < AL; a++)
 			for (unsigned b = 0; b < banks; b++) {
 				float *row = &out.ctab[(static_cast<size_t>(a) * banks + b) * c.ctab_row_stride];

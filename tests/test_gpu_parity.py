@@ -674,8 +674,12 @@ def test_oversampling_factor_one(cfg, gpu_device):
 ], ids=["O28", "O29", "O32-f16", "O64", "O64-oqpsk-u8"])
 def test_large_oversampling_factors(cfg, gpu_device):
     """-O 29 and above: the per-alignment coefficient rows of the v2 std geometry exceed the 160 KB of LDS; mdemod_create
-    used to refuse these valid reference configurations instead of using the v1 kernel."""
+    used to refuse these valid reference configurations instead of using the v1 kernel.  The v3 kernel takes the
+    compact4 table from -O 19 on and keeps them."""
     _check_cfg_against_oracle(cfg)
+    from meteor_demod_amd import Demodulator as D
+    with D(cfg, 4096) as d:
+        assert "v3 rotating register window" in d.kernel_name, d.kernel_name
 
 
 def _check_cfg_against_oracle(cfg):
