@@ -29,6 +29,7 @@ struct mdemod_ctx {
 	float        *d_lut;
 	float        *d_rrc;       /* plain polyphase table [bank][taps] (filter.c:18-22) for the latency kernel */
 	int           hyb_block;   /* hybrid window (tab.rw_hyb): threads per block */
+	bool          v1_global_table;   /* v1 ring kernel with its coefficient table left in global memory (it does not fit the LDS) */
 	bool          use_rot;     /* std geometry on the v3 rotating-window kernel (demod_kernel_rot.hip) instead of v2 */
 	bool          lat_ok;      /* the latency kernel (one stream per wave) fits this configuration */
 	int           lat_ring, lat_span;
@@ -114,7 +115,7 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 		        ? mdemod_launch_demod_rw_wide(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream)
 		                         : mdemod_launch_demod_rw_std(L, ctx->params.bps, (ctx->params.reserved & MDEMOD_FLAG_V2_PACKED) ? 1 : 0, ctx->lds_bytes, stream));
 	else
-		HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->lds_bytes, stream));
+		HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->v1_global_table ? 1 : 0, ctx->lds_bytes, stream));
 	return MDEMOD_OK;
 }
 
@@ -243,7 +244,18 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	}
 	while (ctx->block_threads > 64 && lds_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
 	ctx->lds_bytes = lds_need(ctx->block_threads);
-	if (ctx->lds_bytes > 160 * 1024) { delete ctx; return MDEMOD_ERR_PARAM; }
+	ctx->v1_global_table = false;
+	if (ctx->lds_bytes > 160 * 1024) {
+		/* not even one wave's ring fits next to the table (-O 64 with 129 taps, ...): the v1 kernel reads its coefficients from
+		   global memory then - slow, but the reference takes such a configuration and so does this */
+		if (ctx->tab.use_rw) { delete ctx; return MDEMOD_ERR_PARAM; }
+		ctx->v1_global_table = true;
+		ctx->block_threads = 64 * 3;
+		auto ring_need = [&](int threads) { return 32 * sizeof(float) + static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes; };
+		while (ctx->block_threads > 64 && ring_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
+		ctx->lds_bytes = ring_need(ctx->block_threads);
+		if (ctx->lds_bytes > 160 * 1024) { delete ctx; return MDEMOD_ERR_PARAM; }
+	}
 
 #define CREATE_TRY(expr) do { rc = (expr); if (rc) { mdemod_destroy(ctx); return rc; } } while (0)
 	{

@@ -86,7 +86,7 @@ struct DemodLaunch {
 
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
-hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, size_t lds_bytes, hipStream_t stream);
+hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, int global_table, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_rw_std(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_rot(const DemodLaunch &L, int fmt, int compact, size_t lds_bytes, hipStream_t stream);   /* v3: rotating register window (std geometry); compact: compact4 coefficient table */
 hipError_t mdemod_launch_demod_roth(const DemodLaunch &L, int mid, size_t lds_bytes, hipStream_t stream);   /* v3: hybrid window (float input: VGPRs + AccVGPRs, one wave per SIMD); mid: the 96-slot window (<= 65 taps) instead of the 160-slot one */

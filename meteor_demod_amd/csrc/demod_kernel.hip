@@ -103,7 +103,9 @@ load_granule(const typename Format<FMT>::sample_t *p)
  * waves per SIMD, so the register allocator may use up to 256 VGPRs.  Without the bound hipcc must
  * assume 1024-thread blocks (4 waves/SIMD), caps at 128 VGPRs and spills 300-800 bytes per lane to
  * scratch (= HBM): measured 2x slower. */
-template <int FMT, int OQPSK, int NGW, int CHUNK>
+/* GTAB: the coefficient table stays in global memory (it does not fit the LDS next to the rings: -O 64 with 129 and more taps, ...):
+ * slow, but such a configuration is demodulated instead of refused. */
+template <int FMT, int OQPSK, int NGW, int CHUNK, int GTAB = 0>
 __global__ void __launch_bounds__(256, 2)
 demod_kernel(const DemodLaunch L)
 {
@@ -122,12 +124,12 @@ demod_kernel(const DemodLaunch L)
 
 	/* LDS carve-up: [ctab][tanh lut][ring wave 0][ring wave 1]... */
 	float *ctab = reinterpret_cast<float *>(lds);
-	float *lut = ctab + L.ctab_floats;
+	float *lut = GTAB ? ctab : ctab + L.ctab_floats;
 	const int ring_bytes = C.ring_granules * 64 * GB;
 	unsigned char *ring = reinterpret_cast<unsigned char *>(lut + 32) + wave * ring_bytes;
 	(void)waves_per_block;
 
-	for (uint32_t i = threadIdx.x; i < L.ctab_floats; i += blockDim.x) ctab[i] = L.ctab[i];
+	if (!GTAB) for (uint32_t i = threadIdx.x; i < L.ctab_floats; i += blockDim.x) ctab[i] = L.ctab[i];
 	if (threadIdx.x < 32) lut[threadIdx.x] = L.tanh_lut[threadIdx.x];
 
 	/* ---- per-stream geometry ---- */
@@ -301,7 +303,9 @@ demod_kernel(const DemodLaunch L)
 			int gq = s_hi - (g_hi - (w0 >> 2));
 			gq = (gq < 0) ? gq + G : gq;
 			const int bank = C.interp - 1 - fire_sub;       /* filter.c:52 */
-			const float *row = ctab + (a * C.interp + bank) * C.ctab_row_stride;
+			const float *row;
+			if constexpr (GTAB) row = L.ctab + (a * C.interp + bank) * C.ctab_row_stride;
+			else row = ctab + (a * C.interp + bank) * C.ctab_row_stride;
 
 			/* filter.c:55-62: sequential, oldest first, unfused */
 			float acc_re = 0.0f, acc_im = 0.0f;
@@ -405,12 +409,12 @@ demod_kernel(const DemodLaunch L)
 
 /* ---- host-callable launcher -------------------------------------------------- */
 
-template <int FMT, int OQPSK, int NGW, int CHUNK>
+template <int FMT, int OQPSK, int NGW, int CHUNK, int GTAB = 0>
 static hipError_t
 launch_one(const DemodLaunch &L, int block, size_t lds_bytes, hipStream_t stream)
 {
 	const uint32_t blocks = (L.n_streams + block - 1) / block;
-	auto kfn = demod_kernel<FMT, OQPSK, NGW, CHUNK>;
+	auto kfn = demod_kernel<FMT, OQPSK, NGW, CHUNK, GTAB>;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if (e != hipSuccess) return e;
@@ -420,8 +424,9 @@ launch_one(const DemodLaunch &L, int block, size_t lds_bytes, hipStream_t stream
 
 template <int FMT, int OQPSK>
 static hipError_t
-launch_ngw(const DemodLaunch &L, int block, size_t lds_bytes, hipStream_t stream)
+launch_ngw(const DemodLaunch &L, int block, int gtab, size_t lds_bytes, hipStream_t stream)
 {
+	if (gtab) return launch_one<FMT, OQPSK, 0, 2, 1>(L, block, lds_bytes, stream);
 	switch (L.c.win_granules) {
 	case 17: return launch_one<FMT, OQPSK, 17, 2>(L, block, lds_bytes, stream);   /* -f 32: 65 taps */
 	case 33: return launch_one<FMT, OQPSK, 33, 2>(L, block, lds_bytes, stream);   /* -f 64: 129 taps */
@@ -431,21 +436,21 @@ launch_ngw(const DemodLaunch &L, int block, size_t lds_bytes, hipStream_t stream
 
 template <int FMT>
 static hipError_t
-launch_mode(const DemodLaunch &L, int block, size_t lds_bytes, hipStream_t stream)
+launch_mode(const DemodLaunch &L, int block, int gtab, size_t lds_bytes, hipStream_t stream)
 {
-	return L.c.oqpsk ? launch_ngw<FMT, 1>(L, block, lds_bytes, stream)
-	                 : launch_ngw<FMT, 0>(L, block, lds_bytes, stream);
+	return L.c.oqpsk ? launch_ngw<FMT, 1>(L, block, gtab, lds_bytes, stream)
+	                 : launch_ngw<FMT, 0>(L, block, gtab, lds_bytes, stream);
 }
 
 /* Called by demod_api.cpp. */
 hipError_t
-mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, size_t lds_bytes, hipStream_t stream)
+mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, int global_table, size_t lds_bytes, hipStream_t stream)
 {
 	if (L.c.chunk_granules != 2) return hipErrorInvalidValue;
 	switch (fmt) {
-	case 16: return launch_mode<16>(L, block, lds_bytes, stream);
-	case 8:  return launch_mode<8>(L, block, lds_bytes, stream);
-	case 32: return launch_mode<32>(L, block, lds_bytes, stream);
+	case 16: return launch_mode<16>(L, block, global_table, lds_bytes, stream);
+	case 8:  return launch_mode<8>(L, block, global_table, lds_bytes, stream);
+	case 32: return launch_mode<32>(L, block, global_table, lds_bytes, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -682,6 +682,30 @@ def test_large_oversampling_factors(cfg, gpu_device):
         assert "v3 rotating register window" in d.kernel_name, d.kernel_name
 
 
+@pytest.mark.parametrize("cfg", [
+    DemodConfig(samplerate=1000000, rrc_order=80, interp_factor=64),                 # 161 taps x 64 banks: 4 alignments of them are 176 KB
+    DemodConfig(samplerate=460000, rrc_order=65, interp_factor=64, oqpsk=True, symrate=80000, bps=32),
+], ids=["161taps-O64", "131taps-O64-oqpsk-f32"])
+def test_tables_that_fit_no_lds_are_read_from_global_memory(cfg, gpu_device):
+    """The reference takes any -f / -O; a coefficient table larger than the LDS used to be refused (MDEMOD_ERR_PARAM).  The v1 ring
+    kernel now leaves such a table in global memory."""
+    torch = _torch()
+    rms = {8: 50.0, 16: 5000.0, 32: 0.5}[cfg.bps]
+    streams = [synth.make_stream(700 + i, cfg.samplerate, cfg.symrate, f0_hz=150.0 * i, esn0_db=15.0, rms=rms, oqpsk=cfg.oqpsk, fmt=cfg.bps) for i in range(3)]
+    iqs = [synth.generate_host(s, 20000) for s in streams]
+    with Demodulator(cfg, 3) as d:
+        assert "v1 LDS ring" in d.kernel_name, d.kernel_name
+        got = [[] for _ in range(3)]
+        for lo, hi in ((0, 7001), (7001, 20000)):
+            soft = d.process(torch.from_numpy(np.stack([a[lo:hi] for a in iqs])).cuda())
+            torch.cuda.synchronize()
+            cnt = d.symbol_counts()
+            for i in range(3):
+                got[i].append(soft[i, : int(cnt[i])].cpu().numpy())
+        for i in range(3):
+            assert np.array_equal(np.concatenate(got[i]), O.oracle_demod(cfg, iqs[i])[0]), i
+
+
 def _check_cfg_against_oracle(cfg):
     """-O 1: floor(x / 1) cannot go through the 32-bit reciprocal the symbol clock uses for x / interp (the reciprocal
     of 1 is 2^32); found by tools/config_fuzz.py as an endless loop in the kernel."""

@@ -119,7 +119,7 @@ for ci in range(n_cfg):
                         a = iqs[i % len(iqs)]; print("   input absmax by block", [int(np.abs(a[sum(blocks[:j]): sum(blocks[:j + 1])].astype(np.int64)).max()) if blocks[j] else 0 for j in range(len(blocks))])
                     break
     except Exception as e:
-        # tables that fit no kernel's LDS (-O 29 and up with > 65 taps and float input, and the like) are refused by mdemod_create
+        # (tables that fit no kernel's LDS used to be refused by mdemod_create; the v1 kernel reads them from global memory since r03)
         if "mdemod_create: error -1" in repr(e) and cfg.interp_factor >= 16 and cfg.interp_factor * cfg.taps > 2300:
             kinds["refused: table too large for LDS"] = kinds.get("refused: table too large for LDS", 0) + 1
         else:
