@@ -299,8 +299,9 @@ def other_configs(skip: str, T: int, L: int, local: int) -> dict:
              "x2": (DemodConfig(samplerate=1800000), "not in BASELINE.json: QPSK 72k, 1.8 MS/s s16, default RRC order 32, oversamp 5"),
              "x3": (DemodConfig(samplerate=1024000, bps=32), "not in BASELINE.json: QPSK 72k, 1.024 MS/s f32, default RRC order 32, oversamp 5"),
              "x4": (DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),
-                    "not in BASELINE.json: QPSK 72k, 1 MS/s f32, RRC order 64, oversamp 8 (v3 hybrid window since r03; v1 ring kernel before)")}
-    for tag in ("c3", "c4", "x1", "x2", "x3", "x4"):
+                    "not in BASELINE.json: QPSK 72k, 1 MS/s f32, RRC order 64, oversamp 8 (v3 hybrid window since r03; v1 ring kernel before)"),
+             "x5": (DemodConfig(samplerate=2048000, bps=32), "not in BASELINE.json: QPSK 72k, 2.048 MS/s f32, default RRC order 32, oversamp 5 (nearest to the HBM roofline)")}
+    for tag in ("c3", "c4", "x1", "x2", "x3", "x4", "x5"):
         if tag == skip:
             continue
         cfg, workload = extra[tag] if tag in extra else demod_config(tag)
