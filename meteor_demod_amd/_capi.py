@@ -130,6 +130,7 @@ SIGNATURES = {
     "mdemod_estimate_clock": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "mdemod_plan_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mdemod_device_count": (C.c_int, []),
     "mdemod_demodulate_recording_host": (C.c_int, [_P(MdemodParams), _P(MdemodRecordingOpts), C.c_void_p, C.c_uint64,
                                                    C.c_void_p, C.c_uint64, _P(MdemodRecordingReport)]),

@@ -130,6 +130,72 @@ mdemod_nominal_symbols(const mdemod_ctx *ctx, uint64_t n_samples)
 	return ((static_cast<uint64_t>(steps * per_step * 1.01) + 16 + 7) / 8) * 8;
 }
 
+/* Everything mdemod_create decides without a device: the kernel generation, its tables and geometry, the LDS it needs, whether the
+ * latency kernel fits.  (mdemod_plan_kernel exposes it to the CPU tests.) */
+static int
+plan_context(mdemod_ctx *ctx)
+{
+	const mdemod_params *params = &ctx->params;
+	/* MDEMOD_FLAG_KERNEL_MASK pins a generation (tests cover all three); otherwise the newest that fits.  The v3
+	 * kernels drop the range test of the NCO's turn code and wrap the NCO phase in float arithmetic (demod_device.h): both need
+	 * phase + freq < 4pi, which pll.c's own clamp gives for fmax < 2pi rad/symbol (the default is 0.3) */
+	const uint32_t kforce = params->reserved & MDEMOD_FLAG_KERNEL_MASK;
+	int generation = kforce == 1 ? 0 : (kforce == 2 ? 1 : 2);
+	{
+		HostTables probe;
+		int rc0 = mdemod_host_derive(*params, probe, 1);
+		if (rc0) return rc0;
+		if (!(probe.c.pll_fmax < 6.0f) && generation == 2) generation = 1;
+	}
+	int rc = mdemod_host_derive(*params, ctx->tab, generation);
+	if (rc) return rc;
+	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
+	ctx->use_rot = generation == 2 && ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && !ctx->tab.rw_hyb;
+	ctx->hyb_block = 0;
+
+	/* tunables (experiments only; defaults are the measured best) */
+	DemodConsts &c = ctx->tab.c;
+	if (!ctx->tab.use_rw) {
+		c.ring_granules = c.hpad / 4 + 8;            /* v1: eight granules of slack behind the history (measured best, r01) */
+	}
+	ctx->block_threads = 64 * 3;                     /* v1 kernel: three waves per block (__launch_bounds__(256); measured best, r01) */
+
+	if (ctx->tab.rw_hyb) ctx->hyb_block = MDEMOD_RW_BLOCK;
+	auto lds_need = [&](int threads) {
+		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
+		       (ctx->tab.use_rw ? static_cast<size_t>((ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
+		                          + static_cast<size_t>(ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) * 64     /* soft-symbol staging: a 32-symbol ring (4 x 16 B) per thread */
+		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes);
+	};
+	if (ctx->tab.use_rw && lds_need(ctx->block_threads) > 160 * 1024) {
+		/* The per-alignment coefficient rows of the v2 std geometry grow with -O (16 alignments x interp x 84 floats: past the
+		 * 160 KB of LDS from -O 29 on); the v1 ring kernel keeps 4 alignments and still fits: fall back to it. */
+		rc = mdemod_host_derive(*params, ctx->tab, 0);
+		ctx->use_rot = false;
+		if (rc) return rc;
+		c.ring_granules = c.hpad / 4 + 8;
+	}
+	while (ctx->block_threads > 64 && lds_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
+	ctx->lds_bytes = lds_need(ctx->block_threads);
+	ctx->v1_global_table = false;
+	if (ctx->lds_bytes > 160 * 1024) {
+		/* not even one wave's ring fits next to the table (-O 64 with 129 taps, ...): the v1 kernel reads its coefficients from
+		   global memory then - slow, but the reference takes such a configuration and so does this */
+		if (ctx->tab.use_rw) return MDEMOD_ERR_PARAM;
+		ctx->v1_global_table = true;
+		ctx->block_threads = 64 * 3;
+		auto ring_need = [&](int threads) { return 32 * sizeof(float) + static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes; };
+		while (ctx->block_threads > 64 && ring_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
+		ctx->lds_bytes = ring_need(ctx->block_threads);
+		if (ctx->lds_bytes > 160 * 1024) return MDEMOD_ERR_PARAM;
+	}
+
+	/* like the v3 kernels, the latency kernel takes the NCO's short cuts that need fmax < 2pi (demod_device.h) */
+	ctx->lat_ok = c.pll_fmax < 6.0f &&
+	              mdemod_lat_geometry(c, static_cast<double>(ctx->tab.osf) / (params->oqpsk ? 2.0 : 1.0), &ctx->lat_ring, &ctx->lat_span, &ctx->lat_lds);
+	return MDEMOD_OK;
+}
+
 extern "C" {
 
 uint32_t
@@ -202,60 +268,9 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	if (!ctx) return MDEMOD_ERR_NOMEM;
 	ctx->params = *params;
 	ctx->pipe = nullptr;
-
-	/* MDEMOD_FLAG_KERNEL_MASK pins a generation (tests cover all three); otherwise the newest that fits.  The v3
-	 * kernels drop the range test of the NCO's turn code and wrap the NCO phase in float arithmetic (demod_device.h): both need
-	 * phase + freq < 4pi, which pll.c's own clamp gives for fmax < 2pi rad/symbol (the default is 0.3) */
-	const uint32_t kforce = params->reserved & MDEMOD_FLAG_KERNEL_MASK;
-	int generation = kforce == 1 ? 0 : (kforce == 2 ? 1 : 2);
-	{
-		HostTables probe;
-		int rc0 = mdemod_host_derive(*params, probe, 1);
-		if (rc0) { delete ctx; return rc0; }
-		if (!(probe.c.pll_fmax < 6.0f) && generation == 2) generation = 1;
-	}
-	int rc = mdemod_host_derive(*params, ctx->tab, generation);
+	int rc = plan_context(ctx);
 	if (rc) { delete ctx; return rc; }
-	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
-	ctx->use_rot = generation == 2 && ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && !ctx->tab.rw_hyb;
-	ctx->hyb_block = 0;
-
-	/* tunables (experiments only; defaults are the measured best) */
 	DemodConsts &c = ctx->tab.c;
-	if (!ctx->tab.use_rw) {
-		c.ring_granules = c.hpad / 4 + 8;            /* v1: eight granules of slack behind the history (measured best, r01) */
-	}
-	ctx->block_threads = 64 * 3;                     /* v1 kernel: three waves per block (__launch_bounds__(256); measured best, r01) */
-
-	if (ctx->tab.rw_hyb) ctx->hyb_block = MDEMOD_RW_BLOCK;
-	auto lds_need = [&](int threads) {
-		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
-		       (ctx->tab.use_rw ? static_cast<size_t>((ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
-		                          + static_cast<size_t>(ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) * 64     /* soft-symbol staging: a 32-symbol ring (4 x 16 B) per thread */
-		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes);
-	};
-	if (ctx->tab.use_rw && lds_need(ctx->block_threads) > 160 * 1024) {
-		/* The per-alignment coefficient rows of the v2 std geometry grow with -O (16 alignments x interp x 84 floats: past the
-		 * 160 KB of LDS from -O 29 on); the v1 ring kernel keeps 4 alignments and still fits: fall back to it. */
-		rc = mdemod_host_derive(*params, ctx->tab, 0);
-		ctx->use_rot = false;
-		if (rc) { delete ctx; return rc; }
-		c.ring_granules = c.hpad / 4 + 8;
-	}
-	while (ctx->block_threads > 64 && lds_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
-	ctx->lds_bytes = lds_need(ctx->block_threads);
-	ctx->v1_global_table = false;
-	if (ctx->lds_bytes > 160 * 1024) {
-		/* not even one wave's ring fits next to the table (-O 64 with 129 taps, ...): the v1 kernel reads its coefficients from
-		   global memory then - slow, but the reference takes such a configuration and so does this */
-		if (ctx->tab.use_rw) { delete ctx; return MDEMOD_ERR_PARAM; }
-		ctx->v1_global_table = true;
-		ctx->block_threads = 64 * 3;
-		auto ring_need = [&](int threads) { return 32 * sizeof(float) + static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes; };
-		while (ctx->block_threads > 64 && ring_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
-		ctx->lds_bytes = ring_need(ctx->block_threads);
-		if (ctx->lds_bytes > 160 * 1024) { delete ctx; return MDEMOD_ERR_PARAM; }
-	}
 
 #define CREATE_TRY(expr) do { rc = (expr); if (rc) { mdemod_destroy(ctx); return rc; } } while (0)
 	{
@@ -287,9 +302,6 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	CREATE_TRY(dev_alloc(ctx, &ctx->d_ctab, ctx->tab.ctab.size()));
 	CREATE_TRY(dev_alloc(ctx, &ctx->d_lut, 32));
 	CREATE_TRY(dev_alloc(ctx, &ctx->d_rrc, ctx->tab.rrc.size()));
-	/* like the v3 kernels, the latency kernel takes the NCO's short cuts that need fmax < 2pi (demod_device.h) */
-	ctx->lat_ok = c.pll_fmax < 6.0f &&
-	              mdemod_lat_geometry(c, static_cast<double>(ctx->tab.osf) / (params->oqpsk ? 2.0 : 1.0), &ctx->lat_ring, &ctx->lat_span, &ctx->lat_lds);
 	{
 		/* tables and the power-on state go in on a stream of their own, and only that stream is waited for: a context made while
 		   other contexts run (a second host thread, a recording's tile bank next to its serial head) must not wait for their
@@ -657,6 +669,24 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (ctx->use_rot) return "demod_kernel_rot (v3 rotating register window)";
 	return (ctx->params.bps != 32 && (ctx->params.reserved & MDEMOD_FLAG_V2_PACKED))
 	       ? "demod_kernel_rw (v2 register window, packed)" : "demod_kernel_rw (v2 register window, float)";
+}
+
+int
+mdemod_plan_kernel(const mdemod_params *params, char *name, uint32_t name_cap, uint32_t *lds_bytes, uint32_t *block_threads)
+{
+	if (!params || !name || name_cap == 0 || params->n_streams == 0) return MDEMOD_ERR_PARAM;
+	mdemod_ctx *ctx = new (std::nothrow) mdemod_ctx();
+	if (!ctx) return MDEMOD_ERR_NOMEM;
+	ctx->params = *params;
+	ctx->pipe = nullptr;
+	const int rc = plan_context(ctx);
+	if (rc == MDEMOD_OK) {
+		snprintf(name, name_cap, "%s%s", mdemod_kernel_name(ctx), ctx->v1_global_table && !wants_latency_kernel(ctx) ? " [table in global memory]" : "");
+		if (lds_bytes) *lds_bytes = static_cast<uint32_t>(wants_latency_kernel(ctx) ? ctx->lat_lds : ctx->lds_bytes);
+		if (block_threads) *block_threads = static_cast<uint32_t>(ctx->tab.use_rw ? (ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) : ctx->block_threads);
+	}
+	delete ctx;
+	return rc;
 }
 
 uint32_t

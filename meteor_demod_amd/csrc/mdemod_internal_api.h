@@ -83,6 +83,9 @@ int  mdemod_estimate_clock(const mdemod_params *params, const void *iq_dev, uint
  * of RRC floats, or <0. */
 int  mdemod_derive_tables(const mdemod_params *params, float *rrc_out, uint32_t rrc_cap,
                           float consts_out[8], float lut_out[32]);
+/* What mdemod_create would pick for `params` - host only, no device: the kernel's name as mdemod_kernel_name gives it (a
+ * v1 kernel that leaves its table in global memory is marked), the dynamic LDS bytes and the threads per block. */
+int  mdemod_plan_kernel(const mdemod_params *params, char *name, uint32_t name_cap, uint32_t *lds_bytes, uint32_t *block_threads);
 
 /* RRC polyphase table as filter_init_rrc lays it out (filter.c:18-22):
  * interp*taps floats, bank-major.  Returns number of floats, or <0. */

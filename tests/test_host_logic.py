@@ -293,3 +293,47 @@ def test_tui_draws_its_panes(how):
                   "72000.1 Hz", "0.031", "Data in", "00:01:08/00:02:05 (54.5%)", "Data out", "23.5 MB", "Demodulation complete",
                   "Press any key to exit..."):
         assert piece in screen, (piece, screen)
+
+
+# ---- which kernel a configuration gets (host-only planning: mdemod_plan_kernel) ------------------------------------------
+
+PLAN_CASES = {
+    # (DemodConfig kwargs, forced generation flag) -> piece of the kernel's name
+    "configs[1]": (dict(samplerate=230000), 0, "v3 rotating register window"),
+    "configs[2] oqpsk": (dict(samplerate=230000, symrate=80000, oqpsk=True), 0, "v3 rotating register window"),
+    "configs[3] wide": (dict(samplerate=1000000, rrc_order=64, interp_factor=8), 0, "v3 rotating packed window, wide"),
+    "1.024 MS/s mid": (dict(samplerate=1024000), 0, "v3 rotating packed window, mid"),
+    "1.8 MS/s far": (dict(samplerate=1800000), 0, "v3 rotating packed window, far"),
+    "3.2 MS/s far (44 samples per firing)": (dict(samplerate=3200000), 0, "v3 rotating packed window, far"),
+    "3.4 MS/s: past the far window": (dict(samplerate=3400000), 0, "v1 LDS ring"),
+    "2.048 MS/s long filter: wide": (dict(samplerate=2048000, rrc_order=64, interp_factor=4), 0, "v3 rotating packed window, wide"),
+    "float std": (dict(samplerate=230000, bps=32), 0, "v3 rotating register window"),
+    "float mid -> hybrid": (dict(samplerate=1024000, bps=32), 0, "v3 hybrid window, mid"),
+    "float 2.048 MS/s -> hybrid mid": (dict(samplerate=2048000, bps=32), 0, "v3 hybrid window, mid"),
+    "float long filter -> hybrid": (dict(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32), 0, "v3 hybrid window: float input, 129 taps"),
+    "float long filter at 2.048 MS/s": (dict(samplerate=2048000, rrc_order=64, interp_factor=4, bps=32), 0, "v3 hybrid window: float input, 129 taps"),
+    "float 3.2 MS/s: v1": (dict(samplerate=3200000, bps=32), 0, "v1 LDS ring"),
+    "-O 32: compact table keeps v3": (dict(samplerate=230000, interp_factor=32), 0, "v3 rotating register window"),
+    "161 taps: v1": (dict(samplerate=230000, rrc_order=80), 0, "v1 LDS ring"),
+    "161 taps x 64 banks: table in global memory": (dict(samplerate=1000000, rrc_order=80, interp_factor=64), 0, "[table in global memory]"),
+    "v2 forced, float mid": (dict(samplerate=1024000, bps=32), 2, "v2 register window, mid"),
+    "v2 forced, -O 32: v1": (dict(samplerate=230000, interp_factor=32), 2, "v1 LDS ring"),
+    "v1 forced": (dict(samplerate=230000), 1, "v1 LDS ring"),
+}
+
+
+@pytest.mark.parametrize("case", list(PLAN_CASES))
+def test_kernel_plan_of_a_configuration(case):
+    """Geometry selection is host arithmetic (csrc/demod_host.cpp, plan_context in csrc/demod_api.cpp): no device needed."""
+    import ctypes as C
+    from meteor_demod_amd import DemodConfig, _capi
+    kw, flag, want = PLAN_CASES[case]
+    lib = _capi.lib()
+    p = DemodConfig(**kw).to_c(100000, 0)
+    p.reserved = flag | 0x4                     # generation + MDEMOD_FLAG_LAT_OFF: the lane kernel's plan, whatever the stream count
+    name = C.create_string_buffer(256)
+    lds, block = C.c_uint32(), C.c_uint32()
+    rc = lib.mdemod_plan_kernel(C.byref(p), name, 256, C.byref(lds), C.byref(block))
+    assert rc == 0, rc
+    assert want in name.value.decode(), name.value
+    assert 0 < lds.value <= 160 * 1024 and block.value in (64, 128, 192, 256, 512), (lds.value, block.value)
