@@ -105,7 +105,7 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 		return MDEMOD_OK;
 	}
 	if (ctx->tab.use_rw && ctx->tab.rw_hyb)
-		HIP_TRY(mdemod_launch_demod_roth(L, ctx->tab.rw_mid ? 1 : 0, ctx->lds_bytes, stream));
+		HIP_TRY(mdemod_launch_demod_roth(L, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw && ctx->use_rot)
 		HIP_TRY(mdemod_launch_demod_rot(L, ctx->params.bps, ctx->tab.rw_std_compact ? 1 : 0, ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw && ctx->tab.rw_compact4)
@@ -657,6 +657,7 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (!ctx) return "";
 	if (wants_latency_kernel(ctx)) return "demod_kernel_lat (one stream per wave: FIR farm + serial scalar stage)";
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
+	if (ctx->tab.rw_hyb && ctx->tab.rw_far) return "demod_kernel_roth (v3 hybrid window, far: float input, 65 taps at up to 54 samples per firing, 80 slots in VGPRs + 40 in AccVGPRs)";
 	if (ctx->tab.rw_hyb) return ctx->tab.rw_mid ? "demod_kernel_roth (v3 hybrid window, mid: float input, 65 taps at up to 30 samples per firing, 80 slots in VGPRs + 16 in AccVGPRs)"
 	                                            : "demod_kernel_roth (v3 hybrid window: float input, 129 taps, 80 slots in VGPRs + 80 in AccVGPRs)";
 	if (ctx->tab.rw_compact4) return ctx->tab.rw_wide ? "demod_kernel_rotp (v3 rotating packed window, wide: 129 taps at up to 30 samples per firing)"

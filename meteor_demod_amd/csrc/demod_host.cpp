@@ -137,7 +137,8 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	/* hybrid: float input outside the std geometry, up to 129 taps at up to 15 samples per firing or up to 65 taps at up to 30 (a float window of 160 slots is 320
 	 * registers: the older 80 slots in VGPRs, the newer ones in AccVGPRs, one wave per SIMD: demod_kernel_rot.hip, WinH; with up to 65
 	 * taps - rw_mid as well - the window has 96 slots) */
-	const bool hyb_ok = generation >= 2 && !std_ok && p.bps == 32 && per_firing <= 30.0 && c.taps <= 129;
+	const bool hyb_far_ok = generation >= 2 && !std_ok && p.bps == 32 && per_firing > 30.0 && per_firing <= 54.0 && c.taps <= 65;   /* 120 slots, 55 alignments */
+	const bool hyb_ok = generation >= 2 && !std_ok && p.bps == 32 && ((per_firing <= 30.0 && c.taps <= 129) || hyb_far_ok);
 	/* the long filter at 15..30 samples per firing (s16 / u8): the wide window has the 31 alignments for it and slides once per
 	 * loop iteration, so such a firing takes two iterations */
 	const bool wide_far_ok = generation >= 2 && !std_ok && !wide_ok && !far_ok && per_firing <= 30.0 && c.taps <= 129 && p.bps != 32;
@@ -145,8 +146,8 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	out.rw_hyb = hyb_ok;
 	out.rw_std_compact = false;
 	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok || wide_far_ok);
-	out.rw_mid = out.use_rw && !std_ok && (mid_ok || (hyb_ok && c.taps <= 65));
-	out.rw_far = out.use_rw && far_ok;
+	out.rw_mid = out.use_rw && !std_ok && (mid_ok || (hyb_ok && !hyb_far_ok && c.taps <= 65));
+	out.rw_far = out.use_rw && (far_ok || hyb_far_ok);
 	out.rw_wide = out.use_rw && !std_ok && !mid_ok && !far_ok && !hyb_ok;
 	c.chunk_granules = 2;
 	if (out.use_rw && !out.rw_wide && !out.rw_mid && !out.rw_far && !out.rw_hyb) {
@@ -192,8 +193,8 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		 * copy (bank, k)[i] = P[i + k].  A lane at alignment a reads P[(AMAX - a) + s] for slot s, i.e. copy ((AMAX - a) & 3) at the
 		 * 16-byte aligned index ((AMAX - a) & ~3) + s: every group of four taps is one ds_read_b128.  The FIR's prefetch runs up
 		 * to six groups (24 floats) past the last tap it uses: rows carry that much padding. */
-		const int kTaps = (out.rw_wide || (out.rw_hyb && !out.rw_mid)) ? 129 : 65;
-		const int NW = out.rw_mid ? MDEMOD_RW_MID_NW : (out.rw_far ? MDEMOD_RW_FAR_NW : MDEMOD_RW_WIDE_NW), AMAX = NW - kTaps;
+		const int kTaps = (out.rw_wide || (out.rw_hyb && !out.rw_mid && !out.rw_far)) ? 129 : 65;
+		const int NW = out.rw_mid ? MDEMOD_RW_MID_NW : (out.rw_far ? (out.rw_hyb ? 120 : MDEMOD_RW_FAR_NW) : MDEMOD_RW_WIDE_NW), AMAX = NW - kTaps;
 		const int LP = kTaps + 2 * AMAX;
 		c.hpad = kTaps - 1;
 		c.win_granules = NW / 4;

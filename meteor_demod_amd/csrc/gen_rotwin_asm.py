@@ -248,8 +248,9 @@ def main():
     out.append("#define ROTWIN_FIR_ASM \\\n" + q(fir()).replace("\n", " \\\n"))
     for kind in ("s16", "u8", "f32"):
         out.append("#define ROTWIN_PUT_%s_ASM \\\n" % kind.upper() + q(put(kind)).replace("\n", " \\\n"))
-    # ten AccVGPR chunks: 160-slot window (129 taps); two: 96-slot window (65 taps at up to 15 samples per firing)
-    for NA, sfx in ((NCH, ""), (2, "2")):
+    # ten AccVGPR chunks: 160-slot window (129 taps); two: 96-slot window (65 taps at up to 30 samples per firing); five: 120 slots
+    # (65 taps at up to 54)
+    for NA, sfx in ((NCH, ""), (2, "2"), (5, "5")):
         out.append("#define ROTWIN_FIR_ACC%s_ASM \\\n" % sfx + q(fir_acc(NA, "fira" + sfx)).replace("\n", " \\\n"))
         out.append("#define ROTWIN_MIGRATE%s_ASM \\\n" % sfx + q(migrate(NA, "mig" + sfx)).replace("\n", " \\\n"))
         out.append("#define ROTWIN_PUT_ACC%s_ASM \\\n" % sfx + q(put_acc(NA, "puta" + sfx)).replace("\n", " \\\n"))

@@ -312,7 +312,8 @@ PLAN_CASES = {
     "float 2.048 MS/s -> hybrid mid": (dict(samplerate=2048000, bps=32), 0, "v3 hybrid window, mid"),
     "float long filter -> hybrid": (dict(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32), 0, "v3 hybrid window: float input, 129 taps"),
     "float long filter at 2.048 MS/s": (dict(samplerate=2048000, rrc_order=64, interp_factor=4, bps=32), 0, "v3 hybrid window: float input, 129 taps"),
-    "float 3.2 MS/s: v1": (dict(samplerate=3200000, bps=32), 0, "v1 LDS ring"),
+    "float 3.2 MS/s -> hybrid far": (dict(samplerate=3200000, bps=32), 0, "v3 hybrid window, far"),
+    "float 4 MS/s: v1": (dict(samplerate=4000000, bps=32), 0, "v1 LDS ring"),
     "-O 32: compact table keeps v3": (dict(samplerate=230000, interp_factor=32), 0, "v3 rotating register window"),
     "161 taps: v1": (dict(samplerate=230000, rrc_order=80), 0, "v1 LDS ring"),
     "161 taps x 64 banks: table in global memory": (dict(samplerate=1000000, rrc_order=80, interp_factor=64), 0, "[table in global memory]"),

@@ -10,7 +10,8 @@ cfgs = {"f32 1MS/s -f64 -O8": DemodConfig(samplerate=1000000, rrc_order=64, inte
         "f32 230k -f48": DemodConfig(samplerate=230000, rrc_order=48, bps=32),
         "f32 1.024MS/s default": DemodConfig(samplerate=1024000, bps=32),
         "f32 2.048MS/s default": DemodConfig(samplerate=2048000, bps=32),
-        "f32 2.048MS/s -f64 -O4": DemodConfig(samplerate=2048000, rrc_order=64, interp_factor=4, bps=32)}
+        "f32 2.048MS/s -f64 -O4": DemodConfig(samplerate=2048000, rrc_order=64, interp_factor=4, bps=32),
+        "f32 3.2MS/s default": DemodConfig(samplerate=3200000, bps=32)}
 for name, cfg in cfgs.items():
     rec = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, fmt=32, rms=0.3)
     buf = torch.empty((T * L, 2), dtype=torch.float32, device="cuda")
