@@ -11,7 +11,8 @@ cfgs = {"c4 wide 1MS/s -f64 -O8": DemodConfig(samplerate=1000000, rrc_order=64, 
         "wide u8": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=8),
         "c4 oqpsk 1MS/s": DemodConfig(samplerate=1000000, symrate=80000, oqpsk=True, rrc_order=64, interp_factor=8),
         "2.048MS/s -f64 -O4": DemodConfig(samplerate=2048000, rrc_order=64, interp_factor=4),
-        "3.2MS/s default": DemodConfig(samplerate=3200000), "2.4MS/s u8": DemodConfig(samplerate=2400000, bps=8)}
+        "3.2MS/s default": DemodConfig(samplerate=3200000), "2.4MS/s u8": DemodConfig(samplerate=2400000, bps=8),
+        "6MS/s default": DemodConfig(samplerate=6000000), "10MS/s default": DemodConfig(samplerate=10000000)}
 for name, cfg in cfgs.items():
     rec = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, fmt=cfg.bps, **(dict(rms=40.0) if cfg.bps == 8 else {}))
     buf = torch.empty((T * L, 2), dtype=torch.uint8 if cfg.bps == 8 else torch.int16, device="cuda")
