@@ -95,6 +95,7 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
              (rw, "demod_kernel_rw_wide", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=2"]),
              (CSRC / "demod_kernel_rot.hip", "demod_kernel_rot", ROT_FLAGS),
              (CSRC / "demod_kernel_rotp.hip", "demod_kernel_rotp", ROTP_FLAGS),
+             (CSRC / "demod_kernel_gat.hip", "demod_kernel_gat", ["-fno-slp-vectorize"]),
              (CSRC / "demod_kernel_lat.hip", "demod_kernel_lat", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
              (CSRC / "demod_aux.hip", "demod_aux", []), (CSRC / "recording.hip", "recording", []),
              (CSRC / "demod_api.cpp", "demod_api", []), (CSRC / "host_pipe.cpp", "host_pipe", []),

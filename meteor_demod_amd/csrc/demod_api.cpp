@@ -104,7 +104,9 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 		HIP_TRY(mdemod_launch_demod_lat(L, ctx->params.bps, ctx->d_rrc, ctx->lat_ring, ctx->lat_span, ctx->tab.use_rw ? 1 : 0, ctx->lat_lds, stream));
 		return MDEMOD_OK;
 	}
-	if (ctx->tab.use_rw && ctx->tab.rw_hyb)
+	if (ctx->tab.use_rw && ctx->tab.rw_gather)
+		HIP_TRY(mdemod_launch_demod_gat(L, ctx->tab.c.taps > 65 ? 1 : 0, ctx->lds_bytes, stream));
+	else if (ctx->tab.use_rw && ctx->tab.rw_hyb)
 		HIP_TRY(mdemod_launch_demod_roth(L, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw && ctx->use_rot)
 		HIP_TRY(mdemod_launch_demod_rot(L, ctx->params.bps, ctx->tab.rw_std_compact ? 1 : 0, ctx->lds_bytes, stream));
@@ -150,7 +152,7 @@ plan_context(mdemod_ctx *ctx)
 	int rc = mdemod_host_derive(*params, ctx->tab, generation);
 	if (rc) return rc;
 	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
-	ctx->use_rot = generation == 2 && ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && !ctx->tab.rw_hyb;
+	ctx->use_rot = generation == 2 && ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && !ctx->tab.rw_hyb && !ctx->tab.rw_gather;
 	ctx->hyb_block = 0;
 
 	/* tunables (experiments only; defaults are the measured best) */
@@ -657,6 +659,8 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (!ctx) return "";
 	if (wants_latency_kernel(ctx)) return "demod_kernel_lat (one stream per wave: FIR farm + serial scalar stage)";
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
+	if (ctx->tab.rw_gather) return ctx->tab.c.taps > 65 ? "demod_kernel_gat (v3 gather: s16 input beyond every window, 129 taps, every firing loads its own taps)"
+	                                                     : "demod_kernel_gat (v3 gather: s16 input beyond every window, 65 taps, every firing loads its own taps)";
 	if (ctx->tab.rw_hyb && ctx->tab.rw_far) return "demod_kernel_roth (v3 hybrid window, far: float input, 65 taps at up to 54 samples per firing, 80 slots in VGPRs + 40 in AccVGPRs)";
 	if (ctx->tab.rw_hyb) return ctx->tab.rw_mid ? "demod_kernel_roth (v3 hybrid window, mid: float input, 65 taps at up to 30 samples per firing, 80 slots in VGPRs + 16 in AccVGPRs)"
 	                                            : "demod_kernel_roth (v3 hybrid window: float input, 129 taps, 80 slots in VGPRs + 80 in AccVGPRs)";

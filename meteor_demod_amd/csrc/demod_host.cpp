@@ -142,15 +142,19 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	/* the long filter at 15..30 samples per firing (s16 / u8): the wide window has the 31 alignments for it and slides once per
 	 * loop iteration, so such a firing takes two iterations */
 	const bool wide_far_ok = generation >= 2 && !std_ok && !wide_ok && !far_ok && per_firing <= 30.0 && c.taps <= 129 && p.bps != 32;
+	/* gather: s16 input at rates none of the windows reaches (more than 46 samples per firing, 30 with the long filter): no window,
+	 * every firing loads its own taps (demod_kernel_gat.hip) */
+	const bool gather_ok = generation >= 2 && p.bps == 16 && c.taps <= 129 && !std_ok && !wide_ok && !far_ok && !wide_far_ok;
 	const bool allow_rw = generation >= 1;
+	out.rw_gather = gather_ok;
 	out.rw_hyb = hyb_ok;
 	out.rw_std_compact = false;
-	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok || wide_far_ok);
+	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok || wide_far_ok || gather_ok);
 	out.rw_mid = out.use_rw && !std_ok && (mid_ok || (hyb_ok && !hyb_far_ok && c.taps <= 65));
 	out.rw_far = out.use_rw && (far_ok || hyb_far_ok);
-	out.rw_wide = out.use_rw && !std_ok && !mid_ok && !far_ok && !hyb_ok;
+	out.rw_wide = out.use_rw && !std_ok && !mid_ok && !far_ok && !hyb_ok && !gather_ok;
 	c.chunk_granules = 2;
-	if (out.use_rw && !out.rw_wide && !out.rw_mid && !out.rw_far && !out.rw_hyb) {
+	if (out.use_rw && !out.rw_wide && !out.rw_mid && !out.rw_far && !out.rw_hyb && !out.rw_gather) {
 		/* v2: 80-slot register window, filter embedded as 65 taps (leading zeros), 16 alignments */
 		const int kTaps = 65, NW = 80, AL = NW - kTaps + 1;
 		c.hpad = kTaps - 1;
@@ -185,6 +189,27 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 				float *row = &out.ctab[(static_cast<size_t>(a) * banks + b) * c.ctab_row_stride];
 				for (int k = 0; k < c.taps; k++) row[a + lead + k] = out.rrc[b * taps + k];
 			}
+		return MDEMOD_OK;
+	}
+	if (out.rw_gather) {
+		/* compact4 layout with three alignments: the 0..3 samples between a 16-byte step and the oldest tap */
+		const int kTaps = c.taps <= 65 ? 65 : 129, AMAX = 3, LP = kTaps + 2 * AMAX;
+		c.hpad = kTaps - 1;
+		c.win_granules = (kTaps + 3) / 4;
+		c.ring_granules = 0;
+		c.ctab_row_floats = LP;
+		c.ctab_row_stride = (LP + 3) / 4 * 4;
+		if ((c.ctab_row_stride / 4) % 2 == 0) c.ctab_row_stride += 4;
+		out.ctab.assign(static_cast<size_t>(4) * banks * c.ctab_row_stride, 0.0f);
+		const int lead = kTaps - c.taps;
+		for (unsigned b = 0; b < banks; b++) {
+			std::vector<float> P(static_cast<size_t>(LP) + 4, 0.0f);
+			for (int k = 0; k < c.taps; k++) P[AMAX + lead + k] = out.rrc[b * taps + k];
+			for (int k = 0; k < 4; k++) {
+				float *row = &out.ctab[(static_cast<size_t>(b) * 4 + k) * c.ctab_row_stride];
+				for (int i = 0; i < LP; i++) row[i] = P[i + k];
+			}
+		}
 		return MDEMOD_OK;
 	}
 	out.rw_compact4 = generation >= 2 && (out.rw_wide || out.rw_mid || out.rw_far) && p.bps != 32;

@@ -20,6 +20,7 @@ struct HostTables {
 	bool               rw_far;    /* v2 far geometry: <= 65 taps at 15..30 samples per firing (112-slot packed window, two slides per iteration) */
 	bool               rw_mid;    /* v2 mid geometry: <= 65 taps at 3.6..15 samples per firing (96-slot packed window, compact table) */
 	bool               rw_std_compact; /* std geometry on the v3 kernel with the compact4 coefficient table (large -O) */
+	bool               rw_gather; /* v3 gather geometry: s16 input at rates beyond every window (demod_kernel_gat.hip) */
 	bool               rw_hyb;    /* v3 hybrid window: float input outside the std geometry: <= 129 taps at <= 15 samples per firing (160 slots: 80 in VGPRs + 80 in AccVGPRs) or, with rw_mid, <= 65 taps at <= 30 (96 slots); compact4 table */
 	bool               rw_compact4; /* wide / mid / far on the v3 packed rotating window (demod_kernel_rotp.hip): four shifted copies per bank, 16-byte reads */
 	bool               use_rw;    /* v2 register-window kernel eligible (taps <= 65, <= 3.6 samples per firing) */

@@ -81,6 +81,7 @@ template <int GEO, int FMT>
 struct WinP {
 	static constexpr int kTaps = GeoP<GEO>::kTaps, kBack = kTaps - 1, NW = GeoP<GEO>::NW, SLIDE = 16, AMAX = NW - kTaps,
 	                     MAXSL = GeoP<GEO>::MAXSL, BLOCK = GeoP<GEO>::BLOCK, NCH = NW / SLIDE, GD = FMT == 16 ? 16 : 8, REGSLOTS = 0, ROTN = NCH, RING = 32;
+	static constexpr bool GATHER = false;
 	__device__ __forceinline__ void setup(uint32_t) {}
 	static_assert(kBack % SLIDE == 0 && NW % SLIDE == 0, "history and window are whole chunks");
 

@@ -114,6 +114,9 @@ rotwin_demod(const DemodLaunch &L)
 	constexpr int kBack = W::kBack, SLIDE = W::SLIDE, AMAX = W::AMAX, BLOCK = W::BLOCK, NCH = W::NW / W::SLIDE, GPS = W::SLIDE / 4;
 	constexpr int NST = GPS * W::MAXSL;                /* granules staged ahead of the window */
 	constexpr int ROTN = W::ROTN, RING = W::RING, RGR = RING / 8;      /* output ring: RGR groups of 8 symbols (16 bytes) per lane */
+	/* GATHER: no window at all - every firing loads its own taps from memory (sample rates at which the taps of a firing are a
+	 * minority of the samples that pass: demod_kernel_gat.hip) */
+	constexpr bool GATHER = W::GATHER;
 	static_assert(RING == 32 || RING == 16, "output ring");
 	/* per-lane loop state that is only touched once per firing lives in LDS slots [field][lane] unless the window policy has
 	 * registers to spare for it (W::REGSLOTS: bit 0 err, 1 t_prev, 2 flags, 3 sample index of the last symbol) */
@@ -180,8 +183,9 @@ rotwin_demod(const DemodLaunch &L)
 	}
 
 	/* ---- window: the first kBack slots = history ([stream][kBack] float pairs), the rest = the first granules of the block ---- */
-	{
-		const float2 *hist = reinterpret_cast<const float2 *>(L.st.hist) + (size_t)(valid ? stream : 0) * kBack;
+	const float2 *hist_in = reinterpret_cast<const float2 *>(L.st.hist) + (size_t)(valid ? stream : 0) * kBack;
+	if constexpr (!GATHER) {
+		const float2 *hist = hist_in;
 #pragma unroll 1
 		for (int c = 0; c < kBack / SLIDE; c++) win.put_history(hist + c * SLIDE, valid, __builtin_amdgcn_readfirstlane(c));
 #pragma unroll 1
@@ -193,10 +197,12 @@ rotwin_demod(const DemodLaunch &L)
 		}
 	}
 	int g_load = (W::NW - kBack) / 4;                      /* next block granule to fetch (wave-uniform) */
-	RGran<FMT> stg[NST];
+	RGran<FMT> stg[GATHER ? 1 : NST];
+	if constexpr (!GATHER) {
 #pragma unroll
-	for (int i = 0; i < NST; i++) stg[i] = rot_fetch<FMT>(src, 4 * (g_load + i), n);
-	g_load += NST;
+		for (int i = 0; i < NST; i++) stg[i] = rot_fetch<FMT>(src, 4 * (g_load + i), n);
+		g_load += NST;
+	}
 
 	__syncthreads();                                       /* coefficient rows + LUT visible */
 
@@ -251,6 +257,7 @@ rotwin_demod(const DemodLaunch &L)
 #endif
 
 		/* ---- (2) slide: when nobody needs logical chunk 0 any more it becomes the newest chunk ---- */
+		if constexpr (!GATHER)
 #pragma unroll
 		for (int r = 0; r < W::MAXSL; r++) {
 			const int a_now = v_cur - kBack - base;
@@ -278,11 +285,12 @@ rotwin_demod(const DemodLaunch &L)
 		ROT_TICK(1);
 		/* ---- (3) the firing, if its taps are inside the window ---- */
 		const int a = v_cur - kBack - base;
-		if (fired && a <= AMAX) {
+		if (fired && (GATHER || a <= AMAX)) {
 			fired = false;
 			const int bank = interp - 1 - fire_sub;                     /* filter.c:52 */
 			cf32 y;
-			win.fir(ctab_addr, a, bank, C, __builtin_amdgcn_readfirstlane(rot), y.re, y.im);
+			if constexpr (GATHER) win.fir_gather(ctab_addr, src, hist_in, v_cur, n, bank, C, y.re, y.im);
+			else win.fir(ctab_addr, a, bank, C, __builtin_amdgcn_readfirstlane(rot), y.re, y.im);
 			if (PRIO) __builtin_amdgcn_s_setprio(2);
 			ROT_TICK(2);
 #ifdef ROT_EXP_TIMING

@@ -305,7 +305,10 @@ PLAN_CASES = {
     "1.024 MS/s mid": (dict(samplerate=1024000), 0, "v3 rotating packed window, mid"),
     "1.8 MS/s far": (dict(samplerate=1800000), 0, "v3 rotating packed window, far"),
     "3.2 MS/s far (44 samples per firing)": (dict(samplerate=3200000), 0, "v3 rotating packed window, far"),
-    "3.4 MS/s: past the far window": (dict(samplerate=3400000), 0, "v1 LDS ring"),
+    "3.4 MS/s: past the far window -> gather": (dict(samplerate=3400000), 0, "v3 gather: s16 input beyond every window, 65 taps"),
+    "10 MS/s -> gather": (dict(samplerate=10000000), 0, "v3 gather"),
+    "4 MS/s long filter -> gather": (dict(samplerate=4000000, rrc_order=64, interp_factor=4), 0, "v3 gather: s16 input beyond every window, 129 taps"),
+    "6 MS/s u8: v1": (dict(samplerate=6000000, bps=8), 0, "v1 LDS ring"),
     "2.048 MS/s long filter: wide": (dict(samplerate=2048000, rrc_order=64, interp_factor=4), 0, "v3 rotating packed window, wide"),
     "float std": (dict(samplerate=230000, bps=32), 0, "v3 rotating register window"),
     "float mid -> hybrid": (dict(samplerate=1024000, bps=32), 0, "v3 hybrid window, mid"),
