@@ -105,7 +105,7 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 		return MDEMOD_OK;
 	}
 	if (ctx->tab.use_rw && ctx->tab.rw_gather)
-		HIP_TRY(mdemod_launch_demod_gat(L, ctx->tab.c.taps > 65 ? 1 : 0, ctx->lds_bytes, stream));
+		HIP_TRY(mdemod_launch_demod_gat(L, ctx->params.bps, ctx->tab.c.taps > 65 ? 1 : 0, ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw && ctx->tab.rw_hyb)
 		HIP_TRY(mdemod_launch_demod_roth(L, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw && ctx->use_rot)
@@ -659,8 +659,8 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (!ctx) return "";
 	if (wants_latency_kernel(ctx)) return "demod_kernel_lat (one stream per wave: FIR farm + serial scalar stage)";
 	if (!ctx->tab.use_rw) return "demod_kernel (v1 LDS ring)";
-	if (ctx->tab.rw_gather) return ctx->tab.c.taps > 65 ? "demod_kernel_gat (v3 gather: s16 input beyond every window, 129 taps, every firing loads its own taps)"
-	                                                     : "demod_kernel_gat (v3 gather: s16 input beyond every window, 65 taps, every firing loads its own taps)";
+	if (ctx->tab.rw_gather) return ctx->tab.c.taps > 65 ? "demod_kernel_gat (v3 gather: sample rates beyond every window, 129 taps, every firing loads its own taps)"
+	                                                     : "demod_kernel_gat (v3 gather: sample rates beyond every window, 65 taps, every firing loads its own taps)";
 	if (ctx->tab.rw_hyb && ctx->tab.rw_far) return "demod_kernel_roth (v3 hybrid window, far: float input, 65 taps at up to 54 samples per firing, 80 slots in VGPRs + 40 in AccVGPRs)";
 	if (ctx->tab.rw_hyb) return ctx->tab.rw_mid ? "demod_kernel_roth (v3 hybrid window, mid: float input, 65 taps at up to 30 samples per firing, 80 slots in VGPRs + 16 in AccVGPRs)"
 	                                            : "demod_kernel_roth (v3 hybrid window: float input, 129 taps, 80 slots in VGPRs + 80 in AccVGPRs)";

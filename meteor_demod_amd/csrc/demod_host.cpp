@@ -142,9 +142,9 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	/* the long filter at 15..30 samples per firing (s16 / u8): the wide window has the 31 alignments for it and slides once per
 	 * loop iteration, so such a firing takes two iterations */
 	const bool wide_far_ok = generation >= 2 && !std_ok && !wide_ok && !far_ok && per_firing <= 30.0 && c.taps <= 129 && p.bps != 32;
-	/* gather: s16 input at rates none of the windows reaches (more than 46 samples per firing, 30 with the long filter): no window,
+	/* gather: rates none of the windows reaches (more than 46 samples per firing, 30 with the long filter): no window,
 	 * every firing loads its own taps (demod_kernel_gat.hip) */
-	const bool gather_ok = generation >= 2 && p.bps == 16 && c.taps <= 129 && !std_ok && !wide_ok && !far_ok && !wide_far_ok;
+	const bool gather_ok = generation >= 2 && c.taps <= (p.bps == 32 ? 65 : 129) && !std_ok && !wide_ok && !far_ok && !wide_far_ok && !hyb_ok;
 	const bool allow_rw = generation >= 1;
 	out.rw_gather = gather_ok;
 	out.rw_hyb = hyb_ok;
@@ -192,8 +192,8 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		return MDEMOD_OK;
 	}
 	if (out.rw_gather) {
-		/* compact4 layout with three alignments: the 0..3 samples between a 16-byte step and the oldest tap */
-		const int kTaps = c.taps <= 65 ? 65 : 129, AMAX = 3, LP = kTaps + 2 * AMAX;
+		/* compact4 layout with as many alignments as samples in a 16-byte load: the samples between such a step and the oldest tap */
+		const int kTaps = c.taps <= 65 ? 65 : 129, AMAX = (p.bps == 8 ? 8 : (p.bps == 16 ? 4 : 2)) - 1, LP = kTaps + 2 * AMAX;
 		c.hpad = kTaps - 1;
 		c.win_granules = (kTaps + 3) / 4;
 		c.ring_granules = 0;

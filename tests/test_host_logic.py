@@ -305,10 +305,12 @@ PLAN_CASES = {
     "1.024 MS/s mid": (dict(samplerate=1024000), 0, "v3 rotating packed window, mid"),
     "1.8 MS/s far": (dict(samplerate=1800000), 0, "v3 rotating packed window, far"),
     "3.2 MS/s far (44 samples per firing)": (dict(samplerate=3200000), 0, "v3 rotating packed window, far"),
-    "3.4 MS/s: past the far window -> gather": (dict(samplerate=3400000), 0, "v3 gather: s16 input beyond every window, 65 taps"),
+    "3.4 MS/s: past the far window -> gather": (dict(samplerate=3400000), 0, "v3 gather: sample rates beyond every window, 65 taps"),
     "10 MS/s -> gather": (dict(samplerate=10000000), 0, "v3 gather"),
-    "4 MS/s long filter -> gather": (dict(samplerate=4000000, rrc_order=64, interp_factor=4), 0, "v3 gather: s16 input beyond every window, 129 taps"),
-    "6 MS/s u8: v1": (dict(samplerate=6000000, bps=8), 0, "v1 LDS ring"),
+    "4 MS/s long filter -> gather": (dict(samplerate=4000000, rrc_order=64, interp_factor=4), 0, "v3 gather: sample rates beyond every window, 129 taps"),
+    "6 MS/s u8 -> gather": (dict(samplerate=6000000, bps=8), 0, "v3 gather"),
+    "6 MS/s float -> gather": (dict(samplerate=6000000, bps=32), 0, "v3 gather: sample rates beyond every window, 65 taps"),
+    "6 MS/s float, long filter: v1": (dict(samplerate=6000000, rrc_order=64, interp_factor=4, bps=32), 0, "v1 LDS ring"),
     "2.048 MS/s long filter: wide": (dict(samplerate=2048000, rrc_order=64, interp_factor=4), 0, "v3 rotating packed window, wide"),
     "float std": (dict(samplerate=230000, bps=32), 0, "v3 rotating register window"),
     "float mid -> hybrid": (dict(samplerate=1024000, bps=32), 0, "v3 hybrid window, mid"),
@@ -316,7 +318,7 @@ PLAN_CASES = {
     "float long filter -> hybrid": (dict(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32), 0, "v3 hybrid window: float input, 129 taps"),
     "float long filter at 2.048 MS/s": (dict(samplerate=2048000, rrc_order=64, interp_factor=4, bps=32), 0, "v3 hybrid window: float input, 129 taps"),
     "float 3.2 MS/s -> hybrid far": (dict(samplerate=3200000, bps=32), 0, "v3 hybrid window, far"),
-    "float 4 MS/s: v1": (dict(samplerate=4000000, bps=32), 0, "v1 LDS ring"),
+    "float 4 MS/s -> gather (55.6 samples per firing)": (dict(samplerate=4000000, bps=32), 0, "v3 gather"),
     "-O 32: compact table keeps v3": (dict(samplerate=230000, interp_factor=32), 0, "v3 rotating register window"),
     "161 taps: v1": (dict(samplerate=230000, rrc_order=80), 0, "v1 LDS ring"),
     "161 taps x 64 banks: table in global memory": (dict(samplerate=1000000, rrc_order=80, interp_factor=64), 0, "[table in global memory]"),
