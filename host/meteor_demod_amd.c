@@ -360,6 +360,19 @@ run_tiled(struct worker *w)
 	return pool.rc;
 }
 
+/* an error path of run_exact: the full-screen display comes down first (the reference's main.c:241-244 tears it down on every exit),
+ * so that the message lands on a sane terminal */
+static int
+exact_failed(struct worker *w, int code, const char *what, const char *why)
+{
+#ifdef MDEMOD_TUI
+	if (w->tui) { tui_close(); say = printf; }
+#endif
+	fprintf(stderr, "%s: %s\n", what, why);
+	close_all(w->io, w->n_files);
+	return code;
+}
+
 /* ---- exact mode: this worker's files as ONE batch, one stream per file, block by block (main.c:303-316) ---- */
 static int
 run_exact(struct worker *w)
@@ -371,11 +384,12 @@ run_exact(struct worker *w)
 	mdemod_params p = w->p;
 	mdemod_ctx *ctx = NULL;
 	int rc = mdemod_create(&p, &ctx);
-	if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_create: %s\n", mdemod_strerror(rc)); close_all(io, n_files); return 2; }
+	if (rc != MDEMOD_OK) return exact_failed(w, 2, "mdemod_create", mdemod_strerror(rc));
 	if (!quiet) say("Demodulator initialized\n");                                    /* main.c:219 */
 	if (!quiet && !w->tui && n_files < 64 && io[0].file_len > (64ul << 20))
-		fprintf(stderr, "note: %d file%s demodulated exactly = %d serial stream%s, one GPU wavefront each (a few MS/s); --tiled puts a long "
-		        "recording on many lanes (50x faster, same symbols, soft values within +-1 LSB of these on 99.6-99.9 %%)\n",
+		fprintf(stderr, "note: %d file%s demodulated exactly = %d serial stream%s, one GPU wavefront each (about 3.6 MS/s: slower than the "
+		        "reference on one host core); --tiled puts a long recording on many lanes (50x faster, same symbols, soft values within "
+		        "+-1 LSB of these on 99.6-99.9 %%), and a batch of many files fills the GPU in exact mode\n",
 		        n_files, n_files == 1 ? "" : "s", n_files, n_files == 1 ? "" : "s");
 
 	size_t block_buffers = BLOCK_BUFFERS;
@@ -390,7 +404,7 @@ run_exact(struct worker *w)
 	uint32_t *n_in = malloc(sizeof(uint32_t) * (size_t)n_files), *caps = malloc(sizeof(uint32_t) * (size_t)n_files);
 	uint32_t *n_out = malloc(sizeof(uint32_t) * (size_t)n_files);
 	mdemod_status *st = malloc(sizeof(*st) * (size_t)n_files);
-	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) return 1;
+	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) { mdemod_destroy(ctx); return exact_failed(w, 1, "meteor_demod_amd", "out of memory"); }
 
 	double last_status = -1e18;
 #ifdef MDEMOD_TUI
@@ -413,9 +427,9 @@ run_exact(struct worker *w)
 		}
 		if (!active) break;
 		rc = mdemod_process_host(ctx, iq, n_in, outp, caps, n_out);          /* demod(&sample) x n: main.c:304 */
-		if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_process_host: %s\n", mdemod_strerror(rc)); close_all(io, n_files); return 2; }
+		if (rc != MDEMOD_OK) { mdemod_destroy(ctx); return exact_failed(w, 2, "mdemod_process_host", mdemod_strerror(rc)); }
 		rc = mdemod_get_status(ctx, 0, (uint32_t)n_files, st, NULL);
-		if (rc != MDEMOD_OK) { fprintf(stderr, "mdemod_get_status: %s\n", mdemod_strerror(rc)); close_all(io, n_files); return 2; }
+		if (rc != MDEMOD_OK) { mdemod_destroy(ctx); return exact_failed(w, 2, "mdemod_get_status", mdemod_strerror(rc)); }
 		for (int i = 0; i < n_files; i++)
 			write_gated(&io[i], outp[i], n_out[i], st[i].first_lock_symbol);
 #ifdef MDEMOD_TUI

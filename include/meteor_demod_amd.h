@@ -32,6 +32,18 @@
  * globals persist between per-sample calls, so feeding a recording in blocks of
  * any size gives the same bytes as feeding it in one call.
  *
+ * What "drop-in" means here, and what it does not:
+ *   - The per-sample symbols `int demod_qpsk(float complex *)` / `demod_oqpsk` (demod.h:42,50) and the getter symbols
+ *     pll_get_freq / pll_get_locked / pll_did_lock_once / mm_omega / agc_get_gain (pll.h:20,27,34, timing.h:32, agc.h:18) are
+ *     NOT exported (SURVEY 8(b) suggests them as a shim over a CPU backend; this library has no CPU backend by construction, and a
+ *     symbol returned in place per call would be a kernel launch per sample).  An UNMODIFIED main.c therefore does not link
+ *     against this library: the binding is the block call - the patch to main.c's thread_process shown in INTEGRATION.md 1, or
+ *     the C host shipped in host/ with the reference's option table.
+ *   - Exact mode on ONE stream is one wavefront: about 3.6 Msamples/s on configs[1], SLOWER than the reference on one host core
+ *     (about 26 Msamples/s on the bench host).  The GPU is meant to be used on batches of streams (mdemod_process_*, thousands
+ *     of recordings or tiles at 250 Gsamples/s) or on one long recording through mdemod_demodulate_recording (`--tiled`:
+ *     overlapped tiles, agreement with the serial run at the reference's own perturbation floor, not bit-exact).
+ *
  * Plain C: pointers and sizes only.  Device pointers are raw HIP device
  * addresses; `hip_stream` is a hipStream_t passed as void* (NULL = default).
  * There is no CPU fallback: every entry fails with MDEMOD_ERR_HIP if no gfx950
@@ -299,6 +311,10 @@ typedef struct {
 } mdemod_recording_report;
 
 void mdemod_recording_default_opts(mdemod_recording_opts *opts);
+/* Stream ordering: synchronous for the host (returns when soft_dev is complete), ordered on the device AFTER everything already
+ * queued on hip_stream - a caller may produce iq_dev asynchronously on hip_stream (kernel, cast, non-blocking copy) and call this
+ * without synchronising first: the internal streams (serial head, carrier / clock estimators) wait on an event recorded on
+ * hip_stream at entry.  Work queued on OTHER streams is the caller's to order. */
 int  mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_opts *opts,
                                  const void *iq_dev, uint64_t n_samples,
                                  int8_t *soft_dev, uint64_t soft_cap_symbols,

@@ -167,7 +167,11 @@ plan_context(mdemod_ctx *ctx)
 		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
 		       (ctx->tab.use_rw ? static_cast<size_t>((ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
 		                          + static_cast<size_t>(ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) * 64     /* soft-symbol staging: a 32-symbol ring (4 x 16 B) per thread */
-		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes);
+		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes)
+#ifdef MDEMOD_EXP_LDS_EXTRA            /* experimental builds: the v3 kernels' sine table (rotwin_body.h: ROT_SIN_LUT) */
+		       + ((ctx->use_rot || ctx->tab.rw_compact4) ? static_cast<size_t>(MDEMOD_EXP_LDS_EXTRA) : 0)
+#endif
+		       ;
 	};
 	if (ctx->tab.use_rw && lds_need(ctx->block_threads) > 160 * 1024) {
 		/* The per-alignment coefficient rows of the v2 std geometry grow with -O (16 alignments x interp x 84 floats: past the

@@ -22,6 +22,20 @@
 
 struct cf32 { float re, im; };
 
+/* Wave votes taken on the lane mask itself.  HIP's __all / __any go through an integer per lane (v_cndmask_b32 0/1 + v_cmp_ne_u32:
+ * two VALU instructions of 4.4 SIMD-cycles each per vote, and the loop body votes nine times per firing); the ballot of a
+ * comparison is the comparison's own mask.  Same semantics: over the active lanes. */
+__device__ __forceinline__ bool md_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool md_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
+/* MAX(-b, MIN(b, x)) of the reference's macros (utils.h: `(a) < (b) ? (a) : (b)`) for a bound b > 0, as ONE v_med3_f32 instead of
+ * two comparisons and two selects (each of the four a 4.4-cycle VALU instruction on gfx950: tools/ubench/valu_mix.hip).  Equal for
+ * every finite and infinite x including +-0 (the median of {-b, x, b} is x itself whenever -b <= x <= b, else the bound the
+ * macros pick).  A NaN would come out as -b where the macros keep it - but no NaN reaches these points in a run the reference
+ * defines: a non-finite sample sends the reference's own tanh look-up out of bounds one symbol later (pll.c:154-159, see
+ * md_tanh_lut), and the coefficient tables with a NaN tap are refused. */
+__device__ __forceinline__ float md_clamp_sym(float x, float b) { return __builtin_amdgcn_fmed3f(x, -b, b); }
+
 /* sincos.c:24: x = fx * 0x10000 / (2*M_PI) narrowed to int16.  float*int -> float, the
  * division is double, and the double->int16 narrowing is what x86 compilers emit: cvttsd2si
  * to int32, keep the low 16 bits.  Reference form, with the real division. */
@@ -52,7 +66,7 @@ md_turn_code(float fx)
 	 * reference). */
 	if (CHECKED) {
 		const bool out_of_range = !(fabsf(fx) < 16.0f);
-		if (__builtin_expect(__any(out_of_range), 0)) {
+		if (__builtin_expect(md_any(out_of_range), 0)) {
 			if (out_of_range) n = md_turn_code_div(fx);
 		}
 	}
@@ -69,6 +83,41 @@ md_sin_from_code(int32_t wide)
 	int32_t y = 19900 - ((x2 * 3516) >> 14);                /* sincos.c:31    */
 	y = 16384 - ((x2 * y) >> 14);                           /* sincos.c:32    */
 	return (float)(sign < 0 ? -y : y) * (1.0f / 16384.0f);  /* sincos.c:34 (exact: power of two) */
+}
+
+/* The same value from a table in LDS.  The parabola depends on the turn code only through |x| = |(code & 0x7FFF) - 16384|
+ * (sincos.c:26-32 squares x first) and bit 15 (the sign, sincos.c:34): 16 385 entries replace the integer arithmetic above
+ * (md_sin_lut_fill writes them with that very arithmetic; tests sweep all 65 536 codes through both).  T = float: the entry is
+ * y / 16384 (exact); the negation is 0 - y, not a sign flip: sincos.c:34 converts the INTEGER -y, so a zero stays +0.
+ * T = int16_t: the entry is y, negated as an integer and converted like the reference does. */
+template <typename T>
+__device__ __forceinline__ void
+md_sin_lut_fill(T *tab, int tid, int nthreads)
+{
+	for (int i = tid; i <= 16384; i += nthreads) {
+		const int32_t x2 = (i * i) >> 14;
+		int32_t y = 19900 - ((x2 * 3516) >> 14);
+		y = 16384 - ((x2 * y) >> 14);
+		tab[i] = sizeof(T) == 4 ? (T)((float)y * (1.0f / 16384.0f)) : (T)y;
+	}
+}
+
+template <typename T>
+__device__ __forceinline__ float
+md_sin_from_code_lut(const T *tab, int32_t wide)
+{
+	/* |x| in one instruction (hipcc expands __usad into min, max and a subtraction) */
+	uint32_t ax;
+	asm("v_sad_u32 %0, %1, %2, 0" : "=v"(ax) : "v"(wide & 0x7FFF), "s"(16384));
+	if (sizeof(T) == 4) {
+		/* bit 15 of the code becomes the float's sign bit; adding +0 turns the -0 that gives for y == 0 back into the +0 of
+		 * sincos.c:34's (float)(-0) and leaves every other value alone */
+		const uint32_t yb = __float_as_uint((float)tab[ax]);
+		return __uint_as_float(yb | (((uint32_t)wide << 16) & 0x80000000u)) + 0.0f;
+	} else {
+		const int32_t y = (int32_t)tab[ax];
+		return (float)((wide & 0x8000) ? -y : y) * (1.0f / 16384.0f);
+	}
 }
 
 template <bool CHECKED = true>
@@ -181,7 +230,7 @@ md_wrap_2pi(float xf)
 	const float once = (xf < 0.0f) ? (xf + MD_TWO_PI_F) + MD_TWO_PI_LO : (xf - MD_TWO_PI_F) - MD_TWO_PI_LO;
 	float r = wraps ? once : xf;
 	const bool far = !(fabsf(xf) < MD_FOUR_PI_F);              /* also NaN and inf: fmod's business */
-	if (__builtin_expect(__any(far), 0)) {
+	if (__builtin_expect(md_any(far), 0)) {
 		if (far) r = (float)fmod((double)xf, MD_TWO_PI_D);
 	}
 	return r;
@@ -204,7 +253,7 @@ __device__ __forceinline__ float
 md_tanh_lut_uniform(const float *lut, float v)
 {
 	float t = (v >= 15.0f) ? 1.0f : -1.0f;
-	if (__any(v > -16.0f && v < 15.0f)) t = md_tanh_lut(lut, v);
+	if (md_any(v > -16.0f && v < 15.0f)) t = md_tanh_lut(lut, v);
 	return t;
 }
 
@@ -238,7 +287,7 @@ md_pll_update(PllState &p, const float *lut, float alpha, float beta, float fmax
 	const int changed = (lock_now || unlock_now) ? 1 : 0;
 
 	/* pll.c:125: freq += 0.000001 * updown while unlocked (double; +-1e-6 exactly) */
-	if (__any(!p.locked)) {
+	if (md_any(!p.locked)) {
 		const float swept = (float)((double)p.freq + (p.updown > 0 ? 0.000001 : -0.000001));
 		p.freq = p.locked ? p.freq : swept;
 	}
@@ -246,6 +295,40 @@ md_pll_update(PllState &p, const float *lut, float alpha, float beta, float fmax
 	p.freq = (fmax < p.freq) ? fmax : p.freq;        /* MIN(fmax, freq)  */
 	p.freq = (-fmax > p.freq) ? -fmax : p.freq;      /* MAX(-fmax, .)    */
 	return changed;
+}
+
+/* pll.c:100-130 with the three flags kept PACKED in one word (bit 0 locked, bit 1 locked_once, bit 2 updown > 0: the layout of
+ * the state array), the lock detector as bit arithmetic: v_and / v_or / v_xor / v_add are 2.6-cycle instructions on gfx950, the
+ * compare + select pairs md_pll_update's int fields compile to 4.4 each (and there were nine of each per firing).  Same values,
+ * same order of the float and double operations.  Returns nonzero when `locked` changed; first != 0: the first lock ever. */
+struct PllWord { float phase, freq, err; };
+__device__ __forceinline__ uint32_t
+md_pll_update_packed(PllWord &p, uint32_t &fl, const float *lut, float alpha, float beta, float fmax, float i, float q, uint32_t &first)
+{
+	const float e = md_tanh_lut(lut, i) * q - md_tanh_lut(lut, q) * i;        /* pll.c:143-151 */
+
+	const float ph = p.phase + alpha * e;
+	p.phase = md_wrap_2pi(ph);                                               /* pll.c:113 */
+	p.freq = p.freq + beta * e;
+
+	const float decayed = p.err * (1.0f - 0.001f);
+	p.err = (float)((double)decayed + fabs((double)e) * (double)0.001f);    /* pll.c:117 */
+
+	/* pll.c:117-123: lock below 85, unlock above 105 (the two exclude each other) */
+	const uint32_t below = (p.err < 85.0f) ? 1u : 0u, above = (p.err > 105.0f) ? 1u : 0u;
+	const uint32_t lock_now = below & (fl ^ 1u);                            /* bit 0: locks on this symbol            */
+	const uint32_t unlock_now = above & fl;                                 /* bit 0: unlocks on this symbol          */
+	const uint32_t lock2 = lock_now + lock_now;                             /* the same in bit 1                      */
+	first = lock2 ^ (lock2 & fl);                                           /* bit 1: locks and never had before      */
+	fl = fl | lock_now | lock2;                                             /* locked = locked_once = 1               */
+	fl = fl ^ (fl & unlock_now);                                            /* locked = 0                             */
+
+	/* pll.c:125: freq += 0.000001 * updown while unlocked (double; +-1e-6 exactly) */
+	if (!(fl & 1u)) p.freq = (float)((double)p.freq + ((fl & 4u) ? 0.000001 : -0.000001));
+	/* pll.c:126-128: turn round at +-fmax, then clamp */
+	fl = (p.freq >= fmax) ? (fl & ~4u) : ((p.freq <= -fmax) ? (fl | 4u) : fl);
+	p.freq = md_clamp_sym(p.freq, fmax);                                    /* MAX(-fmax, MIN(fmax, freq)) */
+	return lock_now | unlock_now;
 }
 
 /* timing.c:60-87,90-95 */
@@ -261,8 +344,7 @@ md_timing_update(float &t_phase, float &t_freq, float &t_prev,
 	float fd = t_freq - center;
 	t_phase = (float)((double)t_phase - (MD_TWO_PI_D + (double)(alpha * e)));
 	fd = fd - beta * e;
-	fd = (maxdev < fd) ? maxdev : fd;
-	fd = (-maxdev > fd) ? -maxdev : fd;
+	fd = md_clamp_sym(fd, maxdev);                 /* timing.c:84: MAX(-maxdev, MIN(maxdev, fd)) */
 	t_freq = center + fd;
 }
 
@@ -270,10 +352,8 @@ md_timing_update(float &t_phase, float &t_freq, float &t_prev,
 __device__ __forceinline__ int
 md_quantise(float v)
 {
-	float h = v * 0.5f;                 /* v/2, exact */
-	h = (127.0f < h) ? 127.0f : h;
-	h = (-127.0f > h) ? -127.0f : h;
-	return (int)h;                      /* truncation toward zero */
+	const float h = md_clamp_sym(v * 0.5f, 127.0f);      /* v/2 is exact; main.c:305: MAX(-127, MIN(127, v/2)) */
+	return (int)h;                                       /* truncation toward zero */
 }
 
 #endif

@@ -149,6 +149,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	out.rw_gather = gather_ok;
 	out.rw_hyb = hyb_ok;
 	out.rw_std_compact = false;
+	out.rw_compact4 = false;          /* (assigned again below for the packed windows; the std and gather returns leave before that) */
 	out.use_rw = allow_rw && (std_ok || wide_ok || far_ok || hyb_ok || wide_far_ok || gather_ok);
 	out.rw_mid = out.use_rw && !std_ok && (mid_ok || (hyb_ok && !hyb_far_ok && c.taps <= 65));
 	out.rw_far = out.use_rw && (far_ok || hyb_far_ok);
@@ -166,7 +167,10 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		/* sixteen rows per bank are 5.4 KB: past -O 18 (100 KB) the v3 kernel takes the compact4 layout of the other geometries instead
 		 * (four shifted copies of the padded taps per bank, 1.6 KB: demod_kernel_rot.hip, WinF<.., COMPACT>) - two more instructions
 		 * per firing for the row address, and -O 29 .. 80 stay off the v1 ring kernel */
-		out.rw_std_compact = generation >= 2 && static_cast<size_t>(AL) * banks * c.ctab_row_stride * sizeof(float) > 100 * 1024;
+#ifndef MDEMOD_STD_COMPACT_ABOVE
+#define MDEMOD_STD_COMPACT_ABOVE (100 * 1024)
+#endif
+		out.rw_std_compact = generation >= 2 && static_cast<size_t>(AL) * banks * c.ctab_row_stride * sizeof(float) > MDEMOD_STD_COMPACT_ABOVE;
 		if (out.rw_std_compact) {
 			const int AMAX = NW - kTaps, LP = kTaps + 2 * AMAX;
 			c.ctab_row_floats = LP;

@@ -268,13 +268,13 @@ demod_kernel(const DemodLaunch L)
 				if (t_phase >= thr) fired = true;
 			}
 		}
-		if (__all(done)) break;
+		if (md_all(done)) break;
 
 		/* (3) refill decision (wave-uniform) and fetch, one iteration ahead */
 		if (g_hi < g_need) {
 			const int v_low = done ? 0x3FFFFFFF : (v_cur - hpad);
 			const bool room = (g_hi + CHUNK - G) <= (v_low >> 2);
-			if (__all(room)) {
+			if (md_all(room)) {
 #pragma unroll
 				for (int c = 0; c < CHUNK; c++) {
 					const int m0 = ((g_hi + c) << 2) - hpad;   /* first block sample of the granule */

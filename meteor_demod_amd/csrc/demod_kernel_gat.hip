@@ -64,7 +64,7 @@ struct WinG {
 		const int o = AMAX - d;
 		const uint32_t row = ctab_addr + 4u * (uint32_t)(__mul24(bank * 4 + (o & 3), C.ctab_row_stride) + (o & ~3));
 		gpair_t acc = { 0.0f, 0.0f };
-		if (__builtin_expect(__all(start >= 0 && start + NS <= n), 1)) {
+		if (__builtin_expect(md_all(start >= 0 && start + NS <= n), 1)) {
 			uint4 raw[NS / G];
 #pragma unroll
 			for (int g = 0; g < NS / G; g++) __builtin_memcpy(&raw[g], src + start + G * g, 16);

@@ -1,6 +1,7 @@
 /*
  * demod_kernel_rotp.hip — v3 rotating PACKED register window: the wide (up to 129 taps, <= 15 samples per firing), mid
- * (<= 65 taps, <= 15) and far (<= 65 taps, <= 30) geometries for s16 and u8 input.
+ * (<= 65 taps, <= 15) and far (<= 65 taps, <= 46: 47 alignments) geometries for s16 and u8 input; the wide window also takes 66..129 taps at
+ * 15..30 samples per firing (two loop iterations per firing).
  *
  * The kernel body is rotwin_body.h (shared with demod_kernel_rot.hip); this file is the window policy: 96..160 slots of RAW
  * samples in registers that belong to the generated assembly of rotpk_asm.h (gen_rotpk_asm.py: ring of per-chunk FIR code,
@@ -122,11 +123,11 @@ struct WinP {
 		 * last in chunk (a + kTaps - 1) / 16 */
 		int c_lo = 0;
 #pragma unroll
-		for (int k = 1; 16 * k <= AMAX; k++) c_lo += __all(a >= 16 * k) ? 1 : 0;
+		for (int k = 1; 16 * k <= AMAX; k++) c_lo += md_all(a >= 16 * k) ? 1 : 0;
 		constexpr int C_HI_MAX = (AMAX + kTaps - 1) / 16;
 		int c_hi = C_HI_MAX;
 #pragma unroll
-		for (int k = C_HI_MAX; 16 * k - kTaps >= 0; k--) c_hi -= __all(a <= 16 * k - kTaps) ? 1 : 0;
+		for (int k = C_HI_MAX; 16 * k - kTaps >= 0; k--) c_hi -= md_all(a <= 16 * k - kTaps) ? 1 : 0;
 		int entry = rot + c_lo;
 		entry = entry >= NCH ? entry - NCH : entry;
 		AsmP<GEO, FMT>::fir(addr + 64u * (uint32_t)c_lo, __builtin_amdgcn_readfirstlane(entry), __builtin_amdgcn_readfirstlane(c_hi - c_lo), re, im);

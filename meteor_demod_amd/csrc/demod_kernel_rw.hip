@@ -453,14 +453,14 @@ demod_kernel_rw(const DemodLaunch L)
 				if (t_phase >= thr) fired = true;
 			}
 		}
-		if (__all(done)) break;
+		if (md_all(done)) break;
 		if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 
 		/* ---- (2) slide the window by 8 slots when nobody needs slots 0..7 any more ---- */
 #pragma unroll
 		for (int r = 0; r < G::MAXSL; r++) {
 			const int a_now = v_cur - kBack - base;
-			if (__all(done || a_now >= SLIDE)) {
+			if (md_all(done || a_now >= SLIDE)) {
 #pragma unroll
 				for (int k = 0; k < NW - SLIDE; k++) win[k] = win[k + SLIDE];
 #pragma unroll
@@ -481,7 +481,7 @@ demod_kernel_rw(const DemodLaunch L)
 					asm volatile("" : "+v"(tie) : "v"(win[NW - SLIDE + k]), "v"(win[NW - SLIDE + k + 1]),
 					                              "v"(win[NW - SLIDE + k + 2]), "v"(win[NW - SLIDE + k + 3]));
 				const int m_new = 4 * g_load + tie;
-				if (__all(m_new + 4 * SG - 1 < n)) {
+				if (md_all(m_new + 4 * SG - 1 < n)) {
 #pragma unroll
 					for (int g = 0; g < SG; g++) __builtin_memcpy(&stg[NST - SG + g], src + m_new + 4 * g, sizeof(Gran<FMT>));
 				} else {
@@ -507,8 +507,8 @@ demod_kernel_rw(const DemodLaunch L)
 			cf32 y;
 			/* slots 0..7 carry only zeros for a lane with a >= 8, the last 8 slots only zeros for
 			 * a <= AMAX - 8: when the whole wave agrees the chunk is dropped (exact: acc + 0*x == acc). */
-			const bool skip_first = __all(a >= 8);              /* over the lanes active in this branch */
-			const bool skip_last = __all(a <= AMAX - 8);
+			const bool skip_first = md_all(a >= 8);              /* over the lanes active in this branch */
+			const bool skip_last = md_all(a <= AMAX - 8);
 			fir_window<NW, W, !G::COMPACT, (MDEMOD_RW_PREFETCH == 2 && !PACKED && !G::COMPACT && FMT != 32) ? 2 : 1>(win, row, skip_first, skip_last, y.re, y.im);
 			/* Two waves share a SIMD.  The FIR is ~290 independent VALU instructions, the scalar stage a chain of short
 			 * dependent ones (AGC -> NCO -> mix -> loops): when the arbiter interleaves them evenly, the chain waits behind
@@ -559,14 +559,14 @@ demod_kernel_rw(const DemodLaunch L)
 				 * an LDS state word (deriving "no sample consumed since" from the symbol clock instead measured 2 % slower). */
 				const bool again = (v_cur == sli[S_LASTV * 64]);
 				sli[S_LASTV * 64] = v_cur;
-				const bool any_again = __any(again);
+				const bool any_again = md_any(again);
 				if (any_again) { if (again) sym_call--; }
 				float t_prev = sl[S_TPREV * 64];
 				md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);
 				sl[S_TPREV * 64] = t_prev;
 				int first = 0;
 				const int changed = md_pll_update(pll, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
-				if (__any(changed)) {                      /* rare: one wave-uniform test on the hot path */
+				if (md_any(changed)) {                      /* rare: one wave-uniform test on the hot path */
 				if (first) sli[S_FIRSTLOCK * 64] = (int)sym_call;
 				if (changed) {
 					const int ev_call = sli[S_EVCALL * 64];

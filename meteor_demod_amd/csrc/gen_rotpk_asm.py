@@ -20,7 +20,7 @@ converted at every use:
           its top bit flipped, read as signed, is wavfile.c:61's `byte - 128`).
 
 Registers: window v[256 - NWR .. 255], then 4 temporaries and 16 coefficient registers below it; the compiler stays below those
-(`amdgpu_num_vgpr`, checked by build.py: check_asm_partition).
+(`amdgpu_num_vgpr`; build.py: check_rot_partition scans the emitted assembly of every kernel of this file against its ROTPK_<GEO>_<FMT>_LIMIT, inside build() and in the CPU tests).
 """
 import os
 import sys

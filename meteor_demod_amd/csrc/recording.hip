@@ -898,6 +898,9 @@ struct Stitcher {
 	std::vector<double> tclk, centre, fbar, slope, slope_tile; int nfft = 0; float min_quality = 8.0f; std::vector<uint64_t> wstart; double f_pilot_target = 0;
 	std::vector<double> ge_cx; std::vector<float> ge_th, ge_cq; uint32_t ge_wc = 0; bool ge_no_carrier = true, ge_clock_deferred = false;
 	struct EstThread { std::thread t; int rc = MDEMOD_OK; ~EstThread() { if (t.joinable()) t.join(); } } est;
+	/* recorded on the caller's stream at entry: the estimators read iq_dev on a stream of their own and must come after whatever
+	   the caller queued on hip_stream to produce it (declared after `est`: destroyed once the thread is joined) */
+	struct InputReady { hipEvent_t ev = nullptr; ~InputReady() { if (ev) (void)hipEventDestroy(ev); } } input_ready;
 	/* seeds */
 	std::vector<float> f0, tf, gains; std::vector<int32_t> ud; float *d_f0 = nullptr, *d_tf = nullptr, *d_gain = nullptr; int32_t *d_ud = nullptr;
 	/* the bank's buffers and what the launches leave in them */
@@ -1099,6 +1102,7 @@ struct Stitcher {
 			HTRY(hipStreamCreateWithPriority(&own.s, hipStreamNonBlocking, least));
 		}
 		hipStream_t es = own.s;
+		if (input_ready.ev) HTRY(hipStreamWaitEvent(es, input_ready.ev, 0));
 		DevMem emem;
 		if (need) (*need)(n_samples);                          /* the host-buffer entry is still copying the recording in */
 		nfft = static_cast<int>(mdemod_carrier_window_samples(params, static_cast<uint32_t>(std::min(262144.0, 20536.0 * osf))));
@@ -1651,6 +1655,8 @@ struct Stitcher {
 	int run_all()
 	{
 		TRY(prepare());
+		HTRY(hipEventCreateWithFlags(&input_ready.ev, hipEventDisableTiming));
+		HTRY(hipEventRecord(input_ready.ev, st));
 		try {
 			est.t = std::thread([this]() { est.rc = estimate_grid(); });    /* joined by estimate_carriers, or by ~EstThread on an early return */
 		} catch (...) {

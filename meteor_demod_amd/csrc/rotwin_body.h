@@ -25,6 +25,19 @@
 
 #pragma clang fp contract(off)
 
+#ifndef ROT_SIN_LUT
+#define ROT_SIN_LUT 0            /* 0: fast_sin's parabola in integer arithmetic; 1: int16 table in LDS (32 KB); 2: float table (64 KB) */
+#endif
+#ifndef ROT_OQ_SYNC
+#define ROT_OQ_SYNC 1            /* OQPSK: the lanes of a wave take their I-rail and Q-rail firings in the same loop iterations */
+#endif
+#if ROT_SIN_LUT == 1
+typedef int16_t rot_sinlut_t;
+#elif ROT_SIN_LUT == 2
+typedef float rot_sinlut_t;
+#endif
+#define ROT_SIN_LUT_BYTES ((16385 * (ROT_SIN_LUT == 2 ? 4 : 2) + 15) / 16 * 16)
+
 namespace {
 
 template <int FMT> struct RFmt;
@@ -133,7 +146,14 @@ rotwin_demod(const DemodLaunch &L)
 	uint4 *stage = reinterpret_cast<uint4 *>(lut + 32 + (BLOCK / 64) * (S_COUNT * 64)) + threadIdx.x;
 	const uint32_t ctab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
 	W win;
+#if ROT_SIN_LUT
+	/* fast_sin's parabola as a table behind the output rings (demod_device.h: md_sin_from_code_lut; the host sizes the LDS) */
+	rot_sinlut_t *sintab = reinterpret_cast<rot_sinlut_t *>(stage - threadIdx.x + BLOCK * RGR);
+	md_sin_lut_fill(sintab, (int)threadIdx.x, BLOCK);
+	win.setup(ctab_addr + (uint32_t)(reinterpret_cast<unsigned char *>(stage - threadIdx.x + BLOCK * RGR) - lds) + ROT_SIN_LUT_BYTES);
+#else
 	win.setup(ctab_addr + (uint32_t)(reinterpret_cast<unsigned char *>(stage - threadIdx.x + BLOCK * RGR) - lds));
+#endif
 
 	const DemodConsts &C = L.c;
 	const uint32_t stream = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,6 +227,11 @@ rotwin_demod(const DemodLaunch &L)
 	__syncthreads();                                       /* coefficient rows + LUT visible */
 
 	int rot = 0;                                           /* physical chunk that is logical chunk 0 (wave-uniform) */
+	/* OQPSK: demod.c:62-84 does half the work on the I-rail firing (state 1: one mixer product, no timing or Costas update, no
+	 * symbol).  The lanes of a wave are independent streams and would take their rails in any order; here a loop iteration serves
+	 * ONE rail (wave-uniform `slot`, alternating), a lane whose pending firing is on the other rail waits an iteration - so the
+	 * `emit` branches below are scalar and the I-rail iterations skip that code instead of running it masked off. */
+	int slot = 1;
 	int base = 0;
 	int v_cur = kBack - 1;
 	int isub = 0, fire_sub = 0;
@@ -250,7 +275,7 @@ rotwin_demod(const DemodLaunch &L)
 				if (t_phase >= thr) fired = true;
 			}
 		}
-		if (__all(done)) break;
+		if (md_all(done)) break;
 		ROT_TICK(0);
 #ifdef ROT_EXP_TIMING
 		n_iter++;
@@ -261,7 +286,7 @@ rotwin_demod(const DemodLaunch &L)
 #pragma unroll
 		for (int r = 0; r < W::MAXSL; r++) {
 			const int a_now = v_cur - kBack - base;
-			if (__all(done || a_now >= SLIDE)) {
+			if (md_all(done || a_now >= SLIDE)) {
 				RGran<FMT> g[GPS];
 #pragma unroll
 				for (int i = 0; i < GPS; i++) g[i] = stg[i];
@@ -271,7 +296,7 @@ rotwin_demod(const DemodLaunch &L)
 #pragma unroll
 				for (int i = 0; i + GPS < NST; i++) stg[i] = stg[i + GPS];
 				const int m_new = 4 * g_load;
-				if (__all(m_new + SLIDE - 1 < n)) {
+				if (md_all(m_new + SLIDE - 1 < n)) {
 #pragma unroll
 					for (int i = 0; i < GPS; i++) __builtin_memcpy(&stg[NST - GPS + i], src + m_new + 4 * i, sizeof(RGran<FMT>));
 				} else {
@@ -285,7 +310,7 @@ rotwin_demod(const DemodLaunch &L)
 		ROT_TICK(1);
 		/* ---- (3) the firing, if its taps are inside the window ---- */
 		const int a = v_cur - kBack - base;
-		if (fired && (GATHER || a <= AMAX)) {
+		if (fired && (GATHER || a <= AMAX) && (!(OQPSK && ROT_OQ_SYNC) || dual_state == slot)) {
 			fired = false;
 			const int bank = interp - 1 - fire_sub;                     /* filter.c:52 */
 			cf32 y;
@@ -298,22 +323,27 @@ rotwin_demod(const DemodLaunch &L)
 #endif
 
 			y = md_agc(y, r_gain, r_bias_re, r_bias_im);
-			int fl = ld_flags();
-			PllState pll;
+			uint32_t fl = (uint32_t)ld_flags();          /* bit 0 locked, 1 locked_once, 2 updown > 0, 3 overflow */
+			PllWord pll;
 			pll.phase = r_phase; pll.freq = r_freq;
 			pll.err = ld_err();
-			pll.locked = fl & 1; pll.locked_once = (fl >> 1) & 1; pll.updown = (fl & 4) ? 1 : -1;
 
+#if ROT_SIN_LUT
+			const float sn = md_sin_from_code_lut(sintab, md_turn_code<false>(-pll.phase));
+			const float cs = md_sin_from_code_lut(sintab, md_turn_code<false>((float)((double)(-pll.phase) + MD_HALF_PI_D)));   /* sincos.c:37-40 */
+#else
 			const float sn = md_fast_sin<false>(-pll.phase);
 			const float cs = md_fast_cos<false>(-pll.phase);
+#endif
 			bool emit = true;
 			float out_re, out_im;
 			if (OQPSK) {
 				float inphase = sl[S_INPHASE * 64];
-				if (dual_state == 1) { inphase = y.re * cs - y.im * sn; emit = false; sl[S_INPHASE * 64] = inphase; }   /* demod.c:66-71 */
+				const int rail = ROT_OQ_SYNC ? slot : dual_state;
+				if (rail == 1) { inphase = y.re * cs - y.im * sn; emit = false; sl[S_INPHASE * 64] = inphase; }   /* demod.c:66-71 */
 				out_re = inphase;
 				out_im = y.re * sn + y.im * cs;                                          /* demod.c:76    */
-				dual_state = (dual_state % 2) + 1;                                       /* timing.c:52   */
+				dual_state = 3 - rail;                                                   /* timing.c:52   */
 			} else {
 				out_re = y.re * cs - y.im * sn;
 				out_im = y.re * sn + y.im * cs;
@@ -324,7 +354,7 @@ rotwin_demod(const DemodLaunch &L)
 				/* demod.c:33-47: only the LAST symbol fired inside one input sample survives (see demod_kernel_rw.hip) */
 				const bool again = (v_cur == ld_lastv());
 				st_lastv(v_cur);
-				if (__builtin_expect(__any(again), 0)) { if (again) sym_call--; }
+				if (__builtin_expect(md_any(again), 0)) { if (again) sym_call--; }
 				float t_prev = ld_tprev();
 				md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);
 				st_tprev(t_prev);
@@ -333,19 +363,17 @@ rotwin_demod(const DemodLaunch &L)
 			 * update, next to the Costas update, the AGC's square root and the quantiser, which need nothing from it */
 			rot_clock_fast<KS>(K, OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F, v_end, t_phase, t_freq, isub, v_cur, fire_sub, fired);
 			if (emit) {
-				int first = 0;
-				const int changed = md_pll_update(pll, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
-				if (__builtin_expect(__any(changed), 0)) {
+				uint32_t first = 0;
+				const uint32_t changed = md_pll_update_packed(pll, fl, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
+				if (__builtin_expect(changed != 0, 0)) {          /* a plain divergent branch: skipped when no lane of the wave takes it */
 					if (first) sli[S_FIRSTLOCK * 64] = (int)sym_call;
-					if (changed) {
-						const int ev_call = sli[S_EVCALL * 64];
-						if (ev_call < MDEMOD_MAX_LOCK_EVENTS) {
-							mdemod_lock_event ev;
-							ev.symbol = L.st.n_symbols[stream] + sym_call; ev.locked = pll.locked; ev.pad = 0;
-							L.st.events[(size_t)stream * MDEMOD_MAX_LOCK_EVENTS + ev_call] = ev;
-						}
-						sli[S_EVCALL * 64] = ev_call + 1;
+					const int ev_call = sli[S_EVCALL * 64];
+					if (ev_call < MDEMOD_MAX_LOCK_EVENTS) {
+						mdemod_lock_event ev;
+						ev.symbol = L.st.n_symbols[stream] + sym_call; ev.locked = (int)(fl & 1u); ev.pad = 0;
+						L.st.events[(size_t)stream * MDEMOD_MAX_LOCK_EVENTS + ev_call] = ev;
 					}
+					sli[S_EVCALL * 64] = ev_call + 1;
 				}
 				const uint32_t sym = (uint32_t)(md_quantise(out_re) & 0xFF) | ((uint32_t)(md_quantise(out_im) & 0xFF) << 8);
 				/* RING-symbol ring per lane in LDS, [16-byte group][thread]; every RING symbols one full run (64 bytes for 32) goes out */
@@ -376,10 +404,11 @@ rotwin_demod(const DemodLaunch &L)
 			}
 			r_phase = pll.phase; r_freq = pll.freq;
 			st_err(pll.err);
-			st_flags((fl & 8) | (pll.locked ? 1 : 0) | (pll.locked_once ? 2 : 0) | (pll.updown > 0 ? 4 : 0));
+			st_flags((int)fl);
 			if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
 			ROT_TICK(3);
 		}
+		if (OQPSK && ROT_OQ_SYNC) slot = __builtin_amdgcn_readfirstlane(3 - slot);      /* (keeps it in an SGPR: scalar branches) */
 	} while (--guard);
 #ifdef ROT_EXP_TIMING
 	if (blockIdx.x == 100 && threadIdx.x == 0)

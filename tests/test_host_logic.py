@@ -207,11 +207,38 @@ def test_cli_device_plan_is_round_robin():
 
 
 def test_rotating_window_register_partition():
-    """demod_kernel_rot.hip hands v[ROTWIN_LIMIT..255] to hand-written assembly and keeps hipcc below with `amdgpu_num_vgpr`,
-    whose unit is an observed property of the compiler (two registers on gfx90a+), not a documented one: check the emitted
-    assembly - no compiler-generated instruction may touch a register of the window or of the coefficient buffers."""
-    from meteor_demod_amd.build import check_rot_partition
-    assert check_rot_partition() == []
+    """The v3 kernels hand the top of the VGPR file (and of the AccVGPR file) to hand-written assembly and keep hipcc below with
+    `amdgpu_num_vgpr`, whose unit is an observed property of the compiler (two registers on gfx90a+), not a documented one: check
+    the emitted assembly of EVERY assembly-owning file (demod_kernel_rot.hip: std + hybrid; demod_kernel_rotp.hip: wide / mid /
+    far, s16 / u8, the configs[3] instance among them) - no compiler-generated instruction may touch a register of a window or of
+    the coefficient buffers, no scratch inside the main loops, no scratch at all in the std kernels.  build() runs the same check on
+    the assembly of the objects it links and fails the BUILD on a violation; here it runs on that assembly (or compiles afresh)."""
+    from meteor_demod_amd import build as B
+    files = {"demod_kernel_rot": B.LIB / "demod_kernel_rot.gfx950.s", "demod_kernel_rotp": B.LIB / "demod_kernel_rotp.gfx950.s"}
+    assert B.check_rot_partition(files) == []
+    # every kernel of both files is covered by a limit, and the limits are the generated headers' own
+    limits = B._asm_limits()
+    assert limits["demod_kernel_rot"][0] == 80 and len([k for k in limits if k.startswith("demod_kernel_rotp_")]) == 6
+
+
+def test_register_partition_check_catches_a_violation():
+    """A deliberately lowered limit must be reported (so that a compiler bump that moves a value into the assembly's registers
+    fails the build): the compiler does use the registers just below each limit."""
+    from meteor_demod_amd import build as B
+    limits = B._asm_limits()
+    for stem, key in (("demod_kernel_rot", "demod_kernel_rot"), ("demod_kernel_rotp", "demod_kernel_rotp_WIDE_16_")):
+        path = B.LIB / (stem + ".gfx950.s")
+        if not path.exists():
+            B.build()
+        text = path.read_text()
+        assert B.scan_asm_partition(text, limits, B.SCRATCH_FREE) == []
+        lowered = dict(limits)
+        lowered[key] = (limits[key][0] - 24, limits[key][1])
+        bad = B.scan_asm_partition(text, lowered, B.SCRATCH_FREE)
+        assert bad and all(key.rstrip("_") in b for b in bad), (key, bad[:3])
+    # a kernel that must be scratch-free and is not
+    fake = text.replace("demod_kernel_rotp_WIDE_16_0_ks109", "demod_kernel_rotILi16ELi0ELi14ELi0E_fake")
+    assert any("scratch" in b for b in B.scan_asm_partition(fake, {**limits, "demod_kernel_rotILi16ELi0ELi14ELi0E_fake": (76, 0)}, B.SCRATCH_FREE))
 
 
 def test_carrier_window_rounding_is_host_logic():
