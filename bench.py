@@ -46,6 +46,10 @@ def parse() -> argparse.Namespace:
                          "puts all 64 lanes of a wave on the same L2 channel/sets (measured: 3.4x over-fetch, -3 %% throughput)")
     ap.add_argument("--config", default="c1", choices=["c1", "c3", "c4"], help="c1 = the headline config")
     ap.add_argument("--fanin", action="store_true", help="also gather soft symbols on rank 0 (timed separately)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="dry run of the N > 1 path on ONE GPU: every rank on device 0, gloo for the barrier / the reductions / the "
+                         "fan-in (rows staged through host memory).  Exercises the whole world > 1 control flow where only one GPU can be "
+                         "reached; what it cannot show is the RCCL transport itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -367,6 +371,8 @@ def spawn_ranks(args) -> int:
     import socket
     import torch
     have = torch.cuda.device_count()
+    if args.oversubscribe:
+        have = args.gpus if have >= 1 else 0        # every rank on device 0
     if have < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s); refusing to print an N={have} line "
                          f"labelled as {args.gpus}\n")
@@ -388,13 +394,17 @@ def main() -> None:
     from meteor_demod_amd import Demodulator, synth
     from meteor_demod_amd.sharding import fanin_soft, init_from_env
 
-    rank, local, world = init_from_env()
+    rank, local, world = init_from_env("gloo" if args.oversubscribe else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the demodulator has no CPU path")
+    if args.oversubscribe:
+        local = 0
     torch.cuda.set_device(local)
     dist = torch.distributed if world > 1 else None
+    # device tensors for RCCL, host tensors for the oversubscribed dry run's gloo
+    coll_dev = "cpu" if args.oversubscribe else f"cuda:{local}"
 
     cfg, workload = demod_config(args.config)
     T, L = args.tiles, args.tile_samples
@@ -428,25 +438,44 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
 
+    kernel_ms_ranks = None
     if dist:
-        tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=f"cuda:{local}")
+        tt = torch.tensor([elapsed, kernel_ms, -kernel_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        kernel_ms_ranks = {"min": round(-float(tt[2]), 3), "max": round(float(tt[1]), 3), "this_rank": round(kernel_ms, 3)}   # a straggler GPU shows here
         elapsed, kernel_ms = float(tt[0]), float(tt[1])
 
     fanin_ms = fanin_bytes = None
+    fanin_ok = None
     if args.fanin and dist:
         # fan-in of the soft symbols to rank 0 over RCCL (outside the timed region): rows compacted on the device to the
         # nominal symbol pitch first (0.63 B per input sample instead of the hard-bound 2 B), then one gather
-        counts = torch.from_numpy(d.status_array()["symbols_this_call"].astype("int32")).to(f"cuda:{local}")
+        counts = torch.from_numpy(d.status_array()["symbols_this_call"].astype("int32")).to(coll_dev)
         pitch = d.nominal_pitch(L)
         torch.cuda.synchronize(); dist.barrier()
         t1 = time.perf_counter()
         packed = d.compact(soft, pitch)
-        got, _ = fanin_soft(packed, counts, T * world, dst=0)
+        if args.oversubscribe:
+            packed = packed.cpu()                    # gloo: the rows go through host memory
+        got, got_counts = fanin_soft(packed, counts, T * world, dst=0)
         torch.cuda.synchronize(); dist.barrier()
         fanin_ms = (time.perf_counter() - t1) * 1e3
         fanin_bytes = int(packed.numel()) * (world - 1)
+        if rank == 0:
+            # what arrived is what this rank sent for its own shard, and every row has its count
+            fanin_ok = bool(torch.equal(got[:T].cpu(), packed.cpu()) and int(got_counts.numel()) == T * world and int(got_counts.min()) > 0)
         del packed, got
+
+    # every rank checks sampled tiles of ITS buffer against the oracle (the checker, after the timed region); rank 0 reports
+    ranks_check = None
+    if dist and not args.no_check:
+        try:
+            verdict = spot_check(cfg, d, x, T, L, n_check=2)
+        except Exception as e:                       # (no oracle on this box: report it, never fail the measurement over the checker)
+            verdict = f"not checked: {type(e).__name__}: {e}"
+        ok = torch.tensor([1 if "identical" in verdict else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        ranks_check = (f"every rank: {verdict}" if int(ok[0]) else f"NOT byte-identical on every rank (rank {rank}: {verdict})")
 
     if rank != 0:
         if dist:
@@ -505,12 +534,18 @@ def main() -> None:
                               "valu_instructions_source": f"profiles/hbm_traffic.json (round {prof_round}, SQ_INSTS_VALU)" if valu_per_firing else None},
                      "kernel": d.kernel_name,
                      "kernel_ms": round(kernel_ms, 3),
+                     **({"kernel_ms_over_ranks": kernel_ms_ranks} if kernel_ms_ranks else {}),
                      "algorithmic_bytes_per_sample": round(bytes_per_sample, 4)},
     }
     if fanin_ms is not None:
-        out["fanin"] = {"ms": round(fanin_ms, 2), "bytes_over_xgmi": fanin_bytes,
+        out["fanin"] = {"ms": round(fanin_ms, 2), "rows_of_rank0_intact_and_all_counts_there": fanin_ok, "bytes_over_xgmi": fanin_bytes,
                         "gbytes_per_s": round(fanin_bytes / (fanin_ms * 1e-3) / 1e9, 1), "row_pitch_symbols": d.nominal_pitch(L),
                         "note": "compact to nominal pitch + RCCL gather to rank 0, outside the timed region"}
+    if ranks_check is not None:
+        out["check"] = ranks_check
+    if args.oversubscribe:
+        out["oversubscribed"] = (f"DRY RUN: {world} ranks on ONE GPU (device 0), gloo instead of RCCL - the world > 1 control flow, not a "
+                                 "scaling measurement; `value` is what one GPU gives when it is shared")
     if world == 1 and not args.no_cpu_baseline:
         # The CPU leg: the only place in this file that touches oracle/ — it times the reference's own
         # code on the host cores and (unless --no-check) uses the oracle as CHECKER on sampled tiles.

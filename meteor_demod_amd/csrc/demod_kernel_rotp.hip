@@ -27,24 +27,25 @@ template <> struct GeoP<1> { static constexpr int kTaps = 65, NW = MDEMOD_RW_MID
 template <> struct GeoP<2> { static constexpr int kTaps = 65, NW = MDEMOD_RW_FAR_NW, MAXSL = 2, BLOCK = MDEMOD_RW_BLOCK; };
 static_assert(MDEMOD_RW_WIDE_NW == 160 && MDEMOD_RW_MID_NW == 96 && MDEMOD_RW_FAR_NW == 112, "gen_rotpk_asm.py: GEOS");
 
-/* the assembly of one (geometry, format): FIR over chunks [entry, entry + cnt] of the ring, and the slide */
+/* the assembly of one (geometry, format): FIR over `cnt` + 1 groups of four slots from half-chunk `entry` of the ring (its second
+ * group when `lead`), and the slide */
 template <int GEO, int FMT> struct AsmP;
 #if ROTPK_FORM == 0             /* plain f32 products and sums: the accumulator is two registers */
 #define ROTP_FIR_CALL(TEXT, CLOB)                                                                                             \
 	float ar = 0.0f, ai = 0.0f;                                                                                               \
 	asm volatile(TEXT : [ar] "+v"(ar), [ai] "+v"(ai), [addr] "+v"(addr), [cnt] "+s"(cnt), [tmp] "=&s"(tmp)                    \
-	             : [entry] "s"(entry) : "vcc", "scc", CLOB);                                                                  \
+	             : [entry] "s"(entry), [lead] "s"(lead) : "vcc", "scc", CLOB);                                                \
 	re = ar; im = ai;
 #else                           /* packed products and sums: the accumulator is an aligned register pair */
 #define ROTP_FIR_CALL(TEXT, CLOB)                                                                                             \
 	pair_t acc = { 0.0f, 0.0f };                                                                                              \
 	asm volatile(TEXT : [acc] "+v"(acc), [addr] "+v"(addr), [cnt] "+s"(cnt), [tmp] "=&s"(tmp)                                 \
-	             : [entry] "s"(entry) : "vcc", "scc", CLOB);                                                                  \
+	             : [entry] "s"(entry), [lead] "s"(lead) : "vcc", "scc", CLOB);                                                \
 	re = acc.x; im = acc.y;
 #endif
 #define ROTP_ASM(GEO, NAME, FMT)                                                                                              \
 	template <> struct AsmP<GEO, FMT> {                                                                                       \
-		__device__ static __forceinline__ void fir(uint32_t addr, int entry, int cnt, float &re, float &im)                   \
+		__device__ static __forceinline__ void fir(uint32_t addr, int entry, int lead, int cnt, float &re, float &im)         \
 		{                                                                                                                     \
 			int tmp;                                                                                                          \
 			ROTP_FIR_CALL(ROTPK_##NAME##_##FMT##_FIR_ASM, ROTPK_##NAME##_##FMT##_CLOBBERS)                                     \
@@ -118,19 +119,26 @@ struct WinP {
 		/* compact4 table: per bank the taps padded with AMAX zeros either side, four copies shifted by 0..3 floats: the lane at
 		 * alignment a reads P[(AMAX - a) + s] for slot s = copy ((AMAX - a) & 3) at the 16-byte aligned index ((AMAX - a) & ~3) + s */
 		const int o = AMAX - a;
-		uint32_t addr = ctab_addr + 4u * (uint32_t)(__mul24(bank * 4 + (o & 3), C.ctab_row_stride) + (o & ~3));
-		/* chunks that are padding for every lane of the wave are not entered: the first tap of a lane is in chunk a / 16, its
-		 * last in chunk (a + kTaps - 1) / 16 */
-		int c_lo = 0;
+		uint32_t addr = rot_mad24((uint32_t)(bank * 4 + (o & 3)), 4u * (uint32_t)C.ctab_row_stride, ctab_addr + 4u * (uint32_t)(o & ~3));
+		/* groups of four slots that are padding for every lane of the wave are not run: the first tap of a lane is in group a / 4,
+		 * its last in group (a + kTaps - 1) / 4; the wave's extremes by bisection on votes (one comparison each) */
+		constexpr int QB = AMAX / 4 >= 8 ? 4 : 3;                 /* bits of a / 4 */
+		static_assert(AMAX / 4 < (1 << QB) && (kTaps - 1) % 4 == 0, "alignments in groups of four");
+		int q_lo = 0, q_hi = (1 << QB) - 1;
 #pragma unroll
-		for (int k = 1; 16 * k <= AMAX; k++) c_lo += md_all(a >= 16 * k) ? 1 : 0;
-		constexpr int C_HI_MAX = (AMAX + kTaps - 1) / 16;
-		int c_hi = C_HI_MAX;
-#pragma unroll
-		for (int k = C_HI_MAX; 16 * k - kTaps >= 0; k--) c_hi -= md_all(a <= 16 * k - kTaps) ? 1 : 0;
-		int entry = rot + c_lo;
-		entry = entry >= NCH ? entry - NCH : entry;
-		AsmP<GEO, FMT>::fir(addr + 64u * (uint32_t)c_lo, __builtin_amdgcn_readfirstlane(entry), __builtin_amdgcn_readfirstlane(c_hi - c_lo), re, im);
+		for (int b = QB - 1; b >= 0; b--) {
+			const int t = q_lo + (1 << b);
+			q_lo = md_all(a >= 4 * t) ? t : q_lo;
+			const int u = q_hi - (1 << b);
+			q_hi = md_all(a < 4 * (u + 1)) ? u : q_hi;
+		}
+		q_lo = __builtin_amdgcn_readfirstlane(q_lo); q_hi = __builtin_amdgcn_readfirstlane(q_hi);
+		const int c_lo = q_lo >> 2;                               /* the chunk of the first group */
+		int chunk = rot + c_lo;
+		chunk = chunk >= NCH ? chunk - NCH : chunk;
+		const int entry = 2 * chunk + ((q_lo >> 1) & 1), lead = q_lo & 1;
+		const int cnt = q_hi + (kTaps - 1) / 4 - q_lo;            /* groups to run - 1 */
+		AsmP<GEO, FMT>::fir(addr + 64u * (uint32_t)c_lo, __builtin_amdgcn_readfirstlane(entry), __builtin_amdgcn_readfirstlane(lead), __builtin_amdgcn_readfirstlane(cnt), re, im);
 	}
 };
 

@@ -64,53 +64,80 @@ def jump(tag, idx):
 
 
 def fir(nw, fmt):
+    """The ring of half-chunks (8 slots = two groups of 4 taps), entered and left at GROUP granularity: %[entry] = physical
+    half-chunk of the first group any lane of the wave needs, %[lead] = 1 when that is the half-chunk's second group, %[cnt] =
+    groups to run - 1, %[addr] = coefficient of slot 0 of the entry half-chunk's CHUNK.  (Until round 4 the ring was entered
+    and left by whole 16-slot chunks: 15 slots of padding on average where this has 3 - 8 % of configs[3]'s taps.)"""
     nwr, wb, tb, cb = layout(nw, fmt)
     nch = nw // 16
-    D = 3
+    assert PAIRWAIT, "the group-granular ring is built on the pairwise prefetch"
 
     def load(g):                                # group g of the chunk at %[addr] (g may reach into the next chunk)
         b = cb + 4 * (g % 4)
         return "ds_read_b128 v[%d:%d], %%[addr] offset:%d" % (b, b + 3, 16 * g)
 
-    L = [load(g) for g in range(2 if PAIRWAIT else D)]
-    L += jump("fir", "entry")
-    for p in range(nch):
-        L += [".Lfir_%d_%%=:" % p]
-        for g in range(4):
-            if PAIRWAIT:
-                if g % 2 == 0:
-                    L += [load(g + 2), load(g + 3), "s_waitcnt lgkmcnt(2)"]
-            else:
-                L += [load(g + D), "s_waitcnt lgkmcnt(%d)" % D]
-            hb = cb + 4 * g
+    def group(p, g):
+        hb = cb + 4 * g
 
-            def src(j):                         # the raw word of slot 4g + j of physical chunk p, and the SDWA selects of (re, im)
-                s = 4 * g + j
-                if fmt == 16:
-                    return wb + 16 * p + s, "WORD_0", "WORD_1"
-                return wb + 8 * p + s // 2, "BYTE_%d" % (2 * (s & 1)), "BYTE_%d" % (2 * (s & 1) + 1)
+        def src(j):                         # the raw word of slot 4g + j of physical chunk p, and the SDWA selects of (re, im)
+            s = 4 * g + j
+            if fmt == 16:
+                return wb + 16 * p + s, "WORD_0", "WORD_1"
+            return wb + 8 * p + s // 2, "BYTE_%d" % (2 * (s & 1)), "BYTE_%d" % (2 * (s & 1) + 1)
 
-            def cvt(j):
-                r, a, b = src(j)
-                t = tb + 2 * (j & 1)
-                return ["v_cvt_f32_i32_sdwa v%d, sext(v%d) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:%s" % (t, r, a),
-                        "v_cvt_f32_i32_sdwa v%d, sext(v%d) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:%s" % (t + 1, r, b)]
+        def cvt(j):
+            r, a, b = src(j)
+            t = tb + 2 * (j & 1)
+            return ["v_cvt_f32_i32_sdwa v%d, sext(v%d) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:%s" % (t, r, a),
+                    "v_cvt_f32_i32_sdwa v%d, sext(v%d) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:%s" % (t + 1, r, b)]
 
-            def mul(j):
-                t = tb + 2 * (j & 1)
-                h = hb + 2 * (j // 2)
-                if FORM == 0:
-                    return ["v_mul_f32 v%d, v%d, v%d" % (t, hb + j, t), "v_mul_f32 v%d, v%d, v%d" % (t + 1, hb + j, t + 1)]
-                return ["v_pk_mul_f32 v[%d:%d], v[%d:%d], v[%d:%d] op_sel:[0,%d] op_sel_hi:[1,%d]" % (t, t + 1, t, t + 1, h, h + 1, j & 1, j & 1)]
+        def mul(j):
+            t = tb + 2 * (j & 1)
+            h = hb + 2 * (j // 2)
+            if FORM == 0:
+                return ["v_mul_f32 v%d, v%d, v%d" % (t, hb + j, t), "v_mul_f32 v%d, v%d, v%d" % (t + 1, hb + j, t + 1)]
+            return ["v_pk_mul_f32 v[%d:%d], v[%d:%d], v[%d:%d] op_sel:[0,%d] op_sel_hi:[1,%d]" % (t, t + 1, t, t + 1, h, h + 1, j & 1, j & 1)]
 
-            def add(j):
-                t = tb + 2 * (j & 1)
-                if FORM == 0:
-                    return ["v_add_f32 %%[ar], %%[ar], v%d" % t, "v_add_f32 %%[ai], %%[ai], v%d" % (t + 1)]
-                return ["v_pk_add_f32 %%[acc], %%[acc], v[%d:%d]" % (t, t + 1)]
+        def add(j):
+            t = tb + 2 * (j & 1)
+            if FORM == 0:
+                return ["v_add_f32 %%[ar], %%[ar], v%d" % t, "v_add_f32 %%[ai], %%[ai], v%d" % (t + 1)]
+            return ["v_pk_add_f32 %%[acc], %%[acc], v[%d:%d]" % (t, t + 1)]
 
-            L += cvt(0) + cvt(1) + mul(0) + mul(1) + add(0) + cvt(2) + add(1) + cvt(3) + mul(2) + mul(3) + add(2) + add(3)
-        L += ["v_add_u32 %[addr], 64, %[addr]", "s_sub_u32 %[cnt], %[cnt], 1", "s_cbranch_scc1 .Lfir_end_%="]
+        return cvt(0) + cvt(1) + mul(0) + mul(1) + add(0) + cvt(2) + add(1) + cvt(3) + mul(2) + mul(3) + add(2) + add(3)
+
+    # the coefficients of the first groups, on their way before the jump: four cases (second half of the chunk?, second group of
+    # the half?).  Entering at a second group skips that half-chunk's own prefetch of the NEXT pair: issue it here.
+    L = ["s_bitcmp1_b32 %[entry], 0", "s_cbranch_scc1 .Lpro_h1_%=",
+         "s_bitcmp1_b32 %[lead], 0", "s_cbranch_scc1 .Lpro_01_%=",
+         load(0), load(1), "s_branch .Lpro_done_%=",
+         ".Lpro_01_%=:", load(1), load(2), load(3), "s_waitcnt lgkmcnt(2)", "s_branch .Lpro_done_%=",
+         ".Lpro_h1_%=:", "s_bitcmp1_b32 %[lead], 0", "s_cbranch_scc1 .Lpro_11_%=",
+         load(2), load(3), "s_branch .Lpro_done_%=",
+         ".Lpro_11_%=:", load(3), load(4), load(5), "s_waitcnt lgkmcnt(2)",
+         ".Lpro_done_%=:"]
+    # computed jump to half-chunk %[entry] (all of one size), plus the size of a first group when %[lead]
+    L += ["s_getpc_b64 vcc",
+          ".Lfir_pc_%=:",
+          "s_mul_i32 %[tmp], %[entry], (.Lfir_1_%= - .Lfir_0_%=)",
+          "s_add_u32 %[tmp], %[tmp], (.Lfir_0_%= - .Lfir_pc_%=)",
+          "s_add_u32 vcc_lo, vcc_lo, %[tmp]",
+          "s_addc_u32 vcc_hi, vcc_hi, 0",
+          "s_mul_i32 %[tmp], %[lead], (.Lfir_0g1_%= - .Lfir_0_%=)",
+          "s_add_u32 vcc_lo, vcc_lo, %[tmp]",
+          "s_addc_u32 vcc_hi, vcc_hi, 0",
+          "s_setpc_b64 vcc"]
+    for h in range(2 * nch):
+        p, half = h // 2, h % 2
+        L += [".Lfir_%d_%%=:" % h]
+        L += [load(2 * half + 2), load(2 * half + 3), "s_waitcnt lgkmcnt(2)"]
+        L += group(p, 2 * half)
+        L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cbranch_scc1 .Lfir_end_%="]
+        L += [".Lfir_%dg1_%%=:" % h]
+        L += group(p, 2 * half + 1)
+        # the chunk's base moves on after its second half (an instruction of the same size in the first half keeps the halves alike)
+        L += ["v_add_u32 %[addr], 64, %[addr]" if half else "s_nop 0"]
+        L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cbranch_scc1 .Lfir_end_%="]
     L += ["s_branch .Lfir_0_%=", ".Lfir_end_%=:", "s_waitcnt lgkmcnt(0)"]
     return L
 

@@ -68,6 +68,16 @@ rot_fetch(const typename RFmt<FMT>::sample_t *src, int m0, int n)
 	return g;
 }
 
+/* a * b + c for a, b < 2^24 (b wave-uniform): v_mad_u32_u24 by hand - hipcc turns __mul24 of values it cannot bound into
+ * v_mul_lo_u32 plus a v_bfe_i32 */
+__device__ __forceinline__ uint32_t
+rot_mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t r;
+	asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+	return r;
+}
+
 template <int K>
 __device__ __forceinline__ float
 blind_steps(float p, float f)

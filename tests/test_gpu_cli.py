@@ -54,7 +54,7 @@ def test_cli_spreads_files_over_devices(manifest, tmp_path, gpu_device):
     worker its own batch and its own outputs (streams shard, nothing crosses GPUs).  Two workers on THIS box's one
     GPU exercise all of it (threads, contexts side by side); with two GPUs the same on both.  Outputs = the reference binary's."""
     from meteor_demod_amd import _capi
-    names = ["file_wav_s16", "file_never_locks", "file_wav_s16", "file_never_locks", "file_wav_s16"]
+    names = ["file_wav_s16", "file_never_locks", "file_wav_s16", "file_never_locks", "file_wav_s16", "file_never_locks", "file_wav_s16", "file_wav_s16"]
     paths = []
     for k, n in enumerate(names):
         p = tmp_path / f"{k}_{n}.wav"
@@ -71,6 +71,10 @@ def test_cli_spreads_files_over_devices(manifest, tmp_path, gpu_device):
                 got = Path(str(p) + ".s").read_bytes()
                 if not extra:
                     assert got == load_npz(n)["out"].tobytes(), (devs, n)
+                    # ... and what the same file gives when it is the only one (one worker, one stream)
+                    single = tmp_path / "single.s"
+                    r1 = subprocess.run([str(CLI), "-q", "-o", str(single), str(p)], capture_output=True, text=True, cwd=tmp_path)
+                    assert r1.returncode == 0 and single.read_bytes() == got, (devs, n)
                 else:                            # tiled: same length and lock gate (short files: the head is most of them)
                     assert len(got) == len(load_npz(n)["out"].tobytes()), (devs, n)
 
