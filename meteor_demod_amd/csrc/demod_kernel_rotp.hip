@@ -27,25 +27,25 @@ template <> struct GeoP<1> { static constexpr int kTaps = 65, NW = MDEMOD_RW_MID
 template <> struct GeoP<2> { static constexpr int kTaps = 65, NW = MDEMOD_RW_FAR_NW, MAXSL = 2, BLOCK = MDEMOD_RW_BLOCK; };
 static_assert(MDEMOD_RW_WIDE_NW == 160 && MDEMOD_RW_MID_NW == 96 && MDEMOD_RW_FAR_NW == 112, "gen_rotpk_asm.py: GEOS");
 
-/* the assembly of one (geometry, format): FIR over `cnt` + 1 groups of four slots from half-chunk `entry` of the ring (its second
- * group when `lead`), and the slide */
+/* the assembly of one (geometry, format): the FIR from group `sub` of chunk `entry` of the ring until `cnt` + 1 exit points have
+ * gone by, and the slide */
 template <int GEO, int FMT> struct AsmP;
 #if ROTPK_FORM == 0             /* plain f32 products and sums: the accumulator is two registers */
 #define ROTP_FIR_CALL(TEXT, CLOB)                                                                                             \
 	float ar = 0.0f, ai = 0.0f;                                                                                               \
 	asm volatile(TEXT : [ar] "+v"(ar), [ai] "+v"(ai), [addr] "+v"(addr), [cnt] "+s"(cnt), [tmp] "=&s"(tmp)                    \
-	             : [entry] "s"(entry), [lead] "s"(lead) : "vcc", "scc", CLOB);                                                \
+	             : [entry] "s"(entry), [sub] "s"(sub) : "vcc", "scc", CLOB);                                                \
 	re = ar; im = ai;
 #else                           /* packed products and sums: the accumulator is an aligned register pair */
 #define ROTP_FIR_CALL(TEXT, CLOB)                                                                                             \
 	pair_t acc = { 0.0f, 0.0f };                                                                                              \
 	asm volatile(TEXT : [acc] "+v"(acc), [addr] "+v"(addr), [cnt] "+s"(cnt), [tmp] "=&s"(tmp)                                 \
-	             : [entry] "s"(entry), [lead] "s"(lead) : "vcc", "scc", CLOB);                                                \
+	             : [entry] "s"(entry), [sub] "s"(sub) : "vcc", "scc", CLOB);                                                \
 	re = acc.x; im = acc.y;
 #endif
 #define ROTP_ASM(GEO, NAME, FMT)                                                                                              \
 	template <> struct AsmP<GEO, FMT> {                                                                                       \
-		__device__ static __forceinline__ void fir(uint32_t addr, int entry, int lead, int cnt, float &re, float &im)         \
+		__device__ static __forceinline__ void fir(uint32_t addr, int entry, int sub, int cnt, float &re, float &im)          \
 		{                                                                                                                     \
 			int tmp;                                                                                                          \
 			ROTP_FIR_CALL(ROTPK_##NAME##_##FMT##_FIR_ASM, ROTPK_##NAME##_##FMT##_CLOBBERS)                                     \
@@ -136,9 +136,11 @@ struct WinP {
 		const int c_lo = q_lo >> 2;                               /* the chunk of the first group */
 		int chunk = rot + c_lo;
 		chunk = chunk >= NCH ? chunk - NCH : chunk;
-		const int entry = 2 * chunk + ((q_lo >> 1) & 1), lead = q_lo & 1;
-		const int cnt = q_hi + (kTaps - 1) / 4 - q_lo;            /* groups to run - 1 */
-		AsmP<GEO, FMT>::fir(addr + 64u * (uint32_t)c_lo, __builtin_amdgcn_readfirstlane(entry), __builtin_amdgcn_readfirstlane(lead), __builtin_amdgcn_readfirstlane(cnt), re, im);
+		const int sub = q_lo & 3;                                 /* the first group's place in its chunk */
+		/* exit points of the ring (ROTPK_EXIT slots apart) to pass before leaving: the last tap's group is q_hi + (kTaps - 1) / 4 */
+		constexpr int XS = ROTPK_EXIT / 4;                        /* groups per exit point */
+		const int cnt = (q_hi + (kTaps - 1) / 4) / XS - q_lo / XS;
+		AsmP<GEO, FMT>::fir(addr + 64u * (uint32_t)c_lo, __builtin_amdgcn_readfirstlane(chunk), __builtin_amdgcn_readfirstlane(sub), __builtin_amdgcn_readfirstlane(cnt), re, im);
 	}
 };
 

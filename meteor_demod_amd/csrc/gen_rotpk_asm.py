@@ -31,6 +31,8 @@ FORM = int(os.environ.get("ROTPK_FORM", "1"))
 # coefficient prefetch: 0 = one load and one s_waitcnt per group of 4 taps, three groups ahead; 1 = two loads and one s_waitcnt
 # per PAIR of groups, two groups ahead at the wait (half the s_waitcnt instructions)
 PAIRWAIT = int(os.environ.get("ROTPK_PAIRWAIT", "1"))
+# slots between two points at which the FIR ring can be left: 4 (after every group), 8 (every half-chunk) or 16 (every chunk)
+EXIT = int(os.environ.get("ROTPK_EXIT", "4"))      # (configs[3], GS/s on one box: 16: 423, 8: 429, 4: 432; whole-chunk entry as well: 421)
 
 GEOS = {            # name: (embedded taps, window slots)
     "WIDE": (129, 160),
@@ -64,10 +66,10 @@ def jump(tag, idx):
 
 
 def fir(nw, fmt):
-    """The ring of half-chunks (8 slots = two groups of 4 taps), entered and left at GROUP granularity: %[entry] = physical
-    half-chunk of the first group any lane of the wave needs, %[lead] = 1 when that is the half-chunk's second group, %[cnt] =
-    groups to run - 1, %[addr] = coefficient of slot 0 of the entry half-chunk's CHUNK.  (Until round 4 the ring was entered
-    and left by whole 16-slot chunks: 15 slots of padding on average where this has 3 - 8 % of configs[3]'s taps.)"""
+    """The ring of chunks (16 slots = four groups of 4 taps), ENTERED at group granularity: %[entry] = physical chunk of the first
+    group any lane of the wave needs, %[sub] = that group's place in the chunk, %[cnt] = exit points (every EXIT slots) to pass
+    before leaving, %[addr] = coefficient of slot 0 of the entry chunk.  (Until round 4 the ring was also entered by whole
+    chunks: 7.5 slots of leading padding on average where this has 1.5.)"""
     nwr, wb, tb, cb = layout(nw, fmt)
     nch = nw // 16
     assert PAIRWAIT, "the group-granular ring is built on the pairwise prefetch"
@@ -106,38 +108,43 @@ def fir(nw, fmt):
 
         return cvt(0) + cvt(1) + mul(0) + mul(1) + add(0) + cvt(2) + add(1) + cvt(3) + mul(2) + mul(3) + add(2) + add(3)
 
-    # the coefficients of the first groups, on their way before the jump: four cases (second half of the chunk?, second group of
-    # the half?).  Entering at a second group skips that half-chunk's own prefetch of the NEXT pair: issue it here.
-    L = ["s_bitcmp1_b32 %[entry], 0", "s_cbranch_scc1 .Lpro_h1_%=",
-         "s_bitcmp1_b32 %[lead], 0", "s_cbranch_scc1 .Lpro_01_%=",
-         load(0), load(1), "s_branch .Lpro_done_%=",
-         ".Lpro_01_%=:", load(1), load(2), load(3), "s_waitcnt lgkmcnt(2)", "s_branch .Lpro_done_%=",
-         ".Lpro_h1_%=:", "s_bitcmp1_b32 %[lead], 0", "s_cbranch_scc1 .Lpro_11_%=",
-         load(2), load(3), "s_branch .Lpro_done_%=",
-         ".Lpro_11_%=:", load(3), load(4), load(5), "s_waitcnt lgkmcnt(2)",
+    # the coefficients of the first groups, on their way before the jump: one case per group of the chunk the ring is entered at
+    # (%[sub] = 0..3).  Entering at a second group of a half-chunk skips that half-chunk's own prefetch of the NEXT pair: issue it here.
+    # %[tmp] = offset of the group's code within its chunk's (the four groups differ in size: two carry the prefetch, the last the
+    # loop control).
+    L = ["s_cmp_lg_u32 %[sub], 0", "s_cbranch_scc1 .Lpro_n0_%=",
+         load(0), load(1), "s_mov_b32 %[tmp], 0", "s_branch .Lpro_done_%=",
+         ".Lpro_n0_%=:", "s_cmp_lg_u32 %[sub], 1", "s_cbranch_scc1 .Lpro_n1_%=",
+         load(1), load(2), load(3), "s_mov_b32 %[tmp], (.Lfir_0g1_%= - .Lfir_0_%=)", "s_waitcnt lgkmcnt(2)", "s_branch .Lpro_done_%=",
+         ".Lpro_n1_%=:", "s_cmp_lg_u32 %[sub], 2", "s_cbranch_scc1 .Lpro_n2_%=",
+         load(2), load(3), "s_mov_b32 %[tmp], (.Lfir_0g2_%= - .Lfir_0_%=)", "s_branch .Lpro_done_%=",
+         ".Lpro_n2_%=:", load(3), load(4), load(5), "s_mov_b32 %[tmp], (.Lfir_0g3_%= - .Lfir_0_%=)", "s_waitcnt lgkmcnt(2)",
          ".Lpro_done_%=:"]
-    # computed jump to half-chunk %[entry] (all of one size), plus the size of a first group when %[lead]
+    # computed jump to chunk %[entry] (all of one size), plus the offset of group %[sub] within a chunk
     L += ["s_getpc_b64 vcc",
           ".Lfir_pc_%=:",
-          "s_mul_i32 %[tmp], %[entry], (.Lfir_1_%= - .Lfir_0_%=)",
           "s_add_u32 %[tmp], %[tmp], (.Lfir_0_%= - .Lfir_pc_%=)",
           "s_add_u32 vcc_lo, vcc_lo, %[tmp]",
           "s_addc_u32 vcc_hi, vcc_hi, 0",
-          "s_mul_i32 %[tmp], %[lead], (.Lfir_0g1_%= - .Lfir_0_%=)",
+          "s_mul_i32 %[tmp], %[entry], (.Lfir_1_%= - .Lfir_0_%=)",
           "s_add_u32 vcc_lo, vcc_lo, %[tmp]",
           "s_addc_u32 vcc_hi, vcc_hi, 0",
           "s_setpc_b64 vcc"]
-    for h in range(2 * nch):
-        p, half = h // 2, h % 2
-        L += [".Lfir_%d_%%=:" % h]
-        L += [load(2 * half + 2), load(2 * half + 3), "s_waitcnt lgkmcnt(2)"]
-        L += group(p, 2 * half)
-        L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cbranch_scc1 .Lfir_end_%="]
-        L += [".Lfir_%dg1_%%=:" % h]
-        L += group(p, 2 * half + 1)
-        # the chunk's base moves on after its second half (an instruction of the same size in the first half keeps the halves alike)
-        L += ["v_add_u32 %[addr], 64, %[addr]" if half else "s_nop 0"]
-        L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cbranch_scc1 .Lfir_end_%="]
+    test = ["s_sub_u32 %[cnt], %[cnt], 1", "s_cbranch_scc1 .Lfir_end_%="]
+    for p in range(nch):
+        L += [".Lfir_%d_%%=:" % p]
+        for g in range(4):
+            if g:
+                L += [".Lfir_%dg%d_%%=:" % (p, g)]
+            if g % 2 == 0:
+                L += [load(g + 2), load(g + 3), "s_waitcnt lgkmcnt(2)"]
+            L += group(p, g)
+            # the ring is LEFT at the granularity EXIT (slots): every instruction of loop control costs an issue slot of a wave that
+            # has only one other wave to hide behind, so the finest exit is not the fastest (measured on configs[3]: DESIGN.md 5.0)
+            if g == 3:
+                L += ["v_add_u32 %[addr], 64, %[addr]"] + test        # the chunk's base moves on
+            elif EXIT == 4 or (EXIT == 8 and g == 1):
+                L += test
     L += ["s_branch .Lfir_0_%=", ".Lfir_end_%=:", "s_waitcnt lgkmcnt(0)"]
     return L
 
@@ -164,6 +171,7 @@ def main():
         for fmt in (16, 8):
             nwr, wb, tb, cb = layout(nw, fmt)
             tag = "%s_%d" % (name, fmt)
+            out.append("#define ROTPK_EXIT %d" % EXIT) if (name, fmt) == ("WIDE", 16) else None
             out.append("#define ROTPK_%s_LIMIT %d   /* first register the compiler may not use */" % (tag, cb))
             out.append("#define ROTPK_%s_FIR_ASM \\\n" % tag + q(fir(nw, fmt)).replace("\n", " \\\n"))
             out.append("#define ROTPK_%s_PUT_ASM \\\n" % tag + q(put(nw, fmt)).replace("\n", " \\\n"))

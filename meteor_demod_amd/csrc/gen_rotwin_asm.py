@@ -80,18 +80,18 @@ def fir():
             if PAIRWAIT:
                 if h % 2 == 0:
                     L += [load(x) for x in (h + 2 * DC, h + 2 * DC + 1) if x < NH]
-            elif h + D < NH:
-                L += [load(h + D)]
-            # chunk 0 = half-chunks 0 and 1: each is jumped over on its own, so that half-chunk 1's prefetch is still issued
-            if h < 2:
-                L += ["s_bitcmp1_b32 %[flags], 0", "s_cbranch_scc1 .Lfir_%d_s%d_%%=" % (r, h)]
-            if h == NH - 2:
-                L += ["s_bitcmp1_b32 %[flags], 1", "s_cbranch_scc1 .Lfir_%d_s9_%%=" % r]
-            if PAIRWAIT:
-                if h % 2 == 0:
                     L += ["s_waitcnt lgkmcnt(%d)" % min(2 * DC, max(0, NH - 2 - h))]
             else:
+                if h + D < NH:
+                    L += [load(h + D)]
                 L += ["s_waitcnt lgkmcnt(%d)" % min(D, NH - 1 - h)]
+            # padding the whole wave agrees on is not run, by half-chunks of 4 slots: %[flags] bit h (h = 0, 1, 2) - half-chunk h is
+            # in front of every lane's first tap (each is jumped over on its own, after its prefetch and its wait: the next one
+            # may run); bits 3, 4, 5 - half-chunks 19, 18.., 17.. are behind every lane's last tap (the sum leaves before them)
+            if h < 3:
+                L += ["s_bitcmp1_b32 %%[flags], %d" % h, "s_cbranch_scc1 .Lfir_%d_s%d_%%=" % (r, h)]
+            if h >= NH - 3:
+                L += ["s_bitcmp1_b32 %%[flags], %d" % (3 + NH - 1 - h), "s_cbranch_scc1 .Lfir_%d_s9_%%=" % r]
             hb = CB + 4 * (h % NBUF)
             wq = WB + 16 * ((c + r) % NCH) + 8 * (h & 1)
             if PK == 1:
@@ -130,7 +130,7 @@ def fir():
                 if j + 1 < 4:
                     L += mul(j + 1)
                 L += add(j)
-            if h < 2:
+            if h < 3:
                 L += [".Lfir_%d_s%d_%%=:" % (r, h)]
         L += [".Lfir_%d_s9_%%=:" % r, "s_branch .Lfir_end_%="]
     L += [".Lfir_end_%=:", "s_waitcnt lgkmcnt(0)"]
