@@ -56,6 +56,10 @@ def lib() -> C.CDLL:
         h.mdemod_synth_device.argtypes = [C.POINTER(SynthTables), C.POINTER(SynthStream), C.c_uint32, C.c_uint64,
                                           C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
         h.mdemod_synth_device.restype = C.c_int
+        h.mdemod_synth_truth_probe.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        h.mdemod_synth_truth_probe.restype = C.c_int
+        h.mdemod_synth_truth_count.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+        h.mdemod_synth_truth_count.restype = C.c_int
         assert h.mdemod_synth_tables_size() == C.sizeof(SynthTables)
         assert h.mdemod_synth_stream_size() == C.sizeof(SynthStream)
         _lib = h
@@ -114,3 +118,88 @@ def generate_device(streams, count: int, out=None, n0: int = 0, device: int = 0)
     if rc:
         raise RuntimeError(f"mdemod_synth_device failed ({rc})")
     return out
+
+
+# ---- truth check of a demodulated recording (tests / bench) ------------------------------------------------------------------
+
+def _probe(st: SynthStream, soft, m0: int, count: int, lag_min: int = -40, n_lags: int = 81, device: int = 0):
+    """Best (tx rail, lag, inverted, agreement) for the received I rail and for the received Q rail over symbols [m0, m0 + count)."""
+    out = np.zeros((2, 2, n_lags), dtype=np.uint32)
+    rc = lib().mdemod_synth_truth_probe(st.seed, C.c_void_p(soft.data_ptr()), m0, count, lag_min, n_lags, out.ctypes.data, device)
+    if rc:
+        raise RuntimeError(f"mdemod_synth_truth_probe failed ({rc})")
+    hyp = []
+    for r in range(2):
+        dev = np.abs(out[r].astype(np.int64) - count // 2)
+        t, l = np.unravel_index(int(dev.argmax()), dev.shape)
+        agree = int(out[r, t, l])
+        inv = agree < count // 2
+        hyp.append((int(t), int(lag_min + l), int(inv), (count - agree if inv else agree) / count))
+    return hyp
+
+
+def truth_check(st: SynthStream, soft, first_symbol: int = 0, block: int = 65536, device: int = 0, max_probes: int = 256) -> dict:
+    """Hard decisions of the WHOLE device tensor `soft` (int8 [m, 2], the output of a demodulation of stream `st`) against the
+    symbols the generator transmitted, from `first_symbol` on (skip what was demodulated before the PLL's lock).  The pairing
+    (which transmitted rail each received rail carries, at which lag, with which sign = the PLL's quarter-turn ambiguity) is found
+    on the first block that HAS one (both rails agree with some transmitted rail on more than 95 % of the block) and held; a block
+    whose error rate jumps above 2 % is probed again: another pairing from there on is a rotation change or a symbol slip -
+    counted, and the check carries on with it; no pairing at all (a fade, an unlocked stretch) - the blocks are counted as
+    unresolved until one fits again.  At Es/N0 = 12 dB a correct QPSK demodulation has a rail error rate of Q(sqrt(Es/N0)) ~
+    3.4e-5: the transmitted symbols are not the demodulator's fault."""
+    m = int(soft.shape[0])
+    assert soft.is_cuda and soft.dtype.itemsize == 1 and soft.is_contiguous()
+    nb = (m + block - 1) // block
+    size = np.full(nb, block, dtype=np.int64)
+    size[-1] = m - (nb - 1) * block
+    err = np.zeros((2, nb), dtype=np.int64)
+    state = np.zeros(nb, dtype=np.int8)            # 0: not compared, 1: compared, 2: unresolved (no pairing fits)
+    changes, first_pairing, probes = [], None, 0
+    b = (first_symbol + block - 1) // block
+    hyp = None
+    while b < nb and probes < max_probes:
+        if hyp is None:
+            new = _probe(st, soft, b * block, int(size[b]), device=device)
+            probes += 1
+            if min(new[0][3], new[1][3]) < 0.95:
+                state[b] = 2
+                b += 1
+                continue
+            if first_pairing is None:
+                first_pairing = new
+            elif [x[:3] for x in new] != [x[:3] for x in last]:
+                changes.append({"block": int(b), "symbol": int(b * block), "rx_i": new[0][:3], "rx_q": new[1][:3]})
+            hyp = new
+        last = hyp
+        h6 = (C.c_int32 * 6)(hyp[0][0], hyp[0][1], hyp[0][2], hyp[1][0], hyp[1][1], hyp[1][2])
+        e = np.zeros((2, nb), dtype=np.uint32)
+        rc = lib().mdemod_synth_truth_count(st.seed, C.c_void_p(soft.data_ptr()), m, block, h6, e.ctypes.data, device)
+        if rc:
+            raise RuntimeError(f"mdemod_synth_truth_count failed ({rc})")
+        bad = np.flatnonzero(e[:, b:].max(axis=0) > 0.02 * size[b:])
+        stop = b + int(bad[0]) if len(bad) else nb
+        err[:, b:stop] = e[:, b:stop]
+        state[b:stop] = 1
+        b = stop
+        hyp = None                                   # the block at `stop` is probed afresh
+        if b < nb:
+            # a block that is bad under the pairing it is probed to have: the damage is inside it
+            new = _probe(st, soft, b * block, int(size[b]), device=device)
+            probes += 1
+            if [x[:3] for x in new] == [x[:3] for x in last] and min(new[0][3], new[1][3]) >= 0.95:
+                err[:, b] = e[:, b]
+                state[b] = 1
+                hyp = last
+                b += 1
+    cmp_mask = state == 1
+    compared = int(size[cmp_mask].sum())
+    total = int(err[:, cmp_mask].sum())
+    first_cmp = int(np.argmax(cmp_mask)) if cmp_mask.any() else 0
+    res = {"symbols_compared": compared, "first_symbol_compared": first_cmp * block, "rail_decisions_wrong": total,
+           "rail_error_rate": total / (2 * compared) if compared else None, "pairing_changes": len(changes), "changes": changes[:8],
+           "unresolved_blocks": int((state == 2).sum()), "blocks_not_reached": int((state[(first_symbol + block - 1) // block:] == 0).sum()),
+           "worst_block_error_rate": float((err[:, cmp_mask] / size[cmp_mask]).max()) if compared else None, "block_symbols": block}
+    if first_pairing is not None:
+        res["pairing_rx_i"] = {"tx_rail": "IQ"[first_pairing[0][0]], "lag": first_pairing[0][1], "inverted": bool(first_pairing[0][2])}
+        res["pairing_rx_q"] = {"tx_rail": "IQ"[first_pairing[1][0]], "lag": first_pairing[1][1], "inverted": bool(first_pairing[1][2])}
+    return res

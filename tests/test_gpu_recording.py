@@ -3,7 +3,9 @@
 The head of the result (pilot + tile 0) is the serial reference's own bytes; the rest can only agree with the UNTILED serial
 run statistically: a 1-LSB change of ONE input sample leaves 0.2 % of the reference's own symbols more than 1 LSB away for
 millions of symbols (test_perturbation_floor_of_the_reference below measures it with the oracle).  The bars here sit just
-under that floor: symbol count equal, hard decisions >= 0.9999, no weak seam, +-1 LSB >= 0.996 QPSK / 0.994 OQPSK."""
+under that floor: symbol count equal, hard decisions >= 0.9999, no weak seam, +-1 LSB >= 0.996 QPSK / 0.994 OQPSK - and the floor
+itself is measured between two CONVERGED serial runs while they are apart (_converged_pair), which is what a tile is to the
+serial run."""
 from __future__ import annotations
 
 import numpy as np
@@ -52,6 +54,10 @@ def test_single_recording_parity_on_the_bench_configurations(cfg, n, rms, bar, g
     assert rep2.samples_demodulated < 0.6 * rep.samples_demodulated
 
 
+def _windows(ok, W=4096):
+    return np.array([float(ok[i:i + W].mean()) for i in range(0, len(ok) - W + 1, W)])
+
+
 def _floor(cfg, iq_host, at):
     """The reference against itself with ONE input sample changed by 1 LSB: (+-1 LSB fraction, worst 4096-symbol window) after the
     first differing symbol."""
@@ -63,25 +69,50 @@ def _floor(cfg, iq_host, at):
     d = np.abs(a.astype(np.int16) - b.astype(np.int16)).max(axis=1)
     first = int(np.argmax(d > 0))
     ok = d[first:] <= 1
-    wins = [float(ok[i:i + 4096].mean()) for i in range(0, len(ok) - 4095, 4096)]
-    return float(ok.mean()), min(wins)
+    wins = _windows(ok)
+    return float(ok.mean()), float(wins.min())
+
+
+def _converged_pair(cfg, iq_host, dppm=1.0, skip=60000):
+    """Two CONVERGED runs of the reference on the same samples, while they are apart: the serial run and the serial run's own state
+    at a quarter of the recording with its symbol-clock word moved by `dppm` ppm (the loop pulls that in within a few time
+    constants), compared from `skip` symbols later up to the last symbol on which they differ (two runs of the reference do meet
+    again - every float of the state coincides by chance after 1e5..1e7 symbols - and are identical from then on; a tile, emitted
+    for ~2e4 symbols, has no time to).  Returns the +-1 LSB verdict per symbol: the yardstick for a tile against the serial run."""
+    K = len(iq_host) // 4
+    a, b = O.OracleStream(cfg), O.OracleStream(cfg)
+    a.run(iq_host[:K]); b.run(iq_host[:K])
+    b.state.t_freq = np.float32(b.state.t_freq * (1.0 + dppm * 1e-6))
+    sa, sb = a.run(iq_host[K:])[0], b.run(iq_host[K:])[0]
+    assert len(sa) == len(sb)
+    d = np.abs(sa.astype(np.int16) - sb.astype(np.int16)).max(axis=1)
+    last = int(np.flatnonzero(d > 0)[-1]) + 1 if (d > 0).any() else 0
+    return d[skip:last] <= 1
 
 
 def test_perturbation_floor_of_the_reference():
-    """Not a GPU test of ours but the yardstick for the bars above (oracle only): ONE input sample changed by 1 LSB and the
-    reference's own output has ~0.2 % of its symbols more than 1 LSB away from then on (SURVEY: 0.12 % on its signal)."""
+    """Not a GPU test of ours but the yardstick for the bars here (oracle only): ONE input sample changed by 1 LSB and the
+    reference's own output has ~0.2 % of its symbols more than 1 LSB away from then on (SURVEY: 0.12 % on its signal) - and two
+    converged runs that differ in nothing but a pulled-in 1 ppm of symbol clock are as far apart as that for as long as they ARE
+    apart."""
     st = synth.make_stream(1000, 230000, 72000, f0_hz=1200.0, clock_ppm=-3.5)
-    frac, worst = _floor(C1, synth.generate_host(st, 1 << 23), 2_000_000)
+    x = synth.generate_host(st, 1 << 23)
+    frac, worst = _floor(C1, x, 2_000_000)
     assert 0.995 < frac < 0.9995 and worst < 0.999, (frac, worst)
+    ok = _converged_pair(C1, x)
+    assert len(ok) > 200_000 and 0.995 < float(ok.mean()) < 0.9992, (len(ok), float(ok.mean()))
 
 
-@pytest.mark.parametrize("cfg,n,rms,bar,worst_bar", [(C1, 1 << 25, 6000.0, 0.9965, 0.965), (C3, 1 << 25, 6000.0, 0.994, 0.93), (C4, 1 << 26, 2000.0, 0.998, 0.98)],
+@pytest.mark.parametrize("cfg,n,rms,bar", [(C1, 1 << 25, 6000.0, 0.9965), (C3, 1 << 25, 6000.0, 0.994), (C4, 1 << 26, 2000.0, 0.998)],
                          ids=["configs1-qpsk72k", "configs2-oqpsk80k", "configs3-1MSps-f64-O8"])
-def test_worst_window_and_tile_starts_against_the_floor(cfg, n, rms, bar, worst_bar, gpu_device):
-    """No 4096-symbol stretch of a stitched recording may be far below what the reference does to itself: the worst window of
-    the stitched output is held against the worst window of the reference's own 1-LSB-perturbation run on the same recording
-    (measured r03, profiles/r03_settle_sweep.md: QPSK 0.980 vs the floor's own 0.97-0.99; OQPSK 0.954; 1 MS/s 0.995), and the
-    first 4096 symbols of the tile bodies agree as well as the rest (tiles do not start badly)."""
+def test_worst_window_and_tile_starts_against_the_floor(cfg, n, rms, bar, gpu_device):
+    """No stretch of a stitched recording may be far below what the reference does to itself.  The yardstick is a pair of CONVERGED
+    serial runs while they are apart (_converged_pair; r03 used the 1-LSB perturbation run, which looks better than any tile can be
+    wherever its two runs have met again and are identical).  Held against it: the overall +-1 LSB agreement, the 1st percentile
+    of the 4096-symbol windows, the share of windows below 0.99, and the worst window (a minimum over several times as many
+    windows as the yardstick has: a margin).  And tiles do not start badly: the first 4096 symbols of the tile bodies agree as
+    well as the rest (measured r04 on 2^26 samples, tools/tiled_evidence.py: flat over the tenths of a tile body, the worst windows
+    at arbitrary places inside the bodies, none of them at a seam)."""
     st = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, rms=rms)
     iq = synth.generate_device([st], n)[0]
     out, serial, rep, a = _run(cfg, iq)
@@ -92,10 +123,47 @@ def test_worst_window_and_tile_starts_against_the_floor(cfg, n, rms, bar, worst_
     pos = ((idx / sps - rep.pilot_samples) % rep.tile_samples) * sps
     tiled = idx >= int(rep.exact_symbols)
     head, rest = float(ok[tiled & (pos < 4096)].mean()), float(ok[tiled & (pos >= 4096)].mean())
-    floor_frac, floor_worst = _floor(cfg, iq.cpu().numpy()[: n // 2], n // 16)
-    assert a["within_1lsb"] >= bar and a["worst_window"] >= worst_bar, (a, floor_frac, floor_worst)
-    assert a["worst_window"] >= floor_worst - 0.05, (a["worst_window"], floor_worst)
+    fl = _converged_pair(cfg, iq.cpu().numpy()[: n // 2])
+    assert len(fl) > 100_000, len(fl)
+    wins, fwins = _windows(ok[tiled]), _windows(fl)
+    got = dict(within=float(ok[tiled].mean()), p01=float(np.quantile(wins, 0.01)), low=float((wins < 0.99).mean()), worst=float(wins.min()))
+    floor = dict(within=float(fl.mean()), p01=float(np.quantile(fwins, 0.01)), low=float((fwins < 0.99).mean()), worst=float(fwins.min()))
+    assert a["within_1lsb"] >= bar, (a, floor)
+    assert got["within"] >= floor["within"] - 0.0012, (got, floor)
+    assert got["p01"] >= floor["p01"] - 0.006, (got, floor)
+    assert got["low"] <= 3.0 * floor["low"] + 0.01, (got, floor)
+    assert got["worst"] >= floor["worst"] - 0.03, (got, floor)
     assert head >= rest - 0.002, (head, rest)
+
+
+def test_truth_check_of_a_whole_recording(gpu_device):
+    """EVERY hard decision of a stitched recording against the symbols the generator transmitted (synth.truth_check: a device kernel
+    regenerates them, no serial run needed - bench.py does this for all 2 G symbols of its 6.5 G-sample recording): the rail error
+    rate is the channel's (Q(sqrt(Es/N0)) = 3.4e-5 at 12 dB for QPSK; OQPSK's staggered rails measure 1.7e-4), no pairing change.
+    And the check does see what it is there for: a quarter turn put into the second half of the output is ONE pairing change at
+    the right place, a symbol dropped is another."""
+    import torch
+    for cfg in (C1, C3):
+        st = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0)
+        iq = synth.generate_device([st], 1 << 24)[0]
+        soft, rep = demodulate_recording_native(cfg, iq)
+        soft = soft.contiguous()
+        first = int(rep.first_lock_symbol) + 20000
+        t = synth.truth_check(st, soft, first_symbol=first, block=16384)
+        assert t["symbols_compared"] > 0.9 * (len(soft) - first) and t["pairing_changes"] == 0 and t["unresolved_blocks"] == 0, t
+        assert t["rail_error_rate"] < (1e-4 if not cfg.oqpsk else 4e-4), t
+        if cfg.oqpsk:
+            continue
+        # a rotation jump in the middle: (I, Q) -> (-Q, I) from symbol h on
+        h = (len(soft) // 2) // 16384 * 16384
+        bad = soft.clone()
+        bad[h:, 0], bad[h:, 1] = -soft[h:, 1], soft[h:, 0]
+        t2 = synth.truth_check(st, bad, first_symbol=first, block=16384)
+        assert t2["pairing_changes"] == 1 and t2["changes"][0]["symbol"] == h, t2
+        # a symbol lost at h: everything behind it is one symbol early
+        slip = torch.cat([soft[:h], soft[h + 1:]]).contiguous()
+        t3 = synth.truth_check(st, slip, first_symbol=first, block=16384)
+        assert t3["pairing_changes"] == 1 and abs(t3["changes"][0]["symbol"] - h) <= 16384, t3
 
 
 def test_many_short_tiles_regime_agrees_with_the_serial_reference(gpu_device):
