@@ -142,6 +142,72 @@ def one_core_msps(harness, ref_args, path, n, repeats: int = 2):
     return round(n / best / 1e6, 2)
 
 
+def one_core_all_configs() -> dict:
+    """The reference's own per-sample loop (oracle/_ref/ref_harness time: demod.c + dsp/*.c compiled from /root/reference) as ONE
+    process on the idle host for every single-GPU configuration of BASELINE.json, strict and as-shipped builds: Msamples/s."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_py as O
+    from meteor_demod_amd import synth
+    if not O.have_ref():
+        return {"error": "oracle/_ref not built on this host"}
+    res = {}
+    n = 1 << 22
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        for tag in ("c1", "c3", "c4"):
+            cfg, workload = demod_config(tag)
+            st = synth.make_stream(424242, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, rms=2000.0 if tag == "c4" else 6000.0)
+            path = Path(td) / f"{tag}.raw"
+            synth.generate_host(st, n).tofile(path)
+            res[workload.split(":")[0]] = {"strict_msps": one_core_msps(O.REF_HARNESS, O._ref_args(cfg), path, n),
+                                           "as_shipped_msps": one_core_msps(O.REF_HARNESS_SHIPPED, O._ref_args(cfg), path, n) if O.REF_HARNESS_SHIPPED.exists() else None}
+    res["sample"] = f"2^22 samples per configuration, one process at a time, best of 2"
+    return res
+
+
+def cli_wall_times(local: int) -> dict:
+    """One 2^26-sample configs[1] WAV file end to end (process start, file read, demodulation, .s written), wall seconds: this
+    repository's C host in exact mode (one wavefront: the reference's own bytes) and with --tiled, and the reference's own binary
+    (oracle/_ref/meteor_demod_ref = /root/reference's main.c and all, strict build) on one host core."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_py as O
+    from golden_cases import wav_header
+    from meteor_demod_amd import synth
+    n = 1 << 26
+    st = synth.make_stream(1000, 230000, 72000, f0_hz=1200.0, clock_ppm=-3.5)
+    iq = synth.generate_device([st], n, device=local)[0].cpu().numpy()
+    cli = ROOT / "meteor_demod_amd" / "lib" / "meteor_demod_amd"
+    res = {"file": f"2^26 samples s16 WAV ({n * 4 / 1e6:.0f} MB in /dev/shm), configs[1]"}
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        wav = Path(td) / "rec.wav"
+        with open(wav, "wb") as f:
+            f.write(wav_header(230000, 16, iq.nbytes))
+            f.write(iq.tobytes())
+        del iq
+        outs = {}
+
+        def run(name, cmd, repeat=1):
+            best = None
+            for _ in range(repeat):
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                dt = time.perf_counter() - t0
+                if r.returncode:
+                    res[name] = {"error": (r.stderr or r.stdout)[-200:]}
+                    return
+                best = dt if best is None else min(best, dt)
+            o = Path(cmd[cmd.index("-o") + 1])
+            outs[name] = o.read_bytes()
+            res[name] = {"seconds": round(best, 3), "msamples_per_s": round(n / best / 1e6, 1), "output_bytes": len(outs[name])}
+
+        run("this_host_tiled", [str(cli), "-q", "--tiled", "-o", str(Path(td) / "t.s"), str(wav)], repeat=2)
+        run("this_host_exact", [str(cli), "-q", "-B", "-o", str(Path(td) / "e.s"), str(wav)])
+        if O.REF_BINARY.exists():
+            run("reference_binary_one_core", [str(O.REF_BINARY), "-q", "-B", "-o", str(Path(td) / "r.s"), str(wav)])
+        if "this_host_exact" in outs and "reference_binary_one_core" in outs:
+            res["exact_output_equals_the_reference_binary"] = outs["this_host_exact"] == outs["reference_binary_one_core"]
+    return res
+
+
 def host_cpu_facts() -> dict:
     """What `cores` means on this host: logical CPUs in the affinity mask, distinct physical cores behind them (sysfs topology),
     the cgroup CPU quota if there is one.  256 busy processes on 128 physical cores with SMT are not 256 cores."""
@@ -328,6 +394,7 @@ def recordings_leg(cfg_tag: str, buf, local: int, buf_stream=None) -> dict:
         res["perturbation_floor_" + key] = perturbation_floor(cfg, iq[: 1 << 25])
         del iq
         torch.cuda.empty_cache()
+    res["configs[3] at SURVEY 8(d)'s 6000 LSB"] = c4_at_full_amplitude(local)
     if cfg_tag == "c1" and buf is not None:
         cfg, _ = demod_config("c1")
         serial28 = None
@@ -344,6 +411,97 @@ def recordings_leg(cfg_tag: str, buf, local: int, buf_stream=None) -> dict:
         elif buf.shape[0] > (1 << 28):
             res["configs[1] whole buffer"] = single_recording(cfg, buf, check=False, label_unchecked=True, stream=buf_stream)
     return res
+
+
+def host_fed(local: int) -> dict:
+    """"report host-fed throughput separately".  mdemod_process_host (what the C host calls: host buffers in, host
+    buffers out, PCIe both ways, csrc/host_pipe.cpp) on 16 384 streams x 32 768 samples of configs[1] - never `value`.  The caller's
+    buffers are allocated and touched beforehand (fresh pages would be timed as page faults), the call itself is timed; beside it
+    the rate of the same bytes through plain pinned copies in and out (what the link gives with nothing else to do)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from meteor_demod_amd import DemodConfig, Demodulator, synth
+    cfg = DemodConfig(samplerate=230000)
+    ns, n = 16384, 32768
+    one = synth.generate_host(synth.make_stream(1, 230000, 72000, f0_hz=300.0), n)
+    iq = np.empty((ns, n, 2), dtype=np.int16)
+    iq[:] = one
+    with Demodulator(cfg, ns, device=local) as d:
+        cap = d.max_symbols(n)
+        soft = np.zeros((ns, cap, 2), dtype=np.int8)
+        iq_ptrs = (C.c_void_p * ns)(*[iq.ctypes.data + i * n * 4 for i in range(ns)])
+        counts = (C.c_uint32 * ns)(*([n] * ns))
+        soft_ptrs = (C.c_void_p * ns)(*[soft.ctypes.data + i * cap * 2 for i in range(ns)])
+        caps = (C.c_uint32 * ns)(*([cap] * ns))
+        produced = (C.c_uint32 * ns)()
+        times = []
+        for _ in range(4):
+            d.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = d._lib.mdemod_process_host(d._ctx, iq_ptrs, counts, soft_ptrs, caps, produced)
+            times.append(time.perf_counter() - t0)
+            if rc:
+                return {"error": f"mdemod_process_host: {rc}"}
+        dt = min(times[1:])
+        out_bytes = 2 * int(sum(produced))
+    # the link alone: the same bytes, pinned, one copy each way
+    h_in = torch.empty(ns * n * 2, dtype=torch.int16).pin_memory()
+    d_in = torch.empty_like(h_in, device=f"cuda:{local}")
+    h_out = torch.empty(out_bytes, dtype=torch.int8).pin_memory()
+    d_out = torch.empty_like(h_out, device=f"cuda:{local}")
+    link = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d_in.copy_(h_in, non_blocking=True)
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.synchronize()
+        link.append(time.perf_counter() - t0)
+    in_bytes = ns * n * 4
+    return {"workload": f"{ns} streams x {n} samples of configs[1] through mdemod_process_host (host buffers both ways)",
+            "seconds": round(dt, 4), "msamples_per_s": round(ns * n / dt / 1e6, 1),
+            "gbytes_per_s_in": round(in_bytes / dt / 1e9, 1), "gbytes_per_s_both_ways": round((in_bytes + out_bytes) / dt / 1e9, 1),
+            "input_bytes": in_bytes, "output_bytes": out_bytes,
+            "link_alone_gbytes_per_s_in": round(in_bytes / min(link) / 1e9, 1),
+            "note": "PCIe-inclusive; `value` above is device-resident.  link_alone = the same bytes as one pinned hipMemcpyAsync each way"}
+
+
+def c4_at_full_amplitude(local: int) -> dict:
+    """configs[3] (1 MS/s, -f 64 -O 8) as ONE recording at the 6 000 LSB rms SURVEY 8(d) specifies - the amplitude the other legs
+    avoid (rms 2000), because there the REFERENCE does not demodulate: at 14 samples per symbol its filter output is so large that
+    gain += 1e-4 * (190 - |y|) (agc.c:13-25) overshoots through zero every few symbols.  Reported: how long the serial run is
+    locked at all, how many of ITS hard decisions are the transmitted symbols, the same for the tiled run, and their agreement."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import numpy as np
+    import torch
+    import oracle_py as O
+    from meteor_demod_amd import synth
+    from meteor_demod_amd.recording import agreement, demodulate_recording_native
+    cfg, _ = demod_config("c4")
+    out = {}
+    for rms in (6000.0, 3000.0):
+        st = synth.make_stream(2000, cfg.samplerate, cfg.symrate, f0_hz=1200.0, rms=rms)
+        n = 1 << 25
+        iq = synth.generate_device([st], n, device=local)[0].contiguous()
+        soft, rep = demodulate_recording_native(cfg, iq, device=local)
+        serial, trace, ev = O.oracle_demod(cfg, iq.cpu().numpy(), True)
+        a = agreement(soft.cpu().numpy(), serial)
+        m0, cnt = min(len(serial), int(rep.n_symbols)) // 2, 262144
+        ser_dev = torch.from_numpy(serial).to(soft.device).contiguous()
+        out[f"rms {int(rms)}"] = {
+            "serial_run_locked_fraction": round(float(trace["locked"].mean()), 4), "serial_run_lock_events": len(ev),
+            "serial_decisions_that_are_the_transmitted_symbols": round(synth.best_pairing_agreement(st, ser_dev, m0, cnt, device=local), 4),
+            "tiled_decisions_that_are_the_transmitted_symbols": round(synth.best_pairing_agreement(st, soft.contiguous(), m0, cnt, device=local), 4),
+            "tiled_vs_serial": {"symbols": [a["len_stitched"], a["len_serial"]], "within_1lsb": round(a["within_1lsb"], 4),
+                                "hard_decisions_equal": round(a["hard_decisions_equal"], 4)},
+            "pilot_locked": int(rep.pilot_locked), "rotation_jumps": int(rep.rotation_jumps)}
+        del iq, soft, ser_dev
+        torch.cuda.empty_cache()
+    out["note"] = ("0.5 = no relation to the signal.  At 6000 LSB the reference's own output is not a demodulation of the signal (its AGC is unstable at "
+                   "14 samples per symbol), so there is nothing for a tiled run to agree with; at 3000 LSB both runs make the same decisions")
+    return out
 
 
 def other_configs(skip: str, T: int, L: int, local: int) -> dict:
@@ -603,6 +761,15 @@ def main() -> None:
         del buf, x
         torch.cuda.empty_cache()
         out["other_configs"] = other_configs(args.config, T, L, local)
+        out["cpu_baseline"]["one_core_msps"] = one_core_all_configs()
+        try:
+            out["cli_wall_times"] = cli_wall_times(local)
+        except Exception as e:
+            out["cli_wall_times"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            out["host_fed"] = host_fed(local)
+        except Exception as e:
+            out["host_fed"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

@@ -138,6 +138,13 @@ def _probe(st: SynthStream, soft, m0: int, count: int, lag_min: int = -40, n_lag
     return hyp
 
 
+def best_pairing_agreement(st: SynthStream, soft, m0: int, count: int, device: int = 0) -> float:
+    """Share of the hard decisions of symbols [m0, m0 + count) that agree with the transmitted symbols under the best pairing
+    of rails, lags and signs (the worse of the two received rails): 0.5 = no relation to the signal."""
+    hyp = _probe(st, soft, m0, count, device=device)
+    return float(min(hyp[0][3], hyp[1][3]))
+
+
 def truth_check(st: SynthStream, soft, first_symbol: int = 0, block: int = 65536, device: int = 0, max_probes: int = 256) -> dict:
     """Hard decisions of the WHOLE device tensor `soft` (int8 [m, 2], the output of a demodulation of stream `st`) against the
     symbols the generator transmitted, from `first_symbol` on (skip what was demodulated before the PLL's lock).  The pairing

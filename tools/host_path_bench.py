@@ -5,7 +5,10 @@ import numpy as np, torch
 from meteor_demod_amd import DemodConfig, Demodulator, synth
 
 cfg = DemodConfig(samplerate=230000)
-for ns, n in [(64, 4 << 20), (2048, 1 << 18), (16384, 1 << 15)]:
+import os
+shapes = [(64, 4 << 20), (2048, 1 << 18), (16384, 1 << 15)] if len(sys.argv) < 2 else [(16384, 1 << 15)]
+print("pack threads:", os.environ.get("MDEMOD_PACK_THREADS", "8 (default)"), flush=True)
+for ns, n in shapes:
     one = synth.generate_host(synth.make_stream(1, 230000, 72000, f0_hz=300.0), n)
     blocks = [one] * ns                       # same host buffer for every stream: the copies are still made
     with Demodulator(cfg, ns) as d:
