@@ -39,7 +39,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tiles", type=int, default=393216,
-                    help="tiles (= streams = lanes) per GPU; default = 2 residency rounds of the v2 kernel "
+                    help="tiles (= streams = lanes) per GPU; default = 2 residency rounds of the register-window kernels "
                          "(256 CUs x 12 waves x 64 lanes = 196608 lanes resident)")
     ap.add_argument("--tile-samples", type=int, default=16448,
                     help="IQ samples per tile.  NOT a power of two: lane l reads at base + l*tile_bytes, and a 64 KiB stride "

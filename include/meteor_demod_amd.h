@@ -102,10 +102,10 @@ typedef struct {
 } mdemod_params;
 
 /* mdemod_params.reserved (diagnosis and tests only; every variant produces the same bytes) */
-#define MDEMOD_FLAG_KERNEL_MASK 0x3u    /* 0 = newest generation that fits, 1 = v1 LDS ring, 2 = v2 moving register window, 3 = v3 */
+#define MDEMOD_FLAG_KERNEL_MASK 0x3u    /* 0 or 3 = v3 rotating windows where they apply (the default), 1 = v1 LDS ring; 2 = the retired v2: MDEMOD_ERR_PARAM */
 #define MDEMOD_FLAG_LAT_OFF     0x4u    /* never the wave-per-stream (latency) kernel, however few the streams */
 #define MDEMOD_FLAG_LAT_ON      0x8u    /* always, when the configuration fits it */
-#define MDEMOD_FLAG_V2_PACKED   0x10u   /* v2 std geometry: raw-sample window (3 waves per SIMD) instead of converted floats */
+#define MDEMOD_FLAG_V2_PACKED   0x10u   /* (retired with the v2 kernel in round 4: ignored) */
 
 /* Value snapshot of one stream after a call (replaces the reference's racy
  * getters polled from the UI thread, main.c:231-237,250-258). */

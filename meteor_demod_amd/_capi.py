@@ -26,15 +26,13 @@ MDEMOD_FLAG_KERNEL_MASK, MDEMOD_FLAG_LAT_OFF, MDEMOD_FLAG_LAT_ON, MDEMOD_FLAG_V2
 
 def variant_flags_from_env() -> int:
     """`mdemod_params.reserved` for the test and bench harness: the library itself reads no environment variable, this wrapper
-    does, so that one suite can run every kernel variant.  MDEMOD_KERNEL=v1|v2|v3, MDEMOD_LAT=0|1, MDEMOD_RW_PACKED=1."""
-    f = {"v1": 1, "v2": 2, "v3": 3}.get(_os.environ.get("MDEMOD_KERNEL", ""), 0)
+    does, so that one suite can run every kernel variant.  MDEMOD_KERNEL=v1|v3, MDEMOD_LAT=0|1."""
+    f = {"v1": 1, "v3": 3}.get(_os.environ.get("MDEMOD_KERNEL", ""), 0)
     lat = _os.environ.get("MDEMOD_LAT", "")
     if lat == "0":
         f |= MDEMOD_FLAG_LAT_OFF
     elif lat not in ("", "-1"):
         f |= MDEMOD_FLAG_LAT_ON
-    if _os.environ.get("MDEMOD_RW_PACKED", "0") not in ("", "0"):
-        f |= MDEMOD_FLAG_V2_PACKED
     return f
 
 

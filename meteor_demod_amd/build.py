@@ -156,13 +156,9 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
     out: dict[str, Path] = {}
 
     # --- product library ---------------------------------------------------
-    # (source, object stem, extra flags).  The register-window kernel file is compiled twice: the std geometry with scalar
-    # f32 ops (packed v_pk_* are slower on gfx950) and the max-ILP machine scheduler (measured +1.7 % on configs[1]); the
-    # wide geometry with the default scheduler (max-ILP makes its u8 variants spill inside the main loop).
-    rw = CSRC / "demod_kernel_rw.hip"
+    # (source, object stem, extra flags).  The std rotating-window file takes the max-ILP machine scheduler (measured +1.7 % on
+    # configs[1]); the packed windows the default one (max-ILP makes their u8 variants spill inside the main loop).
     units = [(CSRC / "demod_kernel.hip", "demod_kernel", []),
-             (rw, "demod_kernel_rw_std", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
-             (rw, "demod_kernel_rw_wide", ["-fno-slp-vectorize", "-DMDEMOD_RW_PART=2"]),
              (CSRC / "demod_kernel_rot.hip", "demod_kernel_rot", ROT_FLAGS),
              (CSRC / "demod_kernel_rotp.hip", "demod_kernel_rotp", ROTP_FLAGS),
              (CSRC / "demod_kernel_gat.hip", "demod_kernel_gat", ["-fno-slp-vectorize"]),
@@ -207,6 +203,8 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, Path]:
             raise RuntimeError("register partition of the v3 kernels violated (compiler code in the assembly's registers, or scratch "
                                "where there must be none):\n  " + "\n  ".join(bad[:20]))
         checked.write_text("ok\n")
+    for stale in LIB.glob("demod_kernel_rw_*.o"):            # objects of the v2 kernel (retired in round 4) from an older tree
+        stale.unlink()
     so = LIB / "libmeteor_demod_amd.so"
     if force or _stale(so, objs):
         _run([hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", str(so), *map(str, objs)])

@@ -30,7 +30,7 @@ struct mdemod_ctx {
 	float        *d_rrc;       /* plain polyphase table [bank][taps] (filter.c:18-22) for the latency kernel */
 	int           hyb_block;   /* hybrid window (tab.rw_hyb): threads per block */
 	bool          v1_global_table;   /* v1 ring kernel with its coefficient table left in global memory (it does not fit the LDS) */
-	bool          use_rot;     /* std geometry on the v3 rotating-window kernel (demod_kernel_rot.hip) instead of v2 */
+	bool          use_rot;     /* std geometry: the v3 rotating-window kernel of demod_kernel_rot.hip */
 	bool          lat_ok;      /* the latency kernel (one stream per wave) fits this configuration */
 	int           lat_ring, lat_span;
 	size_t        lat_lds;
@@ -113,9 +113,7 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	else if (ctx->tab.use_rw && ctx->tab.rw_compact4)
 		HIP_TRY(mdemod_launch_demod_rotp(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw)
-		HIP_TRY((ctx->tab.rw_wide || ctx->tab.rw_mid || ctx->tab.rw_far)
-		        ? mdemod_launch_demod_rw_wide(L, ctx->params.bps, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream)
-		                         : mdemod_launch_demod_rw_std(L, ctx->params.bps, (ctx->params.reserved & MDEMOD_FLAG_V2_PACKED) ? 1 : 0, ctx->lds_bytes, stream));
+		return MDEMOD_ERR_PARAM;                      /* (cannot happen: every register-window plan is one of the v3 kernels above) */
 	else
 		HIP_TRY(mdemod_launch_demod(L, ctx->params.bps, ctx->block_threads, ctx->v1_global_table ? 1 : 0, ctx->lds_bytes, stream));
 	return MDEMOD_OK;
@@ -138,19 +136,19 @@ static int
 plan_context(mdemod_ctx *ctx)
 {
 	const mdemod_params *params = &ctx->params;
-	/* MDEMOD_FLAG_KERNEL_MASK pins a generation (tests cover all three); otherwise the newest that fits.  The v3
-	 * kernels drop the range test of the NCO's turn code and wrap the NCO phase in float arithmetic (demod_device.h): both need
-	 * phase + freq < 4pi, which pll.c's own clamp gives for fmax < 2pi rad/symbol (the default is 0.3) */
+	/* MDEMOD_FLAG_KERNEL_MASK pins a generation (the tests run v1 and v3 on the same inputs); otherwise v3 wherever one of its
+	 * windows fits, v1 for the rest.  (v2, the moving register window of round 2, was retired in round 4: every geometry it had is
+	 * served by a v3 kernel, and the one case that used to route to it - a carrier range of 6 rad per symbol or more, for which the
+	 * v3 kernels' float wraps and unchecked turn code do not hold - cannot occur: pll.c:29-33 clamps fmax to 1 rad per symbol,
+	 * and so does demod_host.cpp.) */
 	const uint32_t kforce = params->reserved & MDEMOD_FLAG_KERNEL_MASK;
-	int generation = kforce == 1 ? 0 : (kforce == 2 ? 1 : 2);
-	{
-		HostTables probe;
-		int rc0 = mdemod_host_derive(*params, probe, 1);
-		if (rc0) return rc0;
-		if (!(probe.c.pll_fmax < 6.0f) && generation == 2) generation = 1;
-	}
+	if (kforce == 2) return MDEMOD_ERR_PARAM;         /* the retired generation */
+	const int generation = kforce == 1 ? 0 : 2;
 	int rc = mdemod_host_derive(*params, ctx->tab, generation);
 	if (rc) return rc;
+	/* the v3 and latency kernels wrap the NCO phase in float arithmetic and skip the range test of its turn code
+	 * (demod_device.h): both need phase + freq < 4 pi, i.e. fmax < 2 pi rad per symbol */
+	if (!(ctx->tab.c.pll_fmax < 6.0f)) return MDEMOD_ERR_PARAM;
 	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
 	ctx->use_rot = generation == 2 && ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && !ctx->tab.rw_hyb && !ctx->tab.rw_gather;
 	ctx->hyb_block = 0;
@@ -174,7 +172,7 @@ plan_context(mdemod_ctx *ctx)
 		       ;
 	};
 	if (ctx->tab.use_rw && lds_need(ctx->block_threads) > 160 * 1024) {
-		/* The per-alignment coefficient rows of the v2 std geometry grow with -O (16 alignments x interp x 84 floats: past the
+		/* The per-alignment coefficient rows of the std geometry grow with -O (16 alignments x interp x 84 floats: past the
 		 * 160 KB of LDS from -O 29 on); the v1 ring kernel keeps 4 alignments and still fits: fall back to it. */
 		rc = mdemod_host_derive(*params, ctx->tab, 0);
 		ctx->use_rot = false;
@@ -671,13 +669,7 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 	if (ctx->tab.rw_compact4) return ctx->tab.rw_wide ? "demod_kernel_rotp (v3 rotating packed window, wide: 129 taps at up to 30 samples per firing)"
 	                                 : (ctx->tab.rw_mid ? "demod_kernel_rotp (v3 rotating packed window, mid: 65 taps at up to 15 samples per firing)"
 	                                                    : "demod_kernel_rotp (v3 rotating packed window, far: 65 taps at up to 46 samples per firing)");
-	if (ctx->tab.rw_wide) return "demod_kernel_rw (v2 register window, wide: 129 taps, packed)";
-	if (ctx->tab.rw_far) return "demod_kernel_rw (v2 register window, far: 65 taps at up to 30 samples per firing, packed)";
-	if (ctx->tab.rw_mid) return ctx->params.bps == 32 ? "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, float pairs)"
-	                                                  : "demod_kernel_rw (v2 register window, mid: 65 taps at up to 15 samples per firing, packed)";
-	if (ctx->use_rot) return "demod_kernel_rot (v3 rotating register window)";
-	return (ctx->params.bps != 32 && (ctx->params.reserved & MDEMOD_FLAG_V2_PACKED))
-	       ? "demod_kernel_rw (v2 register window, packed)" : "demod_kernel_rw (v2 register window, float)";
+	return "demod_kernel_rot (v3 rotating register window)";
 }
 
 int
@@ -712,11 +704,11 @@ mdemod_get_history(mdemod_ctx *ctx, uint32_t stream, float *iq_pairs, void *hip_
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
-	const int hfmt = ctx->tab.use_rw ? 32 : ctx->params.bps;     /* v2 keeps converted floats */
+	const int hfmt = ctx->tab.use_rw ? 32 : ctx->params.bps;     /* the register-window kernels keep converted floats */
 	const size_t sb = 2 * static_cast<size_t>(hfmt) / 8, ns = ctx->params.n_streams;
 	const int hpad = ctx->tab.c.hpad;
 	std::vector<unsigned char> raw(static_cast<size_t>(hpad) * sb);
-	if (ctx->tab.use_rw)      /* v2 layout: [stream][hpad] */
+	if (ctx->tab.use_rw)      /* register-window layout: [stream][hpad] */
 		HIP_TRY(hipMemcpyAsync(raw.data(), static_cast<const unsigned char *>(ctx->st.hist) + static_cast<size_t>(stream) * hpad * sb,
 		                       static_cast<size_t>(hpad) * sb, hipMemcpyDeviceToHost, st));
 	else

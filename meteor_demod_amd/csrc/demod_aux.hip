@@ -168,7 +168,7 @@ mdemod_launch_reset(const DemodStateSoA &st, const DemodConsts &c, int fmt, int 
 {
 	if (n_streams == 0) return hipSuccess;
 	const dim3 block(256), grid((n_streams + 255) / 256);
-	if (float_history) fmt = 32;        /* the v2 kernel keeps its history as converted floats */
+	if (float_history) fmt = 32;        /* the register-window kernels keep their history as converted floats */
 	switch (fmt) {
 	case 16:
 		hipLaunchKernelGGL(reset_kernel<uint32_t>, grid, block, 0, stream, st, c.t_center, c.hpad, n_streams, (uint32_t)0, float_history);

@@ -125,6 +125,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	}
 
 	/* ---- kernel selection + geometry ---- */
+	const bool v3 = generation != 0;                  /* 0: the v1 ring kernel whatever the configuration (tests) */
 	const double per_firing = static_cast<double>(out.osf) / (p.oqpsk ? 2.0 : 1.0);   /* samples consumed per firing */
 	const bool std_ok = c.taps <= 65 && per_firing <= 3.6;
 	/* wide: packed window only (s16 / u8), up to 129 taps, up to 15 samples per firing */
@@ -133,19 +134,19 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	 * a 96-slot window instead of 160 */
 	const bool mid_ok = wide_ok && c.taps <= 65;
 	/* far: the short filter at 2-3 MS/s-class rates: up to 30 (v3: 46) samples per firing, two 16-slot slides per iteration */
-	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= (generation >= 2 ? 46.0 : 30.0) && p.bps != 32;   /* (v3: 47 alignments, as many loop iterations per firing as it takes; v2's window moves twice per iteration at most) */
+	const bool far_ok = !std_ok && !wide_ok && c.taps <= 65 && per_firing <= 46.0 && p.bps != 32;   /* (47 alignments, as many loop iterations per firing as it takes) */
 	/* hybrid: float input outside the std geometry, up to 129 taps at up to 15 samples per firing or up to 65 taps at up to 30 (a float window of 160 slots is 320
 	 * registers: the older 80 slots in VGPRs, the newer ones in AccVGPRs, one wave per SIMD: demod_kernel_rot.hip, WinH; with up to 65
 	 * taps - rw_mid as well - the window has 96 slots) */
-	const bool hyb_far_ok = generation >= 2 && !std_ok && p.bps == 32 && per_firing > 30.0 && per_firing <= 54.0 && c.taps <= 65;   /* 120 slots, 55 alignments */
-	const bool hyb_ok = generation >= 2 && !std_ok && p.bps == 32 && ((per_firing <= 30.0 && c.taps <= 129) || hyb_far_ok);
+	const bool hyb_far_ok = v3 && !std_ok && p.bps == 32 && per_firing > 30.0 && per_firing <= 54.0 && c.taps <= 65;   /* 120 slots, 55 alignments */
+	const bool hyb_ok = v3 && !std_ok && p.bps == 32 && ((per_firing <= 30.0 && c.taps <= 129) || hyb_far_ok);
 	/* the long filter at 15..30 samples per firing (s16 / u8): the wide window has the 31 alignments for it and slides once per
 	 * loop iteration, so such a firing takes two iterations */
-	const bool wide_far_ok = generation >= 2 && !std_ok && !wide_ok && !far_ok && per_firing <= 30.0 && c.taps <= 129 && p.bps != 32;
+	const bool wide_far_ok = v3 && !std_ok && !wide_ok && !far_ok && per_firing <= 30.0 && c.taps <= 129 && p.bps != 32;
 	/* gather: rates none of the windows reaches (more than 46 samples per firing, 30 with the long filter): no window,
 	 * every firing loads its own taps (demod_kernel_gat.hip) */
-	const bool gather_ok = generation >= 2 && c.taps <= (p.bps == 32 ? 65 : 129) && !std_ok && !wide_ok && !far_ok && !wide_far_ok && !hyb_ok;
-	const bool allow_rw = generation >= 1;
+	const bool gather_ok = v3 && c.taps <= (p.bps == 32 ? 65 : 129) && !std_ok && !wide_ok && !far_ok && !wide_far_ok && !hyb_ok;
+	const bool allow_rw = v3;
 	out.rw_gather = gather_ok;
 	out.rw_hyb = hyb_ok;
 	out.rw_std_compact = false;
@@ -156,7 +157,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	out.rw_wide = out.use_rw && !std_ok && !mid_ok && !far_ok && !hyb_ok && !gather_ok;
 	c.chunk_granules = 2;
 	if (out.use_rw && !out.rw_wide && !out.rw_mid && !out.rw_far && !out.rw_hyb && !out.rw_gather) {
-		/* v2: 80-slot register window, filter embedded as 65 taps (leading zeros), 16 alignments */
+		/* std: 80-slot register window, filter embedded as 65 taps (leading zeros), 16 alignments */
 		const int kTaps = 65, NW = 80, AL = NW - kTaps + 1;
 		c.hpad = kTaps - 1;
 		c.win_granules = NW / 4;
@@ -170,7 +171,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 #ifndef MDEMOD_STD_COMPACT_ABOVE
 #define MDEMOD_STD_COMPACT_ABOVE (100 * 1024)
 #endif
-		out.rw_std_compact = generation >= 2 && static_cast<size_t>(AL) * banks * c.ctab_row_stride * sizeof(float) > MDEMOD_STD_COMPACT_ABOVE;
+		out.rw_std_compact = v3 && static_cast<size_t>(AL) * banks * c.ctab_row_stride * sizeof(float) > MDEMOD_STD_COMPACT_ABOVE;
 		if (out.rw_std_compact) {
 			const int AMAX = NW - kTaps, LP = kTaps + 2 * AMAX;
 			c.ctab_row_floats = LP;
@@ -216,7 +217,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		}
 		return MDEMOD_OK;
 	}
-	out.rw_compact4 = generation >= 2 && (out.rw_wide || out.rw_mid || out.rw_far) && p.bps != 32;
+	out.rw_compact4 = v3 && (out.rw_wide || out.rw_mid || out.rw_far) && p.bps != 32;
 	if (out.rw_compact4 || out.rw_hyb) {
 		/* v3 packed rotating window: per bank the padded sequence P = AMAX zeros ++ taps ++ AMAX zeros, stored FOUR times:
 		 * copy (bank, k)[i] = P[i + k].  A lane at alignment a reads P[(AMAX - a) + s] for slot s, i.e. copy ((AMAX - a) & 3) at the
@@ -244,32 +245,6 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		}
 		return MDEMOD_OK;
 	}
-	if (out.rw_wide || out.rw_mid || out.rw_far) {
-		/* v2 wide: NW-slot packed window, filter embedded as 129 taps, AMAX + 1 = NW - 128 alignments.
-		 * Compact table: per bank the padded sequence P = AMAX zeros ++ taps ++ AMAX zeros, stored twice:
-		 * array (bank, 0)[i] = P[i], array (bank, 1)[i] = P[i + 1].  A lane at alignment a reads
-		 * P[(AMAX - a) + s] for slot s, i.e. array (bank, o & 1) at the even index (o & ~1) + s. */
-		const int kTaps = out.rw_wide ? 129 : 65;
-		const int NW = out.rw_mid ? MDEMOD_RW_MID_NW : (out.rw_far ? MDEMOD_RW_FAR_NW : MDEMOD_RW_WIDE_NW), AMAX = NW - kTaps;
-		const int LP = kTaps + 2 * AMAX;
-		c.hpad = kTaps - 1;
-		c.win_granules = NW / 4;
-		c.ring_granules = 0;
-		c.ctab_row_floats = LP;
-		c.ctab_row_stride = (LP + 2) / 2 * 2;             /* even number of floats ...                */
-		if ((c.ctab_row_stride / 2) % 2 == 0) c.ctab_row_stride += 2;   /* ... and an odd number of 8-byte words */
-		out.ctab.assign(static_cast<size_t>(2) * banks * c.ctab_row_stride, 0.0f);
-		const int lead = kTaps - c.taps;
-		for (unsigned b = 0; b < banks; b++) {
-			std::vector<float> P(static_cast<size_t>(LP) + 1, 0.0f);
-			for (int k = 0; k < c.taps; k++) P[AMAX + lead + k] = out.rrc[b * taps + k];
-			float *even = &out.ctab[(static_cast<size_t>(b) * 2 + 0) * c.ctab_row_stride];
-			float *odd = &out.ctab[(static_cast<size_t>(b) * 2 + 1) * c.ctab_row_stride];
-			for (int i = 0; i < LP; i++) { even[i] = P[i]; odd[i] = P[i + 1]; }
-		}
-		return MDEMOD_OK;
-	}
-
 	/* v1: LDS ring */
 	c.hpad = ((c.taps - 1 + 7) / 8) * 8;
 	if (c.hpad < 8) c.hpad = 8;

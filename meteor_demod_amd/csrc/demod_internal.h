@@ -11,8 +11,8 @@
 
 #define MDEMOD_WAVE            64
 #define MDEMOD_GRANULE_SAMPLES 4      /* ring granule = 4 consecutive IQ samples */
-#define MDEMOD_RW_STATE_SLOTS   12     /* per-lane LDS state words of the v2 kernel */
-#define MDEMOD_RW_WIDE_BLOCK    512    /* threads per block of the wide v2 geometry */
+#define MDEMOD_RW_STATE_SLOTS   12     /* per-lane LDS state words of the register-window kernels */
+#define MDEMOD_RW_WIDE_BLOCK    512    /* threads per block of the wide geometry */
 #ifndef MDEMOD_RW_WIDE_NW
 #define MDEMOD_RW_WIDE_NW       160    /* window slots of the wide geometry (129 taps + 32 alignments) */
 #define MDEMOD_RW_WIDE_SLIDE    16     /* slots per slide of the wide geometry      */
@@ -21,7 +21,7 @@
 #define MDEMOD_RW_MID_NW        96     /* window slots of the mid geometry (65 taps + 32 alignments)      */
 #define MDEMOD_RW_FAR_NW        112    /* window slots of the far geometry (65 taps + 48 alignments)      */
 #ifndef MDEMOD_RW_BLOCK
-#define MDEMOD_RW_BLOCK         256    /* threads per block of the v2 kernel        */
+#define MDEMOD_RW_BLOCK         256    /* threads per block of the other register-window kernels */
 #endif
 
 /* Loop constants + geometry, passed to the kernel by value. */
@@ -37,7 +37,7 @@ struct DemodConsts {
 	int32_t ctab_row_stride; /* floats between rows (bank-conflict-free stride)   */
 	float   pll_alpha, pll_beta, pll_fmax;
 	float   t_alpha, t_beta, t_center, t_maxdev;
-	/* symbol-clock fast path (v2 kernel): see demod_host.cpp */
+	/* symbol-clock fast path: see demod_host.cpp */
 	int32_t  step_safe;      /* blind steps that provably cannot fire            */
 	int32_t  step_check;     /* predicated checked steps after them              */
 	float    step_fmax;      /* upper bound of the per-step phase increment      */
@@ -87,12 +87,10 @@ struct DemodLaunch {
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, int global_table, size_t lds_bytes, hipStream_t stream);
-hipError_t mdemod_launch_demod_rw_std(const DemodLaunch &L, int fmt, int packed, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_rot(const DemodLaunch &L, int fmt, int compact, size_t lds_bytes, hipStream_t stream);   /* v3: rotating register window (std geometry); compact: compact4 coefficient table */
 hipError_t mdemod_launch_demod_gat(const DemodLaunch &L, int fmt, int long_filter, size_t lds_bytes, hipStream_t stream);   /* v3: gather geometry (no window: every firing loads its taps); long_filter: 129 embedded taps instead of 65 (not for float input) */
 hipError_t mdemod_launch_demod_roth(const DemodLaunch &L, int geom, size_t lds_bytes, hipStream_t stream);   /* v3: hybrid window (float input: VGPRs + AccVGPRs, one wave per SIMD); geom 0: 160 slots (<= 129 taps), 1: 96 slots (<= 65 taps), 2: 120 slots (<= 65 taps, up to 54 samples per firing) */
 hipError_t mdemod_launch_demod_rotp(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mid, 2 far */, size_t lds_bytes, hipStream_t stream);   /* v3: rotating packed window */
-hipError_t mdemod_launch_demod_rw_wide(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mid, 2 far */, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_lat(const DemodLaunch &L, int fmt, const float *rrc_dev, int ring_size, int span, int float_history, size_t lds_bytes, hipStream_t stream);
 bool mdemod_lat_geometry(const DemodConsts &c, double samples_per_firing, int *ring_size, int *span, size_t *lds_bytes);
 hipError_t mdemod_launch_warm(hipStream_t stream);   /* empty kernel: loads the code objects */

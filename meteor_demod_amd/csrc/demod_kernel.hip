@@ -209,7 +209,7 @@ demod_kernel(const DemodLaunch L)
 	int8_t *soft_out = L.soft + (size_t)stream * L.soft_stride * 2;
 	const float thr_q = MD_TWO_PI_F;
 
-	/* Watchdog (see demod_kernel_rw.hip): a wave needs at most a few iterations per interpolated step of its longest
+	/* Watchdog (as in rotwin_body.h): a wave needs at most a few iterations per interpolated step of its longest
 	 * stream; g_need is the wave-uniform number of granules of that stream. */
 	const uint64_t guard64 = 16ull * (uint64_t)(g_need + 2) * (uint64_t)C.interp + 4096ull;
 	uint32_t guard = guard64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)guard64;
@@ -227,7 +227,7 @@ demod_kernel(const DemodLaunch L)
 			staged = false;
 		}
 
-		/* (2) step the symbol clock to the next firing (timing.c:32-57).  Fast path as in the v2
+		/* (2) step the symbol clock to the next firing (timing.c:32-57).  Fast path as in the register-window
 		 * kernel: k_safe blind adds that provably cannot fire (checked per lane), then four checked
 		 * steps (the increment is positive, so "reached thr" is monotone); generic loop otherwise. */
 		if (!fired && !done) {
@@ -349,7 +349,7 @@ demod_kernel(const DemodLaunch L)
 			md_nco_advance(pll.phase, pll.freq);
 
 			if (emit) {
-				/* only the LAST symbol fired inside one input sample is kept (demod.c:33-47, 62-90; see demod_kernel_rw.hip) */
+				/* only the LAST symbol fired inside one input sample is kept (demod.c:33-47, 62-90; see rotwin_body.h) */
 				if (v_cur == v_last_emit) { sym_call--; n_symbols--; }
 				v_last_emit = v_cur;
 				md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);

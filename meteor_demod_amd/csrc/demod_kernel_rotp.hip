@@ -6,7 +6,7 @@
  * The kernel body is rotwin_body.h (shared with demod_kernel_rot.hip); this file is the window policy: 96..160 slots of RAW
  * samples in registers that belong to the generated assembly of rotpk_asm.h (gen_rotpk_asm.py: ring of per-chunk FIR code,
  * 4 instructions per tap, nothing moves on a slide), compact4 coefficient table (demod_host.cpp).  What it replaces is the
- * packed-window C++ of demod_kernel_rw.hip: 6 instructions per tap, 144 v_mov_b32 per slide (one slide per firing at 1 MS/s)
+ * packed-window C++ of round 2's v2 kernel (retired): 6 instructions per tap, 144 v_mov_b32 per slide (one slide per firing at 1 MS/s)
  * and the PHI copies around them - 1 502 VALU instructions per wave-firing on configs[3] where the reference's arithmetic
  * needs 516 (profiles/r02_kernels.md).
  */

@@ -144,7 +144,7 @@ rotwin_demod(const DemodLaunch &L)
 	/* per-lane loop state that is only touched once per firing lives in LDS slots [field][lane] unless the window policy has
 	 * registers to spare for it (W::REGSLOTS: bit 0 err, 1 t_prev, 2 flags, 3 sample index of the last symbol) */
 	constexpr int RS = W::REGSLOTS;
-	constexpr int PRIO = 1;                      /* the scalar stage of a firing (and the symbol clock inside it) at raised wave priority, the FIR and the slide at 0: see demod_kernel_rw.hip */
+	constexpr int PRIO = 1;                      /* the scalar stage of a firing (and the symbol clock inside it) at raised wave priority, the FIR and the slide at 0 (+5 % on configs[1] when round 2 found it) */
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	float *ctab = reinterpret_cast<float *>(lds);
@@ -361,7 +361,7 @@ rotwin_demod(const DemodLaunch &L)
 			md_nco_advance<true>(pll.phase, pll.freq);
 
 			if (emit) {
-				/* demod.c:33-47: only the LAST symbol fired inside one input sample survives (see demod_kernel_rw.hip) */
+				/* demod.c:33-47: only the LAST symbol fired inside one input sample survives (found by fuzzing in round 2: DESIGN.md 5.0) */
 				const bool again = (v_cur == ld_lastv());
 				st_lastv(v_cur);
 				if (__builtin_expect(md_any(again), 0)) { if (again) sym_call--; }

@@ -25,12 +25,10 @@ def _torch():
 
 KERNEL_VARIANTS = {
     # MDEMOD_LAT=0: contexts with few streams would otherwise pick the latency kernel (one stream per wave) by themselves
-    "v3-rot": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "0"},       # rotating register window (std geometry; the other geometries: v2)
-    "v2-float": {"MDEMOD_KERNEL": "v2", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "0"},   # register window, converted floats
-    "v2-packed": {"MDEMOD_KERNEL": "v2", "MDEMOD_RW_PACKED": "1", "MDEMOD_LAT": "0"},  # register window, raw samples (3 waves/SIMD)
-    "v1-ring": {"MDEMOD_KERNEL": "v1", "MDEMOD_RW_PACKED": "1", "MDEMOD_LAT": "0"},    # LDS ring (generic fallback, > 65 taps)
-    "lat": {"MDEMOD_KERNEL": "", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "1"},          # one stream per wave, v2 state layout
-    "lat-v1-state": {"MDEMOD_KERNEL": "v1", "MDEMOD_RW_PACKED": "0", "MDEMOD_LAT": "1"},   # ... on the ring kernel's state layout
+    "v3-rot": {"MDEMOD_KERNEL": "", "MDEMOD_LAT": "0"},       # rotating register windows (the default wherever one fits)
+    "v1-ring": {"MDEMOD_KERNEL": "v1", "MDEMOD_LAT": "0"},    # LDS ring (generic fallback, > 129 taps)
+    "lat": {"MDEMOD_KERNEL": "", "MDEMOD_LAT": "1"},          # one stream per wave, register-window state layout
+    "lat-v1-state": {"MDEMOD_KERNEL": "v1", "MDEMOD_LAT": "1"},   # ... on the ring kernel's state layout
 }
 
 
@@ -225,7 +223,7 @@ WIDE_CFGS = {
     "defaults_1024k_oqpsk_u8": DemodConfig(samplerate=1024000, oqpsk=True, bps=8),
     "defaults_2048k": DemodConfig(samplerate=2048000),                                    # 28.4 samples per symbol: far geometry
     "far_edge_u8": DemodConfig(samplerate=2150000, rrc_order=20, interp_factor=3, bps=8), # 29.9 samples per symbol
-    "defaults_1024k_f32": DemodConfig(samplerate=1024000, bps=32),                        # float input: hybrid window (v3), float-pair window (v2)
+    "defaults_1024k_f32": DemodConfig(samplerate=1024000, bps=32),                        # float input: hybrid window
     "oqpsk_640k_f32": DemodConfig(samplerate=640000, symrate=80000, oqpsk=True, rrc_order=24, interp_factor=4, bps=32),
     "c4_f32": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),      # float input, 129 taps: hybrid window (VGPRs + AccVGPRs)
     "oqpsk80k_1M_f32": DemodConfig(samplerate=1000000, symrate=80000, oqpsk=True, rrc_order=64, interp_factor=8, bps=32),
@@ -253,16 +251,14 @@ WIDE_KERNEL = {"c4_s16": "wide", "c4_u8": "wide", "oqpsk80k_1M": "wide", "taps97
                "c4_f32": "hybrid", "oqpsk80k_1M_f32": "hybrid", "taps97_230k_f32": "hybrid", "taps129_O12_f32": "hybrid", "defaults_2048k_f32": "far-f32", "taps129_2048k_f32": "hybrid", "taps129_2048k": "wide-far", "taps97_1800k_u8": "wide-far", "defaults_3200k": "far-far", "defaults_2400k_u8": "far-far", "defaults_3200k_f32": "hyb-far", "oqpsk_7200k_f32": "hyb-far", "defaults_6000k": "gather", "defaults_10000k": "gather", "taps129_4000k": "gather", "oqpsk_8000k": "gather", "defaults_8000k_u8": "gather", "taps129_6000k_u8": "gather", "defaults_6000k_f32": "gather"}
 
 
-@pytest.mark.parametrize("generation", ["v3", "v2"])
 @pytest.mark.parametrize("name", list(WIDE_CFGS))
-def test_wide_window_batch_chained(name, generation, gpu_device, monkeypatch):
-    """The wide / mid / far / hybrid geometries (up to 129 taps at up to 30 samples per firing, up to 65 at up to 46) on the v3 rotating packed window and on
-    the v2 moving one (packed window, compact coefficient table): 70 distinct streams (more than one wave, every symbol
-    phase) x chained blocks, byte-identical to the oracle, loop state included."""
+def test_wide_window_batch_chained(name, gpu_device, monkeypatch):
+    """The wide / mid / far / hybrid / gather geometries (up to 129 taps at up to 30 samples per firing, up to 65 at up to 46, and beyond) on the v3
+    kernels: 70 distinct streams (more than one wave, every symbol phase) x chained blocks, byte-identical to the oracle, loop state
+    included."""
     torch = _torch()
     cfg = WIDE_CFGS[name]
-    if generation == "v2":
-        monkeypatch.setenv("MDEMOD_KERNEL", "v2")
+    generation = "v3"
     rms = {8: 50.0, 16: 5000.0, 32: 0.3}[cfg.bps]
     ns, blocks = 70, [5000, 3, 9000, 1, 2047]
     streams = [synth.make_stream(8100 + i, cfg.samplerate, cfg.symrate, f0_hz=(i % 9 - 4) * 350.0, clock_ppm=(i % 7 - 3) * 15.0,
@@ -686,7 +682,7 @@ def test_oversampling_factor_one(cfg, gpu_device):
     DemodConfig(samplerate=230000, symrate=80000, interp_factor=64, oqpsk=True, bps=8),
 ], ids=["O28", "O29", "O32-f16", "O64", "O64-oqpsk-u8"])
 def test_large_oversampling_factors(cfg, gpu_device):
-    """-O 29 and above: the per-alignment coefficient rows of the v2 std geometry exceed the 160 KB of LDS; mdemod_create
+    """-O 29 and above: the per-alignment coefficient rows of the std geometry exceed the 160 KB of LDS; mdemod_create
     used to refuse these valid reference configurations instead of using the v1 kernel.  The v3 kernel takes the
     compact4 table from -O 19 on and keeps them."""
     _check_cfg_against_oracle(cfg)

@@ -236,9 +236,13 @@ def test_register_partition_check_catches_a_violation():
         lowered[key] = (limits[key][0] - 24, limits[key][1])
         bad = B.scan_asm_partition(text, lowered, B.SCRATCH_FREE)
         assert bad and all(key.rstrip("_") in b for b in bad), (key, bad[:3])
-    # a kernel that must be scratch-free and is not
-    fake = text.replace("demod_kernel_rotp_WIDE_16_0_ks109", "demod_kernel_rotILi16ELi0ELi14ELi0E_fake")
-    assert any("scratch" in b for b in B.scan_asm_partition(fake, {**limits, "demod_kernel_rotILi16ELi0ELi14ELi0E_fake": (76, 0)}, B.SCRATCH_FREE))
+    # a kernel that must be scratch-free and is not: the first std kernel's metadata says it spills
+    import re
+    text = (B.LIB / "demod_kernel_rot.gfx950.s").read_text()
+    at = re.search(r"^_ZN\w*demod_kernel_rotILi\w+:", text, re.M).start()
+    k = text.index("ScratchSize: 0", at)
+    fake = text[:k] + "ScratchSize: 16" + text[k + len("ScratchSize: 0"):]
+    assert any("scratch" in b for b in B.scan_asm_partition(fake, limits, B.SCRATCH_FREE))
 
 
 def test_carrier_window_rounding_is_host_logic():
@@ -349,8 +353,6 @@ PLAN_CASES = {
     "-O 32: compact table keeps v3": (dict(samplerate=230000, interp_factor=32), 0, "v3 rotating register window"),
     "161 taps: v1": (dict(samplerate=230000, rrc_order=80), 0, "v1 LDS ring"),
     "161 taps x 64 banks: table in global memory": (dict(samplerate=1000000, rrc_order=80, interp_factor=64), 0, "[table in global memory]"),
-    "v2 forced, float mid": (dict(samplerate=1024000, bps=32), 2, "v2 register window, mid"),
-    "v2 forced, -O 32: v1": (dict(samplerate=230000, interp_factor=32), 2, "v1 LDS ring"),
     "v1 forced": (dict(samplerate=230000), 1, "v1 LDS ring"),
 }
 
@@ -370,3 +372,14 @@ def test_kernel_plan_of_a_configuration(case):
     assert rc == 0, rc
     assert want in name.value.decode(), name.value
     assert 0 < lds.value <= 160 * 1024 and block.value in (64, 128, 192, 256, 512), (lds.value, block.value)
+
+
+def test_the_retired_kernel_generation_is_refused():
+    """MDEMOD_FLAG_KERNEL_MASK = 2 named round 2's moving register window; it was retired in round 4 (every geometry it had is a
+    v3 kernel now): asking for it is a parameter error, not a silent substitution."""
+    import ctypes as C
+    from meteor_demod_amd import DemodConfig, _capi
+    p = DemodConfig(samplerate=230000).to_c(1000, 0)
+    p.reserved = 2
+    name = C.create_string_buffer(64)
+    assert _capi.lib().mdemod_plan_kernel(C.byref(p), name, 64, None, None) == -1

@@ -30,6 +30,6 @@ for name, cfg in cfgs.items():
     del buf, x, soft
     torch.cuda.empty_cache()
 '''
-for k in (sys.argv[1:] or ["", "v2"]):
+for k in (sys.argv[1:] or ["", "v1"]):
     print("MDEMOD_KERNEL=%r" % k, flush=True)
     subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MDEMOD_KERNEL=k))

@@ -22,4 +22,4 @@ with Demodulator(cfg, NT) as d:
         if m != want.shape[0] or not np.array_equal(sf[t, :m], want):
             k = min(m, want.shape[0]); diff = np.flatnonzero((sf[t,:k] != want[:k]).any(axis=1))
             bad.append((t, first + t, m, want.shape[0], int(diff[0]) if len(diff) else -1))
-    print(f"variant packed={os.environ.get('MDEMOD_RW_PACKED','1')} kernel={os.environ.get('MDEMOD_KERNEL','v2')}: {NT} tiles, {len(bad)} bad", bad[:8])
+    print(f"kernel={os.environ.get('MDEMOD_KERNEL','v3')}: {NT} tiles, {len(bad)} bad", bad[:8])
