@@ -302,10 +302,12 @@ md_pll_update(PllState &p, const float *lut, float alpha, float beta, float fmax
  * compare + select pairs md_pll_update's int fields compile to 4.4 each (and there were nine of each per firing).  Same values,
  * same order of the float and double operations.  Returns nonzero when `locked` changed; first != 0: the first lock ever. */
 struct PllWord { float phase, freq, err; };
+template <bool UNIFORM = false>
 __device__ __forceinline__ uint32_t
 md_pll_update_packed(PllWord &p, uint32_t &fl, const float *lut, float alpha, float beta, float fmax, float i, float q, uint32_t &first)
 {
-	const float e = md_tanh_lut(lut, i) * q - md_tanh_lut(lut, q) * i;        /* pll.c:143-151 */
+	const float e = UNIFORM ? md_tanh_lut_uniform(lut, i) * q - md_tanh_lut_uniform(lut, q) * i
+	                        : md_tanh_lut(lut, i) * q - md_tanh_lut(lut, q) * i;        /* pll.c:143-151 */
 
 	const float ph = p.phase + alpha * e;
 	p.phase = md_wrap_2pi(ph);                                               /* pll.c:113 */

@@ -83,11 +83,11 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 
 	/* ---- state (wave-uniform) ---- */
 	float gain = L.st.agc_gain[stream], bias_re = L.st.agc_bias_re[stream], bias_im = L.st.agc_bias_im[stream];
-	PllState pll;
+	PllWord pll;
 	pll.phase = L.st.pll_phase[stream]; pll.freq = L.st.pll_freq[stream]; pll.err = L.st.pll_err[stream];
-	int fl = L.st.flags[stream];
-	pll.locked = fl & 1; pll.locked_once = (fl >> 1) & 1; pll.updown = (fl & 4) ? 1 : -1;
-	int dual_state = (fl >> MDEMOD_FLAG_DUAL_SHIFT) & 3;
+	const int fl_in = L.st.flags[stream];
+	uint32_t fl = (uint32_t)fl_in & 7u;                 /* bit 0 locked, 1 locked_once, 2 updown > 0: kept packed (md_pll_update_packed) */
+	int dual_state = (fl_in >> MDEMOD_FLAG_DUAL_SHIFT) & 3;
 	float t_phase = L.st.t_phase[stream], t_freq = L.st.t_freq[stream], t_prev = L.st.t_prev[stream];
 	float inphase = L.st.inphase[stream];
 	const uint64_t nsym0 = L.st.n_symbols[stream];
@@ -185,13 +185,13 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 				if (out_cnt > 0) out_cnt--; else out_base--;
 			}
 			md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);
-			int first = 0;
-			const int changed = md_pll_update<true>(pll, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
+			uint32_t first = 0;
+			const uint32_t changed = md_pll_update_packed<true>(pll, fl, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
 			if (first) first_lock_call = (int)sym_call;
 			if (changed) {
 				if (ev_call < MDEMOD_MAX_LOCK_EVENTS && lane == 0) {
 					mdemod_lock_event ev;
-					ev.symbol = nsym0 + sym_call; ev.locked = pll.locked; ev.pad = 0;
+					ev.symbol = nsym0 + sym_call; ev.locked = (int)(fl & 1u); ev.pad = 0;
 					L.st.events[(size_t)stream * MDEMOD_MAX_LOCK_EVENTS + ev_call] = ev;
 				}
 				ev_call++;
@@ -377,7 +377,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 	if (lane == 0) {
 		L.st.agc_gain[stream] = gain; L.st.agc_bias_re[stream] = bias_re; L.st.agc_bias_im[stream] = bias_im;
 		L.st.pll_phase[stream] = pll.phase; L.st.pll_freq[stream] = pll.freq; L.st.pll_err[stream] = pll.err;
-		L.st.flags[stream] = (pll.locked ? 1 : 0) | (pll.locked_once ? 2 : 0) | (pll.updown > 0 ? 4 : 0) | (dual_state << MDEMOD_FLAG_DUAL_SHIFT);
+		L.st.flags[stream] = (int)(fl & 7u) | (dual_state << MDEMOD_FLAG_DUAL_SHIFT);
 		L.st.t_phase[stream] = t_phase; L.st.t_freq[stream] = t_freq; L.st.t_prev[stream] = t_prev;
 		L.st.inphase[stream] = inphase;
 		L.st.n_samples[stream] += (uint64_t)n;

@@ -10,10 +10,16 @@ def child(configs, steps):
     from bench import demod_config
     from meteor_demod_amd import Demodulator, synth
     T, L = 393216, 16448
+    from meteor_demod_amd import DemodConfig
+    extra = {"x3": DemodConfig(samplerate=1024000, bps=32), "x4": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),
+             "x5": DemodConfig(samplerate=2048000, bps=32), "x1": DemodConfig(samplerate=1024000), "x2": DemodConfig(samplerate=1800000)}
+    T0 = T
     for tag in configs:
-        cfg, _ = demod_config(tag)
-        rec = synth.make_stream(1000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, clock_ppm=-3.5)
-        buf = torch.empty((T * L, 2), dtype=torch.int16, device="cuda")
+        cfg = extra[tag] if tag in extra else demod_config(tag)[0]
+        T = T0 // 2 if cfg.bps == 32 else T0
+        rec = synth.make_stream(1000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, clock_ppm=-3.5, fmt=cfg.bps,
+                                **(dict(rms=0.25, dc=(0.001, -0.002)) if cfg.bps == 32 else {}))
+        buf = torch.empty((T * L, 2), dtype=torch.float32 if cfg.bps == 32 else torch.int16, device="cuda")
         synth.generate_device([rec], T * L, out=buf.view(1, T * L, 2))
         x = buf.view(T, L, 2)
         with Demodulator(cfg, T) as d:
@@ -28,7 +34,7 @@ def child(configs, steps):
             d.reset()
             d.process(x, soft=soft); torch.cuda.synchronize()
             bad = 0
-            picks = [0, 1, 63, 64, 255, 256, 511, 512, T // 2, T - 513, T - 1, 77777, 200001]
+            picks = [0, 1, 63, 64, 255, 256, 511, 512, T // 2, T - 513, T - 1, 77777, T // 2 + 3393]
             for t in picks:
                 st = d.status(int(t), 1)[0]
                 want = O.oracle_demod(cfg, x[int(t)].cpu().numpy())[0]

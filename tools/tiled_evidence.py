@@ -22,6 +22,7 @@ for tag in args:
     iq = synth.generate_device([st], n)[0].contiguous()
     opts = {}
     if "settle" in kw: opts["settle_samples"] = int(float(kw["settle"]) * cfg.samplerate / cfg.symrate)
+    if "margin" in kw: opts["pilot_margin_symbols"] = int(kw["margin"])
     demodulate_recording_native(cfg, iq[: 1 << 21])
     torch.cuda.synchronize(); t0 = time.time()
     soft, rep = demodulate_recording_native(cfg, iq, **opts)
@@ -50,7 +51,7 @@ for tag in args:
     x = iq[: 1 << 25].cpu().numpy(); a = O.oracle_demod(cfg, x)[0]; x[len(x) // 8, 0] += 1; b = O.oracle_demod(cfg, x)[0]
     mm = min(len(a), len(b)); d = np.abs(a[:mm].astype(np.int16) - b[:mm].astype(np.int16)).max(axis=1); first = int(np.argmax(d > 0))
     okf = d[first:] <= 1; fw = [float(okf[i:i + W].mean()) for i in range(0, len(okf) - W + 1, W)]
-    print(json.dumps({"config": name.split(":")[0], "samples": n, "rms": rms, "seconds": round(dt, 3), "symbols": [int(rep.n_symbols), len(serial)],
+    print(json.dumps({"config": name.split(":")[0], "opts": opts, "pilot_samples": int(rep.pilot_samples), "pilot_seconds": round(rep.pilot_seconds, 4), "samples": n, "rms": rms, "seconds": round(dt, 3), "symbols": [int(rep.n_symbols), len(serial)],
                       "tiles": int(rep.n_tiles), "tile_symbols": round(tile_sym, 1), "seam_fixes": int(rep.seam_fixes), "weak_seams": int(rep.weak_seams),
                       "repaired": int(rep.repaired_tiles), "rotation_jumps": int(rep.rotation_jumps), "weak_clock_tiles": int(rep.weak_clock_tiles),
                       "within_1lsb": round(float(ok.mean()), 5), "worst_window": round(float(wins.min()), 4), "windows_below_0.99": int((wins < 0.99).sum()), "windows": len(wins),
