@@ -161,16 +161,20 @@ plan_context(mdemod_ctx *ctx)
 	ctx->block_threads = 64 * 3;                     /* v1 kernel: three waves per block (__launch_bounds__(256); measured best, r01) */
 
 	if (ctx->tab.rw_hyb) ctx->hyb_block = MDEMOD_RW_BLOCK;
+	/* The kernel instances compiled for the BASELINE settings (their symbol clock's blind steps are template parameters: 14 / 6 on
+	 * the std window, 109 on the wide packed one) also keep fast_sin's parabola as a table in LDS (rotwin_body.h, LUT): 64 KB, one
+	 * 512-thread block per CU.  Only when table, coefficient rows, state slots and output rings fit the 160 KB together. */
+	c.sin_lut = ((ctx->use_rot && !ctx->tab.rw_std_compact && c.step_safe == (c.oqpsk ? 6 : 14)) ||
+	             (ctx->tab.rw_compact4 && ctx->tab.rw_wide && params->bps == 16 && !c.oqpsk && c.step_safe == 109)) ? 1 : 0;
+	auto rw_block = [&]() { return ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : (c.sin_lut ? MDEMOD_RW_LUT_BLOCK : MDEMOD_RW_BLOCK); };
 	auto lds_need = [&](int threads) {
 		return (ctx->tab.ctab.size() + 32) * sizeof(float) +
-		       (ctx->tab.use_rw ? static_cast<size_t>((ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
-		                          + static_cast<size_t>(ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) * 64     /* soft-symbol staging: a 32-symbol ring (4 x 16 B) per thread */
-		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes)
-#ifdef MDEMOD_EXP_LDS_EXTRA            /* experimental builds: the v3 kernels' sine table (rotwin_body.h: ROT_SIN_LUT) */
-		       + ((ctx->use_rot || ctx->tab.rw_compact4) ? static_cast<size_t>(MDEMOD_EXP_LDS_EXTRA) : 0)
-#endif
-		       ;
+		       (ctx->tab.use_rw ? static_cast<size_t>(rw_block() / 64) * MDEMOD_RW_STATE_SLOTS * 64 * sizeof(float)
+		                          + static_cast<size_t>(rw_block()) * 64     /* soft-symbol staging: a 32-symbol ring (4 x 16 B) per thread */
+		                          + (c.sin_lut ? static_cast<size_t>(MDEMOD_SIN_LUT_BYTES) : 0)
+		                        : static_cast<size_t>(threads / 64) * c.ring_granules * 64 * 4 * ctx->sample_bytes);
 	};
+	if (c.sin_lut && lds_need(ctx->block_threads) > 160 * 1024) c.sin_lut = 0;      /* (e.g. -O 7 at a rate that has 14 blind steps: 38 KB of rows) */
 	if (ctx->tab.use_rw && lds_need(ctx->block_threads) > 160 * 1024) {
 		/* The per-alignment coefficient rows of the std geometry grow with -O (16 alignments x interp x 84 floats: past the
 		 * 160 KB of LDS from -O 29 on); the v1 ring kernel keeps 4 alignments and still fits: fall back to it. */
@@ -178,6 +182,7 @@ plan_context(mdemod_ctx *ctx)
 		ctx->use_rot = false;
 		if (rc) return rc;
 		c.ring_granules = c.hpad / 4 + 8;
+		c.sin_lut = 0;
 	}
 	while (ctx->block_threads > 64 && lds_need(ctx->block_threads) > 160 * 1024) ctx->block_threads -= 64;
 	ctx->lds_bytes = lds_need(ctx->block_threads);
@@ -684,7 +689,7 @@ mdemod_plan_kernel(const mdemod_params *params, char *name, uint32_t name_cap, u
 	if (rc == MDEMOD_OK) {
 		snprintf(name, name_cap, "%s%s", mdemod_kernel_name(ctx), ctx->v1_global_table && !wants_latency_kernel(ctx) ? " [table in global memory]" : "");
 		if (lds_bytes) *lds_bytes = static_cast<uint32_t>(wants_latency_kernel(ctx) ? ctx->lat_lds : ctx->lds_bytes);
-		if (block_threads) *block_threads = static_cast<uint32_t>(ctx->tab.use_rw ? (ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : MDEMOD_RW_BLOCK) : ctx->block_threads);
+		if (block_threads) *block_threads = static_cast<uint32_t>(ctx->tab.use_rw ? (ctx->tab.rw_wide ? MDEMOD_RW_WIDE_BLOCK : (ctx->tab.c.sin_lut ? MDEMOD_RW_LUT_BLOCK : MDEMOD_RW_BLOCK)) : ctx->block_threads);
 	}
 	delete ctx;
 	return rc;
@@ -819,6 +824,24 @@ mdemod_selftest_turncode(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_misma
 	if (e != hipSuccess) return MDEMOD_ERR_HIP;
 	*n_mismatch = h;
 	if (n_checked) *n_checked = 2ull * 0x41800000ull;
+	return MDEMOD_OK;
+}
+
+int
+mdemod_selftest_sinlut(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch)
+{
+	if (!ctx || !n_mismatch) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	unsigned long long *d = nullptr, h = 0;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(h)));
+	hipError_t e = hipMemset(d, 0, sizeof(h));
+	if (e == hipSuccess) e = mdemod_launch_selftest_sinlut(d, nullptr);
+	if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return MDEMOD_ERR_HIP;
+	*n_mismatch = h;
+	if (n_checked) *n_checked = 4ull * 65536ull;
 	return MDEMOD_OK;
 }
 

@@ -143,7 +143,36 @@ selftest_turncode_kernel(unsigned long long *mismatch)
 	if (bad) atomicAdd(mismatch, bad);
 }
 
+/* fast_sin's parabola from the table in LDS (md_sin_from_code_lut, what the LUT instances of the v3 kernels evaluate) against the
+ * integer arithmetic of sincos.c:26-34 (md_sin_from_code), bit for bit: all 65 536 turn codes, with clean, sign-extended and
+ * arbitrary upper halves of the 32-bit word the turn code arrives in. */
+__global__ void
+selftest_sinlut_kernel(unsigned long long *mismatch)
+{
+	extern __shared__ float sin_tab[];
+	md_sin_lut_fill(sin_tab, (int)threadIdx.x, (int)blockDim.x);
+	__syncthreads();
+	unsigned long long bad = 0;
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < 65536u; c += gridDim.x * blockDim.x) {
+		const uint32_t tops[4] = { 0u, (c & 0x8000u) ? 0xFFFF0000u : 0u, 0x5A5A0000u, 0xFFFF0000u ^ (c << 16) };
+		for (int k = 0; k < 4; k++) {
+			const int32_t wide = (int32_t)(tops[k] | c);
+			bad += (__float_as_uint(md_sin_from_code(wide)) != __float_as_uint(md_sin_from_code_lut(sin_tab, wide))) ? 1 : 0;
+		}
+	}
+	if (bad) atomicAdd(mismatch, bad);
+}
+
 } /* namespace */
+
+hipError_t
+mdemod_launch_selftest_sinlut(unsigned long long *mismatch_dev, hipStream_t stream)
+{
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(selftest_sinlut_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MDEMOD_SIN_LUT_BYTES);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(selftest_sinlut_kernel, dim3(64), dim3(256), MDEMOD_SIN_LUT_BYTES, stream, mismatch_dev);
+	return hipGetLastError();
+}
 
 /* An empty launch: the first launch of a process loads the library's code objects (tens of milliseconds for the generated
  * assembly kernels); mdemod_init_device does it off the critical path of the first demodulation. */

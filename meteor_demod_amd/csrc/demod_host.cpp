@@ -76,6 +76,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	c.interp = p.interp_factor;
 	c.taps = 2 * p.rrc_order + 1;
 	c.oqpsk = p.oqpsk ? 1 : 0;
+	c.sin_lut = 0;                                    /* (decided by plan_context once the kernel instance and its LDS are known) */
 
 	/* demod.c:10-14 */
 	const int mult = p.oqpsk ? 1 : 2;

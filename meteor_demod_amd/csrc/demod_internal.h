@@ -18,6 +18,8 @@
 #define MDEMOD_RW_WIDE_SLIDE    16     /* slots per slide of the wide geometry      */
 #define MDEMOD_RW_WIDE_MAXSL    1      /* slides per loop iteration                 */
 #endif
+#define MDEMOD_SIN_LUT_BYTES    65552  /* fast_sin's parabola as 16 385 floats in LDS, rounded up to 16 bytes (rotwin_body.h, LUT instances) */
+#define MDEMOD_RW_LUT_BLOCK     512    /* threads per block of the std kernel's instances with the sine table: one table per CU */
 #define MDEMOD_RW_MID_NW        96     /* window slots of the mid geometry (65 taps + 32 alignments)      */
 #define MDEMOD_RW_FAR_NW        112    /* window slots of the far geometry (65 taps + 48 alignments)      */
 #ifndef MDEMOD_RW_BLOCK
@@ -42,6 +44,7 @@ struct DemodConsts {
 	int32_t  step_check;     /* predicated checked steps after them              */
 	float    step_fmax;      /* upper bound of the per-step phase increment      */
 	uint32_t interp_magic;   /* floor(2^32/interp)+1: x/interp == mulhi(x, magic) */
+	int32_t  sin_lut;        /* host only: this context launches the kernel instance with the sine table in LDS */
 };
 
 /* Per-stream state, structure-of-arrays in HBM so that lane s of a wave touches
@@ -111,6 +114,7 @@ int  mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA 
 void mdemod_hostpipe_free(void *pipe);
 hipError_t mdemod_launch_selftest_sincos(const float *x, uint32_t n, float *s, float *c, hipStream_t stream);
 hipError_t mdemod_launch_selftest_turncode(unsigned long long *mismatch_dev, hipStream_t stream);
+hipError_t mdemod_launch_selftest_sinlut(unsigned long long *mismatch_dev, hipStream_t stream);
 hipError_t mdemod_launch_selftest_hypot(const float *xy, uint32_t n, float *out, hipStream_t stream);
 #endif
 

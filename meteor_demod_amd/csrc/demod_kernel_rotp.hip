@@ -150,7 +150,7 @@ struct WinP {
 	demod_kernel_rotp_##NAME##_##FMT##_##OQ(const DemodLaunch L) { rotwin_demod<WinP<GEO, FMT>, FMT, OQ, 0>(L); }
 /* configs[3] (72k QPSK in 1 MS/s, -O 8): its 109 blind symbol-clock steps compiled in, like the two LRPT settings of the std kernel */
 __global__ void __launch_bounds__(GeoP<0>::BLOCK, 2) __attribute__((amdgpu_num_vgpr(ROTPK_WIDE_16_LIMIT / 2)))
-demod_kernel_rotp_WIDE_16_0_ks109(const DemodLaunch L) { rotwin_demod<WinP<0, 16>, 16, 0, 109>(L); }
+demod_kernel_rotp_WIDE_16_0_ks109(const DemodLaunch L) { rotwin_demod<WinP<0, 16>, 16, 0, 109, 1>(L); }        /* ... and the sine table in LDS */
 ROTP_KERNEL(0, WIDE, 16, 0) ROTP_KERNEL(0, WIDE, 16, 1) ROTP_KERNEL(0, WIDE, 8, 0) ROTP_KERNEL(0, WIDE, 8, 1)
 ROTP_KERNEL(1, MID, 16, 0) ROTP_KERNEL(1, MID, 16, 1) ROTP_KERNEL(1, MID, 8, 0) ROTP_KERNEL(1, MID, 8, 1)
 ROTP_KERNEL(2, FAR, 16, 0) ROTP_KERNEL(2, FAR, 16, 1) ROTP_KERNEL(2, FAR, 8, 0) ROTP_KERNEL(2, FAR, 8, 1)
@@ -179,6 +179,6 @@ mdemod_launch_demod_rotp(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mi
 		{ { demod_kernel_rotp_FAR_16_0, demod_kernel_rotp_FAR_16_1 }, { demod_kernel_rotp_FAR_8_0, demod_kernel_rotp_FAR_8_1 } },
 	};
 	static const int blocks[3] = { GeoP<0>::BLOCK, GeoP<1>::BLOCK, GeoP<2>::BLOCK };
-	if (geom == 0 && fmt == 16 && !L.c.oqpsk && L.c.step_safe == 109) return launch_rotp(demod_kernel_rotp_WIDE_16_0_ks109, blocks[0], L, lds_bytes, stream);
+	if (geom == 0 && fmt == 16 && !L.c.oqpsk && L.c.step_safe == 109 && L.c.sin_lut) return launch_rotp(demod_kernel_rotp_WIDE_16_0_ks109, blocks[0], L, lds_bytes, stream);
 	return launch_rotp(table[geom][fmt == 16 ? 0 : 1][L.c.oqpsk ? 1 : 0], blocks[geom], L, lds_bytes, stream);
 }

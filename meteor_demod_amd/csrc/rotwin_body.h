@@ -25,18 +25,13 @@
 
 #pragma clang fp contract(off)
 
-#ifndef ROT_SIN_LUT
-#define ROT_SIN_LUT 0            /* 0: fast_sin's parabola in integer arithmetic; 1: int16 table in LDS (32 KB); 2: float table (64 KB) */
-#endif
 #ifndef ROT_OQ_SYNC
 #define ROT_OQ_SYNC 1            /* OQPSK: the lanes of a wave take their I-rail and Q-rail firings in the same loop iterations */
 #endif
-#if ROT_SIN_LUT == 1
-typedef int16_t rot_sinlut_t;
-#elif ROT_SIN_LUT == 2
+/* fast_sin's parabola as a table of 16 385 floats behind the output rings (demod_device.h: md_sin_from_code_lut): the kernel instances
+ * compiled for the BASELINE settings take it (template parameter LUT; the host adds MDEMOD_SIN_LUT_BYTES to their LDS), measured
+ * +1.4 % / +1.2 % / +0.9 % on configs[1] / [2] / [3] - 12 VALU instructions less per evaluation, two evaluations per firing */
 typedef float rot_sinlut_t;
-#endif
-#define ROT_SIN_LUT_BYTES ((16385 * (ROT_SIN_LUT == 2 ? 4 : 2) + 15) / 16 * 16)
 
 namespace {
 
@@ -129,7 +124,7 @@ rot_clock_fast(const RotClockConsts &K, float thr, int v_end, float &t_phase, fl
 
 /* ---- the kernel body ------------------------------------------------------------- */
 
-template <class W, int FMT, int OQPSK, int KS>
+template <class W, int FMT, int OQPSK, int KS, int LUT = 0>
 __device__ __forceinline__ void
 rotwin_demod(const DemodLaunch &L)
 {
@@ -156,14 +151,9 @@ rotwin_demod(const DemodLaunch &L)
 	uint4 *stage = reinterpret_cast<uint4 *>(lut + 32 + (BLOCK / 64) * (S_COUNT * 64)) + threadIdx.x;
 	const uint32_t ctab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
 	W win;
-#if ROT_SIN_LUT
-	/* fast_sin's parabola as a table behind the output rings (demod_device.h: md_sin_from_code_lut; the host sizes the LDS) */
 	rot_sinlut_t *sintab = reinterpret_cast<rot_sinlut_t *>(stage - threadIdx.x + BLOCK * RGR);
-	md_sin_lut_fill(sintab, (int)threadIdx.x, BLOCK);
-	win.setup(ctab_addr + (uint32_t)(reinterpret_cast<unsigned char *>(stage - threadIdx.x + BLOCK * RGR) - lds) + ROT_SIN_LUT_BYTES);
-#else
-	win.setup(ctab_addr + (uint32_t)(reinterpret_cast<unsigned char *>(stage - threadIdx.x + BLOCK * RGR) - lds));
-#endif
+	if constexpr (LUT) md_sin_lut_fill(sintab, (int)threadIdx.x, BLOCK);
+	win.setup(ctab_addr + (uint32_t)(reinterpret_cast<unsigned char *>(stage - threadIdx.x + BLOCK * RGR) - lds) + (LUT ? MDEMOD_SIN_LUT_BYTES : 0));
 
 	const DemodConsts &C = L.c;
 	const uint32_t stream = blockIdx.x * blockDim.x + threadIdx.x;
@@ -338,13 +328,14 @@ rotwin_demod(const DemodLaunch &L)
 			pll.phase = r_phase; pll.freq = r_freq;
 			pll.err = ld_err();
 
-#if ROT_SIN_LUT
-			const float sn = md_sin_from_code_lut(sintab, md_turn_code<false>(-pll.phase));
-			const float cs = md_sin_from_code_lut(sintab, md_turn_code<false>((float)((double)(-pll.phase) + MD_HALF_PI_D)));   /* sincos.c:37-40 */
-#else
-			const float sn = md_fast_sin<false>(-pll.phase);
-			const float cs = md_fast_cos<false>(-pll.phase);
-#endif
+			float sn, cs;
+			if constexpr (LUT) {
+				sn = md_sin_from_code_lut(sintab, md_turn_code<false>(-pll.phase));
+				cs = md_sin_from_code_lut(sintab, md_turn_code<false>((float)((double)(-pll.phase) + MD_HALF_PI_D)));   /* sincos.c:37-40 */
+			} else {
+				sn = md_fast_sin<false>(-pll.phase);
+				cs = md_fast_cos<false>(-pll.phase);
+			}
 			bool emit = true;
 			float out_re, out_im;
 			if (OQPSK) {

@@ -324,6 +324,12 @@ class Demodulator:
         check(self._lib.mdemod_selftest_turncode(self._ctx, C.byref(n), C.byref(bad)), "selftest_turncode")
         return n.value, bad.value
 
+    def selftest_sinlut(self) -> tuple[int, int]:
+        """(turn codes checked, mismatches) of fast_sin's parabola read from the table in LDS against sincos.c's integer arithmetic."""
+        n, bad = C.c_uint64(), C.c_uint64()
+        check(self._lib.mdemod_selftest_sinlut(self._ctx, C.byref(n), C.byref(bad)), "selftest_sinlut")
+        return n.value, bad.value
+
     def selftest_hypot(self, xy: np.ndarray) -> np.ndarray:
         xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
         out = np.empty(xy.shape[0], dtype=np.float32)

@@ -512,6 +512,15 @@ def test_device_turn_code_shortcut_is_exact_everywhere(gpu_device):
     assert n == 2 * 0x41800000 and bad == 0
 
 
+def test_device_sine_table_equals_the_parabola_for_every_turn_code(gpu_device):
+    """The kernel instances of the BASELINE settings read fast_sin's Q14 parabola (sincos.c:26-34) from a table in LDS
+    (md_sin_from_code_lut): bit-identical to the integer arithmetic for all 65 536 turn codes, whatever the upper half of the word
+    (the parabola's own values are pinned against the reference by test_device_fast_sin_cos_match_reference)."""
+    with Demodulator(C1, 1) as d:
+        n, bad = d.selftest_sinlut()
+    assert n == 4 * 65536 and bad == 0
+
+
 def test_device_fast_sin_cos_outside_the_shortcut_range(gpu_device):
     """|x| >= 16 takes the real-division fallback (one wave-uniform test in the kernel): mixed waves of in-range and
     out-of-range arguments against the oracle, up to where the reference's int conversion is defined (|x| < 2e5)."""
