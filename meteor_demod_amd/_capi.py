@@ -180,6 +180,8 @@ def lib() -> C.CDLL:
                 "(python -m meteor_demod_amd.build). There is no CPU fallback.")
         handle = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
+            if _os.environ.get("MDEMOD_LIB_PATH") and not hasattr(handle, name):
+                continue                                   # an older build of the library on A/B duty (tools/ab4.py): newer entries are simply absent
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
