@@ -692,7 +692,7 @@ def main() -> None:
 
     # counters cannot be collected inside a timed run: traffic and the instruction mix are READ from the tracked rocprofv3 profile
     # of this exact command (profiles/hbm_traffic.json, written by tools/make_profile_md.py), keyed by configuration and shape
-    traffic = valu_per_firing = prof_round = simd_busy = None
+    traffic = valu_per_firing = prof_round = simd_busy = pipe_cycles = mean_cost = samples_per_wf = None
     tfile = ROOT / "profiles" / "hbm_traffic.json"
     if tfile.exists():
         try:
@@ -703,6 +703,9 @@ def main() -> None:
                 valu_per_firing = rec_t[key].get("valu_per_wave_firing")
                 simd_busy = rec_t[key].get("simd_valu_busy_frac")
                 prof_round = rec_t[key].get("round")
+                pipe_cycles = rec_t[key].get("valu_pipe_cycles_per_wave_firing")
+                mean_cost = rec_t[key].get("valu_mean_simd_cycles_per_instruction")
+                samples_per_wf = rec_t[key].get("samples_per_wave_firing")
         except Exception:
             traffic = None
     # unfused flops per input sample = 2*interp + (symrate/fs) * (4*taps*F + ~100*F'), F = firings per symbol
@@ -710,6 +713,12 @@ def main() -> None:
     flops_per_sample = 2 * cfg.interp_factor + (cfg.symrate / cfg.samplerate) * (4 * (2 * cfg.rrc_order + 1) * F + 100 * (1.7 if cfg.oqpsk else 1.0))
     VALU_PEAK_TOPS = 78.6         # MI355X: 157.3 TFLOP/s FP32 vector counts FMAs; the reference's unfused mul/add get half of it
     valu_tops = flops_per_sample * (T * L) / (kernel_ms * 1e-3) / 1e12
+    # The peak for the instruction mix this kernel actually issues: a SIMD needs `pipe_cycles` of VALU pipe time per wave-firing
+    # (measured instruction count x mix-weighted measured cost per instruction: tools/valu_cost.py, tools/ubench/valu_mix.hip), so
+    # the chip's 1024 SIMDs at 2.4 GHz finish at most 1024 * 2.4e9 / pipe_cycles wave-firings per second
+    peak_measured = None
+    if pipe_cycles and samples_per_wf:
+        peak_measured = flops_per_sample * samples_per_wf * (1024 * 2.4e9 / pipe_cycles) / 1e12
 
     out = {
         "metric": "IQ Msamples/s demodulated (whole node)", "value": round(value, 1), "unit": "Msamples/s",
@@ -728,6 +737,13 @@ def main() -> None:
                      "traffic_source": (f"profiles/hbm_traffic.json[{args.config}:{T}x{L}] (round {prof_round}): rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of "
                                         "this command, separate --pmc passes; not measured by this run") if traffic else None,
                      "valu": {"achieved_top_s": round(valu_tops, 2), "peak_top_s": VALU_PEAK_TOPS, "frac": round(valu_tops / VALU_PEAK_TOPS, 4),
+                              "peak_measured_top_s": round(peak_measured, 2) if peak_measured else None,
+                              "frac_of_measured": round(valu_tops / peak_measured, 4) if peak_measured else None,
+                              "peak_measured_note": ("the rate at which 1024 SIMDs at 2.4 GHz could issue THIS kernel's VALU mix back to back: "
+                                                     f"{valu_per_firing} VALU instructions per wave-firing (rocprofv3 SQ_INSTS_VALU) x {mean_cost} SIMD cycles each "
+                                                     "(mix-weighted, per-instruction costs measured at two waves per SIMD: tools/ubench/valu_mix.hip, "
+                                                     "tools/valu_cost.py); the 78.6 Top/s above is the data-sheet unfused-FP32 figure, which no mix of "
+                                                     "conversions, selects, f64 and packed instructions can reach") if peak_measured else None,
                               "algorithmic_unfused_flops_per_sample": round(flops_per_sample, 1),
                               "valu_instructions_per_wave_firing": valu_per_firing,
                               # share of a SIMD's 4-cycle issue quanta that carry a VALU instruction (2 waves x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)
