@@ -23,6 +23,7 @@ for tag in args:
     opts = {}
     if "settle" in kw: opts["settle_samples"] = int(float(kw["settle"]) * cfg.samplerate / cfg.symrate)
     if "margin" in kw: opts["pilot_margin_symbols"] = int(kw["margin"])
+    if "tile" in kw: opts["tile_samples"] = int(float(kw["tile"]) * cfg.samplerate / cfg.symrate) // 64 * 64
     demodulate_recording_native(cfg, iq[: 1 << 21])
     torch.cuda.synchronize(); t0 = time.time()
     soft, rep = demodulate_recording_native(cfg, iq, **opts)
