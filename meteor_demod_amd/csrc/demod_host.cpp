@@ -123,6 +123,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		c.step_safe = ks < 0 ? 0 : ks;
 		c.step_check = 4;                                         /* fixed in the kernel */
 		c.interp_magic = static_cast<uint32_t>((1ull << 32) / static_cast<uint64_t>(c.interp)) + 1u;
+		c.step_inv = static_cast<float>((1.0 - 1.0 / 4096.0) / static_cast<double>(c.step_fmax));
 	}
 
 	/* ---- kernel selection + geometry ---- */

@@ -44,6 +44,7 @@ struct DemodConsts {
 	int32_t  step_check;     /* predicated checked steps after them              */
 	float    step_fmax;      /* upper bound of the per-step phase increment      */
 	uint32_t interp_magic;   /* floor(2^32/interp)+1: x/interp == mulhi(x, magic) */
+	float    step_inv;       /* (1 - 2^-12) / step_fmax: steps that fit a phase distance, strictly conservative (clock_jump.h) */
 	int32_t  sin_lut;        /* host only: this context launches the kernel instance with the sine table in LDS */
 };
 

@@ -22,6 +22,7 @@
 
 #include "demod_internal.h"
 #include "demod_device.h"
+#include "clock_jump.h"
 
 #pragma clang fp contract(off)
 
@@ -86,17 +87,19 @@ blind_steps(float p, float f)
  * threshold, then four checked ones (the increment is positive, so "reached" is monotone); every add is the reference's add
  * (k * freq != k rounded adds).  Does nothing when the lane is too close to the threshold or to the end of its block: the
  * caller's generic loop steps those. */
-struct RotClockConsts { int k_safe, steps_need, interp; float f_hi; uint32_t magic; };
+struct RotClockConsts { int k_safe, steps_need, interp; float f_hi; uint32_t magic; float inv; };
 template <int KS>          /* KS > 0: the number of blind steps is known at compile time (the launcher checks it), 0: any */
 __device__ __forceinline__ void
 rot_clock_fast(const RotClockConsts &K, float thr, int v_end, float &t_phase, float t_freq, int &isub, int &v_cur, int &fire_sub, bool &fired)
 {
-	const int k_safe = KS ? KS : K.k_safe, interp = K.interp;
+	int k_safe = KS ? KS : K.k_safe;
+	const int interp = K.interp;
 	/* enough input left for k_safe + 4 steps (the part of the current sample still to be stepped is ignored: conservative) */
-	const bool fast = (t_phase < thr - (float)k_safe * K.f_hi - 1e-3f) && (v_cur + K.steps_need < v_end);
+	const bool fast = (KS == 109 ? (t_phase > CJ109_P_LO && t_phase < CJ109_P_HI) : (t_phase < thr - (float)k_safe * K.f_hi - 1e-3f)) && (v_cur + K.steps_need < v_end);
 	if (fast) {
 		float p = t_phase;
-		if (KS) p = blind_steps<KS>(p, t_freq);                       /* 14: QPSK 72k @ 230 kS/s, -O 5; 6: OQPSK 80k @ 230 kS/s */
+		if (KS == 109) k_safe = clock_jump_109(p, t_freq, thr, K.inv);   /* configs[3]: 30 real additions and three binades in closed form (clock_jump.h) */
+		else if (KS) p = blind_steps<KS>(p, t_freq);                  /* 14: QPSK 72k @ 230 kS/s, -O 5; 6: OQPSK 80k @ 230 kS/s */
 		else {
 			int k = k_safe;
 			for (; k >= 16; k -= 16) p = blind_steps<16>(p, t_freq);
@@ -239,8 +242,8 @@ rotwin_demod(const DemodLaunch &L)
 	bool done = !valid || n == 0;
 	uint32_t sym_call = 0;
 	RotClockConsts K;
-	K.k_safe = C.step_safe; K.f_hi = C.step_fmax; K.magic = C.interp_magic; K.interp = C.interp;
-	K.steps_need = (C.step_safe + 4 + C.interp - 1) / C.interp;      /* samples that hold k_safe + 4 steps */
+	K.k_safe = C.step_safe; K.f_hi = C.step_fmax; K.magic = C.interp_magic; K.interp = C.interp; K.inv = C.step_inv;
+	K.steps_need = ((KS == 109 ? CJ109_MAX_STEPS : C.step_safe) + 4 + C.interp - 1) / C.interp;      /* samples that hold k_safe + 4 steps */
 
 	int n_wave_max = n;
 	for (int o = 32; o > 0; o >>= 1) {

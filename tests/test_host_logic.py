@@ -166,14 +166,14 @@ def test_synth_signal_is_what_it_claims():
     assert abs(peak - 4 * f0) < 20.0
 
 
-def _run_proof(name, *flags):
+def _run_proof(name, *flags, args=()):
     import subprocess
     import tempfile
     src = ROOT / "tools" / "proofs" / name
     with tempfile.TemporaryDirectory() as td:
         exe = Path(td) / "verify"
         subprocess.run(["g++", "-O2", "-ffp-contract=off", *flags, str(src), "-o", str(exe)], check=True)
-        out = subprocess.run([str(exe)], capture_output=True, text=True)
+        out = subprocess.run([str(exe), *args], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     return out.stdout
 
@@ -191,6 +191,15 @@ def test_period_wrap_in_float_arithmetic_proof_holds_on_the_host():
     with 2pi <= |x| < 4pi (demod_device.h: md_nco_advance<true>, md_wrap_2pi)."""
     out = _run_proof("verify_wrap_f32.cpp")
     assert "checked 16777216 floats" in out and "mismatches 0" in out, out
+
+
+def test_symbol_clock_closed_form_proof_holds_on_the_host():
+    """tools/proofs/verify_clock_jump.cpp: the closed-form blind steps of configs[3]'s symbol clock (csrc/clock_jump.h, the very header
+    the kernel compiles) against the reference's sequential rounded additions (timing.c:32-38): every clock word the instance can be
+    launched with (153 009 floats), both ends of the launcher's bound, 64 starting phases each here (the full run behind DESIGN.md
+    took 2 048: 627 M cases) - same final phase bit for bit, same step count, the firing always found by the checked additions."""
+    out = _run_proof("verify_clock_jump.cpp", "-pthread", args=["1", "64"])
+    assert "153009 clock words" in out and ": 0 mismatches" in out and "8368 words with a tie" in out, out
 
 
 def test_cli_device_plan_is_round_robin():
