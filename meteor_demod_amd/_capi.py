@@ -147,6 +147,7 @@ SIGNATURES = {
     "mdemod_selftest_hypot": (C.c_int, [C.c_void_p, _P(C.c_float), C.c_uint32, _P(C.c_float)]),
     "mdemod_selftest_turncode": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
     "mdemod_selftest_sinlut": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
+    "mdemod_selftest_cabsf": (C.c_int, [C.c_void_p, C.c_uint64, _P(C.c_uint64), _P(C.c_uint64)]),
 }
 
 _lib = None

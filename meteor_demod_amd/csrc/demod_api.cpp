@@ -828,6 +828,24 @@ mdemod_selftest_turncode(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_misma
 }
 
 int
+mdemod_selftest_cabsf(mdemod_ctx *ctx, uint64_t pairs, uint64_t *n_mismatch, uint64_t *n_fallback)
+{
+	if (!ctx || !n_mismatch || !pairs) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	unsigned long long *d = nullptr, h[2] = { 0, 0 };
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(h)));
+	hipError_t e = hipMemset(d, 0, sizeof(h));
+	if (e == hipSuccess) e = mdemod_launch_selftest_cabsf(pairs, d, nullptr);
+	if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return MDEMOD_ERR_HIP;
+	*n_mismatch = h[0];
+	if (n_fallback) *n_fallback = h[1];
+	return MDEMOD_OK;
+}
+
+int
 mdemod_selftest_sinlut(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch)
 {
 	if (!ctx || !n_mismatch) return MDEMOD_ERR_PARAM;

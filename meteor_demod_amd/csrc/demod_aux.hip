@@ -129,6 +129,29 @@ selftest_hypot_kernel(const float *xy, uint32_t n, float *out)
 	out[i] = md_cabsf(xy[2 * i], xy[2 * i + 1]);
 }
 
+/* md_cabsf_short (short square root + exact fallback next to a rounding boundary) against md_cabsf_exact on pseudo-random pairs drawn like
+ * the AGC's output (|re|, |im| up to a few hundred), on pairs across the whole float range, and on pairs with a zero: counts the
+ * differences (must be 0) and the lanes that took the fallback. */
+__global__ void
+selftest_cabsf_kernel(uint64_t per_thread, unsigned long long *out /* [2]: mismatches, fallbacks */)
+{
+	uint64_t z = 0x9E3779B97F4A7C15ull * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1);
+	unsigned long long bad = 0;
+	uint32_t fb = 0;
+	for (uint64_t k = 0; k < per_thread; k++) {
+		z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31; z += 0x9E3779B97F4A7C15ull;
+		float re, im;
+		const uint32_t a = (uint32_t)z, b = (uint32_t)(z >> 32);
+		if ((k & 15) == 15) { re = __uint_as_float(a); im = __uint_as_float(b); }                       /* any two floats (NaN and inf among them) */
+		else if ((k & 15) == 14) { re = (k & 16) ? 0.0f : -0.0f; im = __uint_as_float(b & 0x7FFFFFFFu) * 1e-30f; }
+		else { re = ((float)(int32_t)a) * (400.0f / 2147483648.0f); im = ((float)(int32_t)b) * (400.0f / 2147483648.0f); }
+		const float want = md_cabsf_exact(re, im), got = md_cabsf_short(re, im, &fb);
+		bad += (__float_as_uint(want) != __float_as_uint(got)) && !(want != want && got != got);   /* (two NaNs may differ in payload: both are "NaN" to every consumer) */
+	}
+	if (bad) atomicAdd(&out[0], bad);
+	if (fb) atomicAdd(&out[1], (unsigned long long)fb);
+}
+
 /* Every float with |x| < 16, both signs: division-free turn code vs the real division. */
 __global__ void
 selftest_turncode_kernel(unsigned long long *mismatch)
@@ -164,6 +187,14 @@ selftest_sinlut_kernel(unsigned long long *mismatch)
 }
 
 } /* namespace */
+
+hipError_t
+mdemod_launch_selftest_cabsf(uint64_t pairs, unsigned long long *out_dev, hipStream_t stream)
+{
+	const unsigned blocks = 256 * 16, threads = 256;
+	hipLaunchKernelGGL(selftest_cabsf_kernel, dim3(blocks), dim3(threads), 0, stream, (pairs + (uint64_t)blocks * threads - 1) / ((uint64_t)blocks * threads), out_dev);
+	return hipGetLastError();
+}
 
 hipError_t
 mdemod_launch_selftest_sinlut(unsigned long long *mismatch_dev, hipStream_t stream)

@@ -155,13 +155,50 @@ md_sqrt_sumsq(double s)
 	return __builtin_amdgcn_class(s, 0x260) ? s : g;       /* -0, +0, +inf: sqrt(s) == s */
 }
 
-/* cabsf as glibc 2.35 computes it: one double sqrt of the exact double sum of
- * squares, narrowed to float (agc.c:21). */
+/* cabsf as glibc 2.35 computes it: one double sqrt of the exact double sum of squares, narrowed to float (agc.c:21) -
+ * the reference form: a correctly rounded f64 square root (19 instructions). */
 __device__ __forceinline__ float
-md_cabsf(float re, float im)
+md_cabsf_exact(float re, float im)
 {
 	const double s = (double)re * (double)re + (double)im * (double)im;
 	return (float)md_sqrt_sumsq(s);
+}
+
+/* What the kernels call unless they ask for the short form (below). */
+__device__ __forceinline__ float
+md_cabsf(float re, float im)
+{
+	return md_cabsf_exact(re, im);
+}
+
+/* The same float with a shorter square root almost always (round 4; taken by the configs[1] instance of the std kernel, where it
+ * measured +1.9 %: on configs[2] / [3] and in the latency kernel it measured -0.6 % / -0.6 % / -3 %, the exec-mask detour of the
+ * fallback costing what the eight instructions less gain).  Only the FLOAT is wanted, so a square root good to 2^-47 is
+ * enough unless it lands next to a float rounding boundary: g = s * rsq(s) (v_rsq_f64: 2^-24 or better), one Newton step with the
+ * exact residual d = s - g^2 (fma) leaves a relative error of 1.5 eps^2 < 2^-46.  `near`: the 29 mantissa bits the float drops are
+ * within 2^12 double-ulps (2^-40 of the value: 64 times the error bound) of the half-way pattern 1000...0 - there, and for every s
+ * outside [2^-200, 2^200] (zero, denormal results, inf, NaN: one unsigned comparison of the exponent field), the lane takes the
+ * exact path in a divergent branch: 2^-16 of the lane-firings.  Everywhere else RN24 of the approximation IS RN24(RN53(sqrt(s))):
+ * neither rounding has a boundary between the approximation and the root.  mdemod_selftest_cabsf runs 2^32 pairs through both on
+ * the device (0 differences; it also counts the fallbacks). */
+__device__ __forceinline__ float
+md_cabsf_short(float re, float im, uint32_t *fallbacks = nullptr)
+{
+	const double s = (double)re * (double)re + (double)im * (double)im;
+	const double y = __builtin_amdgcn_rsq(s);
+	const double g = s * y, h = 0.5 * y;
+	const double d = __builtin_fma(-g, g, s);
+	const double g1 = __builtin_fma(d, h, g);
+	const uint64_t gb = __builtin_bit_cast(uint64_t, g1), sb = __builtin_bit_cast(uint64_t, s);
+	const uint32_t drop = (uint32_t)gb & 0x1FFFFFFFu;                                   /* what the narrowing to float rounds away */
+	const bool near = (uint32_t)(drop - (0x10000000u - 0x1000u)) < 0x2000u;
+	const bool odd = (uint32_t)((uint32_t)(sb >> 32) - ((1023u - 200u) << 20)) >= (400u << 20);     /* s outside [2^-200, 2^200), or not a positive number */
+	float r = (float)g1;
+	if (__builtin_expect(near || odd, 0)) {
+		r = (float)md_sqrt_sumsq(s);
+		if (fallbacks) *fallbacks += 1;
+	}
+	return r;
 }
 
 /* dsp/agc.c:13-20: bias tracking and scaling (what the rest of the symbol needs) */
@@ -179,20 +216,22 @@ md_agc_apply(cf32 x, float gain, float &bias_re, float &bias_im)
 }
 
 /* dsp/agc.c:21-24: the gain for the NEXT symbol from the magnitude of this one */
+template <bool SHORT = false>
 __device__ __forceinline__ void
 md_agc_gain(cf32 scaled, float &gain)
 {
-	const float mag = md_cabsf(scaled.re, scaled.im);
+	const float mag = SHORT ? md_cabsf_short(scaled.re, scaled.im) : md_cabsf(scaled.re, scaled.im);
 	gain = gain + 0.0001f * (190.0f - mag);
 	gain = (0.0f > gain) ? 0.0f : gain;
 }
 
 /* dsp/agc.c:13-25 */
+template <bool SHORT = false>
 __device__ __forceinline__ cf32
 md_agc(cf32 x, float &gain, float &bias_re, float &bias_im)
 {
 	x = md_agc_apply(x, gain, bias_re, bias_im);
-	md_agc_gain(x, gain);
+	md_agc_gain<SHORT>(x, gain);
 	return x;
 }
 

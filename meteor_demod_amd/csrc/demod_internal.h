@@ -116,6 +116,7 @@ void mdemod_hostpipe_free(void *pipe);
 hipError_t mdemod_launch_selftest_sincos(const float *x, uint32_t n, float *s, float *c, hipStream_t stream);
 hipError_t mdemod_launch_selftest_turncode(unsigned long long *mismatch_dev, hipStream_t stream);
 hipError_t mdemod_launch_selftest_sinlut(unsigned long long *mismatch_dev, hipStream_t stream);
+hipError_t mdemod_launch_selftest_cabsf(uint64_t pairs, unsigned long long *out_dev, hipStream_t stream);
 hipError_t mdemod_launch_selftest_hypot(const float *xy, uint32_t n, float *out, hipStream_t stream);
 #endif
 

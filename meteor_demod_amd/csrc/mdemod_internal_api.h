@@ -105,6 +105,7 @@ int  mdemod_selftest_hypot(mdemod_ctx *ctx, const float *xy, uint32_t n_pairs, f
 /* Exhaustive on-device check of the division-free turn code of fast_sin against the real
  * double division over every float with |x| < 16 (see csrc/demod_device.h). */
 int  mdemod_selftest_turncode(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch);
+int  mdemod_selftest_cabsf(mdemod_ctx *ctx, uint64_t pairs, uint64_t *n_mismatch, uint64_t *n_fallback);   /* the short cabsf against the correctly rounded one on `pairs` pseudo-random pairs */
 int  mdemod_selftest_sinlut(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch);   /* the sine table in LDS against sincos.c's integer arithmetic: every turn code */
 
 #ifdef __cplusplus

@@ -325,7 +325,7 @@ rotwin_demod(const DemodLaunch &L)
 			n_fir++;
 #endif
 
-			y = md_agc(y, r_gain, r_bias_re, r_bias_im);
+			y = md_agc<(KS == 14 && !OQPSK && LUT)>(y, r_gain, r_bias_re, r_bias_im);        /* (the configs[1] instance: the short cabsf, demod_device.h) */
 			uint32_t fl = (uint32_t)ld_flags();          /* bit 0 locked, 1 locked_once, 2 updown > 0, 3 overflow */
 			PllWord pll;
 			pll.phase = r_phase; pll.freq = r_freq;

@@ -324,6 +324,12 @@ class Demodulator:
         check(self._lib.mdemod_selftest_turncode(self._ctx, C.byref(n), C.byref(bad)), "selftest_turncode")
         return n.value, bad.value
 
+    def selftest_cabsf(self, pairs: int = 1 << 32) -> tuple[int, int]:
+        """(mismatches, lanes that took the exact fallback) of the short cabsf against the correctly rounded one on the device."""
+        bad, fb = C.c_uint64(), C.c_uint64()
+        check(self._lib.mdemod_selftest_cabsf(self._ctx, int(pairs), C.byref(bad), C.byref(fb)), "selftest_cabsf")
+        return bad.value, fb.value
+
     def selftest_sinlut(self) -> tuple[int, int]:
         """(turn codes checked, mismatches) of fast_sin's parabola read from the table in LDS against sincos.c's integer arithmetic."""
         n, bad = C.c_uint64(), C.c_uint64()

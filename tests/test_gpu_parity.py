@@ -512,6 +512,18 @@ def test_device_turn_code_shortcut_is_exact_everywhere(gpu_device):
     assert n == 2 * 0x41800000 and bad == 0
 
 
+def test_device_short_cabsf_equals_the_correctly_rounded_one(gpu_device):
+    """agc.c:21's cabsf is (float)sqrt((double)re^2 + (double)im^2).  The kernels take a square root good to 2^-46 (v_rsq_f64 + one
+    Newton step with an exact residual) and fall back to the correctly rounded one wherever the result lies within 2^-40 of a float
+    rounding boundary or the argument is out of the ordinary (demod_device.h: md_cabsf): 2^32 pseudo-random pairs (AGC-like
+    magnitudes, the whole float range, zeros) through both on the device, not one different float; the fallback is taken by ~2^-16
+    of the AGC-like pairs (2 x 2^12 of 2^29 patterns) plus the out-of-range ones."""
+    with Demodulator(C1, 1) as d:
+        bad, fallbacks = d.selftest_cabsf(1 << 32)
+    assert bad == 0, bad
+    assert (1 << 32) // 65536 < fallbacks < (1 << 32) // 8, fallbacks       # near-ties (2^-16 of the pairs) + the pairs drawn out of range on purpose (~5 %)
+
+
 def test_device_sine_table_equals_the_parabola_for_every_turn_code(gpu_device):
     """The kernel instances of the BASELINE settings read fast_sin's Q14 parabola (sincos.c:26-34) from a table in LDS
     (md_sin_from_code_lut): bit-identical to the integer arithmetic for all 65 536 turn codes, whatever the upper half of the word
