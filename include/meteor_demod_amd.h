@@ -98,7 +98,8 @@ typedef struct {
 	int32_t  device;        /* HIP device ordinal                                     */
 	uint32_t n_streams;     /* independent streams held by this context               */
 	uint32_t reserved;      /* 0: the library picks the kernel (what a caller passes).  MDEMOD_FLAG_* below pin a variant: the
-	                           test-suite runs every golden through all of them.  The library reads no environment variable. */
+	                           test-suite runs every golden through all of them.  The library reads one environment variable, MDEMOD_PACK_THREADS
+	                           (threads that pack host buffers in mdemod_process_host, default 8; no result depends on it). */
 } mdemod_params;
 
 /* mdemod_params.reserved (diagnosis and tests only; every variant produces the same bytes) */
@@ -106,6 +107,7 @@ typedef struct {
 #define MDEMOD_FLAG_LAT_OFF     0x4u    /* never the wave-per-stream (latency) kernel, however few the streams */
 #define MDEMOD_FLAG_LAT_ON      0x8u    /* always, when the configuration fits it */
 #define MDEMOD_FLAG_V2_PACKED   0x10u   /* (retired with the v2 kernel in round 4: ignored) */
+#define MDEMOD_FLAG_NO_CLOCK_JUMP 0x20u /* the symbol clock's long runs one rounded addition at a time, not in closed form (csrc/clock_jump.h): A/B only */
 
 /* Value snapshot of one stream after a call (replaces the reference's racy
  * getters polled from the UI thread, main.c:231-237,250-258). */

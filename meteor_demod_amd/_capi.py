@@ -21,18 +21,20 @@ MDEMOD_ERR_HIP = -3
 MDEMOD_ERR_OVERFLOW = -4
 MDEMOD_ERR_RANGE = -5
 MDEMOD_MAX_LOCK_EVENTS = 32
-MDEMOD_FLAG_KERNEL_MASK, MDEMOD_FLAG_LAT_OFF, MDEMOD_FLAG_LAT_ON, MDEMOD_FLAG_V2_PACKED = 0x3, 0x4, 0x8, 0x10
+MDEMOD_FLAG_KERNEL_MASK, MDEMOD_FLAG_LAT_OFF, MDEMOD_FLAG_LAT_ON, MDEMOD_FLAG_V2_PACKED, MDEMOD_FLAG_NO_CLOCK_JUMP = 0x3, 0x4, 0x8, 0x10, 0x20
 
 
 def variant_flags_from_env() -> int:
     """`mdemod_params.reserved` for the test and bench harness: the library itself reads no environment variable, this wrapper
-    does, so that one suite can run every kernel variant.  MDEMOD_KERNEL=v1|v3, MDEMOD_LAT=0|1."""
+    does, so that one suite can run every kernel variant.  MDEMOD_KERNEL=v1|v3, MDEMOD_LAT=0|1, MDEMOD_NO_CLOCK_JUMP=1."""
     f = {"v1": 1, "v3": 3}.get(_os.environ.get("MDEMOD_KERNEL", ""), 0)
     lat = _os.environ.get("MDEMOD_LAT", "")
     if lat == "0":
         f |= MDEMOD_FLAG_LAT_OFF
     elif lat not in ("", "-1"):
         f |= MDEMOD_FLAG_LAT_ON
+    if _os.environ.get("MDEMOD_NO_CLOCK_JUMP", "") not in ("", "0"):
+        f |= MDEMOD_FLAG_NO_CLOCK_JUMP
     return f
 
 

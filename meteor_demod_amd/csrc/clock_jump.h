@@ -26,6 +26,7 @@
 #define MDEMOD_CLOCK_JUMP_H
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define CJ_HD __host__ __device__ __forceinline__
 #else
 #include <math.h>
@@ -64,6 +65,84 @@ clock_jump_109(float &p, float f, float thr, float inv)
 	for (int i = 0; i < CJ109_RB; i++) { prev = p; p = p + f; }
 	cj_jump(p, prev, f, 4.0f, thr - 0.001f, inv, count);
 	return CJ109_R0 + 2 * CJ109_RB + (int)count;
+}
+
+/* ---- any rate: the schedule as numbers (round 4) ----------------------------------------------------------------------------
+ * The same argument for any clock word: real additions from the start of a firing's run (S = 0, or pi for the second rail of an
+ * OQPSK symbol) up to the first binade that holds enough steps to pay for a jump, then jump / three real additions / jump ... up
+ * to the binade of the threshold.  The numbers are wave-uniform and come from the host (cj_schedule below, also what the proof
+ * uses): ra real additions first (the last of them starts inside the first jump binade for every lane whose run starts within
+ * +-3 f_hi of S), then nb binades from 2^b0. */
+typedef struct {
+	int   ra;        /* real additions before the first jump */
+	int   nb;        /* binades jumped through (0: this run does not use jumps) */
+	float B0;        /* 2^b0: the first of them */
+	float lo, hi;    /* the lane's phase at the start of the run must lie in (lo, hi) */
+	int   max_steps; /* no lane takes more steps than this before the checked ones */
+	int   need;      /* input samples that hold max_steps + 4 steps (filled in by the host: -O is its business) */
+} cj_sched;
+
+/* host: the schedule of a run that starts around S and ends at thr, for clock words up to f_hi (and down to f_hi (1 - 5e-4)) */
+static inline cj_sched
+cj_schedule(double S, double thr, double f_hi)
+{
+	cj_sched J = { 0, 0, 1.0f, 0.0f, 0.0f, 0, 0 };
+	const double f_lo = f_hi * (1.0 - 6e-4), w = 3.0 * f_hi;
+	int b_last = 0;                                      /* binade of thr - a bit */
+	while (ldexp(1.0, b_last + 1) < thr - 0.25 * f_hi) b_last++;
+	while (ldexp(1.0, b_last) >= thr - 0.25 * f_hi) b_last--;
+	/* the first binade to jump through: going down from the threshold's, as long as the next lower one holds at least 14 steps and
+	   either lies above the whole start window (the real additions climb into it) or contains it (second OQPSK rail: S = pi in [2, 4)) */
+	int b0 = b_last, inside = 0;
+	while (b0 > -20 && !inside) {
+		const double lower = ldexp(1.0, b0 - 1);
+		if (lower < 14.0 * f_hi) break;
+		if (lower > S + w) { b0--; continue; }
+		if (lower <= S - w && 2.0 * lower > S + w + 2.0 * f_hi) { b0--; inside = 1; }
+		break;
+	}
+	if (inside) J.ra = 1;                                /* every lane is in the binade already: one real addition for the parity */
+	else {
+		if (ldexp(1.0, b0) <= S + w) return J;             /* the window straddles the binade's start */
+		/* ra - 1 additions take the lowest start to 2^b0 at least, and the highest start stays below 2^(b0+1) after ra */
+		J.ra = (int)ceil((ldexp(1.0, b0) - (S - w)) / f_lo) + 1;
+		if (S + w + J.ra * f_hi * (1.0 + 1e-6) >= ldexp(1.0, b0 + 1)) return J;
+	}
+	if (ldexp(1.0, b0) < 14.0 * f_hi || (thr - 0.25 * f_hi) - ldexp(1.0, b_last) < 0) return J;
+	J.nb = b_last - b0 + 1;
+	J.B0 = (float)ldexp(1.0, b0);
+	J.lo = (float)(S - w); J.hi = (float)(S + w);
+	J.max_steps = (int)ceil((thr - (S - w)) / f_lo) + 2;
+	/* worth it?  a jump is about 14 instructions (with its three real additions), a step one */
+	if (J.nb < 1 || J.nb > 8 || J.ra + 14 * J.nb > 0.6 * (thr - S) / f_hi) J.nb = 0;
+	return J;
+}
+
+/* the run of one firing: from p (inside (J.lo, J.hi)) to within three steps below thr; returns the steps taken */
+CJ_HD int
+clock_jump_run(float &p, float f, float thr, float f_hi, float inv, const cj_sched &J)
+{
+	float prev = p, count = 0.0f;
+	int k = J.ra - 1;
+	for (; k >= 8; k -= 8) {
+#pragma unroll
+		for (int i = 0; i < 8; i++) p = p + f;
+	}
+	if (k & 4) { p = p + f; p = p + f; p = p + f; p = p + f; }
+	if (k & 2) { p = p + f; p = p + f; }
+	if (k & 1) p = p + f;
+	prev = p; p = p + f;
+	float B = J.B0;
+	for (int b = 0; b < J.nb; b++) {
+		const bool last = b == J.nb - 1;
+		cj_jump(p, prev, f, B, last ? thr - 0.125f * f_hi : 2.0f * B, inv, count);
+		if (!last) {
+#pragma unroll
+			for (int i = 0; i < CJ109_RB; i++) { prev = p; p = p + f; }
+		}
+		B = 2.0f * B;
+	}
+	return J.ra + CJ109_RB * (J.nb - 1) + (int)count;
 }
 
 #endif

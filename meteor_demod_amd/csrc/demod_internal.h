@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include "../../include/meteor_demod_amd.h"
 #include "mdemod_internal_api.h"
+#include "clock_jump.h"
 
 #define MDEMOD_WAVE            64
 #define MDEMOD_GRANULE_SAMPLES 4      /* ring granule = 4 consecutive IQ samples */
@@ -46,6 +47,7 @@ struct DemodConsts {
 	uint32_t interp_magic;   /* floor(2^32/interp)+1: x/interp == mulhi(x, magic) */
 	float    step_inv;       /* (1 - 2^-12) / step_fmax: steps that fit a phase distance, strictly conservative (clock_jump.h) */
 	int32_t  sin_lut;        /* host only: this context launches the kernel instance with the sine table in LDS */
+	cj_sched jump[2];        /* the symbol clock's runs in closed form (clock_jump.h): [0] from 0, [1] the second rail of an OQPSK symbol; nb == 0: not used */
 };
 
 /* Per-stream state, structure-of-arrays in HBM so that lane s of a wave touches

@@ -87,19 +87,27 @@ blind_steps(float p, float f)
  * threshold, then four checked ones (the increment is positive, so "reached" is monotone); every add is the reference's add
  * (k * freq != k rounded adds).  Does nothing when the lane is too close to the threshold or to the end of its block: the
  * caller's generic loop steps those. */
-struct RotClockConsts { int k_safe, steps_need, interp; float f_hi; uint32_t magic; float inv; };
+struct RotClockConsts { int k_safe, steps_need, interp; float f_hi; uint32_t magic; float inv; const cj_sched *jump; };   /* jump: the launch arguments' two schedules, read where they are used (scalar loads) rather than held in registers */
 template <int KS>          /* KS > 0: the number of blind steps is known at compile time (the launcher checks it), 0: any */
 __device__ __forceinline__ void
-rot_clock_fast(const RotClockConsts &K, float thr, int v_end, float &t_phase, float t_freq, int &isub, int &v_cur, int &fire_sub, bool &fired)
+rot_clock_fast(const RotClockConsts &K, float thr, int v_end, float &t_phase, float t_freq, int &isub, int &v_cur, int &fire_sub, bool &fired, int jidx = -1)
 {
 	int k_safe = KS ? KS : K.k_safe;
 	const int interp = K.interp;
+	/* any rate with a long run of steps per firing: the run's schedule of closed-form jumps (clock_jump.h), wave-uniform; jidx: which
+	 * run this is (0: from 0, 1: the second rail of an OQPSK symbol, from pi; -1: the caller's lanes are not all on the same one) */
+	const bool jump = KS == 0 && jidx >= 0 && K.jump[jidx < 0 ? 0 : jidx].nb > 0;
+	const cj_sched &J = K.jump[jidx < 0 ? 0 : jidx];
 	/* enough input left for k_safe + 4 steps (the part of the current sample still to be stepped is ignored: conservative) */
-	const bool fast = (KS == 109 ? (t_phase > CJ109_P_LO && t_phase < CJ109_P_HI) : (t_phase < thr - (float)k_safe * K.f_hi - 1e-3f)) && (v_cur + K.steps_need < v_end);
+	const bool fast = (KS == 109 ? (t_phase > CJ109_P_LO && t_phase < CJ109_P_HI)
+	                   : jump    ? (t_phase > J.lo && t_phase < J.hi)
+	                             : (t_phase < thr - (float)k_safe * K.f_hi - 1e-3f))
+	                  && (v_cur + (jump ? J.need : K.steps_need) < v_end);
 	if (fast) {
 		float p = t_phase;
 		if (KS == 109) k_safe = clock_jump_109(p, t_freq, thr, K.inv);   /* configs[3]: 30 real additions and three binades in closed form (clock_jump.h) */
 		else if (KS) p = blind_steps<KS>(p, t_freq);                  /* 14: QPSK 72k @ 230 kS/s, -O 5; 6: OQPSK 80k @ 230 kS/s */
+		else if (jump) k_safe = clock_jump_run(p, t_freq, thr, K.f_hi, K.inv, J);
 		else {
 			int k = k_safe;
 			for (; k >= 16; k -= 16) p = blind_steps<16>(p, t_freq);
@@ -244,6 +252,7 @@ rotwin_demod(const DemodLaunch &L)
 	RotClockConsts K;
 	K.k_safe = C.step_safe; K.f_hi = C.step_fmax; K.magic = C.interp_magic; K.interp = C.interp; K.inv = C.step_inv;
 	K.steps_need = ((KS == 109 ? CJ109_MAX_STEPS : C.step_safe) + 4 + C.interp - 1) / C.interp;      /* samples that hold k_safe + 4 steps */
+	K.jump = C.jump;
 
 	int n_wave_max = n;
 	for (int o = 32; o > 0; o >>= 1) {
@@ -365,7 +374,8 @@ rotwin_demod(const DemodLaunch &L)
 			}
 			/* the clock's way to the NEXT firing starts here: a chain of ~20 dependent adds that needs nothing but the timing
 			 * update, next to the Costas update, the AGC's square root and the quantiser, which need nothing from it */
-			rot_clock_fast<KS>(K, OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F, v_end, t_phase, t_freq, isub, v_cur, fire_sub, fired);
+			rot_clock_fast<KS>(K, OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F, v_end, t_phase, t_freq, isub, v_cur, fire_sub, fired,
+			                   OQPSK ? (ROT_OQ_SYNC ? 2 - slot : -1) : 0);
 			if (emit) {
 				uint32_t first = 0;
 				const uint32_t changed = md_pll_update_packed(pll, fl, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);

@@ -202,6 +202,15 @@ def test_symbol_clock_closed_form_proof_holds_on_the_host():
     assert "153009 clock words" in out and ": 0 mismatches" in out and "8368 words with a tie" in out, out
 
 
+def test_symbol_clock_closed_form_at_any_rate_holds_on_the_host():
+    """The same closed form with the schedule as numbers (cj_schedule / clock_jump_run: what the v3 kernels run when a firing's run of
+    steps is long - sample rates from about 1.8 MS/s): 14 sample rates x QPSK / OQPSK x six -O, every run the host would schedule,
+    clock words over the whole range the loop allows plus words that tie in some binade, starting phases over the window the kernel
+    checks per lane."""
+    out = _run_proof("verify_clock_jump.cpp", "-pthread", args=["any", "400", "64"])
+    assert "168 configurations, 89 runs with a schedule" in out and ": 0 mismatches" in out, out
+
+
 def test_cli_device_plan_is_round_robin():
     """host/meteor_demod_amd.c --devices a,b,c --plan: the sharding arithmetic of the C host without files or GPUs - file i on the
     (i mod G)-th device of the list, never more workers than files."""
