@@ -77,7 +77,8 @@ typedef struct {
 	int   ra;        /* real additions before the first jump */
 	int   nb;        /* binades jumped through (0: this run does not use jumps) */
 	float B0;        /* 2^b0: the first of them */
-	float lo, hi;    /* the lane's phase at the start of the run must lie in (lo, hi) */
+	float lo, hi;    /* the common schedule serves starts in (lo, hi) */
+	float floor;     /* a lane that starts in (floor, lo] steps up to lo first; outside (floor, hi): not this way */
 	int   max_steps; /* no lane takes more steps than this before the checked ones */
 	int   need;      /* input samples that hold max_steps + 4 steps (filled in by the host: -O is its business) */
 } cj_sched;
@@ -86,7 +87,7 @@ typedef struct {
 static inline cj_sched
 cj_schedule(double S, double thr, double f_hi)
 {
-	cj_sched J = { 0, 0, 1.0f, 0.0f, 0.0f, 0, 0 };
+	cj_sched J = { 0, 0, 1.0f, 0.0f, 0.0f, 0.0f, 0, 0 };
 	const double f_lo = f_hi * (1.0 - 6e-4), w = 3.0 * f_hi;
 	int b_last = 0;                                      /* binade of thr - a bit */
 	while (ldexp(1.0, b_last + 1) < thr - 0.25 * f_hi) b_last++;
@@ -101,28 +102,47 @@ cj_schedule(double S, double thr, double f_hi)
 		if (lower <= S - w && 2.0 * lower > S + w + 2.0 * f_hi) { b0--; inside = 1; }
 		break;
 	}
-	if (inside) J.ra = 1;                                /* every lane is in the binade already: one real addition for the parity */
-	else {
-		if (ldexp(1.0, b0) <= S + w) return J;             /* the window straddles the binade's start */
+	/* the start window: a run starts in [S - alpha e, S + f - alpha e) (timing.c:79: the loop's correction of the phase).  (lo, hi) is
+	   what the common schedule serves: three steps below S, and above it whatever room the first binade leaves (at 6 MS/s and up the
+	   corrections reach 0.08 rad, five steps).  Lanes between `floor` and lo first step up to lo on their own (real additions, as
+	   many as each needs), lanes outside (floor, hi) take the caller's stepping loop. */
+	const double B = ldexp(1.0, b0);
+	double lo = S - w, hi = S + f_hi + w + 0.25, floor_ = lo - 0.25;
+	int ok = 0;
+	if (inside) {                                        /* every lane is in the binade already: one real addition for the parity */
+		if (lo < B) lo = B;
+		if (floor_ < lo) floor_ = lo;
+		if (hi > 2.0 * B - 2.0 * f_hi) hi = 2.0 * B - 2.0 * f_hi;
+		J.ra = 1;
+		ok = lo <= S - w && hi >= S + f_hi + w;
+	} else {
 		/* ra - 1 additions take the lowest start to 2^b0 at least, and the highest start stays below 2^(b0+1) after ra */
-		J.ra = (int)ceil((ldexp(1.0, b0) - (S - w)) / f_lo) + 1;
-		if (S + w + J.ra * f_hi * (1.0 + 1e-6) >= ldexp(1.0, b0 + 1)) return J;
+		J.ra = (int)ceil((B - lo) / f_lo) + 1;
+		const double room = 2.0 * B - J.ra * f_hi * (1.0 + 1e-6) - 1e-6;
+		if (hi > room) hi = room;
+		ok = hi >= S + f_hi + w;
 	}
-	if (ldexp(1.0, b0) < 14.0 * f_hi || (thr - 0.25 * f_hi) - ldexp(1.0, b_last) < 0) return J;
+	if (!ok) return J;
+	if (B < 14.0 * f_hi || (thr - 0.25 * f_hi) - ldexp(1.0, b_last) < 0) return J;
 	J.nb = b_last - b0 + 1;
-	J.B0 = (float)ldexp(1.0, b0);
-	J.lo = (float)(S - w); J.hi = (float)(S + w);
-	J.max_steps = (int)ceil((thr - (S - w)) / f_lo) + 2;
+	J.B0 = (float)B;
+	J.lo = (float)lo; J.hi = (float)hi; J.floor = (float)floor_;
+	if ((double)J.lo < lo) J.lo = nextafterf(J.lo, 1e30f);
+	if ((double)J.hi > hi) J.hi = nextafterf(J.hi, -1e30f);
+	if ((double)J.floor < floor_) J.floor = nextafterf(J.floor, 1e30f);
+	J.max_steps = (int)ceil((thr - floor_) / f_lo) + 3;
 	/* worth it?  a jump is about 14 instructions (with its three real additions), a step one */
 	if (J.nb < 1 || J.nb > 8 || J.ra + 14 * J.nb > 0.6 * (thr - S) / f_hi) J.nb = 0;
 	return J;
 }
 
-/* the run of one firing: from p (inside (J.lo, J.hi)) to within three steps below thr; returns the steps taken */
+/* the run of one firing: from p (inside (J.floor, J.hi)) to within three steps below thr; returns the steps taken */
 CJ_HD int
 clock_jump_run(float &p, float f, float thr, float f_hi, float inv, const cj_sched &J)
 {
 	float prev = p, count = 0.0f;
+	int early = 0;
+	while (!(p > J.lo)) { p = p + f; early++; }          /* (a lane the loop's correction set back: rare below 3 MS/s) */
 	int k = J.ra - 1;
 	for (; k >= 8; k -= 8) {
 #pragma unroll
@@ -142,7 +162,7 @@ clock_jump_run(float &p, float f, float thr, float f_hi, float inv, const cj_sch
 		}
 		B = 2.0f * B;
 	}
-	return J.ra + CJ109_RB * (J.nb - 1) + (int)count;
+	return early + J.ra + CJ109_RB * (J.nb - 1) + (int)count;
 }
 
 #endif

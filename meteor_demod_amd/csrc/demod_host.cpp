@@ -126,7 +126,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		c.step_inv = static_cast<float>((1.0 - 1.0 / 4096.0) / static_cast<double>(c.step_fmax));
 		/* long runs (a high sample rate times -O): most of the steps in closed form, binade by binade (clock_jump.h; the v3 body only) */
 		const double pi_f = static_cast<double>(static_cast<float>(kPi)), two_pi_f = 2.0 * pi_f;
-		const cj_sched none = { 0, 0, 1.0f, 0.0f, 0.0f, 0, 0 };
+		const cj_sched none = { 0, 0, 1.0f, 0.0f, 0.0f, 0.0f, 0, 0 };
 		c.jump[0] = c.jump[1] = none;
 		if (!(p.reserved & MDEMOD_FLAG_NO_CLOCK_JUMP)) {
 			c.jump[0] = cj_schedule(0.0, p.oqpsk ? pi_f : two_pi_f, static_cast<double>(c.step_fmax));

@@ -100,7 +100,7 @@ rot_clock_fast(const RotClockConsts &K, float thr, int v_end, float &t_phase, fl
 	const cj_sched &J = K.jump[jidx < 0 ? 0 : jidx];
 	/* enough input left for k_safe + 4 steps (the part of the current sample still to be stepped is ignored: conservative) */
 	const bool fast = (KS == 109 ? (t_phase > CJ109_P_LO && t_phase < CJ109_P_HI)
-	                   : jump    ? (t_phase > J.lo && t_phase < J.hi)
+	                   : jump    ? (t_phase > J.floor && t_phase < J.hi)
 	                             : (t_phase < thr - (float)k_safe * K.f_hi - 1e-3f))
 	                  && (v_cur + (jump ? J.need : K.steps_need) < v_end);
 	if (fast) {
@@ -264,7 +264,7 @@ rotwin_demod(const DemodLaunch &L)
 	uint32_t guard = guard64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)guard64;
 #ifdef ROT_EXP_TIMING            /* experiment: where a wave's time goes (s_memtime between the stages; block 100, wave 0 prints) */
 	uint64_t tacc[5] = { 0, 0, 0, 0, 0 }, tlast = clock64();
-	uint32_t n_iter = 0, n_fir = 0, n_slide = 0;
+	uint32_t n_iter = 0, n_fir = 0, n_slide = 0, n_wslow = 0;
 #define ROT_TICK(i) do { const uint64_t t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define ROT_TICK(i) do { } while (0)
@@ -376,6 +376,10 @@ rotwin_demod(const DemodLaunch &L)
 			 * update, next to the Costas update, the AGC's square root and the quantiser, which need nothing from it */
 			rot_clock_fast<KS>(K, OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F, v_end, t_phase, t_freq, isub, v_cur, fire_sub, fired,
 			                   OQPSK ? (ROT_OQ_SYNC ? 2 - slot : -1) : 0);
+#ifdef ROT_EXP_TIMING
+			if (!fired) n_slide++;                     /* (experiment: lanes the fast clock left to the stepping loop) */
+			if (md_any(!fired)) n_wslow++;
+#endif
 			if (emit) {
 				uint32_t first = 0;
 				const uint32_t changed = md_pll_update_packed(pll, fl, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
@@ -425,8 +429,9 @@ rotwin_demod(const DemodLaunch &L)
 		if (OQPSK && ROT_OQ_SYNC) slot = __builtin_amdgcn_readfirstlane(3 - slot);      /* (keeps it in an SGPR: scalar branches) */
 	} while (--guard);
 #ifdef ROT_EXP_TIMING
+	for (int o = 32; o > 0; o >>= 1) n_slide += __shfl_xor(n_slide, o);
 	if (blockIdx.x == 100 && threadIdx.x == 0)
-		printf("ROT_TIMING iters %u firs %u cycles: clock %llu slide %llu fir %llu scalar %llu latch %llu\n", n_iter, n_fir,
+		printf("ROT_TIMING iters %u firs %u (lanes left to the stepping loop: %u of the wave's, in %u firings) cycles: clock %llu slide %llu fir %llu scalar %llu latch %llu\n", n_iter, n_fir, n_slide, n_wslow,
 		       (unsigned long long)tacc[0], (unsigned long long)tacc[1], (unsigned long long)tacc[2], (unsigned long long)tacc[3], (unsigned long long)tacc[4]);
 #endif
 

@@ -57,9 +57,10 @@ generic(int n_f, int n_p0)
 						rng = rng * 6364136223846793005ull + 1442695040888963407ull;
 						float p0;
 						if (j < 8) p0 = S + (j & 1 ? 1 : -1) * (j / 2) * 0.1f * f;
-						else if (j < 16) p0 = j & 1 ? nextafterf(J.lo, 10.0f) + 1e-6f * (j - 8) : nextafterf(J.hi, -10.0f) - 1e-6f * (j - 8);
-						else p0 = J.lo + (J.hi - J.lo) * (float)((rng >> 40) * (1.0 / 16777216.0));
-						if (!(p0 > J.lo && p0 < J.hi)) continue;
+						else if (j < 16) p0 = j & 1 ? nextafterf(J.floor, 10.0f) + 1e-6f * (j - 8) : nextafterf(J.hi, -10.0f) - 1e-6f * (j - 8);
+						else if (j < 24) p0 = J.lo + (j & 1 ? 1e-6f : -1e-6f) * (j - 16);
+						else p0 = J.floor + (J.hi - J.floor) * (float)((rng >> 40) * (1.0 / 16777216.0));
+						if (!(p0 > J.floor && p0 < J.hi)) continue;
 						float ps = p0; int ms = 0;
 						while (!(ps >= thr)) { ps = ps + f; ms++; }
 						float p = p0;
