@@ -516,8 +516,11 @@ def other_configs(skip: str, T: int, L: int, local: int) -> dict:
              "x3": (DemodConfig(samplerate=1024000, bps=32), "not in BASELINE.json: QPSK 72k, 1.024 MS/s f32, default RRC order 32, oversamp 5"),
              "x4": (DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),
                     "not in BASELINE.json: QPSK 72k, 1 MS/s f32, RRC order 64, oversamp 8 (v3 hybrid window since r03; v1 ring kernel before)"),
-             "x5": (DemodConfig(samplerate=2048000, bps=32), "not in BASELINE.json: QPSK 72k, 2.048 MS/s f32, default RRC order 32, oversamp 5 (nearest to the HBM roofline)")}
-    for tag in ("c3", "c4", "x1", "x2", "x3", "x4", "x5"):
+             "x5": (DemodConfig(samplerate=2048000, bps=32), "not in BASELINE.json: QPSK 72k, 2.048 MS/s f32, default RRC order 32, oversamp 5"),
+             "x6": (DemodConfig(samplerate=3200000), "not in BASELINE.json: QPSK 72k, 3.2 MS/s s16 (an RTL-SDR's top rate), default RRC order 32, oversamp 5"),
+             "x7": (DemodConfig(samplerate=10000000), "not in BASELINE.json: QPSK 72k, 10 MS/s s16 (an Airspy's), default RRC order 32, oversamp 5: gather geometry, "
+                                                      "which loads 68 of a symbol's 139 samples - hbm_frac counts them all, as SURVEY 8(d) does")}
+    for tag in ("c3", "c4", "x1", "x2", "x3", "x4", "x5", "x6", "x7"):
         if tag == skip:
             continue
         cfg, workload = extra[tag] if tag in extra else demod_config(tag)
