@@ -73,12 +73,16 @@ fetch(const T *dev, uint32_t first, uint32_t count, std::vector<T> &host, hipStr
 
 /* the wave-per-stream kernel for few streams, the lane-per-stream kernels for many.  Measured r03 (tools/lat_bench.py, MS/s per
  * stream, wave vs lane): configs[1] 3.6 vs 2.5 at 1 024 streams, 3.1 vs 2.5 at 2 048, 2.2 vs 2.5 at 4 096; configs[3] (packed
- * window) 5.3 vs 3.7 at 1 024, 2.7 vs 3.7 at 2 048.  MDEMOD_FLAG_LAT_ON / _OFF pin the choice. */
+ * window) 5.3 vs 3.7 at 1 024, 2.7 vs 3.7 at 2 048.  MDEMOD_FLAG_LAT_ON / _OFF pin the choice.  (r04: the farm's symbol clock takes the
+ * closed-form schedule of clock_jump.h at high sample rates as the v3 kernels do: one stream at 1.8 MS/s 9.3 -> 18.7 MS/s.) */
 bool
 wants_latency_kernel(const mdemod_ctx *ctx)
 {
 	if (!ctx->lat_ok || (ctx->params.reserved & MDEMOD_FLAG_LAT_OFF)) return false;
 	if (ctx->params.reserved & MDEMOD_FLAG_LAT_ON) return true;
+	/* from about 32 samples per firing (3.2 MS/s QPSK, 6 MS/s OQPSK) the farm's batches hold too few firings: one lane of a v3 kernel
+	 * is faster even for ONE stream (r04, tools/one_stream_rates.py: 3.2 MS/s 10.4 vs 9.6 MS/s, OQPSK 80k at 6 MS/s 9.7 vs 8.0) */
+	if (ctx->tab.use_rw && static_cast<double>(ctx->tab.osf) / (ctx->params.oqpsk ? 2.0 : 1.0) > 32.0) return false;
 	return ctx->params.n_streams <= (ctx->tab.rw_compact4 ? 1024u : 2048u);
 }
 

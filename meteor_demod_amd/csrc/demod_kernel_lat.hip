@@ -296,7 +296,8 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		}
 		const uint64_t ok_mask = __ballot(cand_ok);
 		/* steps that may be taken blindly before the block's end needs looking at (timing.c:32-38 stops pushing samples there) */
-		const long long steps_room = (long long)(v_end - 1 - v0) * interp - isub0 - (k_safe + 4) - interp;     /* 2^30 samples x 64 steps: not an int */
+		const int k_most = (!KSAFE && C.jump[0].nb > 0) ? max(k_safe, max(C.jump[0].max_steps, C.jump[1].max_steps)) : k_safe;   /* (the closed-form runs may take a few steps more) */
+		const long long steps_room = (long long)(v_end - 1 - v0) * interp - isub0 - (k_most + 4) - interp;     /* 2^30 samples x 64 steps: not an int */
 		const int steps_limit = steps_room > 0x3FFFFFFF ? 0x3FFFFFFF : (int)steps_room;
 
 		/* ---- (2) serial: firing by firing, wave-uniform; sample positions are only worked out when they matter ---- */
@@ -311,21 +312,27 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		};
 		for (int j = 0; j < kFire; j++) {
 			const float thr = OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F;
-			const bool fast = (t_phase < thr - (float)k_safe * f_hi - 1e-3f) && (steps_done < steps_limit);
+			/* long runs (sample rates from about 1.8 MS/s): the schedule of closed-form jumps the v3 kernels use (clock_jump.h) */
+			const cj_sched &J = C.jump[OQPSK ? dual_state - 1 : 0];
+			const bool jump = !KSAFE && J.nb > 0;
+			const bool fast = (jump ? (t_phase > J.floor && t_phase < J.hi) : (t_phase < thr - (float)k_safe * f_hi - 1e-3f)) && (steps_done < steps_limit);
 			bool regular = false;
 			int m = 0;
 			float ph = t_phase;
 			if (fast) {
 				float p = t_phase;
+				int k_done = k_safe;
 				if (KSAFE) {
 #pragma unroll
 					for (int k = 0; k < KSAFE; k++) p = p + t_freq;
+				} else if (jump) {
+					k_done = clock_jump_run(p, t_freq, thr, f_hi, C.step_inv, J);
 				} else {
 					for (int k = 0; k < k_safe; k++) p = p + t_freq;
 				}
 				const float p1 = p + t_freq, p2 = p1 + t_freq, p3 = p2 + t_freq, p4 = p3 + t_freq;
 				const bool c1 = p1 >= thr, c2 = p2 >= thr, c3 = p3 >= thr, c4 = p4 >= thr;
-				m = k_safe + 1 + (c1 ? 0 : 1) + (c2 ? 0 : 1) + (c3 ? 0 : 1);
+				m = k_done + 1 + (c1 ? 0 : 1) + (c2 ? 0 : 1) + (c3 ? 0 : 1);
 				ph = c3 ? p3 : p4;
 				ph = c2 ? p2 : ph;
 				ph = c1 ? p1 : ph;
