@@ -33,6 +33,9 @@
 #define CJ_HD static inline
 #endif
 
+#ifndef CJ_WORTH
+#define CJ_WORTH 0.6                 /* a schedule is taken when its instructions are under this share of the steps it replaces */
+#endif
 #define CJ109_P_LO  (-0.25f)
 #define CJ109_P_HI  0.30f
 #define CJ109_R0    24
@@ -132,7 +135,7 @@ cj_schedule(double S, double thr, double f_hi)
 	if ((double)J.floor < floor_) J.floor = nextafterf(J.floor, 1e30f);
 	J.max_steps = (int)ceil((thr - floor_) / f_lo) + 3;
 	/* worth it?  a jump is about 14 instructions (with its three real additions), a step one */
-	if (J.nb < 1 || J.nb > 8 || J.ra + 14 * J.nb > 0.6 * (thr - S) / f_hi) J.nb = 0;
+	if (J.nb < 1 || J.nb > 8 || J.ra + 14 * J.nb > CJ_WORTH * (thr - S) / f_hi) J.nb = 0;
 	return J;
 }
 
