@@ -145,7 +145,7 @@ clock_jump_run(float &p, float f, float thr, float f_hi, float inv, const cj_sch
 {
 	float prev = p, count = 0.0f;
 	int early = 0;
-	while (!(p > J.lo)) { p = p + f; early++; }          /* (a lane the loop's correction set back: rare below 3 MS/s) */
+	while (p <= J.lo) { p = p + f; early++; }            /* (a lane the loop's correction set back: rare below 3 MS/s; written so that a NaN clock word, float input gone bad, ends it) */
 	int k = J.ra - 1;
 	for (; k >= 8; k -= 8) {
 #pragma unroll

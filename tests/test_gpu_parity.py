@@ -779,6 +779,32 @@ def test_float_input_ring_kernel_ignores_stale_lds(kernel, gpu_device, monkeypat
             assert np.array_equal(np.concatenate(got[i]), O.oracle_demod(cfg, iqs[i % 6])[0]), i
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("rate,streams", [(3200000, 300), (3200000, 1), (6000000, 300), (1800000, 1)], ids=["hybrid-far", "one-stream", "gather", "lat-1800k"])
+def test_nan_and_inf_samples_end_the_launch_at_rates_with_a_clock_schedule(rate, streams, gpu_device):
+    """Float input gone bad (NaN / Inf samples: every loop word turns NaN, the clock word too) at sample rates whose symbol clock runs on
+    the closed-form schedule (clock_jump.h): the launch ends, the samples are consumed, and a reset context demodulates clean input
+    byte for byte afterwards.  (The schedule's stepping-up loop is written `p <= lo`, false for a NaN, for this.)"""
+    torch = _torch()
+    cfg = DemodConfig(samplerate=rate, bps=32)
+    st = synth.make_stream(91, cfg.samplerate, cfg.symrate, f0_hz=400.0, esn0_db=15.0, rms=0.3, fmt=32)
+    n = 12000 * max(1, rate // 3200000)
+    good = synth.generate_host(st, n)
+    bad = good.copy()
+    bad[n // 3:, 0] = np.nan
+    bad[n // 2:, 1] = np.inf
+    with Demodulator(cfg, streams) as d:
+        d.process(torch.from_numpy(np.stack([bad] * streams)).cuda())
+        torch.cuda.synchronize()
+        assert all(s.n_samples == n for s in d.status())
+        d.reset()
+        soft = d.process(torch.from_numpy(np.stack([good] * streams)).cuda())
+        torch.cuda.synchronize()
+        want = O.oracle_demod(cfg, good)[0]
+        for i in (0, streams - 1):
+            assert np.array_equal(soft[i, : d.status(i, 1)[0].symbols_this_call].cpu().numpy(), want), i
+
+
 @pytest.mark.parametrize("cfg", [
     DemodConfig(samplerate=324459, symrate=36000, interp_factor=2, rrc_order=33, pll_bw=100.0, freq_max=1.5),   # wide window
     DemodConfig(samplerate=230000, pll_bw=100.0, freq_max=1.5),                                                 # std window
