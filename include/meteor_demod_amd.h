@@ -228,7 +228,9 @@ int  mdemod_get_lock_events(mdemod_ctx *ctx, uint32_t stream,
 int  mdemod_get_state(mdemod_ctx *ctx, uint32_t stream, mdemod_stream_state *out,
                       void *hip_stream);
 /* MDEMOD_ERR_PARAM for a carrier state the reference's loop cannot hold: |pll_phase| + |pll_freq| >= 12.5 (pll.c:113
- * keeps the phase inside (-2pi, 2pi), pll.c:126-128 the frequency word inside +-fmax). */
+ * keeps the phase inside (-2pi, 2pi), pll.c:126-128 the frequency word inside +-fmax), or a clock word t_freq further than
+ * centre / 4096 from the centre 2 pi symrate / (samplerate * interp_factor) (timing.c:80-86 keeps it there; a state exported
+ * by mdemod_get_state always passes). */
 int  mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in,
                       void *hip_stream);
 /* Filter history: the last mdemod_history_len() input samples, oldest first,

@@ -513,13 +513,24 @@ carrier_in_domain(const mdemod_stream_state &v)
 	return !(a >= 12.5f);
 }
 
+/* A clock word the reference's loop can hold: timing.c:80-86 keeps it within center / 4096 of the centre, and the kernels' symbol
+ * clock counts on it (steps that provably cannot fire: step_fmax, clock_jump.h).  NaN goes through as in the reference. */
+static bool
+clock_in_domain(const mdemod_ctx *ctx, const mdemod_stream_state &v)
+{
+	const DemodConsts &c = ctx->tab.c;
+	/* (centre + fd is a rounded float sum: the bound carries the same 1e-6 of slack as step_fmax, the one the kernels use) */
+	const double lo = (static_cast<double>(c.t_center) - static_cast<double>(c.t_maxdev)) * (1.0 - 1e-6);
+	return !(v.t_freq > c.step_fmax) && !(static_cast<double>(v.t_freq) < lo);
+}
+
 int
 mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in, void *hip_stream)
 {
 	if (!ctx || !in) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	if (in->t_dual_state != 1 && in->t_dual_state != 2) return MDEMOD_ERR_PARAM;
-	if (!carrier_in_domain(*in)) return MDEMOD_ERR_PARAM;
+	if (!carrier_in_domain(*in) || !clock_in_domain(ctx, *in)) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
@@ -541,7 +552,7 @@ mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void *hip
 {
 	if (!ctx || !seed) return MDEMOD_ERR_PARAM;
 	if (seed->t_dual_state != 1 && seed->t_dual_state != 2) return MDEMOD_ERR_PARAM;
-	if (!carrier_in_domain(*seed)) return MDEMOD_ERR_PARAM;
+	if (!carrier_in_domain(*seed) || !clock_in_domain(ctx, *seed)) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	const int32_t flags = (seed->pll_locked ? MDEMOD_FLAG_LOCKED : 0) | (seed->pll_locked_once ? MDEMOD_FLAG_LOCKED_ONCE : 0) |

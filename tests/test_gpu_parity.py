@@ -171,6 +171,18 @@ def test_state_export_import_continues_exactly(gpu_device, kernel_variant):
         assert st[2].n_samples == iq.shape[0] and st[2].n_symbols == want.shape[0]
         # streams 0,1 of b started cold: they are a different (valid) demodulation
         assert st[0].n_samples == iq.shape[0] - cut
+        # a clock word the reference's timing loop cannot hold (timing.c:80-86: centre +- centre / 4096) is refused, like a carrier
+        # word outside +-fmax: the kernels' symbol clock counts on the bound
+        bad = a.get_state(0)
+        centre = 2 * np.pi * case.cfg.symrate / (case.cfg.samplerate * case.cfg.interp_factor)
+        for f in (centre * (1 + 1.5 / 4096), centre * (1 - 1.5 / 4096), 0.0, -centre):
+            bad.t_freq = float(f)
+            with pytest.raises(Exception, match="mdemod_set_state"):
+                b.set_state(1, bad)
+            with pytest.raises(Exception, match="mdemod_set_state_all"):
+                b.set_state_all(bad)
+        bad.t_freq = float(np.float32(centre * (1 + 0.9 / 4096)))
+        b.set_state(1, bad)
 
 
 # ---- batches: many independent streams, one per lane -----------------------------------------
