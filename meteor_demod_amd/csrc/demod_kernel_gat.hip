@@ -41,7 +41,7 @@ template <> struct GFmt<32> {
 /* KT: embedded taps (65 or 129); NS = KT + G - 1 slots loaded per firing (G = samples per 16-byte load: 4 / 8 / 2) */
 template <int KT, int FMT>
 struct WinG {
-	static constexpr int G = GFmt<FMT>::G, kTaps = KT, kBack = KT - 1, AMAX = G - 1, NS = KT + AMAX, NW = 4 * ((NS + 3) / 4), SLIDE = 4, MAXSL = 1,
+	static constexpr int G = GFmt<FMT>::G, kTaps = KT, kBack = KT - 1, AMAX = G - 1, NS = KT + AMAX, NW = 4 * ((NS + 3) / 4), SLIDE = 4, MAXSL = 1, DEPTH = 1,
 	                     BLOCK = MDEMOD_RW_BLOCK, ROTN = 1, RING = 32, REGSLOTS = 0;
 	static constexpr bool GATHER = true;
 	static_assert(NS % G == 0 && NS / G <= 36, "whole 16-byte loads, and few enough of them to stay in registers");

@@ -22,9 +22,18 @@ namespace {
 typedef float pair_t __attribute__((ext_vector_type(2)));
 
 template <int GEO> struct GeoP;
-template <> struct GeoP<0> { static constexpr int kTaps = 129, NW = MDEMOD_RW_WIDE_NW, MAXSL = 1, BLOCK = MDEMOD_RW_WIDE_BLOCK; };
-template <> struct GeoP<1> { static constexpr int kTaps = 65, NW = MDEMOD_RW_MID_NW, MAXSL = 1, BLOCK = MDEMOD_RW_BLOCK; };
-template <> struct GeoP<2> { static constexpr int kTaps = 65, NW = MDEMOD_RW_FAR_NW, MAXSL = 2, BLOCK = MDEMOD_RW_BLOCK; };
+#ifndef ROTP_WIDE_DEPTH
+#define ROTP_WIDE_DEPTH 1
+#endif
+#ifndef ROTP_MID_DEPTH
+#define ROTP_MID_DEPTH 1
+#endif
+#ifndef ROTP_FAR_DEPTH
+#define ROTP_FAR_DEPTH 2
+#endif
+template <> struct GeoP<0> { static constexpr int kTaps = 129, NW = MDEMOD_RW_WIDE_NW, MAXSL = 1, DEPTH = ROTP_WIDE_DEPTH, BLOCK = MDEMOD_RW_WIDE_BLOCK; };
+template <> struct GeoP<1> { static constexpr int kTaps = 65, NW = MDEMOD_RW_MID_NW, MAXSL = 1, DEPTH = ROTP_MID_DEPTH, BLOCK = MDEMOD_RW_BLOCK; };
+template <> struct GeoP<2> { static constexpr int kTaps = 65, NW = MDEMOD_RW_FAR_NW, MAXSL = 2, DEPTH = ROTP_FAR_DEPTH, BLOCK = MDEMOD_RW_BLOCK; };
 static_assert(MDEMOD_RW_WIDE_NW == 160 && MDEMOD_RW_MID_NW == 96 && MDEMOD_RW_FAR_NW == 112, "gen_rotpk_asm.py: GEOS");
 
 /* the assembly of one (geometry, format): the FIR from group `sub` of chunk `entry` of the ring until `cnt` + 1 exit points have
@@ -82,7 +91,7 @@ ROTP_PUT16(0, WIDE) ROTP_PUT16(1, MID) ROTP_PUT16(2, FAR) ROTP_PUT8(0, WIDE) ROT
 template <int GEO, int FMT>
 struct WinP {
 	static constexpr int kTaps = GeoP<GEO>::kTaps, kBack = kTaps - 1, NW = GeoP<GEO>::NW, SLIDE = 16, AMAX = NW - kTaps,
-	                     MAXSL = GeoP<GEO>::MAXSL, BLOCK = GeoP<GEO>::BLOCK, NCH = NW / SLIDE, GD = FMT == 16 ? 16 : 8, REGSLOTS = 0, ROTN = NCH, RING = 32;
+	                     MAXSL = GeoP<GEO>::MAXSL, DEPTH = GeoP<GEO>::DEPTH, BLOCK = GeoP<GEO>::BLOCK, NCH = NW / SLIDE, GD = FMT == 16 ? 16 : 8, REGSLOTS = 0, ROTN = NCH, RING = 32;
 	static constexpr bool GATHER = false;
 	__device__ __forceinline__ void setup(uint32_t) {}
 	static_assert(kBack % SLIDE == 0 && NW % SLIDE == 0, "history and window are whole chunks");

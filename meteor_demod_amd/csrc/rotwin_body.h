@@ -141,7 +141,8 @@ rotwin_demod(const DemodLaunch &L)
 {
 	typedef typename RFmt<FMT>::sample_t sample_t;
 	constexpr int kBack = W::kBack, SLIDE = W::SLIDE, AMAX = W::AMAX, BLOCK = W::BLOCK, NCH = W::NW / W::SLIDE, GPS = W::SLIDE / 4;
-	constexpr int NST = GPS * W::MAXSL;                /* granules staged ahead of the window */
+	constexpr int NST = GPS * W::DEPTH;                /* granules staged ahead of the window: DEPTH slides' worth (>= MAXSL) */
+	static_assert(W::DEPTH >= W::MAXSL, "a loop iteration may slide MAXSL times");
 	constexpr int ROTN = W::ROTN, RING = W::RING, RGR = RING / 8;      /* output ring: RGR groups of 8 symbols (16 bytes) per lane */
 	/* GATHER: no window at all - every firing loads its own taps from memory (sample rates at which the taps of a firing are a
 	 * minority of the samples that pass: demod_kernel_gat.hip) */
