@@ -74,8 +74,8 @@ clock_jump_109(float &p, float f, float thr, float inv)
  * The same argument for any clock word: real additions from the start of a firing's run (S = 0, or pi for the second rail of an
  * OQPSK symbol) up to the first binade that holds enough steps to pay for a jump, then jump / three real additions / jump ... up
  * to the binade of the threshold.  The numbers are wave-uniform and come from the host (cj_schedule below, also what the proof
- * uses): ra real additions first (the last of them starts inside the first jump binade for every lane whose run starts within
- * +-3 f_hi of S), then nb binades from 2^b0. */
+ * uses): ra real additions first (the last of them starts inside the first jump binade for every lane whose run starts inside
+ * the schedule's window (lo, hi) - lanes a little below it step up to it first), then nb binades from 2^b0. */
 typedef struct {
 	int   ra;        /* real additions before the first jump */
 	int   nb;        /* binades jumped through (0: this run does not use jumps) */
