@@ -111,7 +111,8 @@ launch(mdemod_ctx *ctx, DemodLaunch &L, hipStream_t stream)
 	if (ctx->tab.use_rw && ctx->tab.rw_gather)
 		HIP_TRY(mdemod_launch_demod_gat(L, ctx->params.bps, ctx->tab.c.taps > 65 ? 1 : 0, ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw && ctx->tab.rw_hyb)
-		HIP_TRY(mdemod_launch_demod_roth(L, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0), ctx->lds_bytes, stream));
+		HIP_TRY(mdemod_launch_demod_roth(L, ctx->tab.rw_mid ? 1 : (ctx->tab.rw_far ? 2 : 0),
+		                                 static_cast<double>(ctx->tab.osf) / (ctx->params.oqpsk ? 2.0 : 1.0) > 20.0 ? 1 : 0, ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw && ctx->use_rot)
 		HIP_TRY(mdemod_launch_demod_rot(L, ctx->params.bps, ctx->tab.rw_std_compact ? 1 : 0, ctx->lds_bytes, stream));
 	else if (ctx->tab.use_rw && ctx->tab.rw_compact4)

@@ -95,7 +95,7 @@ struct DemodLaunch {
 hipError_t mdemod_launch_demod(const DemodLaunch &L, int fmt, int block, int global_table, size_t lds_bytes, hipStream_t stream);
 hipError_t mdemod_launch_demod_rot(const DemodLaunch &L, int fmt, int compact, size_t lds_bytes, hipStream_t stream);   /* v3: rotating register window (std geometry); compact: compact4 coefficient table */
 hipError_t mdemod_launch_demod_gat(const DemodLaunch &L, int fmt, int long_filter, size_t lds_bytes, hipStream_t stream);   /* v3: gather geometry (no window: every firing loads its taps); long_filter: 129 embedded taps instead of 65 (not for float input) */
-hipError_t mdemod_launch_demod_roth(const DemodLaunch &L, int geom, size_t lds_bytes, hipStream_t stream);   /* v3: hybrid window (float input: VGPRs + AccVGPRs, one wave per SIMD); geom 0: 160 slots (<= 129 taps), 1: 96 slots (<= 65 taps), 2: 120 slots (<= 65 taps, up to 54 samples per firing) */
+hipError_t mdemod_launch_demod_roth(const DemodLaunch &L, int geom, int many_slides, size_t lds_bytes, hipStream_t stream);   /* v3: hybrid window (float input: VGPRs + AccVGPRs, one wave per SIMD); geom 0: 160 slots (<= 129 taps), 1: 96 slots (<= 65 taps; many_slides: the instance for more than 20 samples per firing), 2: 120 slots (<= 65 taps, up to 54 samples per firing) */
 hipError_t mdemod_launch_demod_rotp(const DemodLaunch &L, int fmt, int geom /* 0 wide, 1 mid, 2 far */, size_t lds_bytes, hipStream_t stream);   /* v3: rotating packed window */
 hipError_t mdemod_launch_demod_lat(const DemodLaunch &L, int fmt, const float *rrc_dev, int ring_size, int span, int float_history, size_t lds_bytes, hipStream_t stream);
 bool mdemod_lat_geometry(const DemodConsts &c, double samples_per_firing, int *ring_size, int *span, size_t *lds_bytes);
