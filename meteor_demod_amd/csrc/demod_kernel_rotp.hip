@@ -33,7 +33,10 @@ template <int GEO> struct GeoP;
 #endif
 template <> struct GeoP<0> { static constexpr int kTaps = 129, NW = MDEMOD_RW_WIDE_NW, MAXSL = 1, DEPTH = ROTP_WIDE_DEPTH, BLOCK = MDEMOD_RW_WIDE_BLOCK; };
 template <> struct GeoP<1> { static constexpr int kTaps = 65, NW = MDEMOD_RW_MID_NW, MAXSL = 1, DEPTH = ROTP_MID_DEPTH, BLOCK = MDEMOD_RW_BLOCK; };
-template <> struct GeoP<2> { static constexpr int kTaps = 65, NW = MDEMOD_RW_FAR_NW, MAXSL = 2, DEPTH = ROTP_FAR_DEPTH, BLOCK = MDEMOD_RW_BLOCK; };
+#ifndef ROTP_FAR_MAXSL
+#define ROTP_FAR_MAXSL 2
+#endif
+template <> struct GeoP<2> { static constexpr int kTaps = 65, NW = MDEMOD_RW_FAR_NW, MAXSL = ROTP_FAR_MAXSL, DEPTH = ROTP_FAR_DEPTH, BLOCK = MDEMOD_RW_BLOCK; };
 static_assert(MDEMOD_RW_WIDE_NW == 160 && MDEMOD_RW_MID_NW == 96 && MDEMOD_RW_FAR_NW == 112, "gen_rotpk_asm.py: GEOS");
 
 /* the assembly of one (geometry, format): the FIR from group `sub` of chunk `entry` of the ring until `cnt` + 1 exit points have
