@@ -791,6 +791,26 @@ def test_float_input_ring_kernel_ignores_stale_lds(kernel, gpu_device, monkeypat
             assert np.array_equal(np.concatenate(got[i]), O.oracle_demod(cfg, iqs[i % 6])[0]), i
 
 
+def test_few_streams_take_the_kernel_that_is_faster_for_them(gpu_device, monkeypatch):
+    """wants_latency_kernel (demod_api.cpp): a context with few streams runs one stream per WAVE up to 32 samples per firing and one per
+    LANE of a v3 kernel above that (where a batch of the wave kernel's FIR farm holds too few firings: tools/one_stream_rates.py); both
+    byte-identical to the oracle, as every variant is."""
+    torch = _torch()
+    monkeypatch.delenv("MDEMOD_LAT", raising=False)
+    monkeypatch.delenv("MDEMOD_KERNEL", raising=False)
+    for rate, oq, want in ((230000, False, "demod_kernel_lat"), (1800000, False, "demod_kernel_lat"), (3200000, False, "demod_kernel_rotp"),
+                           (2400000, True, "demod_kernel_lat"), (6000000, True, "demod_kernel_rotp"), (10000000, False, "demod_kernel_gat")):
+        cfg = DemodConfig(samplerate=rate, symrate=80000 if oq else 72000, oqpsk=oq)
+        st = synth.make_stream(17, cfg.samplerate, cfg.symrate, f0_hz=-500.0, esn0_db=15.0, oqpsk=oq)
+        iq = synth.generate_host(st, 9000 * max(1, rate // 1000000))
+        with Demodulator(cfg, 2) as d:
+            assert want in d.kernel_name, (rate, oq, d.kernel_name)
+            soft = d.process(torch.from_numpy(np.stack([iq, iq])).cuda())
+            torch.cuda.synchronize()
+            w = O.oracle_demod(cfg, iq)[0]
+            assert np.array_equal(soft[1, : d.status(1, 1)[0].symbols_this_call].cpu().numpy(), w), (rate, oq)
+
+
 @pytest.mark.timeout(120)
 @pytest.mark.parametrize("rate,streams", [(3200000, 300), (3200000, 1), (6000000, 300), (1800000, 1)], ids=["hybrid-far", "one-stream", "gather", "lat-1800k"])
 def test_nan_and_inf_samples_end_the_launch_at_rates_with_a_clock_schedule(rate, streams, gpu_device):
