@@ -151,7 +151,13 @@ rotwin_demod(const DemodLaunch &L)
 	/* per-lane loop state that is only touched once per firing lives in LDS slots [field][lane] unless the window policy has
 	 * registers to spare for it (W::REGSLOTS: bit 0 err, 1 t_prev, 2 flags, 3 sample index of the last symbol) */
 	constexpr int RS = W::REGSLOTS;
-	constexpr int PRIO = 1;                      /* the scalar stage of a firing (and the symbol clock inside it) at raised wave priority, the FIR and the slide at 0 (+5 % on configs[1] when round 2 found it) */
+#ifndef ROT_PRIO
+#define ROT_PRIO 1
+#endif
+#ifndef ROT_PRIO_LEVEL
+#define ROT_PRIO_LEVEL 2
+#endif
+	constexpr int PRIO = ROT_PRIO;               /* the scalar stage of a firing (and the symbol clock inside it) at raised wave priority, the FIR and the slide at 0 (+5 % on configs[1] when round 2 found it) */
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	float *ctab = reinterpret_cast<float *>(lds);
@@ -329,7 +335,7 @@ rotwin_demod(const DemodLaunch &L)
 			cf32 y;
 			if constexpr (GATHER) win.fir_gather(ctab_addr, src, hist_in, v_cur, n, bank, C, y.re, y.im);
 			else win.fir(ctab_addr, a, bank, C, __builtin_amdgcn_readfirstlane(rot), y.re, y.im);
-			if (PRIO) __builtin_amdgcn_s_setprio(2);
+			if (PRIO) __builtin_amdgcn_s_setprio(ROT_PRIO_LEVEL);
 			ROT_TICK(2);
 #ifdef ROT_EXP_TIMING
 			n_fir++;
@@ -377,6 +383,9 @@ rotwin_demod(const DemodLaunch &L)
 			 * update, next to the Costas update, the AGC's square root and the quantiser, which need nothing from it */
 			rot_clock_fast<KS>(K, OQPSK ? (float)dual_state * MD_PI_F : MD_TWO_PI_F, v_end, t_phase, t_freq, isub, v_cur, fire_sub, fired,
 			                   OQPSK ? (ROT_OQ_SYNC ? 2 - slot : -1) : 0);
+#ifdef ROT_PRIO_SPLIT                /* experiment: what follows is off the path to the next FIR */
+			if (PRIO) __builtin_amdgcn_s_setprio(ROT_PRIO_SPLIT);
+#endif
 #ifdef ROT_EXP_TIMING
 			if (!fired) n_slide++;                     /* (experiment: lanes the fast clock left to the stepping loop) */
 			if (md_any(!fired)) n_wslow++;
