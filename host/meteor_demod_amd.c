@@ -274,7 +274,14 @@ tiled_one_file(struct worker *w, int f)
 	}
 	if (!data) { fprintf(stderr, "out of memory reading %s\n", io[f].in_name); return 1; }
 	const uint64_t n_samples = len / (2 * (size_t)bps / 8);
-	const uint64_t cap_sym = (uint64_t)((double)n_samples * symrate / samplerate * 1.02) + 4096;
+	/* (rates the library will refuse anyway must not size an allocation: a WAV header may say 0 Hz) */
+	const double nominal = samplerate > 0 && symrate > 0 ? (double)n_samples * symrate / samplerate * 1.02 : -1.0;
+	if (!(nominal >= 0.0 && nominal < 1e15)) {
+		fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(MDEMOD_ERR_PARAM));
+		free(data);
+		return 2;
+	}
+	const uint64_t cap_sym = (uint64_t)nominal + 4096;
 	int8_t *soft_all = malloc(cap_sym * 2);
 	if (!soft_all) { free(data); return 1; }
 	mdemod_recording_opts ro;
@@ -404,7 +411,8 @@ run_exact(struct worker *w)
 	uint32_t *n_in = malloc(sizeof(uint32_t) * (size_t)n_files), *caps = malloc(sizeof(uint32_t) * (size_t)n_files);
 	uint32_t *n_out = malloc(sizeof(uint32_t) * (size_t)n_files);
 	mdemod_status *st = malloc(sizeof(*st) * (size_t)n_files);
-	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) { mdemod_destroy(ctx); return exact_failed(w, 1, "meteor_demod_amd", "out of memory"); }
+#define FREE_BLOCKS() do { free(in_buf); free(soft); free(iq); free(outp); free(n_in); free(caps); free(n_out); free(st); } while (0)
+	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) { FREE_BLOCKS(); mdemod_destroy(ctx); return exact_failed(w, 1, "meteor_demod_amd", "out of memory"); }
 
 	double last_status = -1e18;
 #ifdef MDEMOD_TUI
@@ -427,9 +435,9 @@ run_exact(struct worker *w)
 		}
 		if (!active) break;
 		rc = mdemod_process_host(ctx, iq, n_in, outp, caps, n_out);          /* demod(&sample) x n: main.c:304 */
-		if (rc != MDEMOD_OK) { mdemod_destroy(ctx); return exact_failed(w, 2, "mdemod_process_host", mdemod_strerror(rc)); }
+		if (rc != MDEMOD_OK) { FREE_BLOCKS(); mdemod_destroy(ctx); return exact_failed(w, 2, "mdemod_process_host", mdemod_strerror(rc)); }
 		rc = mdemod_get_status(ctx, 0, (uint32_t)n_files, st, NULL);
-		if (rc != MDEMOD_OK) { mdemod_destroy(ctx); return exact_failed(w, 2, "mdemod_get_status", mdemod_strerror(rc)); }
+		if (rc != MDEMOD_OK) { FREE_BLOCKS(); mdemod_destroy(ctx); return exact_failed(w, 2, "mdemod_get_status", mdemod_strerror(rc)); }
 		for (int i = 0; i < n_files; i++)
 			write_gated(&io[i], outp[i], n_out[i], st[i].first_lock_symbol);
 #ifdef MDEMOD_TUI
@@ -471,6 +479,8 @@ run_exact(struct worker *w)
 		if (io[i].in != stdin) fclose(io[i].in);
 	}
 	mdemod_destroy(ctx);                                                          /* demod_deinit: main.c:273 */
+	FREE_BLOCKS();
+#undef FREE_BLOCKS
 #ifdef MDEMOD_TUI
 	if (w->tui) {                                                                 /* main.c:241-244 */
 		say("Demodulation complete\n");
@@ -587,20 +597,25 @@ main(int argc, char **argv)
 	}
 	struct stream_io *io = calloc((size_t)n_files, sizeof(*io));
 	if (!io) return 1;
+	struct worker *ws = NULL;
+	int n_workers = 0;
+	/* every way out from here on: files closed, nothing left allocated (the sanitizer builds of tests/test_sanitize.py look) */
+#define LEAVE(code) do { close_all(io, n_files); for (int d_ = 0; d_ < n_workers; d_++) free(ws[d_].io); free(ws); \
+		for (int i_ = 0; i_ < n_files; i_++) free(io[i_].out_name); free(io); return (code); } while (0)
 
 	for (int i = 0; i < n_files; i++) {
 		io[i].in_name = argv[optind + i];
 		io[i].in = !strcmp(io[i].in_name, "-") ? stdin : fopen(io[i].in_name, "rb");
-		if (!io[i].in) { fprintf(stderr, "Could not open input file\n"); return 1; }
+		if (!io[i].in) { fprintf(stderr, "Could not open input file\n"); LEAVE(1); }
 		int sr = samplerate, b = bps;
 		if (parse_wav(io[i].in, &sr, &b)) fseek(io[i].in, 0, SEEK_SET);    /* raw: main.c:164-166 */
 		if (i == 0) { samplerate = sr; bps = b; }
-		else if (sr != samplerate || b != bps) { fprintf(stderr, "all inputs of a batch must share rate and format\n"); return 1; }
+		else if (sr != samplerate || b != bps) { fprintf(stderr, "all inputs of a batch must share rate and format\n"); LEAVE(1); }
 	}
 	if (samplerate < 0) {
 		fprintf(stderr, "Could not auto-detect sample rate. Please specify it with -s <samplerate>\n");
 		usage(argv[0]);                                                                /* main.c:170 */
-		return 1;
+		LEAVE(1);
 	}
 	if (!bps) { fprintf(stderr, "Could not auto-detect bits per sample, assuming 16\n"); bps = 16; }
 	/* any other sample size: the reference's reader returns 0 on the first sample (wavfile.c:71-73) and it writes an empty
@@ -620,7 +635,7 @@ main(int argc, char **argv)
 			sprintf(io[i].out_name, "%s.s", io[i].in_name);
 		}
 		io[i].out = fopen(io[i].out_name, "wb");
-		if (!io[i].out) { fprintf(stderr, "Could not open output file\n"); return 1; }
+		if (!io[i].out) { fprintf(stderr, "Could not open output file\n"); LEAVE(1); }
 	}
 
 	int use_tui = 0;
@@ -635,8 +650,7 @@ main(int argc, char **argv)
 	if (!quiet)                                                                        /* main.c:200 */
 		for (int i = 0; i < n_files; i++) say("Input: %s, output: %s\n", io[i].in_name, stdout_mode ? "(stdout)" : io[i].out_name);
 	if (!bps_ok) {
-		for (int i = 0; i < n_files; i++) { if (io[i].out != stdout) fclose(io[i].out); if (io[i].in != stdin) fclose(io[i].in); }
-		return 0;
+		LEAVE(0);
 	}
 	/* file lengths for the progress figure of the status line (main.c:189-193) */
 	for (int i = 0; i < n_files; i++) {
@@ -662,8 +676,9 @@ main(int argc, char **argv)
 		else for (n_dev = 0; n_dev < have && n_dev < MAX_DEVICES; n_dev++) devs[n_dev] = n_dev;
 	}
 	if (n_dev > n_files) n_dev = n_files;
-	struct worker *ws = calloc((size_t)n_dev, sizeof(*ws));
-	if (!ws) return 1;
+	ws = calloc((size_t)n_dev, sizeof(*ws));
+	if (!ws) LEAVE(1);
+	n_workers = n_dev;
 	for (int d = 0; d < n_dev; d++) {
 		struct worker *w = &ws[d];
 		w->index = d; w->p = p; w->p.device = devs[d];
@@ -673,7 +688,7 @@ main(int argc, char **argv)
 		w->jobs = jobs;
 		for (int i = d; i < n_files; i += n_dev) w->n_files++;
 		w->io = calloc((size_t)w->n_files, sizeof(*w->io));
-		if (!w->io) return 1;
+		if (!w->io) LEAVE(1);
 		for (int i = d, k = 0; i < n_files; i += n_dev, k++) w->io[k] = io[i];
 		w->p.n_streams = (uint32_t)w->n_files;
 	}
@@ -681,10 +696,12 @@ main(int argc, char **argv)
 		worker_main(&ws[0]);
 	} else {
 		for (int d = 0; d < n_dev; d++)
-			if (pthread_create(&ws[d].thr, NULL, worker_main, &ws[d])) { fprintf(stderr, "could not start the worker of device %d\n", devs[d]); return 1; }
+			if (pthread_create(&ws[d].thr, NULL, worker_main, &ws[d])) { fprintf(stderr, "could not start the worker of device %d\n", devs[d]); for (int k = 0; k < d; k++) pthread_join(ws[k].thr, NULL); for (int i = 0; i < n_files; i++) { io[i].in = NULL; io[i].out = NULL; } LEAVE(1); }
 		for (int d = 0; d < n_dev; d++) pthread_join(ws[d].thr, NULL);
 	}
 	int rc_all = 0;
 	for (int d = 0; d < n_dev; d++) if (ws[d].rc > rc_all) rc_all = ws[d].rc;
-	return rc_all;
+	/* (the workers closed their files through their own copies of the stream_io entries: nothing of the originals is open any more) */
+	for (int i = 0; i < n_files; i++) { io[i].in = NULL; io[i].out = NULL; }
+	LEAVE(rc_all);
 }

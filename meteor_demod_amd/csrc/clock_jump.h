@@ -36,6 +36,7 @@
 #ifndef CJ_WORTH
 #define CJ_WORTH 0.6                 /* a schedule is taken when its instructions are under this share of the steps it replaces */
 #endif
+#define CJ_MIN_STEPS 16.0            /* shortest run (thr - S, in steps) cj_schedule looks at: nothing shorter pays for a jump (ra + 14 nb against CJ_WORTH x steps) */
 #define CJ109_P_LO  (-0.25f)
 #define CJ109_P_HI  0.30f
 #define CJ109_R0    24
@@ -84,17 +85,24 @@ typedef struct {
 	float floor;     /* a lane that starts in (floor, lo] steps up to lo first; outside (floor, hi): not this way */
 	int   max_steps; /* no lane takes more steps than this before the checked ones */
 	int   need;      /* input samples that hold max_steps + 4 steps (filled in by the host: -O is its business) */
+	int   up_max;    /* no lane in (floor, lo] needs more real additions than this to get above lo (the bound of that loop) */
 } cj_sched;
 
 /* host: the schedule of a run that starts around S and ends at thr, for clock words up to f_hi (and down to f_hi (1 - 5e-4)) */
 static inline cj_sched
 cj_schedule(double S, double thr, double f_hi)
 {
-	cj_sched J = { 0, 0, 1.0f, 0.0f, 0.0f, 0.0f, 0, 0 };
-	const double f_lo = f_hi * (1.0 - 6e-4), w = 3.0 * f_hi;
-	int b_last = 0;                                      /* binade of thr - a bit */
-	while (ldexp(1.0, b_last + 1) < thr - 0.25 * f_hi) b_last++;
-	while (ldexp(1.0, b_last) >= thr - 0.25 * f_hi) b_last--;
+	cj_sched J = { 0, 0, 1.0f, 0.0f, 0.0f, 0.0f, 0, 0, 0 };
+	/* No schedule where none can pay: a jump costs about 14 instructions, so a run of fewer than CJ_MIN_STEPS steps never takes one
+	 * (the "worth it" test at the end says the same, later).  This is also what keeps the searches below finite: with several firings
+	 * per interpolated step (symrate >= 2 fs O for OQPSK, 4 fs O for QPSK - accepted by demod_host.cpp and served by the stepping loop)
+	 * thr - 0.25 f_hi is not positive and has no binade at all (round 4 looped forever there). */
+	if (!(f_hi > 0.0) || !(thr > S) || !(thr - S >= CJ_MIN_STEPS * f_hi) || !(thr < 64.0)) return J;
+	const double f_lo = f_hi * (1.0 - 6e-4), w = 3.0 * f_hi, top = thr - 0.25 * f_hi;   /* top >= 15.75 f_hi > 0 */
+	int b_last = 0;                                      /* binade of thr - a bit: 2^b_last < top <= 2^(b_last + 1), searched in [-64, 6] */
+	while (b_last < 6 && ldexp(1.0, b_last + 1) < top) b_last++;
+	while (b_last > -64 && ldexp(1.0, b_last) >= top) b_last--;
+	if (!(ldexp(1.0, b_last) < top)) return J;
 	/* the first binade to jump through: going down from the threshold's, as long as the next lower one holds at least 14 steps and
 	   either lies above the whole start window (the real additions climb into it) or contains it (second OQPSK rail: S = pi in [2, 4)) */
 	int b0 = b_last, inside = 0;
@@ -127,6 +135,19 @@ cj_schedule(double S, double thr, double f_hi)
 	}
 	if (!ok) return J;
 	if (B < 14.0 * f_hi || (thr - 0.25 * f_hi) - ldexp(1.0, b_last) < 0) return J;
+	/* A jump is short of the binade's end by design: inv carries 2^-12, and it is sized for f_hi while the lane's word may be 6e-4
+	 * below - together up to 8.5e-4 of the binade's steps.  The three real additions after a jump must cross into the next binade
+	 * (at most one step short, plus the floor), the caller's four checked additions must find the firing after the last one (at
+	 * most two short).  Past about 1 100 steps in a binade - clock words under 1.8e-3, fs x O over 2.5e8 - that no longer holds:
+	 * lanes would fall back to the stepping loop one by one (correct, and slower than no schedule).  Found by tests/sanitize/
+	 * fuzz_derive.cpp in round 5; the listed rates of tools/proofs/verify_clock_jump.cpp end at 1.6e8. */
+	{
+		const double slack = 1.0 / 4096.0 + (1.0 - f_lo / f_hi) + 1e-6;
+		for (int b = b0; b <= b_last; b++) {
+			const double lo_b = ldexp(1.0, b), hi_b = b == b_last ? thr : 2.0 * lo_b;
+			if ((hi_b - lo_b) / f_lo * slack > (b == b_last ? 1.8 : 0.9)) return J;
+		}
+	}
 	J.nb = b_last - b0 + 1;
 	J.B0 = (float)B;
 	J.lo = (float)lo; J.hi = (float)hi; J.floor = (float)floor_;
@@ -134,6 +155,7 @@ cj_schedule(double S, double thr, double f_hi)
 	if ((double)J.hi > hi) J.hi = nextafterf(J.hi, -1e30f);
 	if ((double)J.floor < floor_) J.floor = nextafterf(J.floor, 1e30f);
 	J.max_steps = (int)ceil((thr - floor_) / f_lo) + 3;
+	J.up_max = (int)ceil((lo - floor_) / f_lo) + 2;
 	/* worth it?  a jump is about 14 instructions (with its three real additions), a step one */
 	if (J.nb < 1 || J.nb > 8 || J.ra + 14 * J.nb > CJ_WORTH * (thr - S) / f_hi) J.nb = 0;
 	return J;
@@ -145,7 +167,10 @@ clock_jump_run(float &p, float f, float thr, float f_hi, float inv, const cj_sch
 {
 	float prev = p, count = 0.0f;
 	int early = 0;
-	while (p <= J.lo) { p = p + f; early++; }            /* (a lane the loop's correction set back: rare below 3 MS/s; written so that a NaN clock word, float input gone bad, ends it) */
+	/* a lane the loop's correction set back (rare below 3 MS/s).  Bounded by the host's count: a clock word outside the loop's range
+	 * (timing.c:80-86; mdemod_set_state and mdemod_set_clock_seeds keep such words out, this is the second fence) must not spin a wave -
+	 * it leaves p wherever it is and the caller's checked additions / stepping loop take over.  NaN ends it by itself. */
+	for (; early < J.up_max && p <= J.lo; early++) p = p + f;
 	int k = J.ra - 1;
 	for (; k >= 8; k -= 8) {
 #pragma unroll

@@ -599,8 +599,11 @@ mdemod_set_clock_seeds(mdemod_ctx *ctx, const float *t_freq_dev, void *hip_strea
 	if (!ctx || !t_freq_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
-	HIP_TRY(hipMemcpyAsync(ctx->st.t_freq, t_freq_dev, sizeof(float) * ctx->params.n_streams, hipMemcpyDeviceToDevice,
-	                       static_cast<hipStream_t>(hip_stream)));
+	/* clamped on the way in to the words the reference's loop can hold (clock_in_domain above: what mdemod_set_state refuses) */
+	const DemodConsts &c = ctx->tab.c;
+	float lo = static_cast<float>((static_cast<double>(c.t_center) - static_cast<double>(c.t_maxdev)) * (1.0 - 1e-6));
+	if (static_cast<double>(lo) < (static_cast<double>(c.t_center) - static_cast<double>(c.t_maxdev)) * (1.0 - 1e-6)) lo = nextafterf(lo, 1e30f);
+	HIP_TRY(mdemod_launch_clock_seeds(ctx->st, t_freq_dev, lo, c.step_fmax, ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
 }
 

@@ -97,6 +97,17 @@ gain_seed_kernel(DemodStateSoA st, const float *gain, uint32_t n_streams)
 	st.agc_gain[s] = g > 0.0f ? g : 0.0f;                 /* the reference clamps at zero too (agc.c:23) */
 }
 
+/* Clock words from a device array (the stitcher's per-tile estimates): kept inside what timing.c:80-86 can hold, the range the
+ * kernels' symbol clock counts on (step_fmax, clock_jump.h) - the same bounds mdemod_set_state checks on the host.  NaN stays NaN. */
+__global__ void
+clock_seed_kernel(DemodStateSoA st, const float *t_freq, float lo, float hi, uint32_t n_streams)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_streams) return;
+	const float f = t_freq[s];
+	st.t_freq[s] = f < lo ? lo : (f > hi ? hi : f);
+}
+
 /* Host path: the demodulator writes its soft symbols with the hard-bound row pitch (one symbol per input sample);
  * what goes over PCIe is a copy with the nominal pitch.  One block per stream, 16-byte moves (pitches are multiples of
  * 8 symbols). */
@@ -289,6 +300,14 @@ mdemod_launch_gain_seeds(const DemodStateSoA &st, const float *gain_dev, uint32_
 {
 	if (n_streams == 0) return hipSuccess;
 	hipLaunchKernelGGL(gain_seed_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, gain_dev, n_streams);
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_clock_seeds(const DemodStateSoA &st, const float *t_freq_dev, float lo, float hi, uint32_t n_streams, hipStream_t stream)
+{
+	if (n_streams == 0) return hipSuccess;
+	hipLaunchKernelGGL(clock_seed_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st, t_freq_dev, lo, hi, n_streams);
 	return hipGetLastError();
 }
 

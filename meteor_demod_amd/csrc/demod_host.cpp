@@ -8,6 +8,7 @@
 #include "demod_host.h"
 
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -71,6 +72,9 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	 * (goldens one_per_symbol, sub_sample, sub_sample_oqpsk).  Below a quarter of a sample per firing nothing has been tested. */
 	if (static_cast<double>(p.samplerate) * (p.oqpsk ? 2.0 : 1.0) < static_cast<double>(p.symrate) * 0.25) return MDEMOD_ERR_PARAM;
 	if (p.bps != 8 && p.bps != 16 && p.bps != 32) return MDEMOD_ERR_PARAM;
+	/* demod.c:12-13 multiply in int: `multiplier * symrate` and `samplerate * interp_factor`.  Where those overflow the reference is
+	 * undefined; nothing to reproduce, refused. */
+	if (static_cast<int64_t>(p.samplerate) * p.interp_factor > INT32_MAX || static_cast<int64_t>(p.symrate) * 2 > INT32_MAX) return MDEMOD_ERR_PARAM;
 
 	DemodConsts &c = out.c;
 	c.interp = p.interp_factor;
@@ -126,7 +130,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		c.step_inv = static_cast<float>((1.0 - 1.0 / 4096.0) / static_cast<double>(c.step_fmax));
 		/* long runs (a high sample rate times -O): most of the steps in closed form, binade by binade (clock_jump.h; the v3 body only) */
 		const double pi_f = static_cast<double>(static_cast<float>(kPi)), two_pi_f = 2.0 * pi_f;
-		const cj_sched none = { 0, 0, 1.0f, 0.0f, 0.0f, 0.0f, 0, 0 };
+		const cj_sched none = { 0, 0, 1.0f, 0.0f, 0.0f, 0.0f, 0, 0, 0 };
 		c.jump[0] = c.jump[1] = none;
 		if (!(p.reserved & MDEMOD_FLAG_NO_CLOCK_JUMP)) {
 			c.jump[0] = cj_schedule(0.0, p.oqpsk ? pi_f : two_pi_f, static_cast<double>(c.step_fmax));

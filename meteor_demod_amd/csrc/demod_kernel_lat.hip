@@ -296,7 +296,10 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		}
 		const uint64_t ok_mask = __ballot(cand_ok);
 		/* steps that may be taken blindly before the block's end needs looking at (timing.c:32-38 stops pushing samples there) */
-		const int k_most = (!KSAFE && C.jump[0].nb > 0) ? max(k_safe, max(C.jump[0].max_steps, C.jump[1].max_steps)) : k_safe;   /* (the closed-form runs may take a few steps more) */
+		/* (the closed-form runs may take a few steps more; either rail of an OQPSK symbol may have a schedule without the other) */
+		int k_most = k_safe;
+		if (!KSAFE && C.jump[0].nb > 0) k_most = max(k_most, C.jump[0].max_steps);
+		if (!KSAFE && C.jump[1].nb > 0) k_most = max(k_most, C.jump[1].max_steps);
 		const long long steps_room = (long long)(v_end - 1 - v0) * interp - isub0 - (k_most + 4) - interp;     /* 2^30 samples x 64 steps: not an int */
 		const int steps_limit = steps_room > 0x3FFFFFFF ? 0x3FFFFFFF : (int)steps_room;
 

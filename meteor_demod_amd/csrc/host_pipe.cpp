@@ -32,6 +32,7 @@
 #include <unistd.h>
 
 #include "demod_internal.h"
+#include "pack_pool.h"
 
 namespace {
 
@@ -130,106 +131,6 @@ pipe_init(HostPipe *p, uint32_t ns)
 	}
 	p->ready = true;
 	return MDEMOD_OK;
-}
-
-/* A few persistent worker threads for the packing and unpacking of the sub-blocks (memcpy between the caller's buffers and the
- * pinned ring).  Round 3 started fresh std::threads for every sub-block - 2 x 16 spawns of 4..8 threads per call, ~10 ms of a 64 ms
- * call, and the reason MORE threads were slower (measured r04: 4 threads 34.5 GB/s of input, 8..24 threads 30..31).  One pool per
- * process, created on first use, parked on a condition variable between jobs. */
-class PackPool {
-public:
-	static PackPool &get() { static PackPool p; return p; }
-	unsigned size() const { return static_cast<unsigned>(workers.size()) + 1; }          /* + the calling thread */
-	/* run job(i) for i in [0, n_jobs): the workers take jobs off a shared counter, the caller takes its share too and returns when all are done */
-	void run(unsigned n_jobs, const std::function<void(unsigned)> &job)
-	{
-		if (n_jobs == 0) return;
-		/* (a forked child has the pool object but not its threads: it works alone) */
-		if (n_jobs == 1 || workers.empty() || getpid() != owner) { for (unsigned i = 0; i < n_jobs; i++) job(i); return; }
-		std::lock_guard<std::mutex> one_at_a_time(run_m);              /* contexts on several host threads (one per GPU) share the pool */
-		{
-			std::lock_guard<std::mutex> lk(m);
-			cur = &job; total = n_jobs; next = 0; pending = n_jobs; generation++;
-		}
-		cv.notify_all();
-		drain();
-		std::unique_lock<std::mutex> lk(m);
-		done_cv.wait(lk, [&] { return pending == 0; });
-		cur = nullptr;
-	}
-private:
-	PackPool()
-	{
-		const char *e = getenv("MDEMOD_PACK_THREADS");
-		int want = e ? atoi(e) : 0;
-		if (want <= 0 || want > 64) want = 8;
-		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-		const unsigned n = std::min<unsigned>(static_cast<unsigned>(want), hw);
-		for (unsigned i = 1; i < n; i++) workers.emplace_back([this] { loop(); });
-	}
-	~PackPool()
-	{
-		{ std::lock_guard<std::mutex> lk(m); stop = true; }
-		cv.notify_all();
-		for (auto &t : workers) t.join();
-	}
-	void drain()
-	{
-		for (;;) {
-			unsigned i;
-			const std::function<void(unsigned)> *job;
-			{
-				std::lock_guard<std::mutex> lk(m);
-				if (!cur || next >= total) return;
-				i = next++; job = cur;
-			}
-			(*job)(i);
-			std::lock_guard<std::mutex> lk(m);
-			if (--pending == 0) done_cv.notify_all();
-		}
-	}
-	void loop()
-	{
-		uint64_t seen = 0;
-		for (;;) {
-			{
-				std::unique_lock<std::mutex> lk(m);
-				cv.wait(lk, [&] { return stop || generation != seen; });
-				if (stop) return;
-				seen = generation;
-			}
-			drain();
-		}
-	}
-	std::vector<std::thread> workers;
-	const pid_t owner = getpid();
-	std::mutex run_m;
-	std::mutex m;
-	std::condition_variable cv, done_cv;
-	const std::function<void(unsigned)> *cur = nullptr;
-	unsigned total = 0, next = 0, pending = 0;
-	uint64_t generation = 0;
-	bool stop = false;
-};
-
-/* run fn(first, last) over the streams [0, n) on the pool, split by the weights' prefix sums into a few pieces per thread */
-template <typename F>
-void
-parallel_streams(uint32_t n, const std::vector<uint64_t> &weight_prefix, F fn)
-{
-	const uint64_t total = weight_prefix.empty() ? 0 : weight_prefix.back();
-	PackPool &pool = PackPool::get();
-	if (total < (8u << 20) || pool.size() == 1) { fn(0u, n); return; }          /* small jobs: not worth waking anybody */
-	const unsigned pieces = pool.size() * 4;
-	std::vector<uint32_t> cut(pieces + 1, n);
-	cut[0] = 0;
-	uint32_t at = 0;
-	for (unsigned w = 1; w < pieces; w++) {
-		const uint64_t goal = total * w / pieces;
-		while (at < n && weight_prefix[at] < goal) at++;
-		cut[w] = at;
-	}
-	pool.run(pieces, [&](unsigned i) { if (cut[i + 1] > cut[i]) fn(cut[i], cut[i + 1]); });
 }
 
 } /* namespace */

@@ -37,8 +37,8 @@ int  mdemod_set_carrier_seeds(mdemod_ctx *ctx, const float *freq_dev, const int3
 int  mdemod_set_gain_seeds(mdemod_ctx *ctx, const float *gain_dev, void *hip_stream);
 
 /* Per-stream symbol-clock frequency seeds (timing.c:14 `freq`, rad per interpolated sample; device array of n_streams entries).
- * The caller keeps them within centre / 4096 of the centre, as timing.c:80-86 does (the stitcher clamps its estimates: recording.hip,
- * estimate_clocks): the kernels' symbol clock counts on that bound and a device array is not checked here. */
+ * Words outside centre +- centre / 4096 - what timing.c:80-86 can hold, and what the kernels' symbol clock counts on - are clamped to
+ * that range on the device as they are copied in (mdemod_set_state refuses such a word; a device array cannot be refused). */
 int  mdemod_set_clock_seeds(mdemod_ctx *ctx, const float *t_freq_dev, void *hip_stream);
 /* mdemod_get_state for `count` streams from `first` in one round trip (tiles of a recording: thousands of streams). */
 int  mdemod_get_states(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_stream_state *out, void *hip_stream);

@@ -1,0 +1,134 @@
+/*
+ * pack_pool.h — the host threads behind mdemod_process_host's packing and unpacking (host_pipe.cpp).  No HIP in here: the pool is
+ * plain C++ threads, so that tests/sanitize/pool_tsan.cpp can run exactly this code under ThreadSanitizer.
+ */
+#ifndef MDEMOD_PACK_POOL_H
+#define MDEMOD_PACK_POOL_H
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <unistd.h>
+
+namespace {
+
+/* A few persistent worker threads for the packing and unpacking of the sub-blocks (memcpy between the caller's buffers and the
+ * pinned ring).  Round 3 started fresh std::threads for every sub-block - 2 x 16 spawns of 4..8 threads per call, ~10 ms of a 64 ms
+ * call, and the reason MORE threads were slower (measured r04: 4 threads 34.5 GB/s of input, 8..24 threads 30..31).  One pool per
+ * process, created on first use, parked on a condition variable between jobs. */
+class PackPool {
+public:
+	static PackPool &get() { static PackPool p; return p; }
+	unsigned size() const { return static_cast<unsigned>(workers.size()) + 1; }          /* + the calling thread */
+	/* run job(i) for i in [0, n_jobs): the workers take jobs off a shared counter, the caller takes its share too and returns when all are done */
+	void run(unsigned n_jobs, const std::function<void(unsigned)> &job)
+	{
+		if (n_jobs == 0) return;
+		/* (a forked child has the pool object but not its threads: it works alone) */
+		if (n_jobs == 1 || workers.empty() || getpid() != owner) { for (unsigned i = 0; i < n_jobs; i++) job(i); return; }
+		Shared &s = *sh;
+		std::lock_guard<std::mutex> one_at_a_time(s.run_m);            /* contexts on several host threads (one per GPU) share the pool */
+		{
+			std::lock_guard<std::mutex> lk(s.m);
+			s.cur = &job; s.total = n_jobs; s.next = 0; s.pending = n_jobs; s.generation++;
+		}
+		s.cv.notify_all();
+		drain(s);
+		std::unique_lock<std::mutex> lk(s.m);
+		s.done_cv.wait(lk, [&] { return s.pending == 0; });
+		s.cur = nullptr;
+	}
+private:
+	/* everything the threads share lives on the heap, so that a forked child can walk away from it (see ~PackPool) */
+	struct Shared {
+		std::mutex run_m;
+		std::mutex m;
+		std::condition_variable cv, done_cv;
+		const std::function<void(unsigned)> *cur = nullptr;
+		unsigned total = 0, next = 0, pending = 0;
+		uint64_t generation = 0;
+		bool stop = false;
+	};
+	PackPool() : sh(new Shared)
+	{
+		const char *e = getenv("MDEMOD_PACK_THREADS");
+		int want = e ? atoi(e) : 0;
+		if (want <= 0 || want > 64) want = 8;
+		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+		const unsigned n = std::min<unsigned>(static_cast<unsigned>(want), hw);
+		Shared *s = sh;
+		for (unsigned i = 1; i < n; i++) workers.emplace_back([s] { loop(*s); });
+	}
+	~PackPool()
+	{
+		/* A forked child that leaves through exit() has this object but none of its threads, the mutex in whatever state a worker
+		 * held it at the fork, and a condition variable with the parent's parked workers on its books (destroying that one waits
+		 * for them: for ever).  Nothing to stop, nothing to join, nothing to destroy: the thread handles and the shared state are
+		 * leaked on purpose (a joinable std::thread must not be destroyed either). */
+		if (getpid() != owner) { new std::vector<std::thread>(std::move(workers)); return; }
+		{ std::lock_guard<std::mutex> lk(sh->m); sh->stop = true; }
+		sh->cv.notify_all();
+		for (auto &t : workers) t.join();
+		delete sh;
+	}
+	static void drain(Shared &s)
+	{
+		for (;;) {
+			unsigned i;
+			const std::function<void(unsigned)> *job;
+			{
+				std::lock_guard<std::mutex> lk(s.m);
+				if (!s.cur || s.next >= s.total) return;
+				i = s.next++; job = s.cur;
+			}
+			(*job)(i);
+			std::lock_guard<std::mutex> lk(s.m);
+			if (--s.pending == 0) s.done_cv.notify_all();
+		}
+	}
+	static void loop(Shared &s)
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(s.m);
+				s.cv.wait(lk, [&] { return s.stop || s.generation != seen; });
+				if (s.stop) return;
+				seen = s.generation;
+			}
+			drain(s);
+		}
+	}
+	std::vector<std::thread> workers;
+	const pid_t owner = getpid();
+	Shared *const sh;
+};
+
+/* run fn(first, last) over the streams [0, n) on the pool, split by the weights' prefix sums into a few pieces per thread */
+template <typename F>
+void
+parallel_streams(uint32_t n, const std::vector<uint64_t> &weight_prefix, F fn)
+{
+	const uint64_t total = weight_prefix.empty() ? 0 : weight_prefix.back();
+	PackPool &pool = PackPool::get();
+	if (total < (8u << 20) || pool.size() == 1) { fn(0u, n); return; }          /* small jobs: not worth waking anybody */
+	const unsigned pieces = pool.size() * 4;
+	std::vector<uint32_t> cut(pieces + 1, n);
+	cut[0] = 0;
+	uint32_t at = 0;
+	for (unsigned w = 1; w < pieces; w++) {
+		const uint64_t goal = total * w / pieces;
+		while (at < n && weight_prefix[at] < goal) at++;
+		cut[w] = at;
+	}
+	pool.run(pieces, [&](unsigned i) { if (cut[i + 1] > cut[i]) fn(cut[i], cut[i + 1]); });
+}
+
+} /* namespace */
+
+#endif

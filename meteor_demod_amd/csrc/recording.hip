@@ -897,10 +897,11 @@ struct Stitcher {
 	   the clock seed and the carrier's local slope */
 	std::vector<double> tclk, centre, fbar, slope, slope_tile; int nfft = 0; float min_quality = 8.0f; std::vector<uint64_t> wstart; double f_pilot_target = 0;
 	std::vector<double> ge_cx; std::vector<float> ge_th, ge_cq; uint32_t ge_wc = 0; bool ge_no_carrier = true, ge_clock_deferred = false;
-	struct EstThread { std::thread t; int rc = MDEMOD_OK; ~EstThread() { if (t.joinable()) t.join(); } } est;
 	/* recorded on the caller's stream at entry: the estimators read iq_dev on a stream of their own and must come after whatever
-	   the caller queued on hip_stream to produce it (declared after `est`: destroyed once the thread is joined) */
+	   the caller queued on hip_stream to produce it.  Declared BEFORE `est`: members are destroyed in reverse order of declaration,
+	   so on every way out of run_all() the thread is joined first and the event it waits on is destroyed after that. */
 	struct InputReady { hipEvent_t ev = nullptr; ~InputReady() { if (ev) (void)hipEventDestroy(ev); } } input_ready;
+	struct EstThread { std::thread t; int rc = MDEMOD_OK; ~EstThread() { if (t.joinable()) t.join(); } } est;
 	/* seeds */
 	std::vector<float> f0, tf, gains; std::vector<int32_t> ud; float *d_f0 = nullptr, *d_tf = nullptr, *d_gain = nullptr; int32_t *d_ud = nullptr;
 	/* the bank's buffers and what the launches leave in them */

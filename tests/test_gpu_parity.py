@@ -814,9 +814,12 @@ def test_few_streams_take_the_kernel_that_is_faster_for_them(gpu_device, monkeyp
 @pytest.mark.timeout(120)
 @pytest.mark.parametrize("rate,streams", [(3200000, 300), (3200000, 1), (6000000, 300), (1800000, 1)], ids=["hybrid-far", "one-stream", "gather", "lat-1800k"])
 def test_nan_and_inf_samples_end_the_launch_at_rates_with_a_clock_schedule(rate, streams, gpu_device):
-    """Float input gone bad (NaN / Inf samples: every loop word turns NaN, the clock word too) at sample rates whose symbol clock runs on
-    the closed-form schedule (clock_jump.h): the launch ends, the samples are consumed, and a reset context demodulates clean input
-    byte for byte afterwards.  (The schedule's stepping-up loop is written `p <= lo`, false for a NaN, for this.)"""
+    """Float input gone bad (NaN / Inf samples) at sample rates whose symbol clock runs on the closed-form schedule (clock_jump.h): the
+    launch ends, the samples are consumed, and a reset context demodulates clean input byte for byte afterwards.  What the loops hold
+    meanwhile is outside anything the reference defines (its tanh look-up reads out of bounds one symbol after a non-finite sample,
+    pll.c:154-159): here the AGC, the phases and the soft values turn NaN, while the two clamped words - the carrier word and the clock
+    word's deviation - come out of md_clamp_sym (v_med3_f32) as -fmax / -maxdev rather than NaN, and a NaN soft value is emitted as the
+    byte 0x81 (-127; x86's (int8)NaN is 0).  The schedule's stepping-up loop is bounded by a host count and `p <= lo` is false for a NaN."""
     torch = _torch()
     cfg = DemodConfig(samplerate=rate, bps=32)
     st = synth.make_stream(91, cfg.samplerate, cfg.symrate, f0_hz=400.0, esn0_db=15.0, rms=0.3, fmt=32)
@@ -829,6 +832,9 @@ def test_nan_and_inf_samples_end_the_launch_at_rates_with_a_clock_schedule(rate,
         d.process(torch.from_numpy(np.stack([bad] * streams)).cuda())
         torch.cuda.synchronize()
         assert all(s.n_samples == n for s in d.status())
+        # pinned: the clock word stays a finite word of the loop's range, so no later launch can meet a word the schedules do not cover
+        tf = np.array([s.omega for s in d.status()], dtype=np.float64)
+        assert np.all(np.isfinite(tf)), tf[:4]
         d.reset()
         soft = d.process(torch.from_numpy(np.stack([good] * streams)).cuda())
         torch.cuda.synchronize()
