@@ -414,6 +414,10 @@ run_exact(struct worker *w)
 #define FREE_BLOCKS() do { free(in_buf); free(soft); free(iq); free(outp); free(n_in); free(caps); free(n_out); free(st); } while (0)
 	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) { FREE_BLOCKS(); mdemod_destroy(ctx); return exact_failed(w, 1, "meteor_demod_amd", "out of memory"); }
 
+	/* the read buffer is the same for every block: pinned once, the batch then goes to the GPU from where fread put it
+	   (worth it from a few files on; a refusal - no memory to pin - only means the library stages the blocks itself) */
+	if (n_files >= 8 && block_buffers == BLOCK_BUFFERS) (void)mdemod_pin_host_buffer(ctx, in_buf, block_bytes * (size_t)n_files);
+
 	double last_status = -1e18;
 #ifdef MDEMOD_TUI
 	int8_t shown[2 * RINGSIZE];                 /* the latest symbols of stream 0 for the constellation (main.c:238 shows its ring) */

@@ -99,7 +99,7 @@ typedef struct {
 	uint32_t n_streams;     /* independent streams held by this context               */
 	uint32_t reserved;      /* 0: the library picks the kernel (what a caller passes).  MDEMOD_FLAG_* below pin a variant: the
 	                           test-suite runs every golden through all of them.  The library reads one environment variable, MDEMOD_PACK_THREADS
-	                           (threads that pack host buffers in mdemod_process_host, default 8; no result depends on it). */
+	                           (threads that pack host buffers in mdemod_process_host, default 12; no result depends on it). */
 } mdemod_params;
 
 /* mdemod_params.reserved (diagnosis and tests only; every variant produces the same bytes) */
@@ -218,6 +218,18 @@ int  mdemod_process_host(mdemod_ctx *ctx,
                          int8_t *const *soft_host, const uint32_t *soft_cap,
                          uint32_t *n_symbols);
 
+/*
+ * Optional, for a caller that reads into the same buffer block after block (main.c:303 does: wavfile.c's 32 KiB buffer; the C host
+ * here: 4 MiB per file): pins [base, base + bytes) for the HIP runtime (hipHostRegister; ~60 ms per GB, once).  mdemod_process_host
+ * then copies a batch that lies inside a pinned range straight from the caller's pages - when every stream's block has the same
+ * length and the blocks sit one stride apart (iq_host[s] = iq_host[0] + s * stride: a batch read into one buffer) - instead of
+ * staging it through the library's own pinned ring with the CPU.  Any other layout, and anything outside the pinned ranges, takes the
+ * staged path; results never depend on it.  The caller keeps the range mapped until mdemod_unpin_host_buffer (with the same base)
+ * or mdemod_destroy, which unpins what is left.  MDEMOD_ERR_PARAM for a range that overlaps one pinned already.
+ */
+int  mdemod_pin_host_buffer(mdemod_ctx *ctx, const void *base, size_t bytes);
+int  mdemod_unpin_host_buffer(mdemod_ctx *ctx, const void *base);
+
 /* ---- status / state (synchronise with the last call on hip_stream first) -- */
 
 int  mdemod_get_status(mdemod_ctx *ctx, uint32_t first, uint32_t count,
@@ -279,7 +291,7 @@ typedef struct {
 	                                   the pilot's carrier estimate (dead reckoning then rarely holds: repair does the work) (1) */
 	uint32_t clock_seed;            /* 0: every tile's symbol clock from its own spectral line (mdemod_estimate_clock: follows the
 	                                   Doppler on the clock, good to a tenth of the loop's own wander); 1: the pilot's omega for all (0) */
-	int32_t  debug;                 /* 0; 1: stage timings and a per-seam trace of the odd seams on stderr, 2: every seam (0) */
+	int32_t  debug;                 /* 0; 1: stage timings and a per-seam trace of the odd seams on stderr, 2: every seam, 3: and one line per tile (seeds, end state) (0) */
 	int32_t  debug_tile;            /* with debug: also trace the framing of the tiles around this index; -1 = none (-1) */
 } mdemod_recording_opts;
 

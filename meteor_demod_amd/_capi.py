@@ -108,6 +108,8 @@ SIGNATURES = {
                                         C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "mdemod_process_host": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_uint32),
                                       _P(C.c_void_p), _P(C.c_uint32), _P(C.c_uint32)]),
+    "mdemod_pin_host_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mdemod_unpin_host_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mdemod_get_status": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(MdemodStatus), C.c_void_p]),
     "mdemod_get_lock_events": (C.c_int, [C.c_void_p, C.c_uint32, _P(MdemodLockEvent), C.c_uint32,
                                          _P(C.c_uint32), C.c_void_p]),

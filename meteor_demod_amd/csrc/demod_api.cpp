@@ -416,6 +416,24 @@ mdemod_process_host(mdemod_ctx *ctx, const void *const *iq_host, const uint32_t 
 	                           iq_host, n_samples, soft_host, soft_cap, n_symbols);
 }
 
+int
+mdemod_pin_host_buffer(mdemod_ctx *ctx, const void *base, size_t bytes)
+{
+	if (!ctx || !base || !bytes) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	return mdemod_hostpipe_pin(&ctx->pipe, base, bytes);
+}
+
+int
+mdemod_unpin_host_buffer(mdemod_ctx *ctx, const void *base)
+{
+	if (!ctx || !base) return MDEMOD_ERR_PARAM;
+	int rc = select_device(ctx);
+	if (rc) return rc;
+	return mdemod_hostpipe_unpin(ctx->pipe, base);
+}
+
 /* ---- status / state ---------------------------------------------------------- */
 
 

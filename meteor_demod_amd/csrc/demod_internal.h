@@ -116,6 +116,8 @@ int  mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA 
                          const void *const *iq_host, const uint32_t *n_samples,
                          int8_t *const *soft_host, const uint32_t *soft_cap, uint32_t *n_symbols);
 void mdemod_hostpipe_free(void *pipe);
+int  mdemod_hostpipe_pin(void **pipe_slot, const void *base, size_t bytes);
+int  mdemod_hostpipe_unpin(void *pipe, const void *base);
 hipError_t mdemod_launch_selftest_sincos(const float *x, uint32_t n, float *s, float *c, hipStream_t stream);
 hipError_t mdemod_launch_selftest_turncode(unsigned long long *mismatch_dev, hipStream_t stream);
 hipError_t mdemod_launch_selftest_sinlut(unsigned long long *mismatch_dev, hipStream_t stream);

@@ -5,15 +5,20 @@
  * sample (wavfile.c:55-69); a GPU fed from host memory is bound by PCIe, so the work is to
  * keep the link busy: each stream's block is cut into K consecutive sub-blocks (chained
  * calls are exact, the state lives in the context), and sub-block k+1 is packed into pinned
- * memory and copied in while sub-block k is demodulated and sub-block k-1 is copied out and
- * handed back to the caller's buffers:
+ * memory and copied in while sub-block k is demodulated and sub-block k-1 is copied out;
+ * the host hands sub-block k-2 back to the caller's buffers:
  *
- *     CPU pack(k+1) | H2D(k+1)  [stream in]  |  kernel(k) [stream cmp]  |  D2H(k-1) [stream out] | CPU unpack(k-1)
+ *     CPU pack(k+1) | H2D(k+1)  [stream in]  |  kernel(k) [stream cmp]  |  D2H(k-1) [stream out] | CPU unpack(k-2)
  *
- * (the host unpacks k-1 after it has enqueued kernel k and its copies, so the GPU never waits for the CPU; every sub-block's
- * lock events are copied aside on the compute stream because the next launch overwrites the context's list).
- * Two sets of pinned + device staging buffers (grow only), three HIP streams, events for the
- * four hand-offs.  Packing and unpacking are spread over a few host threads.
+ * Round 5 (the link is the bound, so everything else has to stay off its critical path; tools/ubench/h2d_rect.cpp has the rates):
+ *   - THREE staging sets: the host unpacks k-2, whose copy-out finished long ago, instead of waiting for k-1 with its hands in
+ *     its pockets while the copy-in engine runs dry (r04: 40 of 57 GB/s);
+ *   - the pack writes the pinned ring with non-temporal stores (no read-for-ownership of lines the CPU never reads again: the pack
+ *     alone 65 -> 105 GB/s on 16 threads of an EPYC 9575F) on a pool of 12 threads;
+ *   - sub-blocks of ~32 MiB, up to 64 of them: what the pipeline cannot overlap is one pack at the start and one kernel + copy-out +
+ *     unpack at the end, and both are as long as a sub-block.
+ * Every sub-block's lock events are copied aside on the compute stream because the next launch overwrites the context's list.
+ * Pinned + device staging buffers grow only; three HIP streams, events for the hand-offs.
  * After the last sub-block the per-call counters of the context (symbols / lock events of "this
  * call") are rewritten with the totals over all sub-blocks, so the status snapshot means what the
  * header says.
@@ -21,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +36,7 @@
 #include <thread>
 #include <vector>
 #include <unistd.h>
+#include <emmintrin.h>
 
 #include "demod_internal.h"
 #include "pack_pool.h"
@@ -46,8 +53,11 @@ namespace {
 		}                                                                                       \
 	} while (0)
 
-struct Slot {                    /* one of the two staging sets */
-	unsigned char *h_iq = nullptr, *d_iq = nullptr;   size_t iq_bytes = 0;
+constexpr int kSlots = 3;        /* staging sets: one being filled / copied in, one under the kernel / copied out, one being handed back */
+
+struct Slot {                    /* one of the staging sets */
+	unsigned char *h_iq = nullptr;  size_t h_iq_bytes = 0;       /* pinned ring (staged path only)                 */
+	unsigned char *d_iq = nullptr;  size_t d_iq_bytes = 0;
 	int8_t *h_soft = nullptr;  size_t h_soft_bytes = 0;
 	int8_t *d_soft = nullptr;  size_t d_soft_bytes = 0;          /* kernel output, hard-bound pitch              */
 	int8_t *d_pack = nullptr;  size_t d_pack_bytes = 0;          /* the same rows at the nominal pitch: what is copied out */
@@ -62,24 +72,54 @@ struct Slot {                    /* one of the two staging sets */
 	uint32_t width = 0;          /* symbols per stream actually copied out = the largest count of the sub-block */
 };
 
+struct Pin { const unsigned char *base; size_t bytes; };
+
 struct HostPipe {
-	Slot slot[2];
+	Slot slot[kSlots];
+	std::vector<Pin> pins;       /* ranges of the caller's memory registered with the HIP runtime (mdemod_pin_host_buffer) */
 	hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
 	uint32_t ns = 0;
 	bool ready = false;
 };
 
+/* memcpy with non-temporal stores: into the pinned ring (the CPU never reads it again) and into the caller's output rows (640 B ..
+ * a few KB each, every one on another page: a plain memcpy first READS the destination lines it is about to overwrite - one DRAM
+ * round trip per piece that nothing hides; tools/ubench/h2d_rect.cpp: the pack alone 65 -> 105 GB/s).  Whoever calls this fences
+ * (_mm_sfence) before the bytes are handed on. */
+inline void
+stream_copy(unsigned char *dst, const unsigned char *src, size_t n)
+{
+	size_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15;
+	if (head > n) head = n;
+	if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+	size_t i = 0;
+	for (; i + 64 <= n; i += 64) {
+		const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i)), b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 16));
+		const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 32)), d = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 48));
+		_mm_stream_si128(reinterpret_cast<__m128i *>(dst + i), a); _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 16), b);
+		_mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 32), c); _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 48), d);
+	}
+	if (i < n) memcpy(dst + i, src + i, n - i);
+}
+
+/* the first lines of the NEXT piece a thread will read (another row of the caller's, far from this one): on their way while this
+ * piece is copied */
+inline void
+prefetch_piece(const unsigned char *src)
+{
+	_mm_prefetch(reinterpret_cast<const char *>(src), _MM_HINT_NTA); _mm_prefetch(reinterpret_cast<const char *>(src + 64), _MM_HINT_NTA);
+	_mm_prefetch(reinterpret_cast<const char *>(src + 128), _MM_HINT_NTA); _mm_prefetch(reinterpret_cast<const char *>(src + 192), _MM_HINT_NTA);
+}
+
 template <typename T>
 int
-grow_pair(T **host, T **dev, size_t *have, size_t need)
+grow_host_any(T **host, size_t *have, size_t need)
 {
 	if (need <= *have) return MDEMOD_OK;
 	if (*host) (void)hipHostFree(*host);
-	if (*dev) (void)hipFree(*dev);
-	*host = nullptr; *dev = nullptr; *have = 0;
+	*host = nullptr; *have = 0;
 	need += need / 8;                                        /* a little headroom: fewer re-allocations */
 	PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(host), need, hipHostMallocDefault));
-	PIPE_TRY(hipMalloc(reinterpret_cast<void **>(dev), need));
 	*have = need;
 	return MDEMOD_OK;
 }
@@ -96,8 +136,9 @@ grow_host(int8_t **host, size_t *have, size_t need)
 	return MDEMOD_OK;
 }
 
+template <typename T>
 int
-grow_dev(int8_t **dev, size_t *have, size_t need)
+grow_dev(T **dev, size_t *have, size_t need)
 {
 	if (need <= *have) return MDEMOD_OK;
 	if (*dev) (void)hipFree(*dev);
@@ -157,10 +198,41 @@ mdemod_hostpipe_free(void *opaque)
 		if (s.ev_k) (void)hipEventDestroy(s.ev_k);
 		if (s.ev_out) (void)hipEventDestroy(s.ev_out);
 	}
+	for (const Pin &pin : p->pins) (void)hipHostUnregister(const_cast<unsigned char *>(pin.base));
 	if (p->s_in) (void)hipStreamDestroy(p->s_in);
 	if (p->s_cmp) (void)hipStreamDestroy(p->s_cmp);
 	if (p->s_out) (void)hipStreamDestroy(p->s_out);
 	delete p;
+}
+
+/* mdemod_pin_host_buffer / mdemod_unpin_host_buffer (include/meteor_demod_amd.h) */
+int
+mdemod_hostpipe_pin(void **pipe_slot, const void *base, size_t bytes)
+{
+	if (!base || !bytes) return MDEMOD_ERR_PARAM;
+	if (!*pipe_slot) *pipe_slot = new HostPipe();
+	HostPipe *p = static_cast<HostPipe *>(*pipe_slot);
+	const unsigned char *b = static_cast<const unsigned char *>(base);
+	for (const Pin &pin : p->pins)
+		if (b < pin.base + pin.bytes && pin.base < b + bytes) return MDEMOD_ERR_PARAM;       /* overlaps a range that is pinned already */
+	PIPE_TRY(hipHostRegister(const_cast<unsigned char *>(b), bytes, hipHostRegisterDefault));
+	p->pins.push_back({ b, bytes });
+	return MDEMOD_OK;
+}
+
+int
+mdemod_hostpipe_unpin(void *opaque, const void *base)
+{
+	HostPipe *p = static_cast<HostPipe *>(opaque);
+	if (!p || !base) return MDEMOD_ERR_PARAM;
+	for (size_t i = 0; i < p->pins.size(); i++)
+		if (p->pins[i].base == base) {
+			/* (nothing of this context is in flight: mdemod_process_host is synchronous) */
+			PIPE_TRY(hipHostUnregister(const_cast<unsigned char *>(p->pins[i].base)));
+			p->pins.erase(p->pins.begin() + static_cast<long>(i));
+			return MDEMOD_OK;
+		}
+	return MDEMOD_ERR_PARAM;
 }
 
 int
@@ -179,17 +251,69 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		total += n_samples[s];
 		n_max = std::max(n_max, n_samples[s]);
 	}
-	/* sub-blocks of ~32 MiB of input, at most 16, at least 4096 samples of the longest stream each */
-	uint32_t K = static_cast<uint32_t>(std::min<uint64_t>(16, std::max<uint64_t>(1, total * sb / (32u << 20))));
-	while (K > 1 && n_max / K < 4096) K--;
+	/* Rows the copy engine can take straight from the caller's pages: the whole batch inside a range the caller pinned
+	 * (mdemod_pin_host_buffer), every stream as long as the others and one stride apart - a batch read into one buffer (the C
+	 * host's, a [streams][samples] array).  Then a sub-block is ONE two-dimensional copy and the CPU does not touch the input at all
+	 * (r05, tools/ubench/h2d_rect.cpp: 57 GB/s, what the link gives a contiguous pinned copy; the staged path's pack competes with the
+	 * copy engine for the host's memory and holds it at 53).  Anything else is staged through the pinned ring as before. */
+	bool direct = false;
+	size_t row_stride = 0;
+	if (!p->pins.empty() && ns >= 1 && n_max > 0) {
+		const unsigned char *first = static_cast<const unsigned char *>(iq_host[0]);
+		direct = first != nullptr;
+		for (uint32_t s = 0; s < ns && direct; s++) direct = n_samples[s] == n_max;
+		if (direct && ns > 1) {
+			const unsigned char *second = static_cast<const unsigned char *>(iq_host[1]);
+			direct = second > first && static_cast<size_t>(second - first) >= static_cast<size_t>(n_max) * sb;
+			row_stride = direct ? static_cast<size_t>(second - first) : 0;
+			for (uint32_t s = 2; s < ns && direct; s++) direct = static_cast<const unsigned char *>(iq_host[s]) == first + static_cast<size_t>(s) * row_stride;
+		} else if (direct) row_stride = static_cast<size_t>(n_max) * sb;
+		if (direct) {
+			const unsigned char *end = first + static_cast<size_t>(ns - 1) * row_stride + static_cast<size_t>(n_max) * sb;
+			bool inside = false;
+			for (const Pin &pin : p->pins) inside = inside || (first >= pin.base && end <= pin.base + pin.bytes);
+			direct = inside;
+		}
+	}
+	/* Sub-blocks: K consecutive pieces of every stream's block, 16 full-size ones at most (each stream's piece should stay a few
+	 * KB: both host copies pay a DRAM round trip per piece; and a launch hands the filter history over, taps - 1 samples per
+	 * stream, again and again), at least MINSAMP samples of the longest stream each.  What the pipeline cannot overlap is the first
+	 * pack and the last kernel + copy-out + unpack, so the first two and the last two sub-blocks are a quarter and a half of the
+	 * others (r05: 16 equal ones left 3.5 ms of a 41 ms call outside the overlap). */
+#ifndef MDEMOD_PIPE_KMAX
+#define MDEMOD_PIPE_KMAX 16
+#define MDEMOD_PIPE_MINSAMP 2048
+#define MDEMOD_PIPE_SUBBYTES (32u << 20)
+#define MDEMOD_PIPE_RAMP 1
+#endif
+	uint32_t K = static_cast<uint32_t>(std::min<uint64_t>(MDEMOD_PIPE_KMAX, std::max<uint64_t>(1, total * sb / MDEMOD_PIPE_SUBBYTES)));
+	while (K > 1 && n_max / K < MDEMOD_PIPE_MINSAMP) K--;
+	std::vector<uint64_t> cumw(1, 0);                         /* sub-block k covers [cumw[k], cumw[k + 1]) / cumw[K] of every stream */
+	if (MDEMOD_PIPE_RAMP && K >= 8) {
+		K += 2;                                                  /* (the four short ones together are one and a half full ones) */
+		for (uint32_t k = 0; k < K; k++) cumw.push_back(cumw.back() + ((k == 0 || k == K - 1) ? 1 : (k == 1 || k == K - 2) ? 2 : 4));
+	} else {
+		for (uint32_t k = 0; k < K; k++) cumw.push_back(cumw.back() + 1);
+	}
+#ifdef MDEMOD_PIPE_TRACE
+	double tr_pack = 0, tr_unpack = 0, tr_wait_in = 0, tr_enq = 0, tr_layout = 0, tr_wait_out = 0;
+	std::vector<hipEvent_t> tr_e0(80), tr_e1(80), tr_k0(80), tr_k1(80), tr_o1(80);
+	for (int i = 0; i < 80; i++) { (void)hipEventCreate(&tr_e0[i]); (void)hipEventCreate(&tr_e1[i]); (void)hipEventCreate(&tr_k0[i]); (void)hipEventCreate(&tr_k1[i]); (void)hipEventCreate(&tr_o1[i]); }
+	std::vector<double> tr_enq_at(80, 0);
+	auto tr_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double tr_t0 = tr_now();
+#define TR(acc, stmt) do { const double t_ = tr_now(); stmt; acc += tr_now() - t_; } while (0)
+#else
+#define TR(acc, stmt) do { stmt; } while (0)
+#endif
 
 	std::vector<uint32_t> produced(ns, 0), events(ns, 0);
 	std::vector<mdemod_lock_event> ev_store;                  /* merged lock events: [stream][32] (only if any) */
 	int result = MDEMOD_OK;
-	auto sub_lo = [&](uint32_t s, uint32_t k) { return static_cast<uint32_t>(static_cast<uint64_t>(n_samples[s]) * k / K); };
+	auto sub_lo = [&](uint32_t s, uint32_t k) { return static_cast<uint32_t>(static_cast<uint64_t>(n_samples[s]) * cumw[k] / cumw[K]); };
 
 	auto unpack = [&](Slot &sl) -> int {
-		PIPE_TRY(hipEventSynchronize(sl.ev_out));
+		TR(tr_wait_out, PIPE_TRY(hipEventSynchronize(sl.ev_out)));
 		/* common case: every row fits the nominal pitch and h_soft holds it.  A stream that fired on (almost) every sample
 		 * (full-scale transient) exceeds it: then the rows are fetched again, 2-D, from the hard-pitch buffer. */
 		uint32_t widest = 0;
@@ -214,8 +338,10 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 				uint32_t m = sl.h_prod[s];
 				const uint32_t room = soft_cap[s] > produced[s] ? soft_cap[s] - produced[s] : 0;
 				if (m > room) m = room;                           /* overflow is reported below */
-				if (m) memcpy(soft_host[s] + 2 * static_cast<size_t>(produced[s]), sl.h_soft + static_cast<size_t>(s) * sl.width * 2, static_cast<size_t>(m) * 2);
+				if (m) stream_copy(reinterpret_cast<unsigned char *>(soft_host[s]) + 2 * static_cast<size_t>(produced[s]),
+				                   reinterpret_cast<const unsigned char *>(sl.h_soft) + static_cast<size_t>(s) * sl.width * 2, static_cast<size_t>(m) * 2);
 			}
+			_mm_sfence();                                             /* the caller may read its rows from any thread once the call returns */
 		});
 		for (uint32_t s = 0; s < ns; s++) {
 			if (static_cast<uint64_t>(produced[s]) + sl.h_prod[s] > soft_cap[s]) { result = MDEMOD_ERR_OVERFLOW; produced[s] = soft_cap[s]; }
@@ -243,11 +369,11 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 	};
 
 	for (uint32_t k = 0; k < K; k++) {
-		Slot &sl = p->slot[k & 1];
+		Slot &sl = p->slot[k % kSlots];
 		/* ---- layout of sub-block k ---- */
 		std::vector<uint64_t> wpre(ns);
 		uint64_t pos = 0; uint32_t sub_max = 0;
-		if (sl.used_in) PIPE_TRY(hipEventSynchronize(sl.ev_in));          /* h_iq / h_off / h_cnt of this slot are free again */
+		TR(tr_wait_in, if (sl.used_in) PIPE_TRY(hipEventSynchronize(sl.ev_in)));          /* h_iq / h_off / h_cnt of this slot are free again */
 		for (uint32_t s = 0; s < ns; s++) {
 			const uint32_t lo = sub_lo(s, k), hi = sub_lo(s, k + 1);
 			sl.h_off[s] = pos; sl.h_cnt[s] = hi - lo;
@@ -259,11 +385,12 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		const uint32_t cap = ((sub_max + 8 + 7) / 8) * 8;                   /* hard bound: one symbol per input sample */
 		const uint32_t pitch = static_cast<uint32_t>(std::min<uint64_t>(cap, mdemod_nominal_symbols(ctx, sub_max)));
 		const size_t soft_bytes = static_cast<size_t>(cap) * 2 * ns, pack_bytes = static_cast<size_t>(pitch) * 2 * ns;
-		if (iq_bytes > sl.iq_bytes || soft_bytes > sl.d_soft_bytes || pack_bytes > sl.d_pack_bytes || pack_bytes > sl.h_soft_bytes) {
+		if (iq_bytes > sl.d_iq_bytes || (!direct && iq_bytes > sl.h_iq_bytes) || soft_bytes > sl.d_soft_bytes || pack_bytes > sl.d_pack_bytes || pack_bytes > sl.h_soft_bytes) {
 			/* the slot's previous sub-block must be completely through before its buffers are replaced */
 			if (sl.used_out) PIPE_TRY(hipEventSynchronize(sl.ev_out));
-			rc = grow_pair(&sl.h_iq, &sl.d_iq, &sl.iq_bytes, iq_bytes);
+			rc = grow_dev(&sl.d_iq, &sl.d_iq_bytes, iq_bytes);
 			if (rc) return rc;
+			if (!direct) { rc = grow_host_any(&sl.h_iq, &sl.h_iq_bytes, iq_bytes); if (rc) return rc; }
 			rc = grow_dev(&sl.d_soft, &sl.d_soft_bytes, soft_bytes);
 			if (rc) return rc;
 			rc = grow_dev(&sl.d_pack, &sl.d_pack_bytes, pack_bytes);
@@ -271,16 +398,32 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 			rc = grow_host(&sl.h_soft, &sl.h_soft_bytes, pack_bytes);
 			if (rc) return rc;
 		}
-		/* ---- pack (CPU) ---- */
-		parallel_streams(ns, wpre, [&](uint32_t a, uint32_t b) {
-			for (uint32_t s = a; s < b; s++)
+		/* ---- pack (CPU): not for rows the copy engine reads where they are ---- */
+		if (!direct) TR(tr_pack, parallel_streams(ns, wpre, [&](uint32_t a, uint32_t b) {
+			for (uint32_t s = a; s < b; s++) {
+				if (s + 1 < b && sl.h_cnt[s + 1]) prefetch_piece(static_cast<const unsigned char *>(iq_host[s + 1]) + static_cast<size_t>(sub_lo(s + 1, k)) * sb);
 				if (sl.h_cnt[s])
-					memcpy(sl.h_iq + sl.h_off[s] * sb, static_cast<const unsigned char *>(iq_host[s]) + static_cast<size_t>(sub_lo(s, k)) * sb,
-					       static_cast<size_t>(sl.h_cnt[s]) * sb);
-		});
+					stream_copy(sl.h_iq + sl.h_off[s] * sb, static_cast<const unsigned char *>(iq_host[s]) + static_cast<size_t>(sub_lo(s, k)) * sb,
+					            static_cast<size_t>(sl.h_cnt[s]) * sb);
+			}
+			_mm_sfence();                                                  /* the non-temporal stores of this thread are out before the copy engine reads the ring */
+		}));
 		/* ---- H2D: after the kernel that last read this slot's device input ---- */
 		if (sl.used_k) PIPE_TRY(hipStreamWaitEvent(p->s_in, sl.ev_k, 0));
-		if (pos) PIPE_TRY(hipMemcpyAsync(sl.d_iq, sl.h_iq, static_cast<size_t>(pos) * sb, hipMemcpyHostToDevice, p->s_in));
+#ifdef MDEMOD_PIPE_TRACE
+		tr_enq_at[k] = (tr_now() - tr_t0) * 1e3;
+		(void)hipEventRecord(tr_e0[k], p->s_in);
+#endif
+		if (pos && direct) {
+			/* every stream's piece is [lo, lo + cnt) of its row: device rows at the ring's own pitch (8-sample multiples, h_off) */
+			const uint32_t lo = sub_lo(0, k), cnt = sl.h_cnt[0];
+			const size_t dev_pitch = ns > 1 ? static_cast<size_t>(sl.h_off[1] - sl.h_off[0]) * sb : static_cast<size_t>(cnt) * sb;
+			if (cnt) PIPE_TRY(hipMemcpy2DAsync(sl.d_iq, dev_pitch, static_cast<const unsigned char *>(iq_host[0]) + static_cast<size_t>(lo) * sb, row_stride,
+			                                   static_cast<size_t>(cnt) * sb, ns, hipMemcpyHostToDevice, p->s_in));
+		} else if (pos) PIPE_TRY(hipMemcpyAsync(sl.d_iq, sl.h_iq, static_cast<size_t>(pos) * sb, hipMemcpyHostToDevice, p->s_in));
+#ifdef MDEMOD_PIPE_TRACE
+		(void)hipEventRecord(tr_e1[k], p->s_in);
+#endif
 		PIPE_TRY(hipMemcpyAsync(sl.d_off, sl.h_off, sizeof(uint64_t) * ns, hipMemcpyHostToDevice, p->s_in));
 		PIPE_TRY(hipMemcpyAsync(sl.d_cnt, sl.h_cnt, sizeof(uint32_t) * ns, hipMemcpyHostToDevice, p->s_in));
 		PIPE_TRY(hipEventRecord(sl.ev_in, p->s_in)); sl.used_in = true;
@@ -288,22 +431,48 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		PIPE_TRY(hipStreamWaitEvent(p->s_cmp, sl.ev_in, 0));
 		if (sl.used_out) PIPE_TRY(hipStreamWaitEvent(p->s_cmp, sl.ev_out, 0));
 		sl.cap = cap; sl.pitch = pitch;
+#ifdef MDEMOD_PIPE_TRACE
+		(void)hipEventRecord(tr_k0[k], p->s_cmp);
+#endif
 		rc = mdemod_process_device(ctx, sl.d_iq, sl.d_off, sl.d_cnt, sl.d_soft, cap, cap, p->s_cmp);
 		if (rc) return rc;
+		/* (r05, measured: letting this kernel store the rows straight into the pinned host buffer - no copy engine for the way out -
+		 * ends the call without a tail but slows every copy-in by as much: 42.6 ms either way.  The link moves 58 GB/s both ways here.) */
 		PIPE_TRY(mdemod_launch_compact_rows(sl.d_soft, cap, sl.d_pack, pitch, st.sym_this_call, ns, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_prod, st.sym_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_ev, st.ev_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
 		if (K > 1) PIPE_TRY(hipMemcpyAsync(sl.d_events, st.events, sizeof(mdemod_lock_event) * MDEMOD_MAX_LOCK_EVENTS * ns, hipMemcpyDeviceToDevice, p->s_cmp));
+#ifdef MDEMOD_PIPE_TRACE
+		(void)hipEventRecord(tr_k1[k], p->s_cmp);
+#endif
 		PIPE_TRY(hipEventRecord(sl.ev_k, p->s_cmp)); sl.used_k = true;
 		/* ---- D2H of the nominal-pitch copy ---- */
 		PIPE_TRY(hipStreamWaitEvent(p->s_out, sl.ev_k, 0));
 		PIPE_TRY(hipMemcpyAsync(sl.h_soft, sl.d_pack, pack_bytes, hipMemcpyDeviceToHost, p->s_out));
+#ifdef MDEMOD_PIPE_TRACE
+		(void)hipEventRecord(tr_o1[k], p->s_out);
+#endif
 		PIPE_TRY(hipEventRecord(sl.ev_out, p->s_out)); sl.used_out = true;
-		/* ---- hand sub-block k-1 back to the caller while the GPU works on k ---- */
-		if (k >= 1) { rc = unpack(p->slot[(k - 1) & 1]); if (rc) return rc; }
+		/* ---- hand sub-block k-2 back to the caller while k-1 is under the kernel and k on the link (its copy-out is done: no wait) ---- */
+		if (k >= 2) { TR(tr_unpack, rc = unpack(p->slot[(k - 2) % kSlots])); if (rc) return rc; }
 	}
-	rc = unpack(p->slot[(K - 1) & 1]);
+	if (K >= 2) { TR(tr_unpack, rc = unpack(p->slot[(K - 2) % kSlots])); if (rc) return rc; }
+	TR(tr_unpack, rc = unpack(p->slot[(K - 1) % kSlots]));
 	if (rc) return rc;
+#ifdef MDEMOD_PIPE_TRACE
+	fprintf(stderr, "[host_pipe] K %u, total %.2f ms: pack %.2f, unpack (with its waits) %.2f, wait for the ring %.2f, layout %.2f ms; pool %u\n", K, (tr_now() - tr_t0) * 1e3,
+	        tr_pack * 1e3, tr_unpack * 1e3, tr_wait_in * 1e3, tr_layout * 1e3, PackPool::get().size());
+	fprintf(stderr, "[host_pipe]   waits for the copy-out inside unpack: %.2f ms\n", tr_wait_out * 1e3);
+	(void)hipDeviceSynchronize();
+	for (uint32_t k = 0; k < K && k < 80; k++) {
+		float a = 0, b = 0, c = 0, d = 0, e = 0;
+		(void)hipEventElapsedTime(&a, tr_e0[0], tr_e0[k]); (void)hipEventElapsedTime(&b, tr_e0[0], tr_e1[k]);
+		(void)hipEventElapsedTime(&c, tr_e0[0], tr_k0[k]); (void)hipEventElapsedTime(&d, tr_e0[0], tr_k1[k]); (void)hipEventElapsedTime(&e, tr_e0[0], tr_o1[k]);
+		fprintf(stderr, "[host_pipe]   k %2u: enqueued at %6.2f (host clock); H2D %6.2f .. %6.2f, kernel+compact %6.2f .. %6.2f, copy-out done %6.2f (ms after the first H2D began)\n", k, tr_enq_at[k], a, b, c, d, e);
+	}
+	for (int i = 0; i < 80; i++) { (void)hipEventDestroy(tr_e0[i]); (void)hipEventDestroy(tr_e1[i]); (void)hipEventDestroy(tr_k0[i]); (void)hipEventDestroy(tr_k1[i]); (void)hipEventDestroy(tr_o1[i]); }
+	(void)tr_enq;
+#endif
 
 	/* ---- "this call" counters := totals over the sub-blocks ---- */
 	if (K > 1) {

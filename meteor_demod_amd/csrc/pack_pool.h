@@ -58,7 +58,7 @@ private:
 	{
 		const char *e = getenv("MDEMOD_PACK_THREADS");
 		int want = e ? atoi(e) : 0;
-		if (want <= 0 || want > 64) want = 8;
+		if (want <= 0 || want > 64) want = 12;          /* r05, tools/ubench/h2d_rect.cpp: the pack into the pinned ring keeps up with the link from 8 threads on, best at 12..16 */
 		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 		const unsigned n = std::min<unsigned>(static_cast<unsigned>(want), hw);
 		Shared *s = sh;

@@ -1672,7 +1672,19 @@ struct Stitcher {
 		TRY(acquire_and_frame());
 		TRY(settle_body_seams());
 		TRY(hand_over_uncured());
+		if (o.debug >= 3) dump_tiles();
 		return assemble();
+	}
+
+	/* debug >= 3: one line per tile for tools/tile_tail.py (what was the tile given, where did it end up) */
+	void dump_tiles() const
+	{
+		for (size_t i = 0; i < T; i++)
+			fprintf(stderr, "[tile] %zu E %llu len %llu s0 %llu acq %llu frm %llu stl %llu seed_tf %.9g seed_f0 %.9g end_tf %.9g end_f0 %.9g end_gain %.9g cnt %u out_rot %d\n", i,
+			        (unsigned long long)E[i], (unsigned long long)len[i], (unsigned long long)s0[i], (unsigned long long)acq[i], (unsigned long long)frm[i],
+			        (unsigned long long)stl[i], static_cast<double>(tf.size() > i ? tf[i] : 0.0f), static_cast<double>(f0.size() > i ? f0[i] : 0.0f),
+			        static_cast<double>(status_body.size() > i ? status_body[i].omega : 0.0f), static_cast<double>(status_body.size() > i ? status_body[i].pll_freq : 0.0f),
+			        static_cast<double>(status_body.size() > i ? status_body[i].gain : 0.0f), cnt1.size() > i ? cnt1[i] : 0u, out_rot.size() > i ? out_rot[i] : 0);
 	}
 };
 

@@ -213,6 +213,14 @@ class Demodulator:
               "mdemod_process_host")
         return [o[:produced[i]] for i, o in enumerate(outs)]
 
+    def pin_host(self, array: np.ndarray) -> None:
+        """``mdemod_pin_host_buffer``: batches that lie inside ``array`` (rows of equal length, one stride apart) are copied
+        straight from its pages by :meth:`process_host`.  Keep ``array`` alive until :meth:`unpin_host` or :meth:`close`."""
+        check(self._lib.mdemod_pin_host_buffer(self._ctx, C.c_void_p(array.ctypes.data), array.nbytes), "mdemod_pin_host_buffer")
+
+    def unpin_host(self, array: np.ndarray) -> None:
+        check(self._lib.mdemod_unpin_host_buffer(self._ctx, C.c_void_p(array.ctypes.data)), "mdemod_unpin_host_buffer")
+
     # -- status / state ---------------------------------------------------------
     def status(self, first: int = 0, count: int | None = None) -> list[MdemodStatus]:
         count = self.n_streams - first if count is None else count

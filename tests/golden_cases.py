@@ -111,6 +111,23 @@ CASES = [
          note="-s 60000 at 72k symbols/s: 0.83 samples per symbol, every sixth sample holds two firings: only the last survives", seed=7002),
     Case("sub_sample_oqpsk", DemodConfig(samplerate=64000, symrate=80000, oqpsk=True, interp_factor=4), [Segment(50000, dict(f0_hz=60.0, esn0_db=20.0))],
          note="OQPSK 80k in 64 kS/s -O 4: 0.4 samples per firing", seed=7003),
+    # --- symbol rates at and above the INTERPOLATED rate (symrate >= fs x O): the clock word is 2 pi or more, every interpolated step
+    #     fires (timing.c:32-57), the phase accumulator is never brought back under its threshold and climbs through the float binades
+    #     (timing.c:79 takes 2 pi off, the step puts 2 pi x ratio on).  Nothing a receiver would be set to; the reference takes the
+    #     options all the same (main.c:109-123) and so does mdemod_create, up to the bound in demod_host.cpp.  Round 4's cj_schedule
+    #     never returned for ratios from 2 (OQPSK) / 4 (QPSK); ratios of the cases: 2, 3, 6, 4 (-O 2), 3.9, 4 ----------------------
+    Case("sub_step_oqpsk_r2", DemodConfig(samplerate=36000, interp_factor=1, oqpsk=True), [Segment(30000, dict(f0_hz=50.0, esn0_db=20.0))],
+         note="OQPSK 72k in 36 kS/s -O 1: symrate = 2 fs O, one half-symbol firing per step", seed=7101),
+    Case("sub_step_oqpsk_r3", DemodConfig(samplerate=24000, interp_factor=1, oqpsk=True), [Segment(30000, dict(f0_hz=-40.0, esn0_db=20.0))],
+         note="OQPSK 72k in 24 kS/s -O 1: symrate = 3 fs O", seed=7102),
+    Case("sub_step_oqpsk_r6", DemodConfig(samplerate=12000, interp_factor=1, oqpsk=True), [Segment(30000, dict(f0_hz=20.0, esn0_db=20.0))],
+         note="OQPSK 72k in 12 kS/s -O 1: symrate = 6 fs O (the accepted region ends at 8)", seed=7103),
+    Case("sub_step_oqpsk_o2", DemodConfig(samplerate=9000, interp_factor=2, oqpsk=True), [Segment(30000, dict(f0_hz=10.0, esn0_db=20.0))],
+         note="OQPSK 72k in 9 kS/s -O 2: symrate = 4 fs O on the edge of the accepted region (8 fs)", seed=7104),
+    Case("sub_step_qpsk_r3p9", DemodConfig(samplerate=18462, interp_factor=1), [Segment(30000, dict(f0_hz=30.0, esn0_db=20.0))],
+         note="QPSK 72k in 18.462 kS/s -O 1: symrate = 3.9 fs O", seed=7105),
+    Case("sub_step_qpsk_r4", DemodConfig(samplerate=18000, interp_factor=1), [Segment(30000, dict(f0_hz=-25.0, esn0_db=20.0))],
+         note="QPSK 72k in 18 kS/s -O 1: symrate = 4 fs O exactly, the edge of the accepted region", seed=7106),
 ]
 
 BY_NAME = {c.name: c for c in CASES}

@@ -118,6 +118,12 @@ check_schedule(const DemodConsts &c, const cj_sched &J, float S, float thr, Rng 
 	if (J.nb == 0) return true;
 	if (!(J.floor <= J.lo && J.lo < J.hi) || !std::isfinite(J.lo) || !std::isfinite(J.hi) || !(J.B0 > 0.0f)) return false;
 	if (J.max_steps > (1 << 24) || J.up_max > (1 << 24)) return false;
+	/* a clock word from outside the loop's range (the API keeps them out; this is the second fence): the run returns, however wrong */
+	for (float bad : { 0.0f, -c.t_center, 1e-30f, NAN, -INFINITY }) {
+		float q = J.lo;
+		const int k = clock_jump_run(q, bad, thr, c.step_fmax, c.step_inv, J);
+		if (k < 0 && !(bad != bad)) return false;
+	}
 	const float f_min = c.t_center - c.t_maxdev, f_max = c.t_center + c.t_maxdev;
 	for (int a = 0; a < 6; a++) {
 		float f = a == 0 ? f_min : (a == 1 ? f_max : f_min + (f_max - f_min) * (float)r.uni());

@@ -70,6 +70,9 @@ mdemod_destroy(mdemod_ctx *c)
 	free(c->n_samples); free(c->n_symbols); free(c->this_call); free(c);
 }
 
+int mdemod_pin_host_buffer(mdemod_ctx *c, const void *base, size_t bytes) { return (c && base && bytes) ? MDEMOD_OK : MDEMOD_ERR_PARAM; }
+int mdemod_unpin_host_buffer(mdemod_ctx *c, const void *base) { return (c && base) ? MDEMOD_OK : MDEMOD_ERR_PARAM; }
+
 uint64_t mdemod_max_symbols(const mdemod_ctx *ctx, uint64_t n_samples) { (void)ctx; return n_samples + 8; }
 
 /* symbols of samples [first, first + n) of a stream whose bytes start at iq: sample j (absolute) makes one iff j % STUB_DECIM == 0 */

@@ -27,7 +27,7 @@ def _bench(*args, timeout=900):
 @pytest.mark.parametrize("config", ["c1", "c3"])
 def test_bench_two_ranks_oversubscribed_on_one_gpu(gpu_device, config):
     T, L = 4096, 4160
-    r, lines = _bench("--gpus", "2", "--oversubscribe", "--config", config, "--tiles", str(T), "--tile-samples", str(L), "--steps", "2", "--warmup", "1", "--fanin")
+    r, lines = _bench("--gpus", "2", "--oversubscribe", "--config", config, "--tiles", str(T), "--tile-samples", str(L), "--steps", "2", "--warmup", "1")       # (no --fanin: the gather on rank 0 is the default at N > 1 since round 5)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, r.stdout                                  # rank 0 prints ONE line, the other rank nothing
     d = json.loads(lines[0])
@@ -37,8 +37,15 @@ def test_bench_two_ranks_oversubscribed_on_one_gpu(gpu_device, config):
     assert "every rank" in d["check"] and "byte-identical" in d["check"], d["check"]
     per_rank = d["roofline"]["kernel_ms_over_ranks"]
     assert 0 < per_rank["min"] <= per_rank["max"] == d["roofline"]["kernel_ms"]
-    assert d["fanin"]["rows_of_rank0_intact_and_all_counts_there"] is True and d["fanin"]["bytes_over_xgmi"] > 0
+    assert d["fanin"]["rows_intact"] is True and d["fanin"]["bytes_over_xgmi"] > 0 and d["fanin"]["ms"] > 0 and d["fanin"]["gbytes_per_s"] > 0
     assert "DRY RUN" in d["oversubscribed"]
+
+
+def test_bench_two_ranks_no_fanin_flag(gpu_device):
+    r, lines = _bench("--gpus", "2", "--oversubscribe", "--tiles", "4096", "--tile-samples", "4160", "--steps", "1", "--warmup", "0", "--no-fanin", "--no-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert "fanin" not in d and d["n_gpus"] == 2
 
 
 def test_bench_refuses_more_gpus_than_the_node_has(gpu_device):

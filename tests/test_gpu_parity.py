@@ -457,6 +457,47 @@ def test_host_buffer_path_pipelined_sub_blocks(gpu_device):
                 assert ev1[i] == e1[:32] and len(e1) >= 1
 
 
+@pytest.mark.parametrize("fmt", [16, 8, 32])
+def test_host_buffer_path_from_pinned_rows(fmt, gpu_device):
+    """mdemod_pin_host_buffer: a batch inside a pinned range, rows of equal length one stride apart, goes to the GPU straight from
+    the caller's pages (one 2-D copy per sub-block, csrc/host_pipe.cpp) - the bytes are those of the staged path and of the oracle;
+    ragged or scattered batches in the same context fall back to the staged path; chained calls stay exact across both."""
+    import ctypes as C
+    from meteor_demod_amd import _capi
+    cfg = DemodConfig(samplerate=230000, bps=fmt)
+    ns, n, pad = 80, 700_000 if fmt != 32 else 350_000, 24         # > 32 MiB of input per call: several sub-blocks; rows `pad` samples apart
+    kw = dict(rms=60.0, dc=(3.0, -2.0)) if fmt == 8 else (dict(rms=0.4, dc=(0.01, -0.02)) if fmt == 32 else {})
+    streams = [synth.make_stream(9100 + i, 230000, 72000, f0_hz=(i % 5) * 50.0, esn0_db=15.0, fmt=fmt, **kw) for i in range(4)]
+    base = [synth.generate_host(s, n + 40_000) for s in streams]
+    big = np.zeros((ns, n + pad, 2), dtype=base[0].dtype)          # ONE allocation: what a host reading a batch into one buffer has
+    for i in range(ns):
+        big[i, :n] = base[i % 4][:n]
+    with Demodulator(cfg, ns) as d, Demodulator(cfg, ns) as ref:
+        d.pin_host(big)
+        with pytest.raises(_capi.MdemodError):
+            d.pin_host(big[3:5])                                     # overlaps a pinned range
+        outs = d.process_host([big[i, :n] for i in range(ns)])     # uniform rows inside the pin: the direct path
+        want = ref.process_host([base[i % 4][:n].copy() for i in range(ns)])     # scattered copies: the staged path
+        for i in range(ns):
+            assert np.array_equal(outs[i], want[i]), i
+        for i in range(4):
+            assert np.array_equal(outs[i], O.oracle_demod(cfg, base[i][:n])[0]), i
+        # second call, ragged this time (staged although inside the pin), chained on the first: still the oracle's bytes
+        lens = [30_000 - 500 * (i % 9) for i in range(ns)]
+        tail = np.zeros((ns, 40_000, 2), dtype=base[0].dtype)
+        for i in range(ns):
+            tail[i] = base[i % 4][n:]
+        outs2 = d.process_host([tail[i, : lens[i]] for i in range(ns)])
+        for i in range(0, ns, 7):
+            ost = O.OracleStream(cfg)
+            ost.run(base[i % 4][:n])
+            assert np.array_equal(outs2[i], ost.run(base[i % 4][n: n + lens[i]])[0]), i
+        d.unpin_host(big)
+        with pytest.raises(_capi.MdemodError):
+            d.unpin_host(big)                                        # not pinned any more
+        d.pin_host(big)                                              # and again: destroy unpins what is left
+
+
 def test_more_symbols_than_the_nominal_rate(gpu_device):
     """While the symbol clock drains a large phase excursion (full-scale burst after silence, wide loop) it fires on
     every sample: more symbols than samples * symrate / samplerate.  mdemod_max_symbols is the hard bound (one per

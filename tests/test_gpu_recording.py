@@ -309,9 +309,22 @@ def test_bank_primitives_of_the_stitcher(gpu_device):
         for i in range(5):
             m1 = int(a.symbol_counts()[i])
             assert torch.equal(packed[i, :m1], sa[i, :m1])
-        tf = torch.tensor([0.39, 0.3934, 0.3933, 0.4, 0.393], dtype=torch.float32, device="cuda")
+        # clock seeds: words the reference's loop can hold (timing.c:80-86: centre +- centre / 4096) pass as they are; anything else -
+        # zero, negative, tiny, huge: the words that would spin the closed-form clock's stepping loop - is clamped to that
+        # range on the device, and NaN stays NaN (it ends every loop by itself)
+        centre = np.float32(0.393382043)
+        lo, hi = np.float64(centre) * (1 - 1 / 4096) * (1 - 1e-6), np.float64(centre) * (1 + 1 / 4096) * (1 + 2e-6)
+        tf = torch.tensor([0.39, 0.3934, 0.3933, 0.4, 0.0], dtype=torch.float32, device="cuda")
         a.set_clock_seeds(tf)
-        assert [np.float32(s.t_freq) for s in a.get_states()] == [np.float32(v) for v in tf.cpu().tolist()]
+        got = [np.float32(s.t_freq) for s in a.get_states()]
+        assert got[1] == np.float32(0.3934) and got[2] == np.float32(0.3933)
+        assert all(lo <= np.float64(g) <= hi for g in got), got
+        assert got[0] == got[4] == min(got) and got[3] == max(got)
+        a.set_clock_seeds(torch.tensor([-1.0, 1e-30, float("inf"), float("nan"), 0.3934], dtype=torch.float32, device="cuda"))
+        got = [np.float32(s.t_freq) for s in a.get_states()]
+        assert np.isnan(got[3]) and all(lo <= np.float64(g) <= hi for g in got[:3] + got[4:]), got
+        a.process(x[:, :3000].contiguous())                  # and a launch on such seeds ends
+        torch.cuda.synchronize()
         with pytest.raises(ValueError):
             a.process(x.to(torch.float32))                   # wrong dtype for bps=16: refused before any pointer is used
         with pytest.raises(ValueError):
