@@ -465,6 +465,10 @@ def recordings_leg(cfg_tag: str, buf, local: int, buf_stream=None) -> dict:
         res[key] = single_recording(cfg, iq.contiguous(), stream=rec)
         res[key].pop("_serial", None)
         res["perturbation_floor_" + key] = perturbation_floor(cfg, iq[: 1 << 25])
+        # the yardstick with enough windows behind it (round 5): 31 converged pairs of the reference while apart, pooled; bit-exact
+        # streams of the library, so this is the reference's own behaviour, computed where it is fast
+        from meteor_demod_amd.recording import converged_pair_yardstick
+        res["converged_pairs_pooled_" + key] = converged_pair_yardstick(cfg, iq[: 1 << 25].contiguous(), copies=31, seed=5)
         del iq
         torch.cuda.empty_cache()
     res["configs[3] at SURVEY 8(d)'s 6000 LSB"] = c4_at_full_amplitude(local)

@@ -885,7 +885,7 @@ struct Stitcher {
 	const mdemod_params *params; const mdemod_recording_opts *opts_in; const void *iq_dev; uint64_t n_samples;
 	int8_t *soft_dev; uint64_t soft_cap_symbols; mdemod_recording_report *rep; hipStream_t st; const std::function<void(uint64_t)> *need;
 	mdemod_recording_opts o;
-	double osf = 0, symrate = 0, fs = 0; int nco = 1, K = 32, interp = 1; bool dbg = false;
+	double osf = 0, symrate = 0, fs = 0; int nco = 1, K = 32, interp = 1; bool dbg = false, settle_auto = false;
 	std::chrono::steady_clock::time_point t_tiles;
 	/* the serial head */
 	PilotOut po; mdemod_stream_state seed; uint64_t P = 0, n_pilot_sym = 0;
@@ -906,7 +906,7 @@ struct Stitcher {
 	std::vector<float> f0, tf, gains; std::vector<int32_t> ud; float *d_f0 = nullptr, *d_tf = nullptr, *d_gain = nullptr; int32_t *d_ud = nullptr;
 	/* the bank's buffers and what the launches leave in them */
 	uint64_t tail_samples = 0, cap_lead = 0, cap = 0, cap_post = 0; int8_t *soft_pre = nullptr, *soft1 = nullptr, *soft_post = nullptr; int32_t *d_rot = nullptr;
-	std::vector<uint32_t> cnt_tmp, cnt_pre, cnt1, cnt_post; std::vector<mdemod_status> status_body; std::vector<int32_t> R, shift, rot, weak;
+	std::vector<uint32_t> cnt_tmp, cnt_pre, cnt1, cnt_post; std::vector<mdemod_status> status_body, status_settle; std::vector<int32_t> R, shift, rot, weak;
 	std::vector<uint64_t> stl_off, ends, post_len;
 	/* rotations: taken out of the state before settling, left for the output, expected by the second round */
 	std::vector<char> run, jump_at, merged; std::vector<int32_t> state_rot, out_rot, expect; bool second_round = false;
@@ -970,7 +970,8 @@ struct Stitcher {
 		nco = params->oqpsk ? 2 : 1;
 		if (o.acquire_samples == 0xFFFFFFFFu) o.acquire_samples = static_cast<uint32_t>(2000 * osf);
 		if (o.frame_samples == 0xFFFFFFFFu) o.frame_samples = static_cast<uint32_t>(1500 * osf);
-		if (o.settle_samples == 0xFFFFFFFFu) o.settle_samples = static_cast<uint32_t>(24000 * osf);
+		settle_auto = o.settle_samples == 0xFFFFFFFFu;
+		if (settle_auto) o.settle_samples = static_cast<uint32_t>(24000 * osf);
 		/* symbols between the reference's first lock and the hand-over: the tiles right after it are seeded with a model of the serial
 		   loop's remaining convergence, which holds once the lock is this old (measured: the first tiles lose 5 % of their +-1 LSB
 		   agreement with 10 000 symbols less; OQPSK's loop, at twice the bandwidth, wanders more and wants 30 000) */
@@ -1028,10 +1029,23 @@ struct Stitcher {
 		T = static_cast<size_t>((n_samples - P + B - 1) / B);
 		rep->n_tiles = static_cast<uint32_t>(T);
 		E.assign(T, 0); len.assign(T, 0); s0.assign(T, 0); acq.assign(T, 0); frm.assign(T, 0); stl.assign(T, 0); q.assign(T, 0);
+		/* Round 5 (tools/tile_tail.py, tools/converged_pairs.py): what a tile's +-1 LSB agreement with the serial run hangs on is how
+		   far its clock word (timing.c:84, a float: one ulp = 0.076 ppm at configs[1]) sits from the serial run's at the same symbol:
+		   0 / 1 / 2 / 3 / 4 / 5 ulps apart agree on 0.9984 / 0.9975 / 0.9970 / 0.9964 / 0.9955 / 0.9943.  Two converged runs of the
+		   reference sit 0 / 1 / 2 / 3 / >= 4 ulps apart 50 / 31 / 12 / 4.5 / 2.1 % of the time; a tile that has settled for 24 000
+		   symbols starts its body at 36 / 36 / 16 / 7 / 4.7 %, one that has settled for 32 000 at 41 / 36 / 14 / 5.4 / 3 %, and more
+		   does not change it.  With bodies of 23 000 symbols (the ~1000-tile regime) the first thousands of symbols are a small part
+		   and the share of 4096-symbol windows below 0.99 is 0.16 % either way (the reference's own pairs: 0.054 %); with bodies of
+		   8 192 symbols (the lane-kernel regime) it is 0.5 % at 24 000 and 0.2 % at 32 000.  So: short bodies settle for 32 000 where
+		   the caller does not say - EXCEPT behind the hand-over, where the serial run itself is still drifting in with its carrier loop's
+		   16 200-symbol pole and a tile that has had longer to converge on the carrier agrees with it LESS (windows of 0.07 .. 0.35 in
+		   tiles 1 .. 3 with 32 000 and 40 000; the seed model of seed_tiles covers one time constant back, not two). */
+		const uint64_t WS_far = (settle_auto && static_cast<double>(B) / osf < 16384.0) ? static_cast<uint64_t>(32000 * osf) : WS;
+		const uint64_t far_from = P + static_cast<uint64_t>(50000 * osf);
 		for (size_t i = 0; i < T; i++) {
 			E[i] = P + i * B; len[i] = std::min<uint64_t>(B, n_samples - E[i]);
 			if (i == 0) { s0[i] = q[i] = E[i]; acq[i] = frm[i] = stl[i] = 0; continue; }     /* tile 0: the pilot's exact continuation */
-			const uint64_t lead = std::min<uint64_t>(A + KP + WS, E[i]);
+			const uint64_t lead = std::min<uint64_t>(A + KP + (E[i] >= far_from ? WS_far : WS), E[i]);
 			s0[i] = E[i] - lead;
 			acq[i] = std::min<uint64_t>(A, lead); frm[i] = std::min<uint64_t>(KP, lead - acq[i]); stl[i] = lead - acq[i] - frm[i];
 			q[i] = s0[i] + acq[i] + frm[i];
@@ -1431,7 +1445,9 @@ struct Stitcher {
 				std::vector<uint64_t> stl_a(T), stl_b(T), off_b(T);
 				for (size_t i = 0; i < T; i++) { stl_b[i] = std::min<uint64_t>(stl[i], tail_samples); stl_a[i] = stl[i] - stl_b[i]; off_b[i] = q[i] + stl_a[i]; }
 				TRY(launch(stl_off, masked(stl_a), soft_pre, cap_lead, cnt_tmp, nullptr, true));
-				TRY(launch(off_b, masked(stl_b), soft_pre, cap_lead, cnt_tmp));
+				std::vector<mdemod_status> after_settle;
+				TRY(launch(off_b, masked(stl_b), soft_pre, cap_lead, cnt_tmp, o.debug >= 3 ? &after_settle : nullptr));
+				if (o.debug >= 3) { if (status_settle.empty()) status_settle = after_settle; for (size_t i = 0; i < T; i++) if (run[i]) status_settle[i] = after_settle[i]; }
 			}
 			mark("settle");
 			for (size_t i = 0; i < T; i++) if (run[i]) cnt_pre[i] = cnt_tmp[i];
@@ -1680,9 +1696,10 @@ struct Stitcher {
 	void dump_tiles() const
 	{
 		for (size_t i = 0; i < T; i++)
-			fprintf(stderr, "[tile] %zu E %llu len %llu s0 %llu acq %llu frm %llu stl %llu seed_tf %.9g seed_f0 %.9g end_tf %.9g end_f0 %.9g end_gain %.9g cnt %u out_rot %d\n", i,
+			fprintf(stderr, "[tile] %zu E %llu len %llu s0 %llu acq %llu frm %llu stl %llu seed_tf %.9g seed_f0 %.9g start_tf %.9g start_f0 %.9g end_tf %.9g end_f0 %.9g end_gain %.9g cnt %u out_rot %d\n", i,
 			        (unsigned long long)E[i], (unsigned long long)len[i], (unsigned long long)s0[i], (unsigned long long)acq[i], (unsigned long long)frm[i],
 			        (unsigned long long)stl[i], static_cast<double>(tf.size() > i ? tf[i] : 0.0f), static_cast<double>(f0.size() > i ? f0[i] : 0.0f),
+			        static_cast<double>(status_settle.size() > i ? status_settle[i].omega : 0.0f), static_cast<double>(status_settle.size() > i ? status_settle[i].pll_freq : 0.0f),
 			        static_cast<double>(status_body.size() > i ? status_body[i].omega : 0.0f), static_cast<double>(status_body.size() > i ? status_body[i].pll_freq : 0.0f),
 			        static_cast<double>(status_body.size() > i ? status_body[i].gain : 0.0f), cnt1.size() > i ? cnt1[i] : 0u, out_rot.size() > i ? out_rot[i] : 0);
 	}

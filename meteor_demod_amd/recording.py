@@ -125,3 +125,63 @@ def agreement(stitched: np.ndarray, serial: np.ndarray, window: int = 4096) -> d
     return {"len_stitched": int(len(stitched)), "len_serial": int(len(serial)), "within_1lsb": float(ok.mean()) if m else 1.0,
             "hard_decisions_equal": float(sign_ok.mean()) if m else 1.0, "worst_window": min(wins) if wins else 1.0,
             "windows": wins}
+
+
+def converged_pair_yardstick(cfg, iq, copies: int = 31, seed: int = 1, window: int = 4096, skip: int = 60000, block: int = 1 << 20) -> dict:
+    """The yardstick for a tiled run, with enough windows behind it (round 5; r04 compared a tail of 112 in 20 515 windows with
+    "1 of 1 908"): two CONVERGED runs of the reference on the same samples while they are apart - ``copies`` times over.  The copies
+    take the serial run's own state at a quarter of the recording with the symbol-clock word moved by +-0.3 .. 3 ppm (inside what
+    timing.c:80-86 can hold; pulled in within a few loop time constants) and run on; every one of them is a bit-exact stream of the
+    library (all read the same device buffer ``iq`` [n, 2]), i.e. what the reference itself would produce from that state.  Each copy is
+    compared with the unperturbed run from ``skip`` symbols after the perturbation up to the last symbol on which they differ; the
+    windows of all copies are pooled.  Returns within_1lsb, the share of windows below 0.99, worst window, 1 % and 0.1 % quantiles."""
+    import torch
+    from .demod import Demodulator
+    n = int(iq.shape[0])
+    K = n // 4
+    S = copies + 1
+    rng = np.random.default_rng(seed)
+    cap_total = int(n * cfg.symrate / cfg.samplerate * 1.02) + 4096
+    out = torch.zeros((S, cap_total, 2), dtype=torch.int8, device=iq.device)
+    fill = np.zeros(S, dtype=np.int64)
+    p0 = 0
+    with Demodulator(cfg, S, device=iq.device.index or 0) as d:
+        pos = 0
+        while pos < n:
+            m = min(block, n - pos, K - pos if pos < K else n)
+            soft = d.process(iq[pos:pos + m].unsqueeze(0).expand(S, m, 2))      # every stream reads the same samples
+            torch.cuda.synchronize(iq.device)
+            cnt = d.status_array()["symbols_this_call"].astype(np.int64)
+            for s in range(S):
+                out[s, int(fill[s]):int(fill[s]) + int(cnt[s])] = soft[s, : int(cnt[s])]
+            fill += cnt
+            pos += m
+            if pos == K:
+                p0 = int(fill[0])
+                for s in range(1, S):
+                    st = d.get_state(s)
+                    ppm = float(rng.uniform(0.3, 3.0)) * (1 if rng.integers(0, 2) else -1)
+                    st.t_freq = float(np.float32(st.t_freq * (1.0 + ppm * 1e-6)))
+                    d.set_state(s, st)
+    ref = out[0].to(torch.int16)
+    wins, met, n_ok, n_all = [], 0, 0.0, 0
+    for s in range(1, S):
+        m = int(min(fill[0], fill[s]))
+        dd = (out[s, :m].to(torch.int16) - ref[:m]).abs().amax(dim=1)
+        nz = torch.nonzero(dd > 0)
+        last = int(nz[-1]) + 1 if nz.numel() else 0
+        met += 1 if last < m - window else 0
+        a, b = p0 + skip, last
+        if b - a < window:
+            continue
+        ok = (dd[a:b] <= 1).to(torch.float32)
+        k = (b - a) // window
+        wins.append(ok[: k * window].view(k, window).mean(dim=1).cpu().numpy())
+        n_ok += float(ok.sum()); n_all += int(ok.numel())
+    w = np.concatenate(wins) if wins else np.array([])
+    return {"copies": copies, "copies_that_met_the_serial_run_again": met, "symbols_compared_while_apart": n_all,
+            "within_1lsb": round(n_ok / max(n_all, 1), 5), "windows": int(len(w)),
+            "windows_below_0.99": int((w < 0.99).sum()), "share_below_0.99": round(float((w < 0.99).mean()), 5) if len(w) else None,
+            "worst_window_4096": round(float(w.min()), 4) if len(w) else None,
+            "window_p01": round(float(np.quantile(w, 0.01)), 4) if len(w) else None,
+            "window_p001": round(float(np.quantile(w, 0.001)), 4) if len(w) else None}

@@ -123,16 +123,22 @@ def test_worst_window_and_tile_starts_against_the_floor(cfg, n, rms, bar, gpu_de
     pos = ((idx / sps - rep.pilot_samples) % rep.tile_samples) * sps
     tiled = idx >= int(rep.exact_symbols)
     head, rest = float(ok[tiled & (pos < 4096)].mean()), float(ok[tiled & (pos >= 4096)].mean())
-    fl = _converged_pair(cfg, iq.cpu().numpy()[: n // 2])
-    assert len(fl) > 100_000, len(fl)
-    wins, fwins = _windows(ok[tiled]), _windows(fl)
+    # the yardstick, pooled over 31 converged pairs of the reference on the first half of this recording (bit-exact streams of the
+    # library: recording.converged_pair_yardstick; r04 took ONE pair on the CPU - 1 of 1 908 windows below 0.99 says little)
+    from meteor_demod_amd.recording import converged_pair_yardstick
+    y = converged_pair_yardstick(cfg, iq[: n // 2].contiguous(), copies=31, seed=7)
+    assert y["windows"] > 5000, y
+    wins = _windows(ok[tiled])
     got = dict(within=float(ok[tiled].mean()), p01=float(np.quantile(wins, 0.01)), low=float((wins < 0.99).mean()), worst=float(wins.min()))
-    floor = dict(within=float(fl.mean()), p01=float(np.quantile(fwins, 0.01)), low=float((fwins < 0.99).mean()), worst=float(fwins.min()))
+    floor = dict(within=y["within_1lsb"], p01=y["window_p01"], low=y["share_below_0.99"], worst=y["worst_window_4096"])
     assert a["within_1lsb"] >= bar, (a, floor)
-    assert got["within"] >= floor["within"] - 0.0012, (got, floor)
-    assert got["p01"] >= floor["p01"] - 0.006, (got, floor)
-    assert got["low"] <= 3.0 * floor["low"] + 0.01, (got, floor)
-    assert got["worst"] >= floor["worst"] - 0.03, (got, floor)
+    assert got["within"] >= floor["within"] - 0.0008, (got, floor)
+    assert got["p01"] >= floor["p01"] - 0.002, (got, floor)
+    # VERDICT r04's bars.  (Measured r05, tools/tile_tail.py: a tile's windows fall below 0.99 where its clock word sits >= 4 ulps from the
+    # serial run's; tiles are there 3 % of the time, converged pairs 2.1 % - the tail is 0.2 % against the pairs' 0.054 % on configs[1],
+    # equal on configs[2], and no settling length changes that.  The worst window is a minimum: the yardstick's is over 10x as many.)
+    assert got["low"] <= 2.0 * floor["low"] + 0.002, (got, floor)
+    assert got["worst"] >= floor["worst"] - 0.01, (got, floor)
     assert head >= rest - 0.002, (head, rest)
 
 
@@ -399,8 +405,8 @@ def test_rotation_jump_cases_of_round_one(args, gpu_device):
     assert r.returncode == 0 and "failures 0" in r.stdout and "rotation jump 0" in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("args", ["150 9404 51", "150 9304 142"], ids=["oqpsk-u8-255552", "oqpsk-f32-1136000"])
-def test_tiles_the_repair_does_not_cure_are_handed_to_their_predecessors(args, gpu_device):
+@pytest.mark.parametrize("args,settle", [("150 9404 51", "76665"), ("150 9304 142", "")], ids=["oqpsk-u8-255552", "oqpsk-f32-1136000"])
+def test_tiles_the_repair_does_not_cure_are_handed_to_their_predecessors(args, settle, gpu_device):
     """The two OQPSK soak recordings of round 2 (of 260) on which a tile came out a quarter turn off AGAIN, the other way round,
     after its re-run from the checkpoint (it slips on its way in one run and not in the other): one symbol too many, the rest
     of the recording misaligned.  Such a tile's samples are now demodulated by its predecessor's stream, run again from the
@@ -410,7 +416,11 @@ def test_tiles_the_repair_does_not_cure_are_handed_to_their_predecessors(args, g
     import sys
     from conftest import ROOT
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "recording_fuzz.py"), *args.split()], capture_output=True, text=True,
-                       cwd=str(ROOT), timeout=600, env=dict(os.environ, FUZZ_ONLY_OQPSK="1", MDEMOD_RECORDING_DEBUG="1"))
+                       cwd=str(ROOT), timeout=600, env=dict(os.environ, FUZZ_ONLY_OQPSK="1", MDEMOD_RECORDING_DEBUG="1",
+                                                            # (the first case's tiles are 15 600 symbols: since round 5 such tiles settle for 32 000
+                                                            #  symbols by default and the slip that exercises this path is gone - the case is
+                                                            #  replayed with the 24 000 it was found with)
+                                                            **({"FUZZ_SETTLE": settle} if settle else {})))
     assert r.returncode == 0 and "failures 0" in r.stdout and "rotation jump 0" in r.stdout, r.stdout[-2000:]
     assert "'hard_decisions_equal': 1.0" in r.stdout and "handed to their predecessors" in r.stderr, (r.stdout[-1500:], r.stderr[-500:])
 
@@ -639,8 +649,12 @@ def test_recording_follows_the_doppler_on_the_symbol_clock(cfg, bar, gpu_device)
     out, serial, rep, a = _run(cfg, iq)
     assert rep.weak_clock_tiles == 0 and rep.weak_seams == 0 and rep.rotation_jumps == 0
     assert a["len_stitched"] == a["len_serial"] and a["hard_decisions_equal"] > 0.9999 and a["within_1lsb"] > bar, a
-    out1, _, rep1, a1 = _run(cfg, iq, clock_seed="pilot")
-    assert a1["len_stitched"] == a1["len_serial"] and a1["within_1lsb"] < a["within_1lsb"] - 0.0005, (a, a1)
+    # what the per-tile clock seed buys, at equal settling (24 000 symbols for both: since round 5 tiles as short as these settle for
+    # 32 000 by default, and the pilot-seeded ones use the extra third to catch up)
+    stl = int(24000 * cfg.samplerate / cfg.symrate)
+    _, _, _, a0 = _run(cfg, iq, settle_samples=stl)
+    out1, _, rep1, a1 = _run(cfg, iq, clock_seed="pilot", settle_samples=stl)
+    assert a1["len_stitched"] == a1["len_serial"] and a1["within_1lsb"] < a0["within_1lsb"] - 0.0005, (a0, a1)
 
 
 def test_false_locks_of_the_reference(gpu_device):
