@@ -316,7 +316,7 @@ def host_cpu_facts() -> dict:
 
 
 def single_recording(cfg, iq, check: bool = True, serial=None, label_unchecked: bool = False, stream=None) -> dict:
-    """The north star's overlapped tiling of ONE recording: end-to-end latency of
+    """The north star's overlapped tiling of ONE recording (NOTEBOOK.md 3.1): end-to-end latency of
     mdemod_demodulate_recording on the device tensor `iq` [n, 2] and, with `check`, agreement with the untiled serial
     oracle (symbol count, hard decisions, +-1 LSB, the exact prefix byte for byte).  Part of the CPU leg when checked."""
     sys.path.insert(0, str(ROOT / "tests"))
@@ -378,7 +378,7 @@ def single_recording(cfg, iq, check: bool = True, serial=None, label_unchecked: 
                     "exact_prefix_symbols": ex, "exact_prefix_bytes_equal": bool((got[:ex] == serial[:ex]).all()),
                     "within_1lsb": round(a["within_1lsb"], 5), "hard_decisions_equal": round(a["hard_decisions_equal"], 6),
                     "worst_window_4096": round(a["worst_window"], 4),
-                    **{k: v for k, v in _window_stats(ok).items() if k in ("windows_below_0.99", "windows", "window_p01")},
+                    **{k: v for k, v in _window_stats(ok).items() if k in ("windows_below_0.99", "windows", "share_below_0.99", "window_p01")},
                     "within_1lsb_first_4096_of_a_tile_body": round(float(head.mean()), 5) if len(head) else None,
                     "within_1lsb_rest_of_the_tile_bodies": round(float(rest.mean()), 5) if len(rest) else None})
         if t_cpu is not None:
@@ -393,7 +393,7 @@ def _window_stats(ok, W: int = 4096) -> dict:
     import numpy as np
     wins = np.array([float(ok[i:i + W].mean()) for i in range(0, len(ok) - W + 1, W)]) if len(ok) >= W else np.array([])
     return {"within_1lsb": round(float(ok.mean()), 5) if len(ok) else None, "worst_window_4096": round(float(wins.min()), 4) if len(wins) else None,
-            "windows_below_0.99": int((wins < 0.99).sum()), "windows": int(len(wins)),
+            "windows_below_0.99": int((wins < 0.99).sum()), "windows": int(len(wins)), "share_below_0.99": round(float((wins < 0.99).mean()), 5) if len(wins) else None,
             "window_p01": round(float(np.quantile(wins, 0.01)), 4) if len(wins) else None, "symbols_compared": int(len(ok))}
 
 

@@ -14,7 +14,7 @@
  * demodulated as one batch, one stream per file (outputs <input>.s); --tiled demodulates
  * ONE file on many GPU lanes as overlapped tiles (mdemod_demodulate_recording_host: the head
  * up to PLL lock + settling is the reference's own serial run, the rest agrees with it
- * statistically).  --devices a,b,... (default: every GPU of the node when there is more than one file) starts
+ * statistically, NOTEBOOK.md 3.1).  --devices a,b,... (default: every GPU of the node when there is more than one file) starts
  * one worker thread and one library context per GPU: file i goes to GPU i mod G, each worker demodulates its files as its own
  * batch (exact mode) or one after the other (--tiled) and writes its own outputs - no data crosses GPUs.
  *

@@ -253,7 +253,7 @@ int  mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs,
 
 /* ---- overlapped tiles of ONE recording ------------------------------------ */
 
-/* ONE recording on many lanes.  The reference runs a recording as one serial recurrence (main.c:303-316);
+/* ONE recording on many lanes (NOTEBOOK.md 3.1).  The reference runs a recording as one serial recurrence (main.c:303-316);
  * here only its head runs serially (the "pilot": from the reference's power-on state until the carrier loop has locked and
  * settled - those symbols ARE the reference's symbols, lock gate included), the rest as tiles, one lane each:
  *   estimates the carrier (4th-power spectrum, de-chirped) and the symbol clock (symbol-rate line) along the whole recording, on

@@ -33,7 +33,7 @@ __device__ __forceinline__ bool md_all(bool p) { return __builtin_amdgcn_ballot_
  * every finite and infinite x including +-0 (the median of {-b, x, b} is x itself whenever -b <= x <= b, else the bound the
  * macros pick).  A NaN would come out as -b where the macros keep it - but no NaN reaches these points in a run the reference
  * defines: a non-finite sample sends the reference's own tanh look-up out of bounds one symbol later (pll.c:154-159, see
- * md_tanh_lut), and the coefficient tables with a NaN tap are refused (DESIGN.md 8). */
+ * md_tanh_lut), and the coefficient tables with a NaN tap are refused (DESIGN.md 2). */
 __device__ __forceinline__ float md_clamp_sym(float x, float b) { return __builtin_amdgcn_fmed3f(x, -b, b); }
 
 /* sincos.c:24: x = fx * 0x10000 / (2*M_PI) narrowed to int16.  float*int -> float, the

@@ -140,7 +140,7 @@ def fir(nw, fmt):
                 L += [load(g + 2), load(g + 3), "s_waitcnt lgkmcnt(2)"]
             L += group(p, g)
             # the ring is LEFT at the granularity EXIT (slots): every instruction of loop control costs an issue slot of a wave that
-            # has only one other wave to hide behind, so the finest exit is not the fastest (measured on configs[3]: DESIGN.md 5.0)
+            # has only one other wave to hide behind, so the finest exit is not the fastest (measured on configs[3]: NOTEBOOK.md 5.0)
             if g == 3:
                 L += ["v_add_u32 %[addr], 64, %[addr]"] + test        # the chunk's base moves on
             elif EXIT == 4 or (EXIT == 8 and g == 1):

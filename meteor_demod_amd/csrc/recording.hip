@@ -2,7 +2,7 @@
  * recording.hip — ONE recording demodulated on many lanes as overlapped tiles.
  *
  * The reference runs a recording as one serial recurrence (main.c:303-316); see
- * DESIGN.md §3.1 for why tiles cannot equal it bit for bit (a 1-LSB change of one
+ * NOTEBOOK.md §3.1 for why tiles cannot equal it bit for bit (a 1-LSB change of one
  * input sample leaves 0.2 % of the reference's own symbols more than 1 LSB away,
  * for ever) and what is done instead:
  *
@@ -195,7 +195,7 @@ match_heads_kernel(const TailPair *pairs, int K, int32_t *shift_out, int32_t *ro
 	}
 }
 
-/* ---- per-tile carrier estimate (Doppler): z^4 of the samples has a line at 4x the carrier offset -------- */
+/* ---- per-tile carrier estimate (NOTEBOOK.md 3.1, Doppler): z^4 of the samples has a line at 4x the carrier offset -------- */
 
 template <int FMT> struct RawIQ;
 template <> struct RawIQ<16> { typedef int16_t t; __device__ static float2 get(const void *p, uint64_t i) { uint32_t w; __builtin_memcpy(&w, static_cast<const int16_t *>(p) + 2 * i, 4); return make_float2((float)(int16_t)(w & 0xFFFFu), (float)((int32_t)w >> 16)); } };   /* one load per pair */
@@ -877,7 +877,7 @@ run_pilot(const mdemod_params *params, const mdemod_recording_opts &o, const voi
 	return MDEMOD_OK;
 }
 
-/* The entry proper: one object per call, one method per stage of DESIGN.md 3.1 (they used to be one 635-line function).  `need(upto)`,
+/* The entry proper: one object per call, one method per stage of NOTEBOOK.md 3.1 (they used to be one 635-line function).  `need(upto)`,
  * when given, returns once samples [0, upto) of iq_dev are there: the host-buffer entry copies the recording in behind the serial
  * head. */
 struct Stitcher {

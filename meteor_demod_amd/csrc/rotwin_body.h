@@ -157,7 +157,7 @@ rotwin_demod(const DemodLaunch &L)
 #ifndef ROT_PRIO_LEVEL
 #define ROT_PRIO_LEVEL 2
 #endif
-	constexpr int PRIO = ROT_PRIO;               /* the scalar stage of a firing (and the symbol clock inside it) at raised wave priority, the FIR and the slide at 0 (+5 % on configs[1] when round 2 found it) */
+	constexpr int PRIO = ROT_PRIO;               /* the scalar stage of a firing (and the symbol clock inside it) at raised wave priority, the FIR and the slide at 0 (NOTEBOOK.md 5.0: +5 % on configs[1] when round 2 found it) */
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	float *ctab = reinterpret_cast<float *>(lds);
@@ -371,7 +371,7 @@ rotwin_demod(const DemodLaunch &L)
 			md_nco_advance<true>(pll.phase, pll.freq);
 
 			if (emit) {
-				/* demod.c:33-47: only the LAST symbol fired inside one input sample survives (found by fuzzing in round 2: DESIGN.md 5.0) */
+				/* demod.c:33-47: only the LAST symbol fired inside one input sample survives (found by fuzzing in round 2: NOTEBOOK.md 5.0) */
 				const bool again = (v_cur == ld_lastv());
 				st_lastv(v_cur);
 				if (__builtin_expect(md_any(again), 0)) { if (again) sym_call--; }

@@ -1,7 +1,7 @@
 """One long recording on many lanes (BASELINE north star: "the IQ stream tiled into overlapping
 blocks so each block runs the serial PLL/Gardner recurrences").
 
-The scheme lives in the library (``mdemod_demodulate_recording``, csrc/recording.hip):
+The scheme lives in the library (``mdemod_demodulate_recording``, csrc/recording.hip, NOTEBOOK.md 3.1):
 serial pilot -> per-tile carrier / gain seeds -> acquire -> integrators back on their seeds -> frame of
 every tile by dead reckoning of the NCO phase -> settle -> body -> seam check and repair.  This module is
 the ctypes wrapper around it plus the helper the tests and the bench use to compare a result with the

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): ONE recording on many lanes (mdemod_demodulate_recording, csrc/recording.hip).
+"""GPU (-m gpu): ONE recording on many lanes (mdemod_demodulate_recording, csrc/recording.hip, NOTEBOOK.md 3.1).
 
 The head of the result (pilot + tile 0) is the serial reference's own bytes; the rest can only agree with the UNTILED serial
 run statistically: a 1-LSB change of ONE input sample leaves 0.2 % of the reference's own symbols more than 1 LSB away for

@@ -1,7 +1,7 @@
 """Soak test of the overlapped-tile stitcher (mdemod_demodulate_recording, csrc/recording.hip): random sample rates,
 QPSK / OQPSK, input formats, carrier offsets, Doppler ramps, clock errors, tile sizes.  Every recording is demodulated
 natively with spectral carrier seeds and compared with the serial oracle.  A case counts only if the serial run's lock
-is genuine (its PLL frequency is on the synthetic carrier when the pilot hands over), otherwise there is
+is genuine (its PLL frequency is on the synthetic carrier when the pilot hands over, NOTEBOOK.md 3.1), otherwise there is
 no serial stream to compare with.  Usage: recording_fuzz.py [n_cases] [seed] [only_case]
 (FUZZ_TILE / FUZZ_SETTLE / FUZZ_SEEDMODE in the environment override a case's tile size / settling length / carrier_seed when one case is replayed)"""
 import os

@@ -1,5 +1,5 @@
 """Settle lengths BEYOND the default (24 000 symbols) against the serial oracle, configs[2] (OQPSK) and configs[1], two seeds: does more
-settling close the gap to the perturbation floor?  (It does not: DESIGN.md 3.1.)"""
+settling close the gap to the perturbation floor?  (It does not: NOTEBOOK.md 3.1.)"""
 import sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np, torch
