@@ -315,7 +315,7 @@ def host_cpu_facts() -> dict:
             "cpu_model": model}
 
 
-def single_recording(cfg, iq, check: bool = True, serial=None, label_unchecked: bool = False, stream=None) -> dict:
+def single_recording(cfg, iq, check: bool = True, serial=None, label_unchecked: bool = False, stream=None, twins_prefix: int = 0) -> dict:
     """The north star's overlapped tiling of ONE recording (NOTEBOOK.md 3.1): end-to-end latency of
     mdemod_demodulate_recording on the device tensor `iq` [n, 2] and, with `check`, agreement with the untiled serial
     oracle (symbol count, hard decisions, +-1 LSB, the exact prefix byte for byte).  Part of the CPU leg when checked."""
@@ -338,6 +338,12 @@ def single_recording(cfg, iq, check: bool = True, serial=None, label_unchecked: 
            "repaired_tiles": int(rep.repaired_tiles), "rotation_jumps": int(rep.rotation_jumps), "pilot_locked": int(rep.pilot_locked),
            "weak_carrier_tiles": int(rep.weak_carrier_tiles), "weak_clock_tiles": int(rep.weak_clock_tiles),
            "dead_reckoning_residual_rms_rad": round(float(rep.frame_residual_rms), 3)}
+    if twins_prefix:
+        # the yardstick that sees the same signal (round 5): 23 converged twins of the serial run - bit-exact streams of the library,
+        # perturbed at instants spread over the first `twins_prefix` samples - window by window next to the tiled output
+        from meteor_demod_amd.recording import tiled_vs_twins
+        out["vs_twins_same_windows"] = tiled_vs_twins(cfg, iq[: twins_prefix].contiguous(), soft, int(rep.exact_symbols), copies=23)
+        out["vs_twins_same_windows"]["samples"] = int(min(twins_prefix, n))
     if stream is not None:
         # EVERY symbol of the output against the symbols the generator transmitted (a device kernel regenerates them: milliseconds
         # for 2 G symbols, no serial run needed): a rotation jump or a cycle slip anywhere in the recording shows as a pairing change
@@ -462,13 +468,9 @@ def recordings_leg(cfg_tag: str, buf, local: int, buf_stream=None) -> dict:
             rec = synth.make_stream(2000, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0, rms=2000.0 if tag == "c4" else 6000.0)
             iq = synth.generate_device([rec], n, device=local)[0]
         key = workload.split(":")[0]
-        res[key] = single_recording(cfg, iq.contiguous(), stream=rec)
+        res[key] = single_recording(cfg, iq.contiguous(), stream=rec, twins_prefix=n)
         res[key].pop("_serial", None)
         res["perturbation_floor_" + key] = perturbation_floor(cfg, iq[: 1 << 25])
-        # the yardstick with enough windows behind it (round 5): 31 converged pairs of the reference while apart, pooled; bit-exact
-        # streams of the library, so this is the reference's own behaviour, computed where it is fast
-        from meteor_demod_amd.recording import converged_pair_yardstick
-        res["converged_pairs_pooled_" + key] = converged_pair_yardstick(cfg, iq[: 1 << 25].contiguous(), copies=31, seed=5)
         del iq
         torch.cuda.empty_cache()
     res["configs[3] at SURVEY 8(d)'s 6000 LSB"] = c4_at_full_amplitude(local)
@@ -476,7 +478,7 @@ def recordings_leg(cfg_tag: str, buf, local: int, buf_stream=None) -> dict:
         cfg, _ = demod_config("c1")
         serial28 = None
         if buf.shape[0] >= (1 << 28):
-            r = single_recording(cfg, buf[: 1 << 28], stream=buf_stream)
+            r = single_recording(cfg, buf[: 1 << 28], stream=buf_stream, twins_prefix=1 << 27)
             serial28 = r.pop("_serial", None)
             res["configs[1] 2^28 samples"] = r
         if buf.shape[0] > (1 << 28) and serial28 is not None:

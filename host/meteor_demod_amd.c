@@ -412,11 +412,12 @@ run_exact(struct worker *w)
 	uint32_t *n_out = malloc(sizeof(uint32_t) * (size_t)n_files);
 	mdemod_status *st = malloc(sizeof(*st) * (size_t)n_files);
 #define FREE_BLOCKS() do { free(in_buf); free(soft); free(iq); free(outp); free(n_in); free(caps); free(n_out); free(st); } while (0)
-	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) { FREE_BLOCKS(); mdemod_destroy(ctx); return exact_failed(w, 1, "meteor_demod_amd", "out of memory"); }
+	if (!in_buf || !soft || !iq || !outp || !n_in || !caps || !n_out || !st) { mdemod_destroy(ctx); FREE_BLOCKS(); return exact_failed(w, 1, "meteor_demod_amd", "out of memory"); }
 
 	/* the read buffer is the same for every block: pinned once, the batch then goes to the GPU from where fread put it
-	   (worth it from a few files on; a refusal - no memory to pin - only means the library stages the blocks itself) */
-	if (n_files >= 8 && block_buffers == BLOCK_BUFFERS) (void)mdemod_pin_host_buffer(ctx, in_buf, block_bytes * (size_t)n_files);
+	   (a batch of files; one file is a few MiB per call either way.  A refusal - no memory to pin - only means the library stages the
+	   blocks itself.  The context is destroyed, which unpins, BEFORE the buffer is freed on every way out.) */
+	if (n_files >= 2 && block_buffers == BLOCK_BUFFERS) (void)mdemod_pin_host_buffer(ctx, in_buf, block_bytes * (size_t)n_files);
 
 	double last_status = -1e18;
 #ifdef MDEMOD_TUI
@@ -439,9 +440,9 @@ run_exact(struct worker *w)
 		}
 		if (!active) break;
 		rc = mdemod_process_host(ctx, iq, n_in, outp, caps, n_out);          /* demod(&sample) x n: main.c:304 */
-		if (rc != MDEMOD_OK) { FREE_BLOCKS(); mdemod_destroy(ctx); return exact_failed(w, 2, "mdemod_process_host", mdemod_strerror(rc)); }
+		if (rc != MDEMOD_OK) { mdemod_destroy(ctx); FREE_BLOCKS(); return exact_failed(w, 2, "mdemod_process_host", mdemod_strerror(rc)); }
 		rc = mdemod_get_status(ctx, 0, (uint32_t)n_files, st, NULL);
-		if (rc != MDEMOD_OK) { FREE_BLOCKS(); mdemod_destroy(ctx); return exact_failed(w, 2, "mdemod_get_status", mdemod_strerror(rc)); }
+		if (rc != MDEMOD_OK) { mdemod_destroy(ctx); FREE_BLOCKS(); return exact_failed(w, 2, "mdemod_get_status", mdemod_strerror(rc)); }
 		for (int i = 0; i < n_files; i++)
 			write_gated(&io[i], outp[i], n_out[i], st[i].first_lock_symbol);
 #ifdef MDEMOD_TUI

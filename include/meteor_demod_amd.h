@@ -280,8 +280,8 @@ typedef struct {
 	                                   wave: latency kernel) while that fits, else as short as keeps them within 131 072 lanes */
 	uint32_t acquire_samples;       /* 0xFFFFFFFF = 2 000 symbols worth                                                  */
 	uint32_t frame_samples;         /* 0xFFFFFFFF = 1 500 symbols worth                                                  */
-	uint32_t settle_samples;        /* 0xFFFFFFFF = 24 000 symbols worth; 32 000 for tiles shorter than 16 384 symbols that start
-	                                   more than 50 000 symbols behind the hand-over (their bodies follow the settling too closely) */
+	uint32_t settle_samples;        /* 0xFFFFFFFF = 32 000 symbols worth, 24 000 for the tiles that start within 50 000 symbols of the
+	                                   hand-over (the serial run itself is still drifting in there: a longer lead agrees with it less) */
 	uint32_t pilot_block;           /* pilot granularity in samples               (65536)  */
 	uint32_t pilot_margin_symbols;  /* symbols between the first lock and the hand-over; 0xFFFFFFFF = 15 000 (OQPSK: 20 000); 20 000 (30 000) when the tiles take the pilot's clock or carrier word */
 	uint64_t max_pilot_samples;     /* give up waiting for lock after this many; 0xFFFFFFFFFFFFFFFF = 1 500 000 symbols worth: the reference's

@@ -1040,7 +1040,10 @@ struct Stitcher {
 		   the caller does not say - EXCEPT behind the hand-over, where the serial run itself is still drifting in with its carrier loop's
 		   16 200-symbol pole and a tile that has had longer to converge on the carrier agrees with it LESS (windows of 0.07 .. 0.35 in
 		   tiles 1 .. 3 with 32 000 and 40 000; the seed model of seed_tiles covers one time constant back, not two). */
-		const uint64_t WS_far = (settle_auto && static_cast<double>(B) / osf < 16384.0) ? static_cast<uint64_t>(32000 * osf) : WS;
+		/* (measured on the SAME windows as 47 converged twins of the serial run - recording.tiled_vs_twins, where the bad windows are
+		   mostly the signal's: 8 192-symbol bodies 0.41 % of windows below 0.99 against the twins' 0.16 % with 24 000, 0.17 % with 32 000;
+		   23 000-symbol bodies 0.18 % against 0.054 % with 24 000 - so every tile takes the 32 000, not only the short ones) */
+		const uint64_t WS_far = settle_auto ? static_cast<uint64_t>(32000 * osf) : WS;
 		const uint64_t far_from = P + static_cast<uint64_t>(50000 * osf);
 		for (size_t i = 0; i < T; i++) {
 			E[i] = P + i * B; len[i] = std::min<uint64_t>(B, n_samples - E[i]);
