@@ -155,6 +155,15 @@ pipe_init(HostPipe *p, uint32_t ns)
 	if (p->ready) return MDEMOD_OK;
 	/* every resource is created only if it is missing: a call that failed part-way is picked up where it stopped, nothing leaks */
 	p->ns = ns;
+#ifdef MDEMOD_PIPE_PRIO
+	{
+		int lo = 0, hi = 0;
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);          /* lo: numerically greatest = least urgent */
+		if (!p->s_in) PIPE_TRY(hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, lo));
+		if (!p->s_cmp) PIPE_TRY(hipStreamCreateWithPriority(&p->s_cmp, hipStreamNonBlocking, hi));
+		if (!p->s_out) PIPE_TRY(hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, hi));
+	}
+#endif
 	if (!p->s_in) PIPE_TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
 	if (!p->s_cmp) PIPE_TRY(hipStreamCreateWithFlags(&p->s_cmp, hipStreamNonBlocking));
 	if (!p->s_out) PIPE_TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
@@ -436,9 +445,15 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 #endif
 		rc = mdemod_process_device(ctx, sl.d_iq, sl.d_off, sl.d_cnt, sl.d_soft, cap, cap, p->s_cmp);
 		if (rc) return rc;
-		/* (r05, measured: letting this kernel store the rows straight into the pinned host buffer - no copy engine for the way out -
-		 * ends the call without a tail but slows every copy-in by as much: 42.6 ms either way.  The link moves 58 GB/s both ways here.) */
-		PIPE_TRY(mdemod_launch_compact_rows(sl.d_soft, cap, sl.d_pack, pitch, st.sym_this_call, ns, p->s_cmp));
+		/* The rows of the LAST sub-blocks go to the pinned host buffer straight from this kernel (posted writes over the link), not
+		 * through the copy engine: a copy-out lands on whichever engine is free NEXT, which is the one busy with the copy-in in flight,
+		 * so the last three of them queue up behind the last copy-ins and then behind each other - 2.4 ms after the last kernel (r05
+		 * timeline).  For every sub-block it is no gain: the kernel's writes slow each copy-in by 4 %, the same 42.6 ms in total. */
+#ifndef MDEMOD_PIPE_ZC_LAST
+#define MDEMOD_PIPE_ZC_LAST 3
+#endif
+		const bool zc_out = K >= 8 && k + MDEMOD_PIPE_ZC_LAST >= K;
+		PIPE_TRY(mdemod_launch_compact_rows(sl.d_soft, cap, zc_out ? sl.h_soft : sl.d_pack, pitch, st.sym_this_call, ns, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_prod, st.sym_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_ev, st.ev_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
 		if (K > 1) PIPE_TRY(hipMemcpyAsync(sl.d_events, st.events, sizeof(mdemod_lock_event) * MDEMOD_MAX_LOCK_EVENTS * ns, hipMemcpyDeviceToDevice, p->s_cmp));
@@ -448,7 +463,7 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		PIPE_TRY(hipEventRecord(sl.ev_k, p->s_cmp)); sl.used_k = true;
 		/* ---- D2H of the nominal-pitch copy ---- */
 		PIPE_TRY(hipStreamWaitEvent(p->s_out, sl.ev_k, 0));
-		PIPE_TRY(hipMemcpyAsync(sl.h_soft, sl.d_pack, pack_bytes, hipMemcpyDeviceToHost, p->s_out));
+		if (!zc_out) PIPE_TRY(hipMemcpyAsync(sl.h_soft, sl.d_pack, pack_bytes, hipMemcpyDeviceToHost, p->s_out));
 #ifdef MDEMOD_PIPE_TRACE
 		(void)hipEventRecord(tr_o1[k], p->s_out);
 #endif
