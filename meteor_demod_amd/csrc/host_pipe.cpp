@@ -265,23 +265,23 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 	 * host's, a [streams][samples] array).  Then a sub-block is ONE two-dimensional copy and the CPU does not touch the input at all
 	 * (r05, tools/ubench/h2d_rect.cpp: 57 GB/s, what the link gives a contiguous pinned copy; the staged path's pack competes with the
 	 * copy engine for the host's memory and holds it at 53).  Anything else is staged through the pinned ring as before. */
-	bool direct = false;
+	bool direct_all = false;
 	size_t row_stride = 0;
 	if (!p->pins.empty() && ns >= 1 && n_max > 0) {
 		const unsigned char *first = static_cast<const unsigned char *>(iq_host[0]);
-		direct = first != nullptr;
-		for (uint32_t s = 0; s < ns && direct; s++) direct = n_samples[s] == n_max;
-		if (direct && ns > 1) {
+		direct_all = first != nullptr;
+		for (uint32_t s = 0; s < ns && direct_all; s++) direct_all = n_samples[s] == n_max;
+		if (direct_all && ns > 1) {
 			const unsigned char *second = static_cast<const unsigned char *>(iq_host[1]);
-			direct = second > first && static_cast<size_t>(second - first) >= static_cast<size_t>(n_max) * sb;
-			row_stride = direct ? static_cast<size_t>(second - first) : 0;
-			for (uint32_t s = 2; s < ns && direct; s++) direct = static_cast<const unsigned char *>(iq_host[s]) == first + static_cast<size_t>(s) * row_stride;
-		} else if (direct) row_stride = static_cast<size_t>(n_max) * sb;
-		if (direct) {
+			direct_all = second > first && static_cast<size_t>(second - first) >= static_cast<size_t>(n_max) * sb;
+			row_stride = direct_all ? static_cast<size_t>(second - first) : 0;
+			for (uint32_t s = 2; s < ns && direct_all; s++) direct_all = static_cast<const unsigned char *>(iq_host[s]) == first + static_cast<size_t>(s) * row_stride;
+		} else if (direct_all) row_stride = static_cast<size_t>(n_max) * sb;
+		if (direct_all) {
 			const unsigned char *end = first + static_cast<size_t>(ns - 1) * row_stride + static_cast<size_t>(n_max) * sb;
 			bool inside = false;
 			for (const Pin &pin : p->pins) inside = inside || (first >= pin.base && end <= pin.base + pin.bytes);
-			direct = inside;
+			direct_all = inside;
 		}
 	}
 	/* Sub-blocks: K consecutive pieces of every stream's block, 16 full-size ones at most (each stream's piece should stay a few
@@ -390,16 +390,21 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 			wpre[s] = pos;
 			sub_max = std::max(sub_max, hi - lo);
 		}
+		/* experiment knob: the first sub-blocks of a pinned batch staged like any other (see MDEMOD_PIPE_DIRECT_FROM below) */
+#ifndef MDEMOD_PIPE_DIRECT_FROM
+#define MDEMOD_PIPE_DIRECT_FROM 0
+#endif
+		const bool direct_k = direct_all && (K < 8 || k >= MDEMOD_PIPE_DIRECT_FROM);
 		const size_t iq_bytes = static_cast<size_t>(pos) * sb + 64;
 		const uint32_t cap = ((sub_max + 8 + 7) / 8) * 8;                   /* hard bound: one symbol per input sample */
 		const uint32_t pitch = static_cast<uint32_t>(std::min<uint64_t>(cap, mdemod_nominal_symbols(ctx, sub_max)));
 		const size_t soft_bytes = static_cast<size_t>(cap) * 2 * ns, pack_bytes = static_cast<size_t>(pitch) * 2 * ns;
-		if (iq_bytes > sl.d_iq_bytes || (!direct && iq_bytes > sl.h_iq_bytes) || soft_bytes > sl.d_soft_bytes || pack_bytes > sl.d_pack_bytes || pack_bytes > sl.h_soft_bytes) {
+		if (iq_bytes > sl.d_iq_bytes || (!direct_k && iq_bytes > sl.h_iq_bytes) || soft_bytes > sl.d_soft_bytes || pack_bytes > sl.d_pack_bytes || pack_bytes > sl.h_soft_bytes) {
 			/* the slot's previous sub-block must be completely through before its buffers are replaced */
 			if (sl.used_out) PIPE_TRY(hipEventSynchronize(sl.ev_out));
 			rc = grow_dev(&sl.d_iq, &sl.d_iq_bytes, iq_bytes);
 			if (rc) return rc;
-			if (!direct) { rc = grow_host_any(&sl.h_iq, &sl.h_iq_bytes, iq_bytes); if (rc) return rc; }
+			if (!direct_k) { rc = grow_host_any(&sl.h_iq, &sl.h_iq_bytes, iq_bytes); if (rc) return rc; }
 			rc = grow_dev(&sl.d_soft, &sl.d_soft_bytes, soft_bytes);
 			if (rc) return rc;
 			rc = grow_dev(&sl.d_pack, &sl.d_pack_bytes, pack_bytes);
@@ -408,7 +413,7 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 			if (rc) return rc;
 		}
 		/* ---- pack (CPU): not for rows the copy engine reads where they are ---- */
-		if (!direct) TR(tr_pack, parallel_streams(ns, wpre, [&](uint32_t a, uint32_t b) {
+		if (!direct_k) TR(tr_pack, parallel_streams(ns, wpre, [&](uint32_t a, uint32_t b) {
 			for (uint32_t s = a; s < b; s++) {
 				if (s + 1 < b && sl.h_cnt[s + 1]) prefetch_piece(static_cast<const unsigned char *>(iq_host[s + 1]) + static_cast<size_t>(sub_lo(s + 1, k)) * sb);
 				if (sl.h_cnt[s])
@@ -423,7 +428,7 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		tr_enq_at[k] = (tr_now() - tr_t0) * 1e3;
 		(void)hipEventRecord(tr_e0[k], p->s_in);
 #endif
-		if (pos && direct) {
+		if (pos && direct_k) {
 			/* every stream's piece is [lo, lo + cnt) of its row: device rows at the ring's own pitch (8-sample multiples, h_off) */
 			const uint32_t lo = sub_lo(0, k), cnt = sl.h_cnt[0];
 			const size_t dev_pitch = ns > 1 ? static_cast<size_t>(sl.h_off[1] - sl.h_off[0]) * sb : static_cast<size_t>(cnt) * sb;
