@@ -267,20 +267,25 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 	 * copy engine for the host's memory and holds it at 53).  Anything else is staged through the pinned ring as before. */
 	bool direct_all = false;
 	size_t row_stride = 0;
-	if (!p->pins.empty() && ns >= 1 && n_max > 0) {
-		const unsigned char *first = static_cast<const unsigned char *>(iq_host[0]);
-		direct_all = first != nullptr;
+	if (!p->pins.empty() && ns >= 1 && n_max > 0 && iq_host[0]) {
+		/* (addresses compared as integers: the rows need not belong to one object as far as the language is concerned) */
+		const uintptr_t first = reinterpret_cast<uintptr_t>(iq_host[0]);
+		const size_t row_bytes = static_cast<size_t>(n_max) * sb;
+		direct_all = true;
 		for (uint32_t s = 0; s < ns && direct_all; s++) direct_all = n_samples[s] == n_max;
 		if (direct_all && ns > 1) {
-			const unsigned char *second = static_cast<const unsigned char *>(iq_host[1]);
-			direct_all = second > first && static_cast<size_t>(second - first) >= static_cast<size_t>(n_max) * sb;
+			const uintptr_t second = reinterpret_cast<uintptr_t>(iq_host[1]);
+			direct_all = second > first && second - first >= row_bytes;
 			row_stride = direct_all ? static_cast<size_t>(second - first) : 0;
-			for (uint32_t s = 2; s < ns && direct_all; s++) direct_all = static_cast<const unsigned char *>(iq_host[s]) == first + static_cast<size_t>(s) * row_stride;
-		} else if (direct_all) row_stride = static_cast<size_t>(n_max) * sb;
+			for (uint32_t s = 2; s < ns && direct_all; s++) direct_all = reinterpret_cast<uintptr_t>(iq_host[s]) == first + static_cast<uintptr_t>(s) * row_stride;
+		} else if (direct_all) row_stride = row_bytes;
 		if (direct_all) {
-			const unsigned char *end = first + static_cast<size_t>(ns - 1) * row_stride + static_cast<size_t>(n_max) * sb;
+			const uintptr_t end = first + static_cast<uintptr_t>(ns - 1) * row_stride + row_bytes;
 			bool inside = false;
-			for (const Pin &pin : p->pins) inside = inside || (first >= pin.base && end <= pin.base + pin.bytes);
+			for (const Pin &pin : p->pins) {
+				const uintptr_t lo = reinterpret_cast<uintptr_t>(pin.base);
+				inside = inside || (first >= lo && end <= lo + pin.bytes);
+			}
 			direct_all = inside;
 		}
 	}

@@ -216,6 +216,8 @@ class Demodulator:
     def pin_host(self, array: np.ndarray) -> None:
         """``mdemod_pin_host_buffer``: batches that lie inside ``array`` (rows of equal length, one stride apart) are copied
         straight from its pages by :meth:`process_host`.  Keep ``array`` alive until :meth:`unpin_host` or :meth:`close`."""
+        if not array.flags["C_CONTIGUOUS"]:
+            raise ValueError("pin_host wants one contiguous allocation (base pointer + nbytes is what gets pinned)")
         check(self._lib.mdemod_pin_host_buffer(self._ctx, C.c_void_p(array.ctypes.data), array.nbytes), "mdemod_pin_host_buffer")
 
     def unpin_host(self, array: np.ndarray) -> None:

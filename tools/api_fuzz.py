@@ -60,6 +60,30 @@ for ci in range(n_cfg):
                 for i in range(ns):
                     if not np.array_equal(outs[i], want[i]):
                         why = f"host stream {i} len {lens[i]}"; break
+        # ---- host path from rows the caller pinned (round 5): equal lengths, one stride apart, inside ONE pinned array - copied in
+        #      place, no staging; then a ragged call on the same context (staged), chained on the first ----
+        if why is None:
+            n_u = int(rng.choice([64, 1000, 4097, 9000 - 1500]))
+            pad = int(rng.choice([0, 1, 3, 8, 100]))
+            big = np.zeros((ns, n_u + pad, 2), dtype=DT[cfg.bps]) + (128 if cfg.bps == 8 else 0)
+            for i in range(ns):
+                big[i, :n_u] = src[i % 4][:n_u]
+            big = big.astype(DT[cfg.bps])
+            w_u = [O.OracleStream(cfg) for _ in range(min(ns, 4))]
+            first = [w_u[i].run(src[i][:n_u])[0] for i in range(len(w_u))]
+            with Demodulator(cfg, ns) as d:
+                d.pin_host(big)
+                outs = d.process_host([big[i, :n_u] for i in range(ns)])
+                for i in range(ns):
+                    if not np.array_equal(outs[i], first[i % 4] if i % 4 < len(first) else outs[i % 4]):
+                        why = f"pinned host stream {i}"; break
+                if why is None:
+                    l2 = [int(rng.choice([0, 7, 500, 1499])) for _ in range(ns)]
+                    outs2 = d.process_host([src[i % 4][n_u: n_u + l2[i]] for i in range(ns)])
+                    for i in range(min(ns, 4)):
+                        if not np.array_equal(outs2[i], w_u[i].run(src[i][n_u: n_u + l2[i]])[0] if l2[i] else np.zeros((0, 2), np.int8)):
+                            why = f"chained after pinned, stream {i} len {l2[i]}"; break
+                d.unpin_host(big)
     except Exception as ex:
         why = repr(ex)
     done += 1
