@@ -106,6 +106,22 @@ int main(int argc, char **argv)
 		printf("%s: contiguous registered %.1f ms = %.1f GB/s | hipMemcpy2DAsync rows %.1f ms = %.1f GB/s | gather kernel %.1f ms = %.1f GB/s\n",
 		       with_out ? "with 13.5 % going out" : "input only          ", best[0] * 1e3, total / best[0] / 1e9, best[1] * 1e3, total / best[1] / 1e9, best[2] * 1e3, total / best[2] / 1e9);
 	}
+	// after an idle gap: is it the first milliseconds of 2-D copies that are slow?  (events around every sub-block's copy)
+	for (int kind = 0; kind < 2; kind++) {
+		std::vector<hipEvent_t> e(K + 1);
+		for (auto &x : e) CK(hipEventCreate(&x));
+		std::this_thread::sleep_for(std::chrono::milliseconds(300));
+		CK(hipEventRecord(e[0], s_in));
+		for (size_t k = 0; k < K; k++) {
+			if (kind == 0) CK(hipMemcpy2DAsync(d[k & 1], W, h + k * W, row, W, NS, hipMemcpyHostToDevice, s_in));
+			else CK(hipMemcpyAsync(d[k & 1], h + k * sub, sub, hipMemcpyHostToDevice, s_in));
+			CK(hipEventRecord(e[k + 1], s_in));
+		}
+		CK(hipStreamSynchronize(s_in));
+		printf("%s after 300 ms of idle, ms per sub-block:", kind == 0 ? "2-D copies from registered rows" : "contiguous registered copies  ");
+		for (size_t k = 0; k < K; k++) { float ms = 0; CK(hipEventElapsedTime(&ms, e[k], e[k + 1])); printf(" %.2f", ms); }
+		printf("\n");
+	}
 	t0 = now(); CK(hipHostUnregister(h)); printf("unregister %.1f ms\n", (now() - t0) * 1e3);
 	return 0;
 }
