@@ -429,6 +429,14 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		}));
 		/* ---- H2D: after the kernel that last read this slot's device input ---- */
 		if (sl.used_k) PIPE_TRY(hipStreamWaitEvent(p->s_in, sl.ev_k, 0));
+		/* Never more than two copy-ins queued: a 2-D copy that is enqueued while two are still ahead of it runs at 38 GB/s instead of
+		 * 56, and so does the one behind it (r05 timeline: the first three of a pinned batch, which the host enqueues within 0.2 ms
+		 * of each other; any later one that finds two ahead of it).  Waiting for the copy before the previous one costs nothing:
+		 * the link has a whole sub-block queued meanwhile. */
+#ifndef MDEMOD_PIPE_MAX_QUEUED
+#define MDEMOD_PIPE_MAX_QUEUED 2
+#endif
+		if (k >= MDEMOD_PIPE_MAX_QUEUED) PIPE_TRY(hipEventSynchronize(p->slot[(k - MDEMOD_PIPE_MAX_QUEUED) % kSlots].ev_in));
 #ifdef MDEMOD_PIPE_TRACE
 		tr_enq_at[k] = (tr_now() - tr_t0) * 1e3;
 		(void)hipEventRecord(tr_e0[k], p->s_in);
@@ -446,6 +454,7 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		PIPE_TRY(hipMemcpyAsync(sl.d_off, sl.h_off, sizeof(uint64_t) * ns, hipMemcpyHostToDevice, p->s_in));
 		PIPE_TRY(hipMemcpyAsync(sl.d_cnt, sl.h_cnt, sizeof(uint32_t) * ns, hipMemcpyHostToDevice, p->s_in));
 		PIPE_TRY(hipEventRecord(sl.ev_in, p->s_in)); sl.used_in = true;
+
 		/* ---- kernel: after the copy-in, and after the copy-out that last read this slot's device output ---- */
 		PIPE_TRY(hipStreamWaitEvent(p->s_cmp, sl.ev_in, 0));
 		if (sl.used_out) PIPE_TRY(hipStreamWaitEvent(p->s_cmp, sl.ev_out, 0));
