@@ -256,8 +256,12 @@ WIDE_CFGS = {
     "taps129_6000k_u8": DemodConfig(samplerate=6000000, rrc_order=64, interp_factor=3, bps=8),
     "defaults_6000k_f32": DemodConfig(samplerate=6000000, bps=32),
     "oqpsk_7200k_f32": DemodConfig(samplerate=7200000, symrate=80000, oqpsk=True, rrc_order=20, interp_factor=3, bps=32),   # 45 samples per firing
+    # symbol rates at and above the interpolated rate (every step fires: round 5, the region whose schedule search hung) on the long filter
+    "sub_step_wide_oqpsk_r2": DemodConfig(samplerate=36000, interp_factor=1, rrc_order=48, oqpsk=True),          # 97 taps, symrate = 2 fs O
+    "sub_step_wide_qpsk_r4_u8": DemodConfig(samplerate=18000, interp_factor=1, rrc_order=64, bps=8),              # 129 taps, symrate = 4 fs O
+    "sub_step_hybrid_oqpsk_r3_f32": DemodConfig(samplerate=12000, interp_factor=2, rrc_order=64, oqpsk=True, bps=32),   # float input, symrate = 3 fs O
 }
-WIDE_KERNEL = {"c4_s16": "wide", "c4_u8": "wide", "oqpsk80k_1M": "wide", "taps97_os6": "wide", "edge_15_per_symbol": "wide",
+WIDE_KERNEL = {"sub_step_wide_oqpsk_r2": "wide", "sub_step_wide_qpsk_r4_u8": "wide", "sub_step_hybrid_oqpsk_r3_f32": "hybrid", "c4_s16": "wide", "c4_u8": "wide", "oqpsk80k_1M": "wide", "taps97_os6": "wide", "edge_15_per_symbol": "wide",
                "taps65_slow_clock": "mid", "defaults_1024k": "mid", "defaults_1024k_oqpsk_u8": "mid", "defaults_2048k": "far",
                "far_edge_u8": "far", "defaults_1024k_f32": "mid", "oqpsk_640k_f32": "mid",
                "c4_f32": "hybrid", "oqpsk80k_1M_f32": "hybrid", "taps97_230k_f32": "hybrid", "taps129_O12_f32": "hybrid", "defaults_2048k_f32": "far-f32", "taps129_2048k_f32": "hybrid", "taps129_2048k": "wide-far", "taps97_1800k_u8": "wide-far", "defaults_3200k": "far-far", "defaults_2400k_u8": "far-far", "defaults_3200k_f32": "hyb-far", "oqpsk_7200k_f32": "hyb-far", "defaults_6000k": "gather", "defaults_10000k": "gather", "taps129_4000k": "gather", "oqpsk_8000k": "gather", "defaults_8000k_u8": "gather", "taps129_6000k_u8": "gather", "defaults_6000k_f32": "gather"}
