@@ -1,6 +1,7 @@
 /*
  * pack_pool.h — the host threads behind mdemod_process_host's packing and unpacking (host_pipe.cpp).  No HIP in here: the pool is
- * plain C++ threads, so that tests/sanitize/pool_tsan.cpp can run exactly this code under ThreadSanitizer.
+ * plain C++ threads and the streaming copy they run, so that tests/sanitize/pool_test.cpp can run exactly this code under ThreadSanitizer and
+ * AddressSanitizer.
  */
 #ifndef MDEMOD_PACK_POOL_H
 #define MDEMOD_PACK_POOL_H
@@ -14,6 +15,8 @@
 #include <thread>
 #include <vector>
 #include <unistd.h>
+#include <cstring>
+#include <emmintrin.h>
 
 namespace {
 
@@ -127,6 +130,36 @@ parallel_streams(uint32_t n, const std::vector<uint64_t> &weight_prefix, F fn)
 		cut[w] = at;
 	}
 	pool.run(pieces, [&](unsigned i) { if (cut[i + 1] > cut[i]) fn(cut[i], cut[i + 1]); });
+}
+
+
+/* memcpy with non-temporal stores: into the pinned ring (the CPU never reads it again) and into the caller's output rows (640 B ..
+ * a few KB each, every one on another page: a plain memcpy first READS the destination lines it is about to overwrite - one DRAM
+ * round trip per piece that nothing hides; tools/ubench/h2d_rect.cpp: the pack alone 65 -> 105 GB/s).  Whoever calls this fences
+ * (_mm_sfence) before the bytes are handed on. */
+inline void
+stream_copy(unsigned char *dst, const unsigned char *src, size_t n)
+{
+	size_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15;
+	if (head > n) head = n;
+	if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+	size_t i = 0;
+	for (; i + 64 <= n; i += 64) {
+		const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i)), b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 16));
+		const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 32)), d = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 48));
+		_mm_stream_si128(reinterpret_cast<__m128i *>(dst + i), a); _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 16), b);
+		_mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 32), c); _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 48), d);
+	}
+	if (i < n) memcpy(dst + i, src + i, n - i);
+}
+
+/* the first lines of the NEXT piece a thread will read (another row of the caller's, far from this one): on their way while this
+ * piece is copied */
+inline void
+prefetch_piece(const unsigned char *src)
+{
+	_mm_prefetch(reinterpret_cast<const char *>(src), _MM_HINT_NTA); _mm_prefetch(reinterpret_cast<const char *>(src + 64), _MM_HINT_NTA);
+	_mm_prefetch(reinterpret_cast<const char *>(src + 128), _MM_HINT_NTA); _mm_prefetch(reinterpret_cast<const char *>(src + 192), _MM_HINT_NTA);
 }
 
 } /* namespace */

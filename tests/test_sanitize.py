@@ -108,6 +108,13 @@ def test_pack_pool_forked_child_exits(bins):
     assert proc.returncode == 0
 
 
+def test_streaming_copy_equals_memcpy_under_asan(bins):
+    """csrc/pack_pool.h: stream_copy (the pack into the pinned ring and the unpack into the caller's rows: non-temporal stores behind an
+    aligning head and a tail) for every alignment and the lengths around its steps, guard bytes checked."""
+    proc = _run([bins["pool_asan"], "copy"], timeout=120)
+    assert proc.returncode == 0 and b"equal memcpy" in proc.stdout, (proc.stdout + proc.stderr).decode()[-2000:]
+
+
 # ---- the whole C host against the stub backend -------------------------------------------------------------------------------
 
 def _model_output(data: bytes, bps_opt: int, lock: int, decim: int = 3) -> bytes:
