@@ -292,7 +292,9 @@ __device__ __forceinline__ float
 md_tanh_lut_uniform(const float *lut, float v)
 {
 	float t = (v >= 15.0f) ? 1.0f : -1.0f;
-	if (md_any(v > -16.0f && v < 15.0f)) t = md_tanh_lut(lut, v);
+	/* (the look-up is the RARE way: laid out of line, so that the common way is a branch not taken - a lone wave waits ~90 cycles for
+	 * its instruction buffer after every branch it takes: r05, SQ_WAIT_ANY of the latency kernel) */
+	if (__builtin_expect(md_any(v > -16.0f && v < 15.0f), 0)) t = md_tanh_lut(lut, v);
 	return t;
 }
 

@@ -180,15 +180,15 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		md_nco_advance<true>(pll.phase, pll.freq);
 		if (emit) {
 			/* only the LAST symbol fired inside one input sample survives (demod.c:33-47: `*sample` and `ret` are overwritten) */
-			if (same_sample) {
+			if (__builtin_expect(same_sample, 0)) {
 				sym_call--;
 				if (out_cnt > 0) out_cnt--; else out_base--;
 			}
 			md_timing_update(t_phase, t_freq, t_prev, C.t_alpha, C.t_beta, C.t_center, C.t_maxdev, out_im);
 			uint32_t first = 0;
 			const uint32_t changed = md_pll_update_packed<true>(pll, fl, lut, C.pll_alpha, C.pll_beta, C.pll_fmax, out_re, out_im, first);
-			if (first) first_lock_call = (int)sym_call;
-			if (changed) {
+			if (__builtin_expect(first != 0, 0)) first_lock_call = (int)sym_call;
+			if (__builtin_expect(changed != 0, 0)) {
 				if (ev_call < MDEMOD_MAX_LOCK_EVENTS && lane == 0) {
 					mdemod_lock_event ev;
 					ev.symbol = nsym0 + sym_call; ev.locked = (int)(fl & 1u); ev.pad = 0;
@@ -322,7 +322,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 			bool regular = false;
 			int m = 0;
 			float ph = t_phase;
-			if (fast) {
+			if (__builtin_expect(fast, 1)) {
 				float p = t_phase;
 				int k_done = k_safe;
 				if (KSAFE) {
@@ -345,7 +345,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 			const int cidx = steps_done + m - pj;                         /* -1, 0, +1 when the prediction holds */
 			const int idx = kCand * j + cidx + 1;
 			const bool hit = regular && cidx >= -1 && cidx <= 1 && ((ok_mask >> idx) & 1ull);
-			if (!hit) { miss = true; break; }                             /* irregular firing: handled after the loop, the batch ends */
+			if (__builtin_expect(!hit, 0)) { miss = true; break; }                             /* irregular firing: handled after the loop, the batch ends */
 			t_phase = ph;
 			steps_done += m;
 			since_emit += m;
@@ -356,7 +356,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 			/* two firings on one input sample have fewer than interp steps between them: only then look at the positions */
 			const bool emits = !OQPSK || dual_state == 2;
 			bool same = false;
-			if (emits && since_emit < interp) {
+			if (__builtin_expect(emits && since_emit < interp, 0)) {
 				int v, is;
 				locate(v0, isub0, steps_done, v, is);
 				same = (v == sample_of_last_emit());
