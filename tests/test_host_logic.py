@@ -401,3 +401,23 @@ def test_the_retired_kernel_generation_is_refused():
     p.reserved = 2
     name = C.create_string_buffer(64)
     assert _capi.lib().mdemod_plan_kernel(C.byref(p), name, 64, None, None) == -1
+
+
+def test_bench_bound_block_reads_the_tracked_profile():
+    """bench.py's per-configuration bound / ceiling block from profiles/hbm_traffic.json, without a GPU: every BASELINE
+    configuration has its counters, the ceiling lies above what is achieved and far below BASELINE.json's 0.40 for configs[1] / [2]."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ms = {"c1": 24.2, "c3": 48.8, "c4": 14.6}
+    for tag in ("c1", "c3", "c4"):
+        cfg, _ = bench.demod_config(tag)
+        b = bench.bound_block(cfg, tag, 393216, 16448, ms[tag])
+        v = b["valu"]
+        assert b["traffic"] and 1.0 < b["traffic_ratio"] < 1.5, (tag, b["traffic_ratio"])
+        assert v["valu_instructions_per_wave_firing"] and 0.7 < v["simd_valu_busy_frac"] < 1.0
+        assert v["fir_packed_instructions_per_firing"]["floor"] == 2 * cfg.taps
+        assert b["hbm_frac"] < v["pipe_busy_ceiling_hbm_frac"] <= v["ceiling_hbm_frac"] < 0.40, (tag, b["hbm_frac"], v)
+        assert 0.7 < v["frac_of_measured"] < 1.0
+    assert abs(bench.flops_per_sample_of(bench.demod_config("c1")[0]) - 122.7) < 0.5
