@@ -35,6 +35,7 @@ namespace {
 constexpr int kCand = 3;                 /* candidates per firing: predicted step -1, 0, +1 */
 constexpr int kFire = 21;                /* firings per batch: 63 lanes                      */
 constexpr int kMaxChunks = 20;           /* 64-sample chunks prefetched per batch            */
+constexpr int kMirror = 264;             /* ring entries mirrored behind its end: >= the longest window (hpad <= 256, taps <= hpad + 1) */
 
 template <int FMT> struct LFmt;
 template <> struct LFmt<16> {
@@ -68,8 +69,15 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 	const int interp = C.interp, taps = C.taps, hpad = C.hpad;
 	const int mask = ring_size - 1;
 
-	float2 *ring = reinterpret_cast<float2 *>(lds);                       /* ring[v & mask] = sample v of (history ++ block) */
-	float *coef = reinterpret_cast<float *>(ring + ring_size);            /* [bank][taps], filter.c:18-22 */
+	float2 *ring = reinterpret_cast<float2 *>(lds);                       /* ring[v & mask]: sample v of (history ++ block) */
+	/* ... and ring[ring_size + i] = ring[i] for i < kMirror (>= taps): a FIR window that starts anywhere in the ring is ONE linear run
+	   of LDS words, no index arithmetic per tap (round 5: the farm's 65 taps cost 9 instructions each, 3.5 of them the `& mask`) */
+	float *coef = reinterpret_cast<float *>(ring + ring_size + kMirror);  /* [bank][taps], filter.c:18-22 */
+	auto ring_put = [&](int v, float2 s) {
+		const int i = v & mask;
+		ring[i] = s;
+		if (i < kMirror) ring[i + ring_size] = s;
+	};
 	float *lut = coef + interp * taps;
 	float2 *obuf = reinterpret_cast<float2 *>(lut + 32);                  /* demodulated symbols of this batch, quantised when flushed */
 
@@ -99,7 +107,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		float2 h;
 		if (float_history) h = reinterpret_cast<const float2 *>(L.st.hist)[(size_t)stream * hpad + k];
 		else h = F::decode(reinterpret_cast<const sample_t *>(L.st.hist)[(size_t)k * L.n_streams + stream]);
-		ring[k & mask] = h;
+		ring_put(k, h);
 	}
 	int r_hi = hpad;                         /* samples [.., r_hi) are in the ring (wave-uniform) */
 	auto load_chunk = [&](int v0) -> float2 {      /* sample v0 + lane of the virtual stream (zeros past the end) */
@@ -111,7 +119,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 	/* two spans ahead before the first batch */
 	while (r_hi < v_end && r_hi < hpad + 2 * span) {
 		const float2 s = load_chunk(r_hi);
-		if (r_hi + lane < v_end) ring[(r_hi + lane) & mask] = s;
+		if (r_hi + lane < v_end) ring_put(r_hi + lane, s);
 		r_hi = min(v_end, r_hi + 64);
 	}
 	__syncthreads();
@@ -138,7 +146,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 	auto fir_here = [&](int v, int bank) -> cf32 {
 		while (r_hi <= v) {                                                  /* beyond what has been loaded: extend the ring first */
 			const float2 s = load_chunk(r_hi);
-			if (r_hi + lane < v_end) ring[(r_hi + lane) & mask] = s;
+			if (r_hi + lane < v_end) ring_put(r_hi + lane, s);
 			r_hi = min(v_end, r_hi + 64);
 			__syncthreads();
 		}
@@ -280,17 +288,18 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 				const int bank = interp - 1 - fire_sub;                    /* filter.c:52 */
 				if (v < r_hi) {
 					cand_ok = true;
-					int p = (v - taps + 1) & mask;
+					/* filter.c:55-62, sequential, oldest first, unfused: both rails of a tap in one packed multiply and one packed add
+					   (the same four roundings), the window one linear run of the mirrored ring */
+					typedef float v2f __attribute__((ext_vector_type(2)));
+					const v2f *w = reinterpret_cast<const v2f *>(ring + ((v - taps + 1) & mask));
 					const float *h = coef + bank * taps;
-					float ar = 0.0f, ai = 0.0f;
+					v2f acc = { 0.0f, 0.0f };
 					for (int k = 0; k < taps; k++) {
-						const float2 x = ring[p];
 						const float hk = h[k];
-						ar = ar + x.x * hk;
-						ai = ai + x.y * hk;
-						p = (p + 1) & mask;
+						const v2f hh = { hk, hk };
+						acc = acc + w[k] * hh;
 					}
-					yr = ar; yi = ai;
+					yr = acc.x; yi = acc.y;
 				}
 			}
 		}
@@ -376,7 +385,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 #pragma unroll
 		for (int c = 0; c < kMaxChunks; c++)
 			if (c < n_chunks && r_hi0 + 64 * c < v_end && r_hi0 + 64 * c < v0 + 1 + 2 * span && r_hi0 + 64 * c >= r_hi) {
-				if (r_hi0 + 64 * c + lane < v_end) ring[(r_hi0 + 64 * c + lane) & mask] = pend[c];
+				if (r_hi0 + 64 * c + lane < v_end) ring_put(r_hi0 + 64 * c + lane, pend[c]);
 				r_hi = min(v_end, r_hi0 + 64 * c + 64);
 			}
 		__syncthreads();
@@ -447,7 +456,7 @@ mdemod_lat_geometry(const DemodConsts &c, double samples_per_firing, int *ring_s
 	if ((sp + 63) / 64 + 1 > kMaxChunks) return false;
 	int ring = 256;
 	while (ring < c.hpad + 3 * sp + 128) ring *= 2;
-	const size_t bytes = static_cast<size_t>(ring) * 8 + (static_cast<size_t>(c.interp) * c.taps + 32) * 4 + 64 * 8 + 64;
+	const size_t bytes = static_cast<size_t>(ring + kMirror) * 8 + (static_cast<size_t>(c.interp) * c.taps + 32) * 4 + 64 * 8 + 64;
 	if (bytes > 64 * 1024) return false;
 	*ring_size = ring; *span = sp; *lds_bytes = bytes;
 	return true;
