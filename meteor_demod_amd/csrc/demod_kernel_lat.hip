@@ -263,9 +263,17 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		float2 pend[kMaxChunks];
 		const int r_hi0 = r_hi;
 		const int v0 = v_cur, isub0 = isub;
-#pragma unroll
-		for (int c = 0; c < kMaxChunks; c++)
-			if (c < n_chunks && r_hi0 + 64 * c < v_end && r_hi0 + 64 * c < v0 + 1 + 2 * span) pend[c] = load_chunk(r_hi0 + 64 * c);
+		/* chunks c with c < n_chunks, r_hi0 + 64 c < v_end and r_hi0 + 64 c < v0 + 1 + 2 span: the first n_valid of them.  pend[] has to
+		   stay in registers (static indices: the chain is written out), but the everyday rates need three or four chunks, not
+		   twenty tests of three conditions each: groups of four, the later groups behind one test (round 5) */
+		const int pf_lim = min(v_end, v0 + 1 + 2 * span) - r_hi0;
+		const int n_valid = pf_lim <= 0 ? 0 : min(n_chunks, (pf_lim + 63) >> 6);
+#define LAT_PF(c) if ((c) < n_valid) pend[c] = load_chunk(r_hi0 + 64 * (c));
+#define LAT_PF4(c) LAT_PF(c) LAT_PF((c) + 1) LAT_PF((c) + 2) LAT_PF((c) + 3)
+		LAT_PF4(0)
+		if (n_valid > 4) { LAT_PF4(4) if (n_valid > 8) { LAT_PF4(8) if (n_valid > 12) { LAT_PF4(12) if (n_valid > 16) { LAT_PF4(16) } } } }
+#undef LAT_PF4
+#undef LAT_PF
 
 		/* ---- (1) farm: lane -> (firing j, candidate c); lane j also keeps the prediction of firing j for the serial part ---- */
 		t_phase = uni(t_phase); t_freq = uni(t_freq);                    /* wave-uniform by construction: pin them to scalars */
@@ -382,12 +390,15 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		/* ---- (3) flush the batch's symbols: lane i writes symbol out_base + i ---- */
 		flush();
 		/* ---- (4) commit the prefetched chunks ---- */
-#pragma unroll
-		for (int c = 0; c < kMaxChunks; c++)
-			if (c < n_chunks && r_hi0 + 64 * c < v_end && r_hi0 + 64 * c < v0 + 1 + 2 * span && r_hi0 + 64 * c >= r_hi) {
-				if (r_hi0 + 64 * c + lane < v_end) ring_put(r_hi0 + 64 * c + lane, pend[c]);
-				r_hi = min(v_end, r_hi0 + 64 * c + 64);
-			}
+		/* (a chunk the careful way has loaded by itself meanwhile is not written again) */
+#define LAT_CM(c) if ((c) < n_valid && r_hi0 + 64 * (c) >= r_hi) { \
+			if (r_hi0 + 64 * (c) + lane < v_end) ring_put(r_hi0 + 64 * (c) + lane, pend[c]); \
+			r_hi = min(v_end, r_hi0 + 64 * (c) + 64); }
+#define LAT_CM4(c) LAT_CM(c) LAT_CM((c) + 1) LAT_CM((c) + 2) LAT_CM((c) + 3)
+		LAT_CM4(0)
+		if (n_valid > 4) { LAT_CM4(4) if (n_valid > 8) { LAT_CM4(8) if (n_valid > 12) { LAT_CM4(12) if (n_valid > 16) { LAT_CM4(16) } } } }
+#undef LAT_CM4
+#undef LAT_CM
 		__syncthreads();
 	}
 	if (guard == 0 && !done) overflow = 1;                                /* watchdog fired: reported as overflow */
