@@ -298,6 +298,18 @@ md_tanh_lut_uniform(const float *lut, float v)
 	return t;
 }
 
+/* ... and for the two rails of one symbol behind ONE test (pll.c:143-151 looks both up) */
+__device__ __forceinline__ void
+md_tanh_lut_uniform2(const float *lut, float a, float b, float &ta, float &tb)
+{
+	ta = (a >= 15.0f) ? 1.0f : -1.0f;
+	tb = (b >= 15.0f) ? 1.0f : -1.0f;
+	if (__builtin_expect(md_any((a > -16.0f && a < 15.0f) || (b > -16.0f && b < 15.0f)), 0)) {
+		ta = md_tanh_lut(lut, a);
+		tb = md_tanh_lut(lut, b);
+	}
+}
+
 struct PllState {
 	float phase, freq, err;
 	int   locked, locked_once, updown;
@@ -347,8 +359,10 @@ template <bool UNIFORM = false>
 __device__ __forceinline__ uint32_t
 md_pll_update_packed(PllWord &p, uint32_t &fl, const float *lut, float alpha, float beta, float fmax, float i, float q, uint32_t &first)
 {
-	const float e = UNIFORM ? md_tanh_lut_uniform(lut, i) * q - md_tanh_lut_uniform(lut, q) * i
-	                        : md_tanh_lut(lut, i) * q - md_tanh_lut(lut, q) * i;        /* pll.c:143-151 */
+	float ti, tq;
+	if (UNIFORM) md_tanh_lut_uniform2(lut, i, q, ti, tq);
+	else { ti = md_tanh_lut(lut, i); tq = md_tanh_lut(lut, q); }
+	const float e = ti * q - tq * i;                                        /* pll.c:143-151 */
 
 	const float ph = p.phase + alpha * e;
 	p.phase = md_wrap_2pi(ph);                                               /* pll.c:113 */
