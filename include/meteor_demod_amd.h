@@ -62,7 +62,8 @@ extern "C" {
 #define MDEMOD_ABI_VERSION 3
 
 /* Error codes (the reference surfaces none: demod_init returns void and drops
- * filter_init_rrc's status, demod.c:14). */
+ * filter_init_rrc's status, demod.c:14).  Nothing in the library calls exit() or abort(), and no C++ exception leaves it: an
+ * allocation or a thread that the host refuses comes back as MDEMOD_ERR_NOMEM from the entry it happened in. */
 enum {
 	MDEMOD_OK            =  0,
 	MDEMOD_ERR_PARAM     = -1,   /* bad argument / unsupported configuration */

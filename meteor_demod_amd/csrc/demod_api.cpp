@@ -220,7 +220,7 @@ mdemod_abi_version(void)
 
 int
 mdemod_init_device(int device)
-{
+try {
 	if (hipSetDevice(device) != hipSuccess) return MDEMOD_ERR_HIP;
 	if (hipFree(nullptr) != hipSuccess) return MDEMOD_ERR_HIP;             /* forces the context */
 	/* ... and the code objects (loaded at the first launch of a process), on a stream of its own */
@@ -229,14 +229,14 @@ mdemod_init_device(int device)
 	const bool ok = mdemod_launch_warm(s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
 	(void)hipStreamDestroy(s);
 	return ok ? MDEMOD_OK : MDEMOD_ERR_HIP;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_device_count(void)
-{
+try {
 	int n = 0;
 	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
-}
+} MDEMOD_API_CATCH
 
 const char *
 mdemod_strerror(int code)
@@ -255,7 +255,7 @@ mdemod_strerror(int code)
 int
 mdemod_derive_tables(const mdemod_params *params, float *rrc_out, uint32_t rrc_cap,
                      float consts_out[8], float lut_out[32])
-{
+try {
 	if (!params) return MDEMOD_ERR_PARAM;
 	HostTables t;
 	int rc = mdemod_host_derive(*params, t);
@@ -271,7 +271,7 @@ mdemod_derive_tables(const mdemod_params *params, float *rrc_out, uint32_t rrc_c
 	}
 	if (lut_out) memcpy(lut_out, t.tanh_lut, sizeof(t.tanh_lut));
 	return static_cast<int>(t.rrc.size());
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_create(const mdemod_params *params, mdemod_ctx **out)
@@ -282,6 +282,7 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	if (!ctx) return MDEMOD_ERR_NOMEM;
 	ctx->params = *params;
 	ctx->pipe = nullptr;
+	try {
 	int rc = plan_context(ctx);
 	if (rc) { delete ctx; return rc; }
 	DemodConsts &c = ctx->tab.c;
@@ -332,6 +333,10 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 		if (e != hipSuccess || rc_reset != MDEMOD_OK) { mdemod_destroy(ctx); return rc_reset != MDEMOD_OK ? rc_reset : MDEMOD_ERR_HIP; }
 	}
 #undef CREATE_TRY
+	} catch (...) {                                    /* (see MDEMOD_API_CATCH; what the context holds so far is given back) */
+		mdemod_destroy(ctx);
+		return MDEMOD_ERR_NOMEM;
+	}
 	*out = ctx;
 	return MDEMOD_OK;
 }
@@ -348,7 +353,7 @@ mdemod_destroy(mdemod_ctx *ctx)
 
 int
 mdemod_reset(mdemod_ctx *ctx, void *hip_stream)
-{
+try {
 	if (!ctx) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -357,7 +362,7 @@ mdemod_reset(mdemod_ctx *ctx, void *hip_stream)
 	HIP_TRY(mdemod_launch_reset(ctx->st, ctx->tab.c, ctx->params.bps, ctx->tab.use_rw ? 1 : 0, ctx->params.n_streams,
 	                            static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 uint64_t
 mdemod_max_symbols(const mdemod_ctx *ctx, uint64_t n_samples)
@@ -373,7 +378,7 @@ int
 mdemod_process_device_uniform(mdemod_ctx *ctx, const void *iq_dev, uint64_t iq_stride_samples,
                               uint32_t n_samples, int8_t *soft_dev, uint64_t soft_stride_symbols,
                               uint32_t soft_cap_symbols, void *hip_stream)
-{
+try {
 	if (!ctx || (!iq_dev && n_samples) || !soft_dev) return MDEMOD_ERR_PARAM;
 	if (n_samples > 0x3FFFFF00u) return MDEMOD_ERR_PARAM;
 	if (soft_cap_symbols > soft_stride_symbols) return MDEMOD_ERR_PARAM;
@@ -384,13 +389,13 @@ mdemod_process_device_uniform(mdemod_ctx *ctx, const void *iq_dev, uint64_t iq_s
 	L.iq = iq_dev; L.iq_stride = iq_stride_samples; L.n_samples = n_samples;
 	L.soft = soft_dev; L.soft_stride = soft_stride_symbols; L.soft_cap = soft_cap_symbols;
 	return launch(ctx, L, static_cast<hipStream_t>(hip_stream));
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_process_device(mdemod_ctx *ctx, const void *iq_dev, const uint64_t *iq_offset_dev,
                       const uint32_t *n_samples_dev, int8_t *soft_dev, uint64_t soft_stride_symbols,
                       uint32_t soft_cap_symbols, void *hip_stream)
-{
+try {
 	if (!ctx || !iq_dev || !iq_offset_dev || !n_samples_dev || !soft_dev) return MDEMOD_ERR_PARAM;
 	if (soft_cap_symbols > soft_stride_symbols) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
@@ -400,12 +405,12 @@ mdemod_process_device(mdemod_ctx *ctx, const void *iq_dev, const uint64_t *iq_of
 	L.iq = iq_dev; L.iq_offset = iq_offset_dev; L.n_samples_arr = n_samples_dev;
 	L.soft = soft_dev; L.soft_stride = soft_stride_symbols; L.soft_cap = soft_cap_symbols;
 	return launch(ctx, L, static_cast<hipStream_t>(hip_stream));
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_process_host(mdemod_ctx *ctx, const void *const *iq_host, const uint32_t *n_samples,
                     int8_t *const *soft_host, const uint32_t *soft_cap, uint32_t *n_symbols)
-{
+try {
 	if (!ctx || !iq_host || !n_samples || !soft_host || !soft_cap) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -414,32 +419,32 @@ mdemod_process_host(mdemod_ctx *ctx, const void *const *iq_host, const uint32_t 
 	HIP_TRY(hipDeviceSynchronize());
 	return mdemod_hostpipe_run(ctx, &ctx->pipe, ctx->st, ctx->params.n_streams, ctx->sample_bytes,
 	                           iq_host, n_samples, soft_host, soft_cap, n_symbols);
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_pin_host_buffer(mdemod_ctx *ctx, const void *base, size_t bytes)
-{
+try {
 	if (!ctx || !base || !bytes) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	return mdemod_hostpipe_pin(&ctx->pipe, base, bytes);
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_unpin_host_buffer(mdemod_ctx *ctx, const void *base)
-{
+try {
 	if (!ctx || !base) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	return mdemod_hostpipe_unpin(ctx->pipe, base);
-}
+} MDEMOD_API_CATCH
 
 /* ---- status / state ---------------------------------------------------------- */
 
 
 int
 mdemod_get_status(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_status *out, void *hip_stream)
-{
+try {
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	if (static_cast<uint64_t>(first) + count > ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	if (!count) return MDEMOD_OK;
@@ -470,12 +475,12 @@ mdemod_get_status(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_status
 		o.overflow = ovf[i];
 	}
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_get_lock_events(mdemod_ctx *ctx, uint32_t stream, mdemod_lock_event *out, uint32_t cap,
                        uint32_t *n, void *hip_stream)
-{
+try {
 	if (!ctx || !n) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	int rc = select_device(ctx);
@@ -493,7 +498,7 @@ mdemod_get_lock_events(mdemod_ctx *ctx, uint32_t stream, mdemod_lock_event *out,
 		HIP_TRY(hipStreamSynchronize(st));
 	}
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 #define ONE(field, hostvar, dir)                                                                   \
 	HIP_TRY(hipMemcpyAsync(dir ? static_cast<void *>(ctx->st.field + stream) : static_cast<void *>(&(hostvar)), \
@@ -502,7 +507,7 @@ mdemod_get_lock_events(mdemod_ctx *ctx, uint32_t stream, mdemod_lock_event *out,
 
 int
 mdemod_get_state(mdemod_ctx *ctx, uint32_t stream, mdemod_stream_state *out, void *hip_stream)
-{
+try {
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	int rc = select_device(ctx);
@@ -520,7 +525,7 @@ mdemod_get_state(mdemod_ctx *ctx, uint32_t stream, mdemod_stream_state *out, voi
 	out->pll_updown = (flags & MDEMOD_FLAG_UPDOWN_POS) ? 1 : -1;
 	out->t_dual_state = (flags >> MDEMOD_FLAG_DUAL_SHIFT) & 3;
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 /* A carrier phase / frequency word the reference's loop can hold: pll.c:113 leaves the phase inside (-2pi, 2pi), pll.c:60 adds
  * the frequency word, pll.c:126-128 clamp that to +-fmax.  The kernels' NCO relies on |phase| + |freq| < 4pi (demod_device.h:
@@ -545,7 +550,7 @@ clock_in_domain(const mdemod_ctx *ctx, const mdemod_stream_state &v)
 
 int
 mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in, void *hip_stream)
-{
+try {
 	if (!ctx || !in) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	if (in->t_dual_state != 1 && in->t_dual_state != 2) return MDEMOD_ERR_PARAM;
@@ -563,12 +568,12 @@ mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in
 	ONE(n_samples, v.n_samples, 1); ONE(n_symbols, v.n_symbols, 1); ONE(first_lock, v.first_lock_symbol, 1);
 	HIP_TRY(hipStreamSynchronize(st));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 #undef ONE
 
 int
 mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void *hip_stream)
-{
+try {
 	if (!ctx || !seed) return MDEMOD_ERR_PARAM;
 	if (seed->t_dual_state != 1 && seed->t_dual_state != 2) return MDEMOD_ERR_PARAM;
 	if (!carrier_in_domain(*seed) || !clock_in_domain(ctx, *seed)) return MDEMOD_ERR_PARAM;
@@ -579,41 +584,41 @@ mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void *hip
 	HIP_TRY(mdemod_launch_seed(ctx->st, ctx->tab.c, *seed, flags, ctx->params.bps, ctx->tab.use_rw ? 1 : 0,
 	                           ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, void *hip_stream)
-{
+try {
 	if (!ctx || !quarter_turns_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	HIP_TRY(mdemod_launch_rotate(ctx->st, quarter_turns_dev, ctx->params.n_streams, ctx->params.oqpsk ? 1 : 0, static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_set_carrier_seeds(mdemod_ctx *ctx, const float *freq_dev, const int32_t *updown_dev, void *hip_stream)
-{
+try {
 	if (!ctx || !freq_dev || !updown_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	HIP_TRY(mdemod_launch_carrier_seeds(ctx->st, freq_dev, updown_dev, ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_set_gain_seeds(mdemod_ctx *ctx, const float *gain_dev, void *hip_stream)
-{
+try {
 	if (!ctx || !gain_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	HIP_TRY(mdemod_launch_gain_seeds(ctx->st, gain_dev, ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_set_clock_seeds(mdemod_ctx *ctx, const float *t_freq_dev, void *hip_stream)
-{
+try {
 	if (!ctx || !t_freq_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -623,11 +628,11 @@ mdemod_set_clock_seeds(mdemod_ctx *ctx, const float *t_freq_dev, void *hip_strea
 	if (static_cast<double>(lo) < (static_cast<double>(c.t_center) - static_cast<double>(c.t_maxdev)) * (1.0 - 1e-6)) lo = nextafterf(lo, 1e30f);
 	HIP_TRY(mdemod_launch_clock_seeds(ctx->st, t_freq_dev, lo, c.step_fmax, ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_get_states(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_stream_state *out, void *hip_stream)
-{
+try {
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	if (static_cast<uint64_t>(first) + count > ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	if (!count) return MDEMOD_OK;
@@ -655,11 +660,11 @@ mdemod_get_states(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_stream
 		o.n_samples = nsamp[i]; o.n_symbols = nsym[i]; o.first_lock_symbol = fl[i];
 	}
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_copy_state(mdemod_ctx *dst, mdemod_ctx *src, void *hip_stream)
-{
+try {
 	if (!dst || !src) return MDEMOD_ERR_PARAM;
 	const mdemod_params &a = dst->params, &b = src->params;
 	if (a.n_streams != b.n_streams || a.bps != b.bps || a.device != b.device || dst->tab.use_rw != src->tab.use_rw ||
@@ -677,7 +682,7 @@ mdemod_copy_state(mdemod_ctx *dst, mdemod_ctx *src, void *hip_stream)
 	                       hipMemcpyDeviceToDevice, st));
 	HIP_TRY(hipMemcpyAsync(d.events, s.events, sizeof(mdemod_lock_event) * MDEMOD_MAX_LOCK_EVENTS * n, hipMemcpyDeviceToDevice, st));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 uint64_t
 mdemod_nominal_pitch(const mdemod_ctx *ctx, uint64_t n_samples)
@@ -688,14 +693,14 @@ mdemod_nominal_pitch(const mdemod_ctx *ctx, uint64_t n_samples)
 int
 mdemod_compact_soft(mdemod_ctx *ctx, const int8_t *soft_dev, uint64_t soft_stride_symbols,
                     int8_t *out_dev, uint64_t out_pitch_symbols, void *hip_stream)
-{
+try {
 	if (!ctx || !soft_dev || !out_dev || (soft_stride_symbols & 7) || (out_pitch_symbols & 7)) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	HIP_TRY(mdemod_launch_compact_rows(soft_dev, soft_stride_symbols, out_dev, out_pitch_symbols, ctx->st.sym_this_call,
 	                                   ctx->params.n_streams, static_cast<hipStream_t>(hip_stream)));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 const char *
 mdemod_kernel_name(const mdemod_ctx *ctx)
@@ -716,7 +721,7 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 
 int
 mdemod_plan_kernel(const mdemod_params *params, char *name, uint32_t name_cap, uint32_t *lds_bytes, uint32_t *block_threads)
-{
+try {
 	if (!params || !name || name_cap == 0 || params->n_streams == 0) return MDEMOD_ERR_PARAM;
 	mdemod_ctx *ctx = new (std::nothrow) mdemod_ctx();
 	if (!ctx) return MDEMOD_ERR_NOMEM;
@@ -730,7 +735,7 @@ mdemod_plan_kernel(const mdemod_params *params, char *name, uint32_t name_cap, u
 	}
 	delete ctx;
 	return rc;
-}
+} MDEMOD_API_CATCH
 
 uint32_t
 mdemod_history_len(const mdemod_ctx *ctx)
@@ -740,7 +745,7 @@ mdemod_history_len(const mdemod_ctx *ctx)
 
 int
 mdemod_get_history(mdemod_ctx *ctx, uint32_t stream, float *iq_pairs, void *hip_stream)
-{
+try {
 	if (!ctx || !iq_pairs) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	int rc = select_device(ctx);
@@ -764,11 +769,11 @@ mdemod_get_history(mdemod_ctx *ctx, uint32_t stream, float *iq_pairs, void *hip_
 		else memcpy(&iq_pairs[2*k], p, 8);
 	}
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs, void *hip_stream)
-{
+try {
 	if (!ctx || !iq_pairs) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	int rc = select_device(ctx);
@@ -797,42 +802,42 @@ mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs, void
 		                         sb, hpad, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 /* ---- tables -------------------------------------------------------------------- */
 
 int
 mdemod_get_rrc_table(const mdemod_ctx *ctx, float *out, uint32_t cap)
-{
+try {
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	if (cap < ctx->tab.rrc.size()) return MDEMOD_ERR_PARAM;
 	memcpy(out, ctx->tab.rrc.data(), ctx->tab.rrc.size() * sizeof(float));
 	return static_cast<int>(ctx->tab.rrc.size());
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_get_loop_constants(const mdemod_ctx *ctx, float out[8])
-{
+try {
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	const DemodConsts &c = ctx->tab.c;
 	const float v[8] = { c.pll_alpha, c.pll_beta, c.pll_fmax, c.t_alpha, c.t_beta, c.t_center, c.t_maxdev, ctx->tab.osf };
 	memcpy(out, v, sizeof(v));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_get_tanh_lut(const mdemod_ctx *ctx, float out[32])
-{
+try {
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	memcpy(out, ctx->tab.tanh_lut, sizeof(ctx->tab.tanh_lut));
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 /* ---- device self-tests of the scalar primitives --------------------------------- */
 
 int
 mdemod_selftest_sincos(mdemod_ctx *ctx, const float *x, uint32_t n, float *sin_out, float *cos_out)
-{
+try {
 	if (!ctx || !x || !sin_out || !cos_out) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -844,11 +849,11 @@ mdemod_selftest_sincos(mdemod_ctx *ctx, const float *x, uint32_t n, float *sin_o
 	if (e == hipSuccess) e = hipMemcpy(cos_out, d + 2 * static_cast<size_t>(n), sizeof(float) * n, hipMemcpyDeviceToHost);
 	(void)hipFree(d);
 	return e == hipSuccess ? MDEMOD_OK : MDEMOD_ERR_HIP;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_selftest_turncode(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch)
-{
+try {
 	if (!ctx || !n_mismatch) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -862,11 +867,11 @@ mdemod_selftest_turncode(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_misma
 	*n_mismatch = h;
 	if (n_checked) *n_checked = 2ull * 0x41800000ull;
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_selftest_cabsf(mdemod_ctx *ctx, uint64_t pairs, uint64_t *n_mismatch, uint64_t *n_fallback)
-{
+try {
 	if (!ctx || !n_mismatch || !pairs) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -880,11 +885,11 @@ mdemod_selftest_cabsf(mdemod_ctx *ctx, uint64_t pairs, uint64_t *n_mismatch, uin
 	*n_mismatch = h[0];
 	if (n_fallback) *n_fallback = h[1];
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_selftest_sinlut(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch)
-{
+try {
 	if (!ctx || !n_mismatch) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -898,11 +903,11 @@ mdemod_selftest_sinlut(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatc
 	*n_mismatch = h;
 	if (n_checked) *n_checked = 4ull * 65536ull;
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 int
 mdemod_selftest_hypot(mdemod_ctx *ctx, const float *xy, uint32_t n_pairs, float *out)
-{
+try {
 	if (!ctx || !xy || !out) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -913,6 +918,6 @@ mdemod_selftest_hypot(mdemod_ctx *ctx, const float *xy, uint32_t n_pairs, float 
 	if (e == hipSuccess) e = hipMemcpy(out, d + 2 * static_cast<size_t>(n_pairs), sizeof(float) * n_pairs, hipMemcpyDeviceToHost);
 	(void)hipFree(d);
 	return e == hipSuccess ? MDEMOD_OK : MDEMOD_ERR_HIP;
-}
+} MDEMOD_API_CATCH
 
 } /* extern "C" */

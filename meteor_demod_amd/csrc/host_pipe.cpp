@@ -15,8 +15,11 @@
  *     its pockets while the copy-in engine runs dry (r04: 40 of 57 GB/s);
  *   - the pack writes the pinned ring with non-temporal stores (no read-for-ownership of lines the CPU never reads again: the pack
  *     alone 65 -> 105 GB/s on 16 threads of an EPYC 9575F) on a pool of 12 threads;
- *   - sub-blocks of ~32 MiB, up to 64 of them: what the pipeline cannot overlap is one pack at the start and one kernel + copy-out +
- *     unpack at the end, and both are as long as a sub-block.
+ *   - up to 16 full-size sub-blocks of >= 32 MiB between two short ones at either end (a quarter, a half): what the pipeline cannot
+ *     overlap is one pack / copy-in at the start and one kernel + copy-out + unpack at the end, and both are as long as a sub-block;
+ *   - rows inside a range the caller pinned (mdemod_pin_host_buffer) are copied from where they are, one 2-D copy per sub-block.
+ * A call that fails part-way waits for whatever it has queued before it returns (Drain below): the copy engine may be reading the
+ * caller's rows and writing this function's vectors.
  * Every sub-block's lock events are copied aside on the compute stream because the next launch overwrites the context's list.
  * Pinned + device staging buffers grow only; three HIP streams, events for the hand-offs.
  * After the last sub-block the per-call counters of the context (symbols / lock events of "this
@@ -73,6 +76,16 @@ struct Slot {                    /* one of the staging sets */
 
 struct Pin { const unsigned char *base; size_t bytes; };
 
+struct HostPipe;
+/* every way out of mdemod_hostpipe_run, the failing ones too, leaves nothing in flight */
+struct Drain {
+	HostPipe *p;
+	explicit Drain(HostPipe *pipe) : p(pipe) {}
+	~Drain();
+	Drain(const Drain &) = delete;
+	Drain &operator=(const Drain &) = delete;
+};
+
 struct HostPipe {
 	Slot slot[kSlots];
 	std::vector<Pin> pins;       /* ranges of the caller's memory registered with the HIP runtime (mdemod_pin_host_buffer) */
@@ -80,6 +93,13 @@ struct HostPipe {
 	uint32_t ns = 0;
 	bool ready = false;
 };
+
+Drain::~Drain()
+{
+	if (p->s_in) (void)hipStreamSynchronize(p->s_in);
+	if (p->s_cmp) (void)hipStreamSynchronize(p->s_cmp);
+	if (p->s_out) (void)hipStreamSynchronize(p->s_out);
+}
 
 template <typename T>
 int
@@ -294,6 +314,7 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 	std::vector<uint32_t> produced(ns, 0), events(ns, 0);
 	std::vector<mdemod_lock_event> ev_store;                  /* merged lock events: [stream][32] (only if any) */
 	int result = MDEMOD_OK;
+	const Drain drain(p);                                     /* declared after the vectors the queued copies read: destroyed before them */
 	auto sub_lo = [&](uint32_t s, uint32_t k) { return static_cast<uint32_t>(static_cast<uint64_t>(n_samples[s]) * cumw[k] / cumw[K]); };
 
 	auto unpack = [&](Slot &sl) -> int {

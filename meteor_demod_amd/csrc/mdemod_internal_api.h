@@ -10,6 +10,11 @@
 #include "../../include/meteor_demod_amd.h"
 
 #ifdef __cplusplus
+/* The boundary is C: no exception may cross it (a caller written in C has nothing to catch it with, and an uncaught one is abort()).
+ * Every int-returning entry is a function-try-block that ends in this: std::bad_alloc from a vector, std::system_error from a thread
+ * that could not be started and anything else come back as MDEMOD_ERR_NOMEM - "a resource was not to be had". */
+#include <new>
+#define MDEMOD_API_CATCH catch (...) { return MDEMOD_ERR_NOMEM; }
 extern "C" {
 #endif
 

@@ -653,7 +653,7 @@ extern "C" int
 mdemod_estimate_carrier_chirp(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
                               const uint64_t *starts_dev, const float *chirp_dev, uint32_t n_windows, uint32_t window_samples,
                               float *freq_dev, float *quality_dev, void *hip_stream)
-{
+try {
 	if (!params || !iq_dev || !starts_dev || !freq_dev || !quality_dev || n_samples == 0) return MDEMOD_ERR_PARAM;
 	if (params->samplerate <= 0 || params->symrate <= 0 || (params->bps != 8 && params->bps != 16 && params->bps != 32)) return MDEMOD_ERR_PARAM;
 	if (n_windows == 0) return MDEMOD_OK;
@@ -683,21 +683,21 @@ mdemod_estimate_carrier_chirp(const mdemod_params *params, const void *iq_dev, u
 #undef LAUNCH_LINE
 	HTRY(hipGetLastError());
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 extern "C" int
 mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
                         const uint64_t *starts_dev, uint32_t n_windows, uint32_t window_samples,
                         float *freq_dev, float *quality_dev, void *hip_stream)
-{
+try {
 	return mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, starts_dev, nullptr, n_windows, window_samples, freq_dev, quality_dev, hip_stream);
-}
+} MDEMOD_API_CATCH
 
 extern "C" int
 mdemod_estimate_clock(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
                       const uint64_t *starts_dev, const float *carrier_dev, const float *chirp_dev,
                       uint32_t n_windows, uint32_t window_samples, float *t_freq_dev, float *quality_dev, void *hip_stream)
-{
+try {
 	if (!params || !iq_dev || !starts_dev || !t_freq_dev || !quality_dev || n_samples == 0) return MDEMOD_ERR_PARAM;
 	if (params->samplerate <= 0 || params->symrate <= 0 || params->interp_factor <= 0 || (params->bps != 8 && params->bps != 16 && params->bps != 32)) return MDEMOD_ERR_PARAM;
 	if (n_windows == 0) return MDEMOD_OK;
@@ -729,7 +729,7 @@ mdemod_estimate_clock(const mdemod_params *params, const void *iq_dev, uint64_t 
 #undef LAUNCH_CLK
 	HTRY(hipGetLastError());
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH
 
 extern "C" void
 mdemod_recording_default_opts(mdemod_recording_opts *o)
@@ -1727,9 +1727,9 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
                             const void *iq_dev, uint64_t n_samples,
                             int8_t *soft_dev, uint64_t soft_cap_symbols,
                             mdemod_recording_report *rep, void *hip_stream)
-{
+try {
 	return demodulate_recording_impl(params, opts_in, iq_dev, n_samples, soft_dev, soft_cap_symbols, rep, hip_stream, nullptr);
-}
+} MDEMOD_API_CATCH
 
 /* Host-buffer convenience (PCIe inclusive): what the C CLI's --tiled mode calls.  The head goes in first; the rest of the
  * recording is copied by a second thread on its own stream while the serial head runs (one wave, ~0.1 s: about what 1 GB of
@@ -1739,7 +1739,7 @@ mdemod_demodulate_recording_host(const mdemod_params *params, const mdemod_recor
                                  const void *iq_host, uint64_t n_samples,
                                  int8_t *soft_host, uint64_t soft_cap_symbols,
                                  mdemod_recording_report *rep)
-{
+try {
 	if (!params || !iq_host || !soft_host || !rep) return MDEMOD_ERR_PARAM;
 	const bool dbg = opts && opts->debug != 0;
 	const auto t_in = std::chrono::steady_clock::now();
@@ -1795,4 +1795,4 @@ mdemod_demodulate_recording_host(const mdemod_params *params, const mdemod_recor
 	}
 	mark("symbols copied out");
 	return MDEMOD_OK;
-}
+} MDEMOD_API_CATCH

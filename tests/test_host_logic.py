@@ -421,3 +421,23 @@ def test_bench_bound_block_reads_the_tracked_profile():
         assert b["hbm_frac"] < v["pipe_busy_ceiling_hbm_frac"] <= v["ceiling_hbm_frac"] < 0.40, (tag, b["hbm_frac"], v)
         assert 0.7 < v["frac_of_measured"] < 1.0
     assert abs(bench.flops_per_sample_of(bench.demod_config("c1")[0]) - 122.7) < 0.5
+
+
+def test_no_exception_crosses_the_c_boundary():
+    """Every int-returning extern "C" entry of the library is a function-try-block ending in MDEMOD_API_CATCH (mdemod_create has
+    its own, which also gives the half-built context back): a std::bad_alloc inside the library must come back as
+    MDEMOD_ERR_NOMEM, not as abort() in a caller written in C."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "meteor_demod_amd", "csrc")
+    api = open(os.path.join(root, "demod_api.cpp")).read()
+    block = api[api.index('extern "C" {'):api.index('} /* extern "C" */')]
+    entries = re.findall(r"\nint\n(mdemod_\w+)\(([^{]*?)\)\n(try )?\{", block)
+    assert len(entries) >= 30
+    unguarded = [name for name, _args, guard in entries if not guard and name != "mdemod_create"]
+    assert not unguarded, unguarded
+    assert "mdemod_destroy(ctx);\n\t\treturn MDEMOD_ERR_NOMEM;" in block              # mdemod_create's own handler
+    rec = open(os.path.join(root, "recording.hip")).read()
+    for name, guard in re.findall(r'extern "C" int\n(mdemod_\w+)\([^{]*?\)\n(try )?\{', rec):
+        assert guard, name
+    assert block.count("} MDEMOD_API_CATCH") == len(entries) - 1
