@@ -163,6 +163,17 @@ selftest_cabsf_kernel(uint64_t per_thread, unsigned long long *out /* [2]: misma
 	if (fb) atomicAdd(&out[1], (unsigned long long)fb);
 }
 
+/* The lock events of this call, of the streams that have any, into a list of the same layout (mdemod_process_host keeps every
+ * sub-block's events aside: the next launch overwrites the context's list).  Almost always nothing to do: streams lock once. */
+__global__ void
+copy_events_kernel(const mdemod_lock_event *src, const uint32_t *ev_this_call, mdemod_lock_event *dst, uint32_t n_streams)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_streams) return;
+	const uint32_t n = min(ev_this_call[s], (uint32_t)MDEMOD_MAX_LOCK_EVENTS);
+	for (uint32_t e = 0; e < n; e++) dst[(size_t)s * MDEMOD_MAX_LOCK_EVENTS + e] = src[(size_t)s * MDEMOD_MAX_LOCK_EVENTS + e];
+}
+
 /* Every float with |x| < 16, both signs: division-free turn code vs the real division. */
 __global__ void
 selftest_turncode_kernel(unsigned long long *mismatch)
@@ -317,6 +328,14 @@ mdemod_launch_compact_rows(const int8_t *src, uint64_t src_pitch_sym, int8_t *ds
 {
 	if (n_streams == 0) return hipSuccess;
 	hipLaunchKernelGGL(compact_rows_kernel, dim3(n_streams), dim3(128), 0, stream, src, src_pitch_sym, dst, dst_pitch_sym, counts_dev, n_streams);
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_copy_events(const DemodStateSoA &st, mdemod_lock_event *dst, uint32_t n_streams, hipStream_t stream)
+{
+	if (n_streams == 0) return hipSuccess;
+	hipLaunchKernelGGL(copy_events_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st.events, st.ev_this_call, dst, n_streams);
 	return hipGetLastError();
 }
 

@@ -300,6 +300,9 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		for (uint32_t k = 0; k < K; k++) cumw.push_back(cumw.back() + 1);
 	}
 #ifdef MDEMOD_PIPE_TRACE
+	/* diagnosis only (results are wrong with any of them): MDEMOD_PIPE_SKIP bit 0 no kernel / compaction, bit 1 no copy-out, bit 2 no
+	   CPU unpack, bit 3 no compaction only, bit 4 no demodulation kernel only - which of them slows the copy-ins from 2.36 ms alone to 2.48 ms in the pipeline? */
+	const int tr_skip = getenv("MDEMOD_PIPE_SKIP") ? atoi(getenv("MDEMOD_PIPE_SKIP")) : 0;
 	double tr_pack = 0, tr_unpack = 0, tr_wait_in = 0, tr_enq = 0, tr_layout = 0, tr_wait_out = 0;
 	std::vector<hipEvent_t> tr_e0(80), tr_e1(80), tr_k0(80), tr_k1(80), tr_o1(80);
 	for (int i = 0; i < 80; i++) { (void)hipEventCreate(&tr_e0[i]); (void)hipEventCreate(&tr_e1[i]); (void)hipEventCreate(&tr_k0[i]); (void)hipEventCreate(&tr_k1[i]); (void)hipEventCreate(&tr_o1[i]); }
@@ -315,6 +318,8 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 	std::vector<mdemod_lock_event> ev_store;                  /* merged lock events: [stream][32] (only if any) */
 	int result = MDEMOD_OK;
 	const Drain drain(p);                                     /* declared after the vectors the queued copies read: destroyed before them */
+	/* (Starting the sub-blocks on multiples of 128 or 1 024 samples of a stream - whole bus transactions for the copy engine - was
+	 * measured in r05: the same 55.7 GB/s per 2-D copy as with pieces that begin anywhere.) */
 	auto sub_lo = [&](uint32_t s, uint32_t k) { return static_cast<uint32_t>(static_cast<uint64_t>(n_samples[s]) * cumw[k] / cumw[K]); };
 
 	auto unpack = [&](Slot &sl) -> int {
@@ -341,6 +346,9 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		parallel_streams(ns, w, [&](uint32_t a, uint32_t b) {
 			for (uint32_t s = a; s < b; s++) {
 				uint32_t m = sl.h_prod[s];
+#ifdef MDEMOD_PIPE_TRACE
+				if (tr_skip & 4) m = 0;
+#endif
 				const uint32_t room = soft_cap[s] > produced[s] ? soft_cap[s] - produced[s] : 0;
 				if (m > room) m = room;                           /* overflow is reported below */
 				if (m) stream_copy(reinterpret_cast<unsigned char *>(soft_host[s]) + 2 * static_cast<size_t>(produced[s]),
@@ -453,6 +461,9 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 #ifdef MDEMOD_PIPE_TRACE
 		(void)hipEventRecord(tr_k0[k], p->s_cmp);
 #endif
+#ifdef MDEMOD_PIPE_TRACE
+		if (!(tr_skip & (1 | 16)))
+#endif
 		rc = mdemod_process_device(ctx, sl.d_iq, sl.d_off, sl.d_cnt, sl.d_soft, cap, cap, p->s_cmp);
 		if (rc) return rc;
 		/* The rows of the LAST sub-blocks go to the pinned host buffer straight from this kernel (posted writes over the link), not
@@ -463,16 +474,24 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 #define MDEMOD_PIPE_ZC_LAST 3
 #endif
 		const bool zc_out = K >= 8 && k + MDEMOD_PIPE_ZC_LAST >= K;
+#ifdef MDEMOD_PIPE_TRACE
+		if (!(tr_skip & (1 | 8)))
+#endif
 		PIPE_TRY(mdemod_launch_compact_rows(sl.d_soft, cap, zc_out ? sl.h_soft : sl.d_pack, pitch, st.sym_this_call, ns, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_prod, st.sym_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_ev, st.ev_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
-		if (K > 1) PIPE_TRY(hipMemcpyAsync(sl.d_events, st.events, sizeof(mdemod_lock_event) * MDEMOD_MAX_LOCK_EVENTS * ns, hipMemcpyDeviceToDevice, p->s_cmp));
+		/* (only the events there are: the whole list is 512 bytes per stream - 8 MB and 0.46 ms of blit kernel per sub-block at 16 384
+		   streams, the last of them in the call's tail; r05) */
+		if (K > 1) PIPE_TRY(mdemod_launch_copy_events(st, sl.d_events, ns, p->s_cmp));
 #ifdef MDEMOD_PIPE_TRACE
 		(void)hipEventRecord(tr_k1[k], p->s_cmp);
 #endif
 		PIPE_TRY(hipEventRecord(sl.ev_k, p->s_cmp)); sl.used_k = true;
 		/* ---- D2H of the nominal-pitch copy ---- */
 		PIPE_TRY(hipStreamWaitEvent(p->s_out, sl.ev_k, 0));
+#ifdef MDEMOD_PIPE_TRACE
+		if (!(tr_skip & 2))
+#endif
 		if (!zc_out) PIPE_TRY(hipMemcpyAsync(sl.h_soft, sl.d_pack, pack_bytes, hipMemcpyDeviceToHost, p->s_out));
 #ifdef MDEMOD_PIPE_TRACE
 		(void)hipEventRecord(tr_o1[k], p->s_out);
