@@ -533,7 +533,10 @@ main(int argc, char **argv)
 	int quiet = 0, batch = 0, oqpsk = 0, bps = 0, samplerate = -1, stdout_mode = 0, device = 0, tiled = 0;
 	int tile_samples = 0, pilot_margin = -1, carrier_seed = -1, update_interval = -1;
 	const char *output_fname = NULL;
-	int devs[MAX_DEVICES], n_dev = 0, plan = 0, force_tui = 0, jobs = 4;
+	int devs[MAX_DEVICES], n_dev = 0, plan = 0, jobs = 4;
+#ifdef MDEMOD_TUI
+	int force_tui = 0;
+#endif
 	int c;
 
 	while ((c = getopt_long(argc, argv, "a:Bb:d:f:hm:o:O:qR:r:s:S:v", longopts, NULL)) != -1) {
@@ -545,7 +548,11 @@ main(int argc, char **argv)
 			if (!n_dev) { fprintf(stderr, "--devices: a comma separated list of GPU ordinals\n"); return 1; }
 			break;
 		case 0x07: plan = 1; break;
+#ifdef MDEMOD_TUI
 		case 0x09: force_tui = 1; break;
+#else
+		case 0x09: break;                             /* --tui in a build without the display: accepted, nothing to draw */
+#endif
 		case 0x0a: jobs = atoi(optarg); if (jobs < 1) { fprintf(stderr, "--jobs: a positive number\n"); return 1; } break;
 		case 0x08:
 #ifdef MDEMOD_TUI
@@ -605,8 +612,14 @@ main(int argc, char **argv)
 	struct worker *ws = NULL;
 	int n_workers = 0;
 	/* every way out from here on: files closed, nothing left allocated (the sanitizer builds of tests/test_sanitize.py look) */
-#define LEAVE(code) do { close_all(io, n_files); for (int d_ = 0; d_ < n_workers; d_++) free(ws[d_].io); free(ws); \
-		for (int i_ = 0; i_ < n_files; i_++) free(io[i_].out_name); free(io); return (code); } while (0)
+#define LEAVE(code) do { \
+		close_all(io, n_files); \
+		for (int d_ = 0; d_ < n_workers; d_++) { free(ws[d_].io); } \
+		free(ws); \
+		for (int i_ = 0; i_ < n_files; i_++) { free(io[i_].out_name); } \
+		free(io); \
+		return (code); \
+	} while (0)
 
 	for (int i = 0; i < n_files; i++) {
 		io[i].in_name = argv[optind + i];

@@ -165,7 +165,7 @@ cj_schedule(double S, double thr, double f_hi)
 CJ_HD int
 clock_jump_run(float &p, float f, float thr, float f_hi, float inv, const cj_sched &J)
 {
-	float prev = p, count = 0.0f;
+	float count = 0.0f;
 	int early = 0;
 	/* a lane the loop's correction set back (rare below 3 MS/s).  Bounded by the host's count: a clock word outside the loop's range
 	 * (timing.c:80-86; mdemod_set_state and mdemod_set_clock_seeds keep such words out, this is the second fence) must not spin a wave -
@@ -179,7 +179,8 @@ clock_jump_run(float &p, float f, float thr, float f_hi, float inv, const cj_sch
 	if (k & 4) { p = p + f; p = p + f; p = p + f; p = p + f; }
 	if (k & 2) { p = p + f; p = p + f; }
 	if (k & 1) p = p + f;
-	prev = p; p = p + f;
+	float prev = p;
+	p = p + f;
 	float B = J.B0;
 	for (int b = 0; b < J.nb; b++) {
 		const bool last = b == J.nb - 1;
