@@ -1,0 +1,141 @@
+"""GPU tests (-m gpu): the kernels stay inside what they were given.  There is no address sanitizer for the device on this pool, so the
+output rows sit in a buffer of canaries (before the first row, behind the last, between a row's capacity and the row stride, behind a
+stream's own symbols) and the input streams sit in a buffer of full-scale garbage (a sample read from outside a stream's block, and
+used, changes the bytes against the oracle's).  Every kernel family, ragged batches with empty and one-sample streams, stream counts
+that are no multiple of a wave or a block."""
+from __future__ import annotations
+
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from meteor_demod_amd import DemodConfig, Demodulator, synth
+from meteor_demod_amd.demod import check
+
+pytestmark = pytest.mark.gpu
+
+CANARY = 0x5A
+# (name, configuration, environment, part of the kernel's name)
+FAMILIES = [
+    ("std_qpsk", DemodConfig(samplerate=230000), {"MDEMOD_LAT": "0"}, "demod_kernel_rot "),
+    ("std_oqpsk_u8", DemodConfig(samplerate=230000, symrate=80000, oqpsk=True, bps=8), {"MDEMOD_LAT": "0"}, "demod_kernel_rot "),
+    ("wide", DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8), {"MDEMOD_LAT": "0"}, "demod_kernel_rotp"),
+    ("mid", DemodConfig(samplerate=1024000), {"MDEMOD_LAT": "0"}, "demod_kernel_rotp"),
+    ("far_u8", DemodConfig(samplerate=2150000, rrc_order=20, interp_factor=3, bps=8), {"MDEMOD_LAT": "0"}, "demod_kernel_rotp"),
+    ("hybrid_f32", DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32), {"MDEMOD_LAT": "0"}, "demod_kernel_roth"),
+    ("gather", DemodConfig(samplerate=10000000), {"MDEMOD_LAT": "0"}, "demod_kernel_gat"),
+    ("v1_ring", DemodConfig(samplerate=230000), {"MDEMOD_LAT": "0", "MDEMOD_KERNEL": "v1"}, "demod_kernel "),
+    ("v1_ring_f32", DemodConfig(samplerate=230000, bps=32), {"MDEMOD_LAT": "0", "MDEMOD_KERNEL": "v1"}, "demod_kernel "),
+    ("latency", DemodConfig(samplerate=230000), {"MDEMOD_LAT": "1"}, "demod_kernel_lat"),
+    ("latency_oqpsk_f32", DemodConfig(samplerate=640000, symrate=80000, oqpsk=True, rrc_order=24, interp_factor=4, bps=32), {"MDEMOD_LAT": "1"}, "demod_kernel_lat"),
+]
+NP_DTYPE = {8: np.uint8, 16: np.int16, 32: np.float32}
+
+
+def _garbage(shape, bps, rng):
+    if bps == 8:
+        return rng.choice(np.array([0, 255], np.uint8), size=shape)
+    if bps == 16:
+        return rng.choice(np.array([-32768, 32767], np.int16), size=shape)
+    return rng.choice(np.array([-3.0e4, 3.0e4], np.float32), size=shape)
+
+
+@pytest.mark.parametrize("name,cfg,env,kernel", FAMILIES, ids=[f[0] for f in FAMILIES])
+@pytest.mark.parametrize("tight", [False, True], ids=["roomy", "tight"])
+def test_kernels_stay_inside_their_rows(name, cfg, env, kernel, tight, gpu_device, monkeypatch):
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    per_sym = cfg.samplerate / cfg.symrate
+    base = int(400 * per_sym)                                            # a few hundred symbols per stream: the oracle finishes in seconds
+    lens = [0, 1, 2, base, base + 1, 63, 64, 65, 3 * base + 7, 0, base // 2, 5, 2 * base, base + 3, 17, base, 4 * base + 1]
+    lens += [base + i for i in range(70 - len(lens))]                    # 70 streams: more than a wave, no multiple of anything
+    ns = len(lens)
+    streams = [synth.make_stream(9000 + i, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=37.0 * i - 900.0, esn0_db=15.0) for i in range(ns)]
+    dt = NP_DTYPE[cfg.bps]
+    iqs = []
+    for s, n in zip(streams, lens):
+        a = synth.generate_host(s, n) if n else np.zeros((0, 2), np.int16)
+        if cfg.bps == 8:
+            a = (np.clip(a // 64, -128, 127) + 128).astype(np.uint8)
+        elif cfg.bps == 32:
+            a = a.astype(np.float32)
+        iqs.append(a)
+    # the streams inside full-scale garbage, at odd sample offsets (no 16-byte alignment)
+    offsets, pos = [], 301
+    for a in iqs:
+        offsets.append(pos)
+        pos += a.shape[0] + int(rng.integers(1, 9))
+    flat = _garbage((pos + 500, 2), cfg.bps, rng).astype(dt)
+    for o, a in zip(offsets, iqs):
+        flat[o:o + a.shape[0]] = a
+    with Demodulator(cfg, ns) as d:
+        assert kernel in d.kernel_name + " ", d.kernel_name
+        cap = d.max_symbols(max(lens)) if not tight else 96              # tight: most streams produce more than fits (overflow reported, nothing written behind cap)
+        stride = cap + 24
+        pad = 4096
+        big = torch.full((pad + ns * stride * 2 + pad,), CANARY, dtype=torch.int8, device="cuda")
+        soft = big[pad: pad + ns * stride * 2].view(ns, stride, 2)
+        flat_d = torch.from_numpy(flat).cuda()
+        off_d = torch.tensor(offsets, dtype=torch.int64).cuda()
+        cnt_d = torch.tensor(lens, dtype=torch.int32).cuda()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(d._lib.mdemod_process_device(d._ctx, C.c_void_p(flat_d.data_ptr()), C.c_void_p(off_d.data_ptr()), C.c_void_p(cnt_d.data_ptr()),
+                                           C.c_void_p(soft.data_ptr()), stride, cap, stream), "mdemod_process_device")
+        torch.cuda.synchronize()
+        st = d.status()
+        got = big.cpu().numpy()
+    assert (got[:pad] == CANARY).all(), "bytes written in front of the first row"
+    assert (got[pad + ns * stride * 2:] == CANARY).all(), "bytes written behind the last row"
+    rows = got[pad: pad + ns * stride * 2].reshape(ns, stride, 2)
+    assert (rows[:, cap:] == CANARY).all(), "bytes written between a row's capacity and the stride"
+    for i, a in enumerate(iqs):
+        want = O.oracle_demod(cfg, a)[0] if a.shape[0] else np.zeros((0, 2), np.int8)
+        assert st[i].symbols_this_call == want.shape[0], (i, lens[i])
+        assert st[i].overflow == (1 if want.shape[0] > cap else 0), i
+        m = min(cap, want.shape[0])
+        assert np.array_equal(rows[i, :m], want[:m]), (i, lens[i])      # full-scale garbage either side of the block changed nothing
+        assert (rows[i, m:cap] == CANARY).all(), (i, "bytes written behind the stream's own symbols")
+
+
+@pytest.mark.parametrize("log2n", [17, 21], ids=["one_block", "fourteen_sub_blocks"])
+@pytest.mark.parametrize("pinned", [False, True], ids=["staged", "pinned_rows"])
+def test_host_entry_stays_inside_the_callers_rows(pinned, log2n, gpu_device):
+    """mdemod_process_host: output rows of the caller's inside canaries (the unpack's streaming stores: an aligning head, 64-byte
+    bodies, a tail), input rows inside full-scale garbage; several sub-blocks (the pipeline), capacities that fit exactly."""
+    cfg = DemodConfig(samplerate=230000)
+    rng = np.random.default_rng(77)
+    ns, n = 48, 1 << log2n                                                # 25 MB: one block; 400 MB: 12 sub-blocks + the short ones at either end, the last three out through the compaction kernel
+    st = synth.make_stream(4242, cfg.samplerate, cfg.symrate, f0_hz=250.0, esn0_db=15.0)
+    one = synth.generate_host(st, n + ns)
+    gap = 37                                                              # samples of garbage between the rows
+    buf = _garbage((ns, n + gap, 2), 16, rng).astype(np.int16)
+    for s in range(ns):
+        buf[s, :n] = one[s: s + n]                                        # every stream its own shift of the signal
+    want = [O.oracle_demod(cfg, np.ascontiguousarray(buf[s, :n]))[0] for s in range(0, ns, 12)]
+    with Demodulator(cfg, ns) as d:
+        if pinned:
+            d.pin_host(buf)
+        caps = [d.max_symbols(n)] * ns
+        caps[0] = want[0].shape[0]                                        # exactly what stream 0 produces: the last byte written is the row's last
+        stride = max(caps) + 19
+        pad = 1000
+        out = np.full(pad + ns * stride * 2 + pad, CANARY, np.int8)
+        rows = out[pad: pad + ns * stride * 2].reshape(ns, stride, 2)
+        iq_ptrs = (C.c_void_p * ns)(*[buf[s].ctypes.data for s in range(ns)])
+        counts = (C.c_uint32 * ns)(*([n] * ns))
+        soft_ptrs = (C.c_void_p * ns)(*[rows[s].ctypes.data for s in range(ns)])
+        soft_caps = (C.c_uint32 * ns)(*caps)
+        produced = (C.c_uint32 * ns)()
+        check(d._lib.mdemod_process_host(d._ctx, iq_ptrs, counts, soft_ptrs, soft_caps, produced), "mdemod_process_host")
+        if pinned:
+            d.unpin_host(buf)
+    assert (out[:pad] == CANARY).all() and (out[pad + ns * stride * 2:] == CANARY).all()
+    for s in range(ns):
+        assert (rows[s, produced[s]:] == CANARY).all(), s
+    for k, s in enumerate(range(0, ns, 12)):
+        assert produced[s] == want[k].shape[0] and np.array_equal(rows[s, : produced[s]], want[k]), s
