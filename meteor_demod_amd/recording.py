@@ -81,10 +81,11 @@ def estimate_clock_native(cfg, iq, starts, window_samples: int, device: int = 0,
 def demodulate_recording_native(cfg, iq, tile_samples: int = 0, acquire_samples: int = AUTO, frame_samples: int = AUTO,
                                 settle_samples: int = AUTO, repair: bool = True, pilot_block: int = 65536,
                                 pilot_margin_symbols: int = AUTO, max_pilot_samples: int = 0xFFFFFFFFFFFFFFFF, match_symbols: int = 192,
-                                device: int = 0, carrier_seed: str = "spectrum", soft_capacity: int = 0, clock_seed: str = "spectrum"):
+                                device: int = 0, carrier_seed: str = "spectrum", soft_capacity: int = 0, clock_seed: str = "spectrum", soft=None):
     """``mdemod_demodulate_recording`` on a device tensor [n, 2]: returns (soft int8 [m, 2] device tensor, report).
     Lengths in samples; 0 / AUTO take the library's defaults (see include/meteor_demod_amd.h).
-    ``soft_capacity`` (symbols; 0 = nominal rate + 5 % + 65536) is what the callee checks its output against."""
+    ``soft_capacity`` (symbols; 0 = nominal rate + 5 % + 65536) is what the callee checks its output against; ``soft``: the
+    caller's own [capacity, 2] int8 device tensor to write into (the bounds tests put canaries around it)."""
     import ctypes as C
     import torch
     from . import _capi
@@ -103,7 +104,12 @@ def demodulate_recording_native(cfg, iq, tile_samples: int = 0, acquire_samples:
     n = int(iq.shape[0])
     p = cfg.to_c(1, device)
     cap = int(soft_capacity) or int(n * cfg.symrate / cfg.samplerate * 1.05) + 65536   # stitched output: nominal rate + slack (checked by the callee)
-    soft = torch.empty((cap, 2), dtype=torch.int8, device=iq.device)
+    if soft is None:
+        soft = torch.empty((cap, 2), dtype=torch.int8, device=iq.device)
+    elif not (soft.is_cuda and soft.dtype == torch.int8 and soft.dim() == 2 and soft.shape[1] == 2 and soft.is_contiguous() and soft.device == iq.device):
+        raise ValueError("soft must be a contiguous [capacity, 2] int8 tensor on the input's device")
+    else:
+        cap = int(soft.shape[0])
     rep = _capi.MdemodRecordingReport()
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     _capi.check(lib.mdemod_demodulate_recording(C.byref(p), C.byref(opts), C.c_void_p(iq.data_ptr()), n,

@@ -139,3 +139,33 @@ def test_host_entry_stays_inside_the_callers_rows(pinned, log2n, gpu_device):
         assert (rows[s, produced[s]:] == CANARY).all(), s
     for k, s in enumerate(range(0, ns, 12)):
         assert produced[s] == want[k].shape[0] and np.array_equal(rows[s, : produced[s]], want[k]), s
+
+
+@pytest.mark.parametrize("tag,cfg,log2n", [("qpsk", DemodConfig(samplerate=230000), 23), ("oqpsk", DemodConfig(samplerate=230000, symrate=80000, oqpsk=True), 23)],
+                         ids=["qpsk", "oqpsk"])
+def test_recording_entry_stays_inside_its_output(tag, cfg, log2n, gpu_device):
+    """mdemod_demodulate_recording (serial head + tile banks + stitching + compaction): the stitched output inside canaries, with
+    room to spare and with exactly the capacity it needs; one symbol less is MDEMOD_ERR_OVERFLOW and still writes nothing outside."""
+    import torch
+    from meteor_demod_amd.recording import demodulate_recording_native
+    n = 1 << log2n
+    st = synth.make_stream(515, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=800.0, esn0_db=14.0)
+    iq = synth.generate_device([st], n)[0].contiguous()
+    ref, rep0 = demodulate_recording_native(cfg, iq)
+    m = int(rep0.n_symbols)
+    assert m > 0.9 * n * cfg.symrate / cfg.samplerate and rep0.n_tiles > 1
+    pad = 8192
+    for cap, ok in ((m + 5000, True), (m, True), (m - 1, False)):
+        big = torch.full((pad + 2 * cap + pad,), CANARY, dtype=torch.int8, device="cuda")
+        soft = big[pad: pad + 2 * cap].view(cap, 2)
+        if ok:
+            out, rep = demodulate_recording_native(cfg, iq, soft=soft)
+            assert int(rep.n_symbols) == m and torch.equal(out, ref)
+        else:
+            with pytest.raises(RuntimeError, match="-4|overflow|OVERFLOW"):
+                demodulate_recording_native(cfg, iq, soft=soft)
+        torch.cuda.synchronize()
+        got = big.cpu().numpy()
+        assert (got[:pad] == CANARY).all() and (got[pad + 2 * cap:] == CANARY).all(), (cap, ok)
+        if ok:
+            assert (got[pad + 2 * m: pad + 2 * cap] == CANARY).all(), "bytes written behind the recording's own symbols"
