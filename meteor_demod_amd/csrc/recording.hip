@@ -1036,8 +1036,8 @@ struct Stitcher {
 		   symbols starts its body at 36 / 36 / 16 / 7 / 4.7 %, one that has settled for 32 000 at 41 / 36 / 14 / 5.4 / 3 %, and more
 		   does not change it.  With bodies of 23 000 symbols (the ~1000-tile regime) the first thousands of symbols are a small part
 		   and the share of 4096-symbol windows below 0.99 is 0.16 % either way (the reference's own pairs: 0.054 %); with bodies of
-		   8 192 symbols (the lane-kernel regime) it is 0.5 % at 24 000 and 0.2 % at 32 000.  So: short bodies settle for 32 000 where
-		   the caller does not say - EXCEPT behind the hand-over, where the serial run itself is still drifting in with its carrier loop's
+		   8 192 symbols (the lane-kernel regime) it is 0.5 % at 24 000 and 0.2 % at 32 000.  So: tiles settle for 32 000 where
+		   the caller does not say (all of them: see the next comment) - EXCEPT behind the hand-over, where the serial run itself is still drifting in with its carrier loop's
 		   16 200-symbol pole and a tile that has had longer to converge on the carrier agrees with it LESS (windows of 0.07 .. 0.35 in
 		   tiles 1 .. 3 with 32 000 and 40 000; the seed model of seed_tiles covers one time constant back, not two). */
 		/* (measured on the SAME windows as 47 converged twins of the serial run - recording.tiled_vs_twins, where the bad windows are
