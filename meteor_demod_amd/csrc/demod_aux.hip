@@ -166,12 +166,17 @@ selftest_cabsf_kernel(uint64_t per_thread, unsigned long long *out /* [2]: misma
 /* The lock events of this call, of the streams that have any, into a list of the same layout (mdemod_process_host keeps every
  * sub-block's events aside: the next launch overwrites the context's list).  Almost always nothing to do: streams lock once. */
 __global__ void
-copy_events_kernel(const mdemod_lock_event *src, const uint32_t *ev_this_call, mdemod_lock_event *dst, uint32_t n_streams)
+copy_events_kernel(const mdemod_lock_event *src, const uint32_t *ev_this_call, mdemod_lock_event *dst, uint32_t n_streams,
+                   const uint32_t *sym_this_call, uint32_t *sym_out, uint32_t *ev_out)
 {
 	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n_streams) return;
-	const uint32_t n = min(ev_this_call[s], (uint32_t)MDEMOD_MAX_LOCK_EVENTS);
+	const uint32_t n_ev = ev_this_call[s];
+	const uint32_t n = min(n_ev, (uint32_t)MDEMOD_MAX_LOCK_EVENTS);
 	for (uint32_t e = 0; e < n; e++) dst[(size_t)s * MDEMOD_MAX_LOCK_EVENTS + e] = src[(size_t)s * MDEMOD_MAX_LOCK_EVENTS + e];
+	/* the two counters of this launch, straight into the caller's (pinned host) arrays when it gives any */
+	if (sym_out) sym_out[s] = sym_this_call[s];
+	if (ev_out) ev_out[s] = n_ev;
 }
 
 /* Every float with |x| < 16, both signs: division-free turn code vs the real division. */
@@ -332,10 +337,11 @@ mdemod_launch_compact_rows(const int8_t *src, uint64_t src_pitch_sym, int8_t *ds
 }
 
 hipError_t
-mdemod_launch_copy_events(const DemodStateSoA &st, mdemod_lock_event *dst, uint32_t n_streams, hipStream_t stream)
+mdemod_launch_copy_events(const DemodStateSoA &st, mdemod_lock_event *dst, uint32_t n_streams, uint32_t *sym_out, uint32_t *ev_out, hipStream_t stream)
 {
 	if (n_streams == 0) return hipSuccess;
-	hipLaunchKernelGGL(copy_events_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st.events, st.ev_this_call, dst, n_streams);
+	hipLaunchKernelGGL(copy_events_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, st.events, st.ev_this_call, dst, n_streams,
+	                   st.sym_this_call, sym_out, ev_out);
 	return hipGetLastError();
 }
 

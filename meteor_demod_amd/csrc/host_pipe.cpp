@@ -314,6 +314,12 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 #define TR(acc, stmt) do { stmt; } while (0)
 #endif
 
+#ifdef MDEMOD_PIPE_TRACE_LIGHT
+	/* three events and two host times per call: the copy-ins' span without the per-sub-block events of MDEMOD_PIPE_TRACE, which move things */
+	hipEvent_t lt_first, lt_last_in, lt_last_k;
+	(void)hipEventCreate(&lt_first); (void)hipEventCreate(&lt_last_in); (void)hipEventCreate(&lt_last_k);
+	const auto lt_t0 = std::chrono::steady_clock::now();
+#endif
 	std::vector<uint32_t> produced(ns, 0), events(ns, 0);
 	std::vector<mdemod_lock_event> ev_store;                  /* merged lock events: [stream][32] (only if any) */
 	int result = MDEMOD_OK;
@@ -440,6 +446,9 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		tr_enq_at[k] = (tr_now() - tr_t0) * 1e3;
 		(void)hipEventRecord(tr_e0[k], p->s_in);
 #endif
+#ifdef MDEMOD_PIPE_TRACE_LIGHT
+		if (k == 0) (void)hipEventRecord(lt_first, p->s_in);
+#endif
 		if (pos && direct_k) {
 			/* every stream's piece is [lo, lo + cnt) of its row: device rows at the ring's own pitch (8-sample multiples, h_off) */
 			const uint32_t lo = sub_lo(0, k), cnt = sl.h_cnt[0];
@@ -449,6 +458,9 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 		} else if (pos) PIPE_TRY(hipMemcpyAsync(sl.d_iq, sl.h_iq, static_cast<size_t>(pos) * sb, hipMemcpyHostToDevice, p->s_in));
 #ifdef MDEMOD_PIPE_TRACE
 		(void)hipEventRecord(tr_e1[k], p->s_in);
+#endif
+#ifdef MDEMOD_PIPE_TRACE_LIGHT
+		if (k + 1 == K) (void)hipEventRecord(lt_last_in, p->s_in);
 #endif
 		PIPE_TRY(hipMemcpyAsync(sl.d_off, sl.h_off, sizeof(uint64_t) * ns, hipMemcpyHostToDevice, p->s_in));
 		PIPE_TRY(hipMemcpyAsync(sl.d_cnt, sl.h_cnt, sizeof(uint32_t) * ns, hipMemcpyHostToDevice, p->s_in));
@@ -473,18 +485,32 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 #ifndef MDEMOD_PIPE_ZC_LAST
 #define MDEMOD_PIPE_ZC_LAST 3
 #endif
-		const bool zc_out = K >= 8 && k + MDEMOD_PIPE_ZC_LAST >= K;
+#ifndef MDEMOD_PIPE_ZC_FIRST
+#define MDEMOD_PIPE_ZC_FIRST 0
+#endif
+		const bool zc_out = K >= 8 && (k + MDEMOD_PIPE_ZC_LAST >= K || k < MDEMOD_PIPE_ZC_FIRST);
 #ifdef MDEMOD_PIPE_TRACE
 		if (!(tr_skip & (1 | 8)))
 #endif
 		PIPE_TRY(mdemod_launch_compact_rows(sl.d_soft, cap, zc_out ? sl.h_soft : sl.d_pack, pitch, st.sym_this_call, ns, p->s_cmp));
+#ifdef MDEMOD_PIPE_COUNTS_BY_COPY
 		PIPE_TRY(hipMemcpyAsync(sl.h_prod, st.sym_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
 		PIPE_TRY(hipMemcpyAsync(sl.h_ev, st.ev_this_call, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, p->s_cmp));
+#endif
 		/* (only the events there are: the whole list is 512 bytes per stream - 8 MB and 0.46 ms of blit kernel per sub-block at 16 384
 		   streams, the last of them in the call's tail; r05) */
-		if (K > 1) PIPE_TRY(mdemod_launch_copy_events(st, sl.d_events, ns, p->s_cmp));
+#ifdef MDEMOD_PIPE_COUNTS_BY_COPY
+		if (K > 1) PIPE_TRY(mdemod_launch_copy_events(st, sl.d_events, ns, nullptr, nullptr, p->s_cmp));
+#else
+		/* ... and the launch's two counters per stream into the slot's pinned arrays by the same kernel: as copies they sat in a copy
+		   engine's queue until the kernel was through, and the runtime may put the next 2-D copy-in behind them (r05) */
+		PIPE_TRY(mdemod_launch_copy_events(st, sl.d_events, ns, sl.h_prod, sl.h_ev, p->s_cmp));
+#endif
 #ifdef MDEMOD_PIPE_TRACE
 		(void)hipEventRecord(tr_k1[k], p->s_cmp);
+#endif
+#ifdef MDEMOD_PIPE_TRACE_LIGHT
+		if (k + 1 == K) (void)hipEventRecord(lt_last_k, p->s_cmp);
 #endif
 		PIPE_TRY(hipEventRecord(sl.ev_k, p->s_cmp)); sl.used_k = true;
 		/* ---- D2H of the nominal-pitch copy ---- */
@@ -518,6 +544,16 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 	(void)tr_enq;
 #endif
 
+#ifdef MDEMOD_PIPE_TRACE_LIGHT
+	{
+		const double host_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - lt_t0).count() * 1e3;
+		(void)hipDeviceSynchronize();
+		float a = 0, b = 0;
+		(void)hipEventElapsedTime(&a, lt_first, lt_last_in); (void)hipEventElapsedTime(&b, lt_first, lt_last_k);
+		fprintf(stderr, "[host_pipe] K %u: copy-ins span %.2f ms, last kernel done %.2f ms after the first copy-in began; host loop + unpack %.2f ms\n", K, a, b, host_ms);
+		(void)hipEventDestroy(lt_first); (void)hipEventDestroy(lt_last_in); (void)hipEventDestroy(lt_last_k);
+	}
+#endif
 	/* ---- "this call" counters := totals over the sub-blocks ---- */
 	if (K > 1) {
 		PIPE_TRY(hipMemcpyAsync(st.sym_this_call, produced.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice, p->s_cmp));
