@@ -179,6 +179,17 @@ copy_events_kernel(const mdemod_lock_event *src, const uint32_t *ev_this_call, m
 	if (ev_out) ev_out[s] = n_ev;
 }
 
+/* Offsets and counts of a launch whose streams are all `count` samples long and `pitch` samples apart (mdemod_process_host on rows
+ * the caller pinned: nothing to copy in besides the samples themselves). */
+__global__ void
+fill_uniform_rows_kernel(uint64_t *off, uint32_t *cnt, uint64_t pitch, uint32_t count, uint32_t n_streams)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_streams) return;
+	off[s] = (uint64_t)s * pitch;
+	cnt[s] = count;
+}
+
 /* Every float with |x| < 16, both signs: division-free turn code vs the real division. */
 __global__ void
 selftest_turncode_kernel(unsigned long long *mismatch)
@@ -333,6 +344,14 @@ mdemod_launch_compact_rows(const int8_t *src, uint64_t src_pitch_sym, int8_t *ds
 {
 	if (n_streams == 0) return hipSuccess;
 	hipLaunchKernelGGL(compact_rows_kernel, dim3(n_streams), dim3(128), 0, stream, src, src_pitch_sym, dst, dst_pitch_sym, counts_dev, n_streams);
+	return hipGetLastError();
+}
+
+hipError_t
+mdemod_launch_fill_uniform_rows(uint64_t *off_dev, uint32_t *cnt_dev, uint64_t pitch_samples, uint32_t count, uint32_t n_streams, hipStream_t stream)
+{
+	if (n_streams == 0) return hipSuccess;
+	hipLaunchKernelGGL(fill_uniform_rows_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, off_dev, cnt_dev, pitch_samples, count, n_streams);
 	return hipGetLastError();
 }
 

@@ -107,6 +107,7 @@ hipError_t mdemod_launch_rotate(const DemodStateSoA &st, const int32_t *quarter_
 hipError_t mdemod_launch_gain_seeds(const DemodStateSoA &st, const float *gain_dev, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_clock_seeds(const DemodStateSoA &st, const float *t_freq_dev, float lo, float hi, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_carrier_seeds(const DemodStateSoA &st, const float *freq_dev, const int32_t *updown_dev, uint32_t n_streams, hipStream_t stream);
+hipError_t mdemod_launch_fill_uniform_rows(uint64_t *off_dev, uint32_t *cnt_dev, uint64_t pitch_samples, uint32_t count, uint32_t n_streams, hipStream_t stream);
 hipError_t mdemod_launch_copy_events(const DemodStateSoA &st, mdemod_lock_event *dst, uint32_t n_streams, uint32_t *sym_out, uint32_t *ev_out, hipStream_t stream);
 hipError_t mdemod_launch_compact_rows(const int8_t *src, uint64_t src_pitch_sym, int8_t *dst, uint64_t dst_pitch_sym,
                                       const uint32_t *counts_dev, uint32_t n_streams, hipStream_t stream);

@@ -405,7 +405,12 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 #define MDEMOD_PIPE_DIRECT_FROM 0
 #endif
 		const bool direct_k = direct_all && (K < 8 || k >= MDEMOD_PIPE_DIRECT_FROM);
-		const size_t iq_bytes = static_cast<size_t>(pos) * sb + 64;
+		/* the launch's offsets and counts travel behind the samples in the same ring and the same copy (staged path) or are written by
+		   a kernel (pinned rows: every stream as long as the others, one pitch apart) - as two copies of their own on the copy-in
+		   stream they sat between every two sub-blocks' samples, 0.03-0.04 ms of idle link each time (r05) */
+		const size_t meta_at = (static_cast<size_t>(pos) * sb + 63) & ~static_cast<size_t>(63);
+		const size_t meta_bytes = static_cast<size_t>(ns) * (sizeof(uint64_t) + sizeof(uint32_t));
+		const size_t iq_bytes = meta_at + meta_bytes + 64;
 		const uint32_t cap = ((sub_max + 8 + 7) / 8) * 8;                   /* hard bound: one symbol per input sample */
 		const uint32_t pitch = static_cast<uint32_t>(std::min<uint64_t>(cap, mdemod_nominal_symbols(ctx, sub_max)));
 		const size_t soft_bytes = static_cast<size_t>(cap) * 2 * ns, pack_bytes = static_cast<size_t>(pitch) * 2 * ns;
@@ -455,28 +460,37 @@ mdemod_hostpipe_run(mdemod_ctx *ctx, void **pipe_slot, const DemodStateSoA &st, 
 			const size_t dev_pitch = ns > 1 ? static_cast<size_t>(sl.h_off[1] - sl.h_off[0]) * sb : static_cast<size_t>(cnt) * sb;
 			if (cnt) PIPE_TRY(hipMemcpy2DAsync(sl.d_iq, dev_pitch, static_cast<const unsigned char *>(iq_host[0]) + static_cast<size_t>(lo) * sb, row_stride,
 			                                   static_cast<size_t>(cnt) * sb, ns, hipMemcpyHostToDevice, p->s_in));
-		} else if (pos) PIPE_TRY(hipMemcpyAsync(sl.d_iq, sl.h_iq, static_cast<size_t>(pos) * sb, hipMemcpyHostToDevice, p->s_in));
+		} else if (!direct_k) {
+			memcpy(sl.h_iq + meta_at, sl.h_off, sizeof(uint64_t) * ns);
+			memcpy(sl.h_iq + meta_at + sizeof(uint64_t) * ns, sl.h_cnt, sizeof(uint32_t) * ns);
+			PIPE_TRY(hipMemcpyAsync(sl.d_iq, sl.h_iq, meta_at + meta_bytes, hipMemcpyHostToDevice, p->s_in));
+		}
 #ifdef MDEMOD_PIPE_TRACE
 		(void)hipEventRecord(tr_e1[k], p->s_in);
 #endif
 #ifdef MDEMOD_PIPE_TRACE_LIGHT
 		if (k + 1 == K) (void)hipEventRecord(lt_last_in, p->s_in);
 #endif
-		PIPE_TRY(hipMemcpyAsync(sl.d_off, sl.h_off, sizeof(uint64_t) * ns, hipMemcpyHostToDevice, p->s_in));
-		PIPE_TRY(hipMemcpyAsync(sl.d_cnt, sl.h_cnt, sizeof(uint32_t) * ns, hipMemcpyHostToDevice, p->s_in));
 		PIPE_TRY(hipEventRecord(sl.ev_in, p->s_in)); sl.used_in = true;
 
 		/* ---- kernel: after the copy-in, and after the copy-out that last read this slot's device output ---- */
 		PIPE_TRY(hipStreamWaitEvent(p->s_cmp, sl.ev_in, 0));
 		if (sl.used_out) PIPE_TRY(hipStreamWaitEvent(p->s_cmp, sl.ev_out, 0));
 		sl.cap = cap; sl.pitch = pitch;
+		const uint64_t *k_off = reinterpret_cast<const uint64_t *>(sl.d_iq + meta_at);
+		const uint32_t *k_cnt = reinterpret_cast<const uint32_t *>(sl.d_iq + meta_at + sizeof(uint64_t) * ns);
+		if (direct_k) {
+			/* (after the kernel that last read this slot's arrays: the compute stream is in order) */
+			PIPE_TRY(mdemod_launch_fill_uniform_rows(sl.d_off, sl.d_cnt, ns > 1 ? sl.h_off[1] - sl.h_off[0] : 0, sl.h_cnt[0], ns, p->s_cmp));
+			k_off = sl.d_off; k_cnt = sl.d_cnt;
+		}
 #ifdef MDEMOD_PIPE_TRACE
 		(void)hipEventRecord(tr_k0[k], p->s_cmp);
 #endif
 #ifdef MDEMOD_PIPE_TRACE
 		if (!(tr_skip & (1 | 16)))
 #endif
-		rc = mdemod_process_device(ctx, sl.d_iq, sl.d_off, sl.d_cnt, sl.d_soft, cap, cap, p->s_cmp);
+		rc = mdemod_process_device(ctx, sl.d_iq, k_off, k_cnt, sl.d_soft, cap, cap, p->s_cmp);
 		if (rc) return rc;
 		/* The rows of the LAST sub-blocks go to the pinned host buffer straight from this kernel (posted writes over the link), not
 		 * through the copy engine: a copy-out lands on whichever engine is free NEXT, which is the one busy with the copy-in in flight,
