@@ -36,6 +36,8 @@ constexpr int kCand = 3;                 /* candidates per firing: predicted ste
 constexpr int kFire = 21;                /* firings per batch: 63 lanes                      */
 constexpr int kMaxChunks = 20;           /* 64-sample chunks prefetched per batch            */
 constexpr int kMirror = 264;             /* ring entries mirrored behind its end: >= the longest window (hpad <= 256, taps <= hpad + 1) */
+constexpr int kMaxHpad = 256;            /* mdemod_lat_geometry refuses longer histories: the mirror above and the four rounds of 64 lanes that save the history */
+static_assert(kMirror >= kMaxHpad + 1 && kMirror % 8 == 0, "a FIR window must fit the mirrored run");
 
 template <int FMT> struct LFmt;
 template <> struct LFmt<16> {
@@ -477,7 +479,7 @@ launch_lat(const DemodLaunch &L, const float *rrc, int ring_size, int span, int 
 bool
 mdemod_lat_geometry(const DemodConsts &c, double samples_per_firing, int *ring_size, int *span, size_t *lds_bytes)
 {
-	if (c.hpad > 256) return false;
+	if (c.hpad > kMaxHpad) return false;
 	const int sp = static_cast<int>(kFire * samples_per_firing * 1.01) + 8;
 	if ((sp + 63) / 64 + 1 > kMaxChunks) return false;
 	int ring = 256;
