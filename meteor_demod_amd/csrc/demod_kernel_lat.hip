@@ -258,6 +258,13 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		return true;
 	};
 
+#ifdef LAT_EXP_TIMING
+	/* experiment builds only (tools/build_exp_lat.sh x -DLAT_EXP_TIMING): where a batch's time goes, by s_memtime, printed by stream 0 */
+	unsigned long long tm_pf = 0, tm_farm = 0, tm_serial = 0, tm_flush = 0, tm_commit = 0, tm_batches = 0, tm_fired = 0;
+#define LAT_TM(acc) do { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tm_last; tm_last = now_; } while (0)
+#else
+#define LAT_TM(acc) do { } while (0)
+#endif
 	while (!done && guard) {
 		/* ---- the tail of the block (and blocks shorter than a batch): firing by firing ---- */
 		if (v_end - 1 - v_cur <= span + 8) {
@@ -265,8 +272,15 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 			flush();
 			continue;
 		}
+#ifdef LAT_EXP_TIMING
+		unsigned long long tm_last = __builtin_readcyclecounter();
+		tm_batches++;
+#endif
 		/* ---- (0) prefetch: the chunks that extend the ring by one span, committed after the farm ---- */
-		float2 pend[kMaxChunks];
+		/* the RAW samples: converting them here would wait for the loads (a batch's prefetch stage stood for 1 100 cycles at configs[1],
+		   2 600 at configs[3] - one trip to HBM - before the farm could start; r05, -DLAT_EXP_TIMING); they are converted when they are
+		   committed, a whole serial stage later */
+		sample_t pend[kMaxChunks];
 		const int r_hi0 = r_hi;
 		const int v0 = v_cur, isub0 = isub;
 		/* chunks c with c < n_chunks, r_hi0 + 64 c < v_end and r_hi0 + 64 c < v0 + 1 + 2 span: the first n_valid of them.  pend[] has to
@@ -274,13 +288,14 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		   twenty tests of three conditions each: groups of four, the later groups behind one test (round 5) */
 		const int pf_lim = min(v_end, v0 + 1 + 2 * span) - r_hi0;
 		const int n_valid = pf_lim <= 0 ? 0 : min(n_chunks, (pf_lim + 63) >> 6);
-#define LAT_PF(c) if ((c) < n_valid) pend[c] = load_chunk(r_hi0 + 64 * (c));
+#define LAT_PF(c) if ((c) < n_valid) { const int m_ = r_hi0 + 64 * (c) + lane - hpad; if (m_ < n) pend[c] = src[m_]; }
 #define LAT_PF4(c) LAT_PF(c) LAT_PF((c) + 1) LAT_PF((c) + 2) LAT_PF((c) + 3)
 		LAT_PF4(0)
 		if (n_valid > 4) { LAT_PF4(4) if (n_valid > 8) { LAT_PF4(8) if (n_valid > 12) { LAT_PF4(12) if (n_valid > 16) { LAT_PF4(16) } } } }
 #undef LAT_PF4
 #undef LAT_PF
 
+		LAT_TM(tm_pf);
 		/* ---- (1) farm: lane -> (firing j, candidate c); lane j also keeps the prediction of firing j for the serial part ---- */
 		t_phase = uni(t_phase); t_freq = uni(t_freq);                    /* wave-uniform by construction: pin them to scalars */
 		const float phase0 = t_phase, inv_f0 = 1.0f / t_freq;
@@ -336,6 +351,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		const long long steps_room = (long long)(v_end - 1 - v0) * interp - isub0 - (k_most + 4) - interp;     /* 2^30 samples x 64 steps: not an int */
 		const int steps_limit = steps_room > 0x3FFFFFFF ? 0x3FFFFFFF : (int)steps_room;
 
+		LAT_TM(tm_farm);
 		/* ---- (2) serial: firing by firing, wave-uniform; sample positions are only worked out when they matter ---- */
 		int steps_done = 0;                                              /* interpolated steps since the batch start */
 		int emit_steps = -1;                                             /* steps_done at the last symbol emitted in this batch */
@@ -404,12 +420,17 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		   it is done the careful way; the prediction is stale after it, so the batch ended there */
 		if (miss) careful_firing();
 
+		LAT_TM(tm_serial);
+#ifdef LAT_EXP_TIMING
+		tm_fired += (unsigned long long)j;
+#endif
 		/* ---- (3) flush the batch's symbols: lane i writes symbol out_base + i ---- */
 		flush();
+		LAT_TM(tm_flush);
 		/* ---- (4) commit the prefetched chunks ---- */
 		/* (a chunk the careful way has loaded by itself meanwhile is not written again) */
 #define LAT_CM(c) if ((c) < n_valid && r_hi0 + 64 * (c) >= r_hi) { \
-			if (r_hi0 + 64 * (c) + lane < v_end) ring_put(r_hi0 + 64 * (c) + lane, pend[c]); \
+			if (r_hi0 + 64 * (c) + lane < v_end) ring_put(r_hi0 + 64 * (c) + lane, F::decode(pend[c])); \
 			r_hi = min(v_end, r_hi0 + 64 * (c) + 64); }
 #define LAT_CM4(c) LAT_CM(c) LAT_CM((c) + 1) LAT_CM((c) + 2) LAT_CM((c) + 3)
 		LAT_CM4(0)
@@ -417,7 +438,14 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 #undef LAT_CM4
 #undef LAT_CM
 		__syncthreads();
+		LAT_TM(tm_commit);
 	}
+#ifdef LAT_EXP_TIMING
+	if (lane == 0 && stream == 0 && tm_batches)
+		printf("[lat] %llu batches, %llu firings in them: ticks per batch prefetch %.0f farm %.0f serial %.0f (%.1f per firing) flush %.0f commit %.0f\n", tm_batches, tm_fired,
+		       (double)tm_pf / tm_batches, (double)tm_farm / tm_batches, (double)tm_serial / tm_batches, (double)tm_serial / (double)(tm_fired ? tm_fired : 1),
+		       (double)tm_flush / tm_batches, (double)tm_commit / tm_batches);
+#endif
 	if (guard == 0 && !done) overflow = 1;                                /* watchdog fired: reported as overflow */
 
 	/* ---- store state ---- */
