@@ -11,7 +11,7 @@
 template <int MODE>
 __global__ void chain(float *out, uint64_t *cycles, int lanes, int reps)
 {
-	float a = threadIdx.x * 1e-9f, b = 1.0f, c = 2.0f, d = 3.0f;
+	float a = threadIdx.x * 1e-9f, b = 1.0f, c = 2.0f, d = (MODE == 6 || MODE == 7) ? -3.0f : 3.0f;
 	double x = threadIdx.x * 1e-9, y = 1.5;
 	uint64_t t0 = 0, t1 = 0;
 	if ((int)threadIdx.x < lanes) {
@@ -47,6 +47,22 @@ __global__ void chain(float *out, uint64_t *cycles, int lanes, int reps)
 				for (int u = 0; u < 4; u++) {
 					asm volatile("v_cmp_lt_f32 vcc, %1, %2\n v_cndmask_b32 %0, %1, %2, vcc\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %2" : "+v"(a) : "v"(b), "v"(c) : "vcc");
 				}
+			} else if (MODE == 6) {        /* a branch that is never taken behind every add (condition from a VALU compare) */
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					asm volatile("v_add_f32 %0, %0, %1\n v_cmp_lt_f32 vcc, %0, %2\n s_cbranch_vccnz 1f\n v_add_f32 %0, %0, %1\n1:" : "+v"(a) : "v"(b), "v"(d) : "vcc");
+			} else if (MODE == 7) {        /* the same instructions with an s_nop where the branch was */
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					asm volatile("v_add_f32 %0, %0, %1\n v_cmp_lt_f32 vcc, %0, %2\n s_nop 0\n v_add_f32 %0, %0, %1" : "+v"(a) : "v"(b), "v"(d) : "vcc");
+			} else if (MODE == 8) {        /* a never-taken branch on a SCALAR condition */
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					asm volatile("v_add_f32 %0, %0, %1\n s_cmp_eq_u32 s20, 12345\n s_cbranch_scc1 1f\n v_add_f32 %0, %0, %1\n1:" : "+v"(a) : "v"(b) : "s20", "scc");
+			} else if (MODE == 9) {        /* a TAKEN branch over nothing */
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					asm volatile("v_add_f32 %0, %0, %1\n s_cmp_lg_u32 s20, 12345\n s_cbranch_scc1 1f\n1:\n v_add_f32 %0, %0, %1" : "+v"(a) : "v"(b) : "s20", "scc");
 			}
 		}
 		t1 = __builtin_readcyclecounter();
@@ -83,5 +99,9 @@ int main()
 	run<3>("v_add_f32 ; s_add_u32 alternating", 16);
 	run<4>("v_cmp ; s_and ; v_cndmask ; v_add", 16);
 	run<5>("v_cmp ; v_cndmask ; v_add ; v_add", 16);
+	run<6>("v_add ; v_cmp ; s_cbranch_vccnz (never) ; v_add", 16);
+	run<7>("v_add ; v_cmp ; s_nop ; v_add", 16);
+	run<8>("v_add ; s_cmp ; s_cbranch_scc1 (never) ; v_add", 16);
+	run<9>("v_add ; s_cmp ; s_cbranch_scc1 (taken) ; v_add", 16);
 	return 0;
 }
