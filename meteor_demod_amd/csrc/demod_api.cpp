@@ -71,19 +71,28 @@ fetch(const T *dev, uint32_t first, uint32_t count, std::vector<T> &host, hipStr
 	return MDEMOD_OK;
 }
 
-/* the wave-per-stream kernel for few streams, the lane-per-stream kernels for many.  Measured r03 (tools/lat_bench.py, MS/s per
- * stream, wave vs lane): configs[1] 3.6 vs 2.5 at 1 024 streams, 3.1 vs 2.5 at 2 048, 2.2 vs 2.5 at 4 096; configs[3] (packed
- * window) 5.3 vs 3.7 at 1 024, 2.7 vs 3.7 at 2 048.  MDEMOD_FLAG_LAT_ON / _OFF pin the choice.  (r04: the farm's symbol clock takes the
- * closed-form schedule of clock_jump.h at high sample rates as the v3 kernels do: one stream at 1.8 MS/s 9.3 -> 18.7 MS/s.) */
+/* the wave-per-stream kernel for few streams, the lane-per-stream kernels for many.  A wave runs its one stream 2-3 times faster than
+ * a lane does, until every SIMD has a wave or two and the vector unit - 63 of 64 lanes of it idle - is the bound: the wave kernel
+ * levels off at a TOTAL rate (10-11 GS/s at configs[1], 5.5-6 at configs[2], 15-17 at configs[3], 25-28 at 2 MS/s) while the lane
+ * kernels keep their per-stream rate up to 131 072 streams.  Measured r05 (tools/lat_bench.py, MS/s per stream, wave vs lane):
+ * configs[1] 3.8 vs 2.1 at 2 048 streams, 2.5 vs 2.1 at 4 096, 1.3 vs 2.1 at 8 192; configs[2] 1.34 vs 1.06 at 4 096, 0.72 vs 1.06
+ * at 8 192; 97 taps of float input at 230 kS/s 2.15 vs 1.41 at 4 096; configs[3] 5.9 vs 4.0 at 2 048, 3.7 vs 4.0 at 4 096 (float
+ * input 5.8 vs 4.7, 3.6 vs 4.7); 1.024 MS/s 7.9 vs 7.1 at 1 024, 4.1 vs 7.0 at 2 048 (float input 4.1 vs 6.0); 2.048 MS/s 17.9 vs
+ * 9.1 at 1 024, 9.7 vs 10.2 at 2 048.  MDEMOD_FLAG_LAT_ON / _OFF pin the choice.  (r04: the farm's symbol clock takes the closed-form
+ * schedule of clock_jump.h at high sample rates as the v3 kernels do: one stream at 1.8 MS/s 9.3 -> 18.7 MS/s.) */
 bool
 wants_latency_kernel(const mdemod_ctx *ctx)
 {
 	if (!ctx->lat_ok || (ctx->params.reserved & MDEMOD_FLAG_LAT_OFF)) return false;
 	if (ctx->params.reserved & MDEMOD_FLAG_LAT_ON) return true;
+	const double per_firing = static_cast<double>(ctx->tab.osf) / (ctx->params.oqpsk ? 2.0 : 1.0);
 	/* from about 32 samples per firing (3.2 MS/s QPSK, 6 MS/s OQPSK) the farm's batches hold too few firings: one lane of a v3 kernel
 	 * is faster even for ONE stream (r04, tools/one_stream_rates.py: 3.2 MS/s 10.4 vs 9.6 MS/s, OQPSK 80k at 6 MS/s 9.7 vs 8.0) */
-	if (ctx->tab.use_rw && static_cast<double>(ctx->tab.osf) / (ctx->params.oqpsk ? 2.0 : 1.0) > 32.0) return false;
-	return ctx->params.n_streams <= (ctx->tab.rw_compact4 ? 1024u : 2048u);
+	if (ctx->tab.use_rw && per_firing > 32.0) return false;
+	/* where the two meet (the table above): the mid and far windows' lanes are quick, the wide one's less so, and at a few samples
+	 * per firing a lane spends most of its time in the per-symbol arithmetic the wave does no faster */
+	const uint32_t most = (ctx->tab.use_rw && (ctx->tab.rw_mid || ctx->tab.rw_far)) ? 1024u : (per_firing >= 8.0 ? 2048u : 4096u);
+	return ctx->params.n_streams <= most;
 }
 
 int

@@ -6,7 +6,11 @@ import numpy as np, torch
 import oracle_py as O
 from meteor_demod_amd import DemodConfig, Demodulator, synth
 CFG = {"c1": DemodConfig(samplerate=230000), "c3": DemodConfig(samplerate=230000, symrate=80000, oqpsk=True),
-       "c4": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8)}
+       "c4": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8),
+       # other kernel families on the lane side (where does a context change over to them?)
+       "c1f": DemodConfig(samplerate=230000, bps=32), "c4f": DemodConfig(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32),
+       "mid": DemodConfig(samplerate=1024000), "midf": DemodConfig(samplerate=1024000, bps=32), "far": DemodConfig(samplerate=2048000),
+       "t97": DemodConfig(samplerate=230000, rrc_order=48, interp_factor=5, bps=32), "c1u8": DemodConfig(samplerate=230000, bps=8)}
 for tag in [a for a in sys.argv[1:] if a in CFG] or ["c1", "c3", "c4"]:
     cfg = CFG[tag]
     n = 1 << 20
@@ -15,6 +19,8 @@ for tag in [a for a in sys.argv[1:] if a in CFG] or ["c1", "c3", "c4"]:
         x = synth.generate_device([st], n)[0].unsqueeze(0).expand(ns, n, 2).contiguous() if ns <= 1024 else None
         if x is None:
             x = synth.generate_device([st], n // 8)[0].unsqueeze(0).expand(ns, n // 8, 2).contiguous()
+        if cfg.bps == 32: x = x.float()
+        elif cfg.bps == 8: x = (torch.clamp(torch.div(x, 64, rounding_mode="floor"), -128, 127) + 128).to(torch.uint8)
         m = x.shape[1]
         res = {}
         for lat in ("0", "1"):
