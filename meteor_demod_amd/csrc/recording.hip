@@ -1018,8 +1018,19 @@ struct Stitcher {
 			/* Up to ~1000 tiles run one per WAVE (latency kernel, 1.9x a lane's rate with a SIMD to itself): a recording of up to
 			   1000 x 41 072 symbols is cut into that many; a longer one into tiles for one residency round of the lane kernels
 			   (131 072 lanes, with slack). */
-			const double b_sym = rest_sym / 1000.0 <= 41072.0 ? std::max(8192.0, rest_sym / 1000.0)
-			                                                   : std::min(41072.0, std::max(8192.0, rest_sym / 126976.0));
+			double b_sym = rest_sym / 1000.0 <= 41072.0 ? std::max(8192.0, rest_sym / 1000.0)
+			                                             : std::min(41072.0, std::max(8192.0, rest_sym / 126976.0));
+			/* Between 1 000 and 2 048 such tiles (2^27 .. 2^28 samples at configs[1]) the lane kernels would run ~5 000 .. 10 000 tiles
+			   of 8 192 symbols on a GPU they do not fill, each lane its lead + tile at a lane's rate; 2 048 waves still run one or two
+			   to a SIMD where the library picks the wave kernel for a bank that size (r05: wants_latency_kernel; configs[1] 2^27 tile
+			   phase 72 -> 50 ms, 2^28 72 -> 66 ms), with bodies of 20 000 .. 41 072 symbols like the 1 000-tile regime's. */
+			if (rest_sym / 1000.0 > 41072.0 && rest_sym / 2048.0 <= 41072.0) {
+				mdemod_params probe = *params;
+				probe.n_streams = 2048;
+				char which[96] = "";
+				if (mdemod_plan_kernel(&probe, which, sizeof(which), nullptr, nullptr) == MDEMOD_OK && strstr(which, "demod_kernel_lat"))
+					b_sym = rest_sym / 2048.0;
+			}
 			o.tile_samples = std::max<uint32_t>(4096, (static_cast<uint32_t>(b_sym * osf) + 63) / 64 * 64);
 			if ((o.tile_samples & (o.tile_samples - 1)) == 0) o.tile_samples += 64;
 		}

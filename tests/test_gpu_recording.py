@@ -168,14 +168,18 @@ def test_truth_check_of_a_whole_recording(gpu_device):
         assert t3["pairing_changes"] == 1 and abs(t3["changes"][0]["symbol"] - h) <= 16384, t3
 
 
-def test_many_short_tiles_regime_agrees_with_the_serial_reference(gpu_device):
-    """SURVEY C2-class sizes: 2^27 samples are cut into > 5 000 tiles of 8 192 symbols for the lane kernels (the regime the
-    bench times at 2^28 and on its whole buffer: lane-kernel tile banks, the shortest tiles, dead-reckoning chains ten times
-    longer than in the 1 000-tile tests above) - held to the same bars against the UNTILED serial oracle."""
+@pytest.mark.parametrize("regime", ["2048-wave-tiles", "many-short-lane-tiles"])
+def test_long_recording_in_both_tile_regimes_agrees_with_the_serial_reference(regime, gpu_device):
+    """SURVEY C2-class sizes, 2^27 samples.  By default (r05) a recording between 1 000 and 2 048 x 41 072 symbols is cut into 2 048
+    tiles for the wave kernel; forced to 8 192-symbol tiles it is the regime the bench times on its whole buffer: > 5 000 lane-kernel
+    tiles, the shortest ones, dead-reckoning chains ten times longer than in the 1 000-tile tests above.  Both held to the same bars
+    against the UNTILED serial oracle."""
     st = synth.make_stream(1000, 230000, 72000, f0_hz=1200.0, clock_ppm=-3.5)
     iq = synth.generate_device([st], 1 << 27)[0]
-    out, serial, rep, a = _run(C1, iq)
-    assert rep.n_tiles > 2048 and rep.pilot_locked == 1, rep.n_tiles
+    kw = {} if regime == "2048-wave-tiles" else {"tile_samples": 26176}
+    out, serial, rep, a = _run(C1, iq, **kw)
+    assert rep.pilot_locked == 1
+    assert (2000 < rep.n_tiles <= 2048) if regime == "2048-wave-tiles" else rep.n_tiles > 4096, rep.n_tiles
     assert rep.weak_seams == 0 and rep.rotation_jumps == 0 and rep.frame_misses <= rep.n_tiles // 50
     assert a["len_stitched"] == a["len_serial"]
     assert a["hard_decisions_equal"] >= 0.9999 and a["within_1lsb"] >= 0.9965 and a["worst_window"] >= 0.96, a

@@ -1,5 +1,5 @@
 """The +-1 LSB agreement of the stitcher against the serial oracle over many noise / data seeds of the bench signals
-(recording_check.py uses one): recording_seeds.py [c1|c3|c4] [n_seeds=12] [log2=24] [key=value: fmax=Hz esn0=dB rms= bps= fs= doppler=Hz/s]"""
+(recording_check.py uses one): recording_seeds.py [c1|c3|c4] [n_seeds=12] [log2=24] [key=value: fmax=Hz esn0=dB rms= bps= fs= doppler=Hz/s tile=samples]"""
 import sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
@@ -28,7 +28,7 @@ for k in range(n_seeds):
                            esn0_db=esn0, fmt=bps, doppler_hz_per_s=dop, clock_ppm_per_s=dop / 137.1, **amp)
     iq = synth.generate_device([st], n)[0]
     serial, tr, ev = O.oracle_demod(cfg, iq.cpu().numpy(), True)
-    soft, rep = demodulate_recording_native(cfg, iq)
+    soft, rep = demodulate_recording_native(cfg, iq, **({"tile_samples": int(kv["tile"])} if "tile" in kv else {}))
     a = agreement(soft.cpu().numpy(), serial); a.pop("windows")
     steps = 2 if cfg.oqpsk else 1
     kk = min(int(rep.pilot_symbols), len(tr) - 1)
