@@ -3,7 +3,7 @@ QPSK / OQPSK, input formats, carrier offsets, Doppler ramps, clock errors, tile 
 natively with spectral carrier seeds and compared with the serial oracle.  A case counts only if the serial run's lock
 is genuine (its PLL frequency is on the synthetic carrier when the pilot hands over, NOTEBOOK.md 3.1), otherwise there is
 no serial stream to compare with.  Usage: recording_fuzz.py [n_cases] [seed] [only_case]
-(FUZZ_TILE / FUZZ_SETTLE / FUZZ_SEEDMODE in the environment override a case's tile size / settling length / carrier_seed when one case is replayed)"""
+(FUZZ_SYMBOLS=lo,hi / FUZZ_RAMPS=a,b,.. draw the length in symbols / the Doppler ramps from there; FUZZ_TILE / FUZZ_SETTLE / FUZZ_SEEDMODE in the environment override a case's tile size / settling length / carrier_seed when one case is replayed)"""
 import os
 import dataclasses
 import sys
@@ -28,10 +28,15 @@ for ci in range(n_cases):
     bps = int(rng.choice([8, 16, 16, 32]))
     cfg = DemodConfig(samplerate=samplerate, symrate=symrate, oqpsk=oqpsk, bps=bps)
     ramp = float(rng.choice([0.0, 10.0, -25.0, 40.0, -40.0]))
+    if os.environ.get("FUZZ_RAMPS"):                       # long recordings: ramps that keep the carrier inside the loop's range
+        ramp = float(rng.choice([float(v) for v in os.environ["FUZZ_RAMPS"].split(",")]))
     # start on the side the sweep meets first (the reference sweeps up from 0): keeps its lock genuine in most cases
     f0 = float(rng.uniform(100.0, 900.0)) if ramp <= 0 else float(rng.uniform(-200.0, 600.0))
     ppm = float(rng.uniform(-30.0, 30.0))
     n = int(rng.integers(3_000_000, 9_000_000))
+    if os.environ.get("FUZZ_SYMBOLS"):                     # e.g. 42e6,83e6: the 2 048-wave-tile grid of round 5
+        lo_s, hi_s = (float(v) for v in os.environ["FUZZ_SYMBOLS"].split(","))
+        n = int(rng.uniform(lo_s, hi_s) * osf)
     # s16 amplitude scaled down with the oversampling: at 1 MS/s an RMS of 6000 LSB drives the reference's AGC into a
     # 0 <-> 0.019 limit cycle (its step is absolute, agc.c:13-25), where no two runs agree on anything
     amp = {8: dict(rms=40.0, dc=(1.5, -1.0)), 16: dict(rms=float(rng.choice([1500.0, 6000.0])) * min(1.0, 3.2 / osf)),
