@@ -226,7 +226,8 @@ int  mdemod_process_host(mdemod_ctx *ctx,
  * length and the blocks sit one stride apart (iq_host[s] = iq_host[0] + s * stride: a batch read into one buffer) - instead of
  * staging it through the library's own pinned ring with the CPU.  Any other layout, and anything outside the pinned ranges, takes the
  * staged path; results never depend on it.  The caller keeps the range mapped until mdemod_unpin_host_buffer (with the same base)
- * or mdemod_destroy, which unpins what is left.  MDEMOD_ERR_PARAM for a range that overlaps one pinned already.
+ * or mdemod_destroy, which unpins what is left.  MDEMOD_ERR_PARAM for a range that overlaps one pinned already through this call.
+ * Memory that is pinned anyway (from hipHostMalloc, or registered by the caller) is accepted and left as it is.
  */
 int  mdemod_pin_host_buffer(mdemod_ctx *ctx, const void *base, size_t bytes);
 int  mdemod_unpin_host_buffer(mdemod_ctx *ctx, const void *base);

@@ -74,7 +74,7 @@ struct Slot {                    /* one of the staging sets */
 	uint32_t width = 0;          /* symbols per stream actually copied out = the largest count of the sub-block */
 };
 
-struct Pin { const unsigned char *base; size_t bytes; };
+struct Pin { const unsigned char *base; size_t bytes; bool ours; };      /* ours: registered by this library (memory the caller got from hipHostMalloc is pinned already) */
 
 struct HostPipe;
 /* every way out of mdemod_hostpipe_run, the failing ones too, leaves nothing in flight */
@@ -197,7 +197,7 @@ mdemod_hostpipe_free(void *opaque)
 		if (s.ev_k) (void)hipEventDestroy(s.ev_k);
 		if (s.ev_out) (void)hipEventDestroy(s.ev_out);
 	}
-	for (const Pin &pin : p->pins) (void)hipHostUnregister(const_cast<unsigned char *>(pin.base));
+	for (const Pin &pin : p->pins) if (pin.ours) (void)hipHostUnregister(const_cast<unsigned char *>(pin.base));
 	if (p->s_in) (void)hipStreamDestroy(p->s_in);
 	if (p->s_cmp) (void)hipStreamDestroy(p->s_cmp);
 	if (p->s_out) (void)hipStreamDestroy(p->s_out);
@@ -214,8 +214,18 @@ mdemod_hostpipe_pin(void **pipe_slot, const void *base, size_t bytes)
 	const unsigned char *b = static_cast<const unsigned char *>(base);
 	for (const Pin &pin : p->pins)
 		if (b < pin.base + pin.bytes && pin.base < b + bytes) return MDEMOD_ERR_PARAM;       /* overlaps a range that is pinned already */
-	PIPE_TRY(hipHostRegister(const_cast<unsigned char *>(b), bytes, hipHostRegisterDefault));
-	p->pins.push_back({ b, bytes });
+	/* memory that is pinned already (hipHostMalloc, or registered by the caller) is taken as it is and left as it is */
+	hipPointerAttribute_t attr;
+	const hipError_t q = hipPointerGetAttributes(&attr, b);
+	if (q == hipSuccess && attr.type == hipMemoryTypeHost) {
+		p->pins.push_back({ b, bytes, false });
+		return MDEMOD_OK;
+	}
+	if (q != hipSuccess) (void)hipGetLastError();                 /* (pageable memory: an error or "unregistered", by runtime version) */
+	const hipError_t e = hipHostRegister(const_cast<unsigned char *>(b), bytes, hipHostRegisterDefault);
+	if (e == hipErrorHostMemoryAlreadyRegistered) (void)hipGetLastError();
+	else PIPE_TRY(e);
+	p->pins.push_back({ b, bytes, e == hipSuccess });
 	return MDEMOD_OK;
 }
 
@@ -227,7 +237,7 @@ mdemod_hostpipe_unpin(void *opaque, const void *base)
 	for (size_t i = 0; i < p->pins.size(); i++)
 		if (p->pins[i].base == base) {
 			/* (nothing of this context is in flight: mdemod_process_host is synchronous) */
-			PIPE_TRY(hipHostUnregister(const_cast<unsigned char *>(p->pins[i].base)));
+			if (p->pins[i].ours) PIPE_TRY(hipHostUnregister(const_cast<unsigned char *>(p->pins[i].base)));
 			p->pins.erase(p->pins.begin() + static_cast<long>(i));
 			return MDEMOD_OK;
 		}

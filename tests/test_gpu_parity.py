@@ -502,6 +502,29 @@ def test_host_buffer_path_from_pinned_rows(fmt, gpu_device):
         d.pin_host(big)                                              # and again: destroy unpins what is left
 
 
+def test_host_buffer_path_from_memory_that_is_pinned_already(gpu_device):
+    """mdemod_pin_host_buffer on memory the caller got pinned from the runtime (torch's pinned allocator = hipHostMalloc): accepted, the
+    rows are copied from where they are, and unpinning / destroying the context leaves the caller's allocation alone."""
+    torch = _torch()
+    ns, n = 64, 1 << 16
+    buf_t = torch.empty((ns, n, 2), dtype=torch.int16).pin_memory()
+    buf = buf_t.numpy()
+    st = synth.make_stream(31, 230000, 72000, f0_hz=120.0, esn0_db=15.0)
+    one = synth.generate_host(st, n + ns)
+    for s in range(ns):
+        buf[s] = one[s: s + n]
+    want = [O.oracle_demod(C1, np.ascontiguousarray(buf[s]))[0] for s in (0, 17, 63)]
+    for rounds in range(2):                                              # the second context pins the same memory again
+        with Demodulator(C1, ns) as d:
+            d.pin_host(buf)
+            out = d.process_host([buf[s] for s in range(ns)])
+            if rounds == 0:
+                d.unpin_host(buf)                                        # ... and the first one lets go by hand, the second by closing
+        for k, s in enumerate((0, 17, 63)):
+            assert np.array_equal(out[s], want[k]), (rounds, s)
+    assert buf_t.is_pinned() and int(buf_t[5, 7, 1]) == int(one[5 + 7, 1])   # still there, still the caller's
+
+
 def test_more_symbols_than_the_nominal_rate(gpu_device):
     """While the symbol clock drains a large phase excursion (full-scale burst after silence, wide loop) it fires on
     every sample: more symbols than samples * symrate / samplerate.  mdemod_max_symbols is the hard bound (one per
