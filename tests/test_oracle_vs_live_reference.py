@@ -59,3 +59,53 @@ def test_restatement_equals_the_live_reference(seed):
         assert got_trace.tobytes() == want_trace.tobytes(), (cfg, s)        # every float of every symbol, bit for bit
         checked += 1
     assert checked >= 130
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(not O.REF_BINARY.exists(), reason="the reference's own CLI binary is not here")
+def test_file_model_equals_the_live_reference_binary(tmp_path):
+    """The file level (whole 32 KiB reads, 1024-byte chunks behind the lock gate, the double-length final flush): the
+    oracle's file model against the reference's own CLI binary on random files - WAV and raw, the three formats, QPSK / OQPSK, -O / -f /
+    -b, lengths that end anywhere inside a read.  (Lengths whose last chunk is more than half full make the reference's final flush
+    read past its ring, main.c:321: those are trimmed away here as in tests/golden/make_golden.py.)"""
+    import subprocess
+    from golden_cases import wav_header
+    rng = np.random.default_rng(2025)
+    checked = locked_cases = 0
+    for case in range(44):
+        oqpsk = bool(rng.random() < 0.35)
+        bps = int(rng.choice([8, 16, 16, 32]))
+        fs = int(rng.choice([230000, 230400, 288000, 144000, 460000]))
+        symrate = 80000 if oqpsk else 72000
+        interp, order, bw = int(rng.choice([5, 5, 3, 8])), int(rng.choice([32, 32, 17, 48])), float(rng.choice([1.0, 1.0, 2.0]))
+        cfg = DemodConfig(samplerate=fs, symrate=symrate, oqpsk=oqpsk, bps=bps, interp_factor=interp, rrc_order=order, pll_bw=bw)
+        if not np.isfinite(O.OracleStream(cfg).rrc_table()).all():            # (230.4 kS/s OQPSK 80k -O 5: 0/0 on a tap - the reference's LUT index is then anything)
+            continue
+        never = case % 9 == 8                                                 # a carrier outside the loop's range: the gate never opens
+        amp = {8: dict(rms=50.0, dc=(2.0, -1.0)), 16: {}, 32: dict(rms=0.4, dc=(0.0, 0.0))}[bps]
+        st = synth.make_stream(5000 + case, fs, symrate, oqpsk=oqpsk, fmt=bps, f0_hz=6000.0 if never else float(rng.uniform(-150, 150)), esn0_db=18.0, **amp)
+        n0 = int(rng.integers(40000, 260000))
+        for trim in range(64):
+            iq = synth.generate_host(st, n0 - trim * 997)
+            body = iq.tobytes()
+            used = (len(body) // 32768) * 32768
+            nsym = len(O.oracle_demod(cfg, np.frombuffer(body[:used], dtype=iq.dtype).reshape(-1, 2))[0])
+            if 2 * (nsym % 512) <= 512:
+                break
+        else:
+            continue
+        container = "wav" if rng.random() < 0.6 else "raw"
+        args = ["-O", str(interp), "-f", str(order), "-b", repr(bw)] + (["-m", "oqpsk", "-r", str(symrate)] if oqpsk else [])
+        if container == "raw":
+            args += ["-s", str(fs), "--bps", str(bps)]
+        data = (wav_header(fs, bps, len(body)) if container == "wav" else b"") + body
+        inp, out = tmp_path / f"in{case}.{container}", tmp_path / f"out{case}.s"
+        inp.write_bytes(data)
+        subprocess.run([str(O.REF_BINARY), "-q", "-B", "-o", str(out), *args, str(inp)], check=True, capture_output=True, timeout=120)
+        want = out.read_bytes()
+        got = O.OracleStream(cfg).file_model(body, bps)
+        assert got == want, (case, cfg, container, len(body), len(got), len(want))
+        checked += 1
+        locked_cases += len(want) > 2048
+        inp.unlink(); out.unlink()
+    assert checked >= 30 and locked_cases >= 20
