@@ -79,7 +79,7 @@ def test_file_model_equals_the_live_reference_binary(tmp_path):
         symrate = 80000 if oqpsk else 72000
         interp, order, bw = int(rng.choice([5, 5, 3, 8])), int(rng.choice([32, 32, 17, 48])), float(rng.choice([1.0, 1.0, 2.0]))
         cfg = DemodConfig(samplerate=fs, symrate=symrate, oqpsk=oqpsk, bps=bps, interp_factor=interp, rrc_order=order, pll_bw=bw)
-        if not np.isfinite(O.OracleStream(cfg).rrc_table()).all():            # (230.4 kS/s OQPSK 80k -O 5: 0/0 on a tap - the reference's LUT index is then anything)
+        if not np.isfinite(O.OracleStream(cfg).rrc_table()).all():            # (230.4 kS/s at 80k symbols/s -O 5: a zero denominator on a tap, filter.c:86-93 - inf in the table, NaN out of the FIR, and the reference indexes its LUT with it)
             continue
         never = case % 9 == 8                                                 # a carrier outside the loop's range: the gate never opens
         amp = {8: dict(rms=50.0, dc=(2.0, -1.0)), 16: {}, 32: dict(rms=0.4, dc=(0.0, 0.0))}[bps]
