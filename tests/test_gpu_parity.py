@@ -989,3 +989,30 @@ def test_random_option_combinations_match_oracle(idx, gpu_device):
             want = ost.run(iqs[i])[0]
             assert np.array_equal(np.concatenate(got[i]), want), (idx, i, cfg)
             assert np.float32(st[i].pll_freq) == np.float32(ost.state.pll_freq) and st[i].locked == ost.state.locked
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (the reference built from /root/reference) did not travel with this checkout")
+@pytest.mark.parametrize("seed", [21, 22])
+def test_hip_equals_the_live_reference(seed, gpu_device, kernel_variant):
+    """Not through the restatement: the HIP path against the REFERENCE ITSELF (oracle/_ref/ref_harness = the reference's own objects,
+    built in the survey container and carried along) on random settings - every kernel variant, byte for byte."""
+    torch = _torch()
+    rng = np.random.default_rng(seed)
+    done = 0
+    while done < 8:
+        oqpsk = bool(rng.random() < 0.4)
+        symrate = int(rng.choice([72000, 80000]))
+        cfg = DemodConfig(samplerate=int(symrate * float(rng.uniform(1.4, 16.0))), symrate=symrate, oqpsk=oqpsk, interp_factor=int(rng.integers(1, 9)),
+                          rrc_order=int(rng.integers(8, 66)), pll_bw=float(rng.choice([0.5, 1.0, 2.0])), bps=int(rng.choice([8, 16, 32])))
+        if not np.isfinite(O.OracleStream(cfg).rrc_table()).all():
+            continue
+        st = synth.make_stream(int(rng.integers(1, 1 << 30)), cfg.samplerate, cfg.symrate, oqpsk=oqpsk, f0_hz=float(rng.uniform(-900, 900)), esn0_db=14.0,
+                               fmt=cfg.bps, **({"rms": 40.0} if cfg.bps == 8 else {"rms": 0.3} if cfg.bps == 32 else {}))
+        iq = synth.generate_host(st, int(2500 * cfg.samplerate / cfg.symrate))
+        want, _ = O.ref_demod(cfg, iq)
+        with Demodulator(cfg, 3) as d:
+            soft = d.process(torch.from_numpy(np.stack([iq, iq, iq])).cuda())
+            torch.cuda.synchronize()
+            m = d.status(2, 1)[0].symbols_this_call
+            assert m == want.shape[0] and np.array_equal(soft[2, :m].cpu().numpy(), want), (cfg, d.kernel_name)
+        done += 1
