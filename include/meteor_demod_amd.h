@@ -161,7 +161,12 @@ int  mdemod_device_count(void);
 
 /* Replaces demod_init (demod.c:8-15).  Derives loop constants, RRC taps and the
  * tanh LUT on the host with the reference's exact mixed float/double
- * expressions, uploads them, allocates per-stream state. */
+ * expressions, uploads them, allocates per-stream state.
+ * MDEMOD_ERR_PARAM: -O outside 1..64, -f outside 1..256, a sample format other than 8 / 16 / 32 bits, fewer than a quarter of an
+ * input sample per firing, samplerate x interp or 2 x symrate beyond int (demod.c:12-13 multiplies in int), a carrier range of
+ * 6 rad per symbol or more, and settings whose RRC table has a tap that is not finite (filter.c:86-93 divides by zero where
+ * samples-per-symbol x -O / 2.4 lands on a tap - 230.4 kS/s OQPSK 80k with -O 5, 1.08 MS/s with -O 4 -; the reference's output is
+ * undefined there; another -O is the way out, and the message on stderr says so). */
 int  mdemod_create(const mdemod_params *params, mdemod_ctx **out);
 /* Replaces demod_deinit (demod.c:18-21). */
 void mdemod_destroy(mdemod_ctx *ctx);

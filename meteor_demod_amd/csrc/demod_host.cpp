@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -114,6 +115,15 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 		for (unsigned i = 0; i < taps; i++)
 			out.rrc[j * taps + i] = rrc_tap(static_cast<int>(i * banks + j), taps * banks,
 			                                out.osf * static_cast<float>(banks), rrc_alpha);
+	/* filter.c:86-93 has no guard for t = 1/(4 alpha): where samples-per-symbol x -O / 2.4 lands on a tap (230.4 kS/s at 80 000
+	 * symbols/s with -O 5; 1.08 MS/s at 72 000 with -O 4) the tap is x/0 or 0/0.  The reference then filters inf / NaN into its
+	 * loops and indexes its tanh table with (int)NaN (pll.c:154-159): nothing to reproduce.  Refused, with the way out. */
+	for (float tap : out.rrc)
+		if (!std::isfinite(tap)) {
+			fprintf(stderr, "meteor_demod_amd: the RRC filter for %d samples/s, %d symbols/s, -O %d has a tap that is not finite (filter.c:86-93 divides by "
+			                "zero there; the reference's output is undefined): choose another -O\n", p.samplerate, p.symrate, p.interp_factor);
+			return MDEMOD_ERR_PARAM;
+		}
 
 	/* ---- symbol-clock fast path constants ---- */
 	{

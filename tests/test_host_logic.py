@@ -441,3 +441,25 @@ def test_no_exception_crosses_the_c_boundary():
     for name, guard in re.findall(r'extern "C" int\n(mdemod_\w+)\([^{]*?\)\n(try )?\{', rec):
         assert guard, name
     assert block.count("} MDEMOD_API_CATCH") == len(entries) - 1
+
+
+@pytest.mark.parametrize("kw", [dict(samplerate=230400, symrate=80000, oqpsk=True, interp_factor=5), dict(samplerate=1080000, interp_factor=4),
+                                dict(samplerate=230400, symrate=80000, oqpsk=True, interp_factor=5, rrc_order=48)],
+                         ids=["oqpsk80k-230.4k-O5", "1.08M-O4", "order48"])
+def test_a_filter_with_a_tap_that_is_not_finite_is_refused(kw, capfd):
+    """filter.c:86-93 divides by zero where samples-per-symbol x -O / 2.4 lands on a tap; the reference then runs inf / NaN through its
+    loops and indexes its tanh table with (int)NaN - its oracle restatement segfaults there as the reference does.  The library refuses
+    such a table (MDEMOD_ERR_PARAM, with the way out on stderr); one -O further the same rates are fine."""
+    import ctypes as C
+    import dataclasses
+    from meteor_demod_amd import DemodConfig, _capi
+    lib = _capi.lib()
+    cfg = DemodConfig(**kw)
+    name = C.create_string_buffer(200)
+    p = cfg.to_c(1, 0)
+    assert lib.mdemod_plan_kernel(C.byref(p), name, 200, None, None) == _capi.MDEMOD_ERR_PARAM
+    assert "choose another -O" in capfd.readouterr().err
+    rrc = (C.c_float * 8192)()
+    assert lib.mdemod_derive_tables(C.byref(p), rrc, 8192, None, None) == _capi.MDEMOD_ERR_PARAM
+    p2 = dataclasses.replace(cfg, interp_factor=cfg.interp_factor + 1).to_c(1, 0)
+    assert lib.mdemod_plan_kernel(C.byref(p2), name, 200, None, None) == 0
