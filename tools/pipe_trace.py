@@ -1,6 +1,6 @@
 """One mdemod_process_host call on the bench's host-fed shape from rows the caller pinned, three times, wall time each: the program behind
 a -DMDEMOD_PIPE_TRACE build (tools/build_exp_pipe.sh; MDEMOD_LIB_PATH) and its MDEMOD_PIPE_SKIP diagnosis knobs.
-    MDEMOD_LIB_PATH=gpurun_exp/trace.so [MDEMOD_PIPE_SKIP=1] python tools/pipe_trace.py [staged]"""
+    MDEMOD_LIB_PATH=gpurun_exp/trace.so [MDEMOD_PIPE_SKIP=1] python tools/pipe_trace.py [staged] [warm] [thp]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -9,7 +9,15 @@ from meteor_demod_amd import DemodConfig, Demodulator, synth
 ns, n = 16384, 1 << 15
 cfg = DemodConfig(samplerate=230000)
 one = synth.generate_host(synth.make_stream(1, 230000, 72000, f0_hz=300.0), n)
-buf = np.empty((ns, n, 2), np.int16)
+if "thp" in sys.argv:                         # the caller's buffer on transparent huge pages: fewer translations for the copy engine?
+    import mmap
+    mm = mmap.mmap(-1, ns * n * 4 + (2 << 20))
+    mm.madvise(mmap.MADV_HUGEPAGE)
+    raw = np.frombuffer(mm, dtype=np.uint8)
+    skip = (-raw.ctypes.data) % (2 << 20)
+    buf = raw[skip: skip + ns * n * 4].view(np.int16).reshape(ns, n, 2)
+else:
+    buf = np.empty((ns, n, 2), np.int16)
 buf[:] = one
 with Demodulator(cfg, ns) as d:
     if "staged" not in sys.argv: d.pin_host(buf)
