@@ -119,7 +119,12 @@ parallel_streams(uint32_t n, const std::vector<uint64_t> &weight_prefix, F fn)
 {
 	const uint64_t total = weight_prefix.empty() ? 0 : weight_prefix.back();
 	PackPool &pool = PackPool::get();
-	if (total < (8u << 20) || pool.size() == 1) { fn(0u, n); return; }          /* small jobs: not worth waking anybody */
+	/* small jobs are not worth waking anybody - but "small" is a megabyte, not eight: the last (quarter) sub-block of a pipelined call is
+	   4.6 MB of 640-byte pieces at the bench shape, and one thread took a millisecond over it with nothing left to hide it behind (r05) */
+#ifndef MDEMOD_POOL_MIN_BYTES
+#define MDEMOD_POOL_MIN_BYTES (1u << 20)
+#endif
+	if (total < MDEMOD_POOL_MIN_BYTES || pool.size() == 1) { fn(0u, n); return; }
 	const unsigned pieces = pool.size() * 4;
 	std::vector<uint32_t> cut(pieces + 1, n);
 	cut[0] = 0;

@@ -26,7 +26,7 @@ race(int callers, int rounds)
 			std::vector<int> hits(n_jobs, 0);
 			PackPool::get().run(n_jobs, [&](unsigned i) { hits[i]++; });
 			for (int h : hits) if (h != 1) bad++;
-			/* parallel_streams: above the 8 MB threshold, ragged weights (some streams empty) */
+			/* parallel_streams: above the threshold (1 MB), ragged weights (some streams empty) */
 			const uint32_t n = 50 + (uint32_t)((c + r) % 200);
 			std::vector<uint64_t> prefix(n);
 			uint64_t acc = 0;
