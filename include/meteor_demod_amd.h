@@ -39,7 +39,7 @@
  *     symbol returned in place per call would be a kernel launch per sample).  An UNMODIFIED main.c therefore does not link
  *     against this library: the binding is the block call - the patch to main.c's thread_process shown in INTEGRATION.md 1, or
  *     the C host shipped in host/ with the reference's option table.
- *   - Exact mode on ONE stream is one wavefront: about 3.6 Msamples/s on configs[1], SLOWER than the reference on one host core
+ *   - Exact mode on ONE stream is one wavefront: about 5 Msamples/s on configs[1] (r05), SLOWER than the reference on one host core
  *     (about 26 Msamples/s on the bench host).  The GPU is meant to be used on batches of streams (mdemod_process_*, thousands
  *     of recordings or tiles at 250 Gsamples/s) or on one long recording through mdemod_demodulate_recording (`--tiled`:
  *     overlapped tiles, agreement with the serial run at the reference's own perturbation floor, not bit-exact).
