@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define MDEMOD_ABI_VERSION 3
+#define MDEMOD_ABI_VERSION 4    /* 4 (r05): + mdemod_pin_host_buffer / mdemod_unpin_host_buffer; settings with a non-finite RRC tap refused */
 
 /* Error codes (the reference surfaces none: demod_init returns void and drops
  * filter_init_rrc's status, demod.c:14).  Nothing in the library calls exit() or abort(), and no C++ exception leaves it: an

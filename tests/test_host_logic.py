@@ -42,7 +42,7 @@ def test_header_symbols_are_all_exported():
 
 def test_abi_version_and_struct_layouts():
     lib = _capi.lib()
-    assert lib.mdemod_abi_version() == 3
+    assert lib.mdemod_abi_version() == 4
     assert C.sizeof(_capi.MdemodParams) == 48
     assert C.sizeof(_capi.MdemodStatus) == 56
     assert C.sizeof(_capi.MdemodLockEvent) == 16
