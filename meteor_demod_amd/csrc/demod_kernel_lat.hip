@@ -446,6 +446,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		       (double)tm_pf / tm_batches, (double)tm_farm / tm_batches, (double)tm_serial / tm_batches, (double)tm_serial / (double)(tm_fired ? tm_fired : 1),
 		       (double)tm_flush / tm_batches, (double)tm_commit / tm_batches);
 #endif
+#undef LAT_TM
 	if (guard == 0 && !done) overflow = 1;                                /* watchdog fired: reported as overflow */
 
 	/* ---- store state ---- */
