@@ -261,6 +261,7 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 #ifdef LAT_EXP_TIMING
 	/* experiment builds only (tools/build_exp_lat.sh x -DLAT_EXP_TIMING): where a batch's time goes, by s_memtime, printed by stream 0 */
 	unsigned long long tm_pf = 0, tm_farm = 0, tm_serial = 0, tm_flush = 0, tm_commit = 0, tm_batches = 0, tm_fired = 0;
+	unsigned long long tm_c[3] = { 0, 0, 0 }, tm_miss = 0;
 #define LAT_TM(acc) do { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tm_last; tm_last = now_; } while (0)
 #else
 #define LAT_TM(acc) do { } while (0)
@@ -395,6 +396,9 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 			const int cidx = steps_done + m - pj;                         /* -1, 0, +1 when the prediction holds */
 			const int idx = kCand * j + cidx + 1;
 			const bool hit = regular && cidx >= -1 && cidx <= 1 && ((ok_mask >> idx) & 1ull);
+#ifdef LAT_EXP_TIMING
+			if (hit) tm_c[cidx + 1]++; else tm_miss++;
+#endif
 			if (__builtin_expect(!hit, 0)) { miss = true; break; }                             /* irregular firing: handled after the loop, the batch ends */
 			t_phase = ph;
 			steps_done += m;
@@ -445,6 +449,8 @@ demod_kernel_lat(const DemodLaunch L, const float *rrc, int ring_size, int span,
 		printf("[lat] %llu batches, %llu firings in them: ticks per batch prefetch %.0f farm %.0f serial %.0f (%.1f per firing) flush %.0f commit %.0f\n", tm_batches, tm_fired,
 		       (double)tm_pf / tm_batches, (double)tm_farm / tm_batches, (double)tm_serial / tm_batches, (double)tm_serial / (double)(tm_fired ? tm_fired : 1),
 		       (double)tm_flush / tm_batches, (double)tm_commit / tm_batches);
+	if (lane == 0 && stream == 0 && tm_batches)
+		printf("[lat] candidate taken: one step early %llu, as predicted %llu, one step late %llu; misses %llu\n", tm_c[0], tm_c[1], tm_c[2], tm_miss);
 #endif
 #undef LAT_TM
 	if (guard == 0 && !done) overflow = 1;                                /* watchdog fired: reported as overflow */
