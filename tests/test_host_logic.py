@@ -463,3 +463,22 @@ def test_a_filter_with_a_tap_that_is_not_finite_is_refused(kw, capfd):
     assert lib.mdemod_derive_tables(C.byref(p), rrc, 8192, None, None) == _capi.MDEMOD_ERR_PARAM
     p2 = dataclasses.replace(cfg, interp_factor=cfg.interp_factor + 1).to_c(1, 0)
     assert lib.mdemod_plan_kernel(C.byref(p2), name, 200, None, None) == 0
+
+
+@pytest.mark.parametrize("kw,most", [(dict(samplerate=230000), 4096), (dict(samplerate=230000, symrate=80000, oqpsk=True), 4096),
+                                     (dict(samplerate=230000, rrc_order=48, bps=32), 4096),
+                                     (dict(samplerate=1000000, rrc_order=64, interp_factor=8), 2048), (dict(samplerate=1000000, rrc_order=64, interp_factor=8, bps=32), 2048),
+                                     (dict(samplerate=1024000), 1024), (dict(samplerate=1024000, bps=32), 1024), (dict(samplerate=2048000), 1024)],
+                         ids=["configs1", "configs2", "97taps-f32-230k", "configs3", "configs3-f32", "mid-1.024M", "mid-1.024M-f32", "far-2.048M"])
+def test_where_a_context_hands_over_from_the_wave_kernel_to_the_lane_kernels(kw, most):
+    """wants_latency_kernel (demod_api.cpp, measured r05 with tools/lat_bench.py): one stream per WAVE up to `most` streams, one per lane
+    of the configuration's v3 kernel from there on - decided without a device (mdemod_plan_kernel)."""
+    import ctypes as C
+    from meteor_demod_amd import DemodConfig, _capi
+    lib = _capi.lib()
+    cfg = DemodConfig(**kw)
+    name = C.create_string_buffer(200)
+    for n, wave in ((1, True), (most, True), (most + 1, False), (65536, False)):
+        p = cfg.to_c(n, 0)
+        assert lib.mdemod_plan_kernel(C.byref(p), name, 200, None, None) == 0
+        assert (b"demod_kernel_lat" in name.value) == wave, (n, name.value)
