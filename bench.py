@@ -140,13 +140,14 @@ def demod_config(tag: str):
 
 def cpu_baseline(cfg) -> dict:
     """Reference CPU path on this host: one single-threaded process per core (the reference has
-    exactly one demod thread, main.c:218), each on the same 2^23-sample recording."""
+    exactly one demod thread, main.c:218), each on the same 2^24-sample recording (about 10 s of CPU
+    work per build: the contract's bounded sample)."""
     sys.path.insert(0, str(ROOT / "tests"))
     import numpy as np
     import oracle_py as O
     from meteor_demod_amd import synth
 
-    n = 1 << 23
+    n = 1 << 24
     st = synth.make_stream(424242, cfg.samplerate, cfg.symrate, oqpsk=cfg.oqpsk, f0_hz=1200.0)
     try:
         iq = synth.generate_device([st], n).cpu().numpy()[0]
@@ -198,7 +199,7 @@ def cpu_baseline(cfg) -> dict:
     extra = {"builds_msps": builds} if kind == "reference" else {}
     return {"value": round(agg, 2), "unit": "Msamples/s", "cores": procs, "nproc": os.cpu_count(), "kind": kind, **extra, "host": host,
             "per_core_msps": round(n / (sum(per) / len(per)) / 1e6, 2),
-            "sample": f"{procs} single-threaded processes (one per physical core, capped by the cgroup CPU quota) x 2^23-sample {cfg.symrate // 1000}k recording "
+            "sample": f"{procs} single-threaded processes (one per physical core, capped by the cgroup CPU quota) x 2^24-sample {cfg.symrate // 1000}k recording "
                       f"({procs * n / 1e6:.0f} M samples, {sum(per):.1f} s CPU, {wall:.1f} s wall); value = the faster of the builds listed"}
 
 
