@@ -236,6 +236,18 @@ struct worker {
 	int         rc;                      /* exit code of this worker: 0 ok, 1 host error, 2 library error */
 };
 
+/* the code in words plus what the library has to add (mdemod_last_error: it prints nothing itself), taken at once - the text belongs
+ * to the failing call and the next call into the library may replace it */
+static const char *
+why_of(int rc)
+{
+	static __thread char buf[640];
+	const char *more = mdemod_last_error();
+	if (more && *more) snprintf(buf, sizeof buf, "%s: %s", mdemod_strerror(rc), more);
+	else snprintf(buf, sizeof buf, "%s", mdemod_strerror(rc));
+	return buf;
+}
+
 /* ---- --tiled: each file on many lanes: read it whole (32768-byte buffers only, wavfile.c:55), one library call per file.  The
  * serial head of a recording keeps one wavefront busy for ~0.1 s and its file takes as long to read: up to `jobs` files of a worker
  * are in flight at once, each on a host thread of its own (the library calls are independent: own contexts, own streams).
@@ -295,7 +307,7 @@ tiled_one_file(struct worker *w, int f)
 	int rc2 = mdemod_demodulate_recording_host(&p, &ro, data, n_samples, soft_all, cap_sym, &rr);
 	const double t_lib = now_ms();
 	if (rc2 != MDEMOD_OK) {
-		fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", mdemod_strerror(rc2));
+		fprintf(stderr, "mdemod_demodulate_recording_host: %s\n", why_of(rc2));
 		free(data); free(soft_all);
 		return 2;
 	}
@@ -391,7 +403,7 @@ run_exact(struct worker *w)
 	mdemod_params p = w->p;
 	mdemod_ctx *ctx = NULL;
 	int rc = mdemod_create(&p, &ctx);
-	if (rc != MDEMOD_OK) return exact_failed(w, 2, "mdemod_create", mdemod_strerror(rc));
+	if (rc != MDEMOD_OK) return exact_failed(w, 2, "mdemod_create", why_of(rc));
 	if (!quiet) say("Demodulator initialized\n");                                    /* main.c:219 */
 	if (!quiet && !w->tui && n_files < 64 && io[0].file_len > (64ul << 20))
 		fprintf(stderr, "note: %d file%s demodulated exactly = %d serial stream%s, one GPU wavefront each (about 3.6 MS/s: slower than the "
@@ -440,9 +452,9 @@ run_exact(struct worker *w)
 		}
 		if (!active) break;
 		rc = mdemod_process_host(ctx, iq, n_in, outp, caps, n_out);          /* demod(&sample) x n: main.c:304 */
-		if (rc != MDEMOD_OK) { mdemod_destroy(ctx); FREE_BLOCKS(); return exact_failed(w, 2, "mdemod_process_host", mdemod_strerror(rc)); }
+		if (rc != MDEMOD_OK) { const char *why = why_of(rc); mdemod_destroy(ctx); FREE_BLOCKS(); return exact_failed(w, 2, "mdemod_process_host", why); }
 		rc = mdemod_get_status(ctx, 0, (uint32_t)n_files, st, NULL);
-		if (rc != MDEMOD_OK) { mdemod_destroy(ctx); FREE_BLOCKS(); return exact_failed(w, 2, "mdemod_get_status", mdemod_strerror(rc)); }
+		if (rc != MDEMOD_OK) { const char *why = why_of(rc); mdemod_destroy(ctx); FREE_BLOCKS(); return exact_failed(w, 2, "mdemod_get_status", why); }
 		for (int i = 0; i < n_files; i++)
 			write_gated(&io[i], outp[i], n_out[i], st[i].first_lock_symbol);
 #ifdef MDEMOD_TUI

@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define MDEMOD_ABI_VERSION 4    /* 4 (r05): + mdemod_pin_host_buffer / mdemod_unpin_host_buffer; settings with a non-finite RRC tap refused */
+#define MDEMOD_ABI_VERSION 5    /* 5 (r06): + mdemod_last_error; the library no longer writes to stderr.  4 (r05): + mdemod_pin_host_buffer / mdemod_unpin_host_buffer; settings with a non-finite RRC tap refused */
 
 /* Error codes (the reference surfaces none: demod_init returns void and drops
  * filter_init_rrc's status, demod.c:14).  Nothing in the library calls exit() or abort(), and no C++ exception leaves it: an
@@ -72,6 +72,13 @@ enum {
 	MDEMOD_ERR_OVERFLOW  = -4,   /* soft-symbol capacity too small           */
 	MDEMOD_ERR_RANGE     = -5    /* stream index out of range                */
 };
+/* What went wrong, in words, when a code alone does not say it: which setting was refused and why, which HIP call failed with
+ * which runtime message.  The library itself prints nothing (it may sit behind a caller's own terminal UI, as the reference's
+ * demodulator sits behind tui.c); only with MDEMOD_DEBUG in the environment is the same text also written to stderr.
+ * The text belongs to the CALLING THREAD's most recent entry that returned < 0 ("" when that entry had nothing to add to its code,
+ * and after any entry that succeeded); it stays valid until that thread calls into the library again.  Never NULL.
+ * (The reference has no counterpart: demod_init returns void, demod.c:14 drops filter_init_rrc's status.) */
+const char *mdemod_last_error(void);
 
 /* Defaults of the reference CLI (demod.h:8-15). */
 #define MDEMOD_DEFAULT_SYM_RATE   72000
@@ -166,7 +173,7 @@ int  mdemod_device_count(void);
  * input sample per firing, samplerate x interp or 2 x symrate beyond int (demod.c:12-13 multiplies in int), a carrier range of
  * 6 rad per symbol or more, and settings whose RRC table has a tap that is not finite (filter.c:86-93 divides by zero where
  * samples-per-symbol x -O / 2.4 lands on a tap - 230.4 kS/s OQPSK 80k with -O 5, 1.08 MS/s with -O 4 -; the reference's output is
- * undefined there; another -O is the way out, and the message on stderr says so). */
+ * undefined there; another -O is the way out, and mdemod_last_error() says so). */
 int  mdemod_create(const mdemod_params *params, mdemod_ctx **out);
 /* Replaces demod_deinit (demod.c:18-21). */
 void mdemod_destroy(mdemod_ctx *ctx);

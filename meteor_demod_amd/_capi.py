@@ -96,6 +96,7 @@ class MdemodRecordingReport(C.Structure):
 _P = C.POINTER
 SIGNATURES = {
     "mdemod_abi_version": (C.c_uint32, []),
+    "mdemod_last_error": (C.c_char_p, []),
     "mdemod_strerror": (C.c_char_p, [C.c_int]),
     "mdemod_init_device": (C.c_int, [C.c_int]),
     "mdemod_create": (C.c_int, [_P(MdemodParams), _P(C.c_void_p)]),
@@ -160,7 +161,8 @@ _lib = None
 class MdemodError(RuntimeError):
     def __init__(self, code: int, what: str):
         self.code = code
-        super().__init__(f"{what}: error {code} ({strerror(code)})")
+        self.detail = last_error()          # mdemod_last_error(): this thread's failing call, read before anything else calls in
+        super().__init__(f"{what}: error {code} ({strerror(code)})" + (f": {self.detail}" if self.detail else ""))
 
 
 def hip_runtime_first() -> None:
@@ -196,6 +198,12 @@ def lib() -> C.CDLL:
 
 def strerror(code: int) -> str:
     return lib().mdemod_strerror(code).decode()
+
+
+def last_error() -> str:
+    """``mdemod_last_error``: what the calling thread's most recent failing entry had to say beyond its code ("" if nothing)."""
+    fn = getattr(lib(), "mdemod_last_error", None)
+    return (fn() or b"").decode(errors="replace") if fn is not None else ""
 
 
 def check(code: int, what: str) -> int:

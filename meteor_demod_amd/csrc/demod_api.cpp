@@ -45,7 +45,7 @@ namespace {
 	do {                                                                                \
 		hipError_t e_ = (expr);                                                         \
 		if (e_ != hipSuccess) {                                                         \
-			fprintf(stderr, "meteor_demod_amd: %s failed: %s (%s:%d)\n", #expr,         \
+			mdm_note_error("%s failed: %s (%s:%d)", #expr,                           \
 			        hipGetErrorString(e_), __FILE__, __LINE__);                         \
 			return e_ == hipErrorOutOfMemory ? MDEMOD_ERR_NOMEM : MDEMOD_ERR_HIP;       \
 		}                                                                               \
@@ -156,13 +156,13 @@ plan_context(mdemod_ctx *ctx)
 	 * v3 kernels' float wraps and unchecked turn code do not hold - cannot occur: pll.c:29-33 clamps fmax to 1 rad per symbol,
 	 * and so does demod_host.cpp.) */
 	const uint32_t kforce = params->reserved & MDEMOD_FLAG_KERNEL_MASK;
-	if (kforce == 2) return MDEMOD_ERR_PARAM;         /* the retired generation */
+	if (kforce == 2) { mdm_note_error("kernel generation 2 (round 2's moving register window) was retired: 0 / 3 = the rotating windows, 1 = the LDS ring"); return MDEMOD_ERR_PARAM; }
 	const int generation = kforce == 1 ? 0 : 2;
 	int rc = mdemod_host_derive(*params, ctx->tab, generation);
 	if (rc) return rc;
 	/* the v3 and latency kernels wrap the NCO phase in float arithmetic and skip the range test of its turn code
 	 * (demod_device.h): both need phase + freq < 4 pi, i.e. fmax < 2 pi rad per symbol */
-	if (!(ctx->tab.c.pll_fmax < 6.0f)) return MDEMOD_ERR_PARAM;
+	if (!(ctx->tab.c.pll_fmax < 6.0f)) { mdm_note_error("a carrier range of %g rad per symbol: 6 or more cannot be held (pll.c:113 wraps the phase once per symbol)", static_cast<double>(ctx->tab.c.pll_fmax)); return MDEMOD_ERR_PARAM; }
 	ctx->sample_bytes = 2 * static_cast<size_t>(params->bps) / 8;
 	ctx->use_rot = generation == 2 && ctx->tab.use_rw && !ctx->tab.rw_wide && !ctx->tab.rw_mid && !ctx->tab.rw_far && !ctx->tab.rw_hyb && !ctx->tab.rw_gather;
 	ctx->hyb_block = 0;
@@ -229,7 +229,7 @@ mdemod_abi_version(void)
 
 int
 mdemod_init_device(int device)
-try {
+try { MDEMOD_API_ENTER
 	if (hipSetDevice(device) != hipSuccess) return MDEMOD_ERR_HIP;
 	if (hipFree(nullptr) != hipSuccess) return MDEMOD_ERR_HIP;             /* forces the context */
 	/* ... and the code objects (loaded at the first launch of a process), on a stream of its own */
@@ -242,7 +242,7 @@ try {
 
 int
 mdemod_device_count(void)
-try {
+try { MDEMOD_API_ENTER
 	int n = 0;
 	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 } MDEMOD_API_CATCH
@@ -264,7 +264,7 @@ mdemod_strerror(int code)
 int
 mdemod_derive_tables(const mdemod_params *params, float *rrc_out, uint32_t rrc_cap,
                      float consts_out[8], float lut_out[32])
-try {
+try { MDEMOD_API_ENTER
 	if (!params) return MDEMOD_ERR_PARAM;
 	HostTables t;
 	int rc = mdemod_host_derive(*params, t);
@@ -285,10 +285,11 @@ try {
 int
 mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 {
-	if (!params || !out || params->n_streams == 0) return MDEMOD_ERR_PARAM;
+	MDEMOD_API_ENTER
+	if (!params || !out || params->n_streams == 0) { mdm_note_error("mdemod_create: params, out and at least one stream are needed"); return MDEMOD_ERR_PARAM; }
 	*out = nullptr;
 	mdemod_ctx *ctx = new (std::nothrow) mdemod_ctx();
-	if (!ctx) return MDEMOD_ERR_NOMEM;
+	if (!ctx) { mdm_note_error("mdemod_create: no memory for a context"); return MDEMOD_ERR_NOMEM; }
 	ctx->params = *params;
 	ctx->pipe = nullptr;
 	try {
@@ -300,7 +301,7 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	{
 		hipError_t e = hipSetDevice(params->device);
 		if (e != hipSuccess) {
-			fprintf(stderr, "meteor_demod_amd: no usable HIP device %d: %s\n", params->device, hipGetErrorString(e));
+			mdm_note_error("no usable HIP device %d: %s", params->device, hipGetErrorString(e));
 			delete ctx;
 			return MDEMOD_ERR_HIP;
 		}
@@ -343,6 +344,7 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 	}
 #undef CREATE_TRY
 	} catch (...) {                                    /* (see MDEMOD_API_CATCH; what the context holds so far is given back) */
+		mdm_note_error("mdemod_create: a C++ exception reached the boundary (allocation failed)");
 		mdemod_destroy(ctx);
 		return MDEMOD_ERR_NOMEM;
 	}
@@ -362,7 +364,7 @@ mdemod_destroy(mdemod_ctx *ctx)
 
 int
 mdemod_reset(mdemod_ctx *ctx, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -387,7 +389,7 @@ int
 mdemod_process_device_uniform(mdemod_ctx *ctx, const void *iq_dev, uint64_t iq_stride_samples,
                               uint32_t n_samples, int8_t *soft_dev, uint64_t soft_stride_symbols,
                               uint32_t soft_cap_symbols, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || (!iq_dev && n_samples) || !soft_dev) return MDEMOD_ERR_PARAM;
 	if (n_samples > 0x3FFFFF00u) return MDEMOD_ERR_PARAM;
 	if (soft_cap_symbols > soft_stride_symbols) return MDEMOD_ERR_PARAM;
@@ -404,7 +406,7 @@ int
 mdemod_process_device(mdemod_ctx *ctx, const void *iq_dev, const uint64_t *iq_offset_dev,
                       const uint32_t *n_samples_dev, int8_t *soft_dev, uint64_t soft_stride_symbols,
                       uint32_t soft_cap_symbols, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !iq_dev || !iq_offset_dev || !n_samples_dev || !soft_dev) return MDEMOD_ERR_PARAM;
 	if (soft_cap_symbols > soft_stride_symbols) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
@@ -419,7 +421,7 @@ try {
 int
 mdemod_process_host(mdemod_ctx *ctx, const void *const *iq_host, const uint32_t *n_samples,
                     int8_t *const *soft_host, const uint32_t *soft_cap, uint32_t *n_symbols)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !iq_host || !n_samples || !soft_host || !soft_cap) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -432,7 +434,7 @@ try {
 
 int
 mdemod_pin_host_buffer(mdemod_ctx *ctx, const void *base, size_t bytes)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !base || !bytes) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -441,7 +443,7 @@ try {
 
 int
 mdemod_unpin_host_buffer(mdemod_ctx *ctx, const void *base)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !base) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -453,7 +455,7 @@ try {
 
 int
 mdemod_get_status(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_status *out, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	if (static_cast<uint64_t>(first) + count > ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	if (!count) return MDEMOD_OK;
@@ -489,7 +491,7 @@ try {
 int
 mdemod_get_lock_events(mdemod_ctx *ctx, uint32_t stream, mdemod_lock_event *out, uint32_t cap,
                        uint32_t *n, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !n) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	int rc = select_device(ctx);
@@ -516,7 +518,7 @@ try {
 
 int
 mdemod_get_state(mdemod_ctx *ctx, uint32_t stream, mdemod_stream_state *out, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	int rc = select_device(ctx);
@@ -547,23 +549,36 @@ carrier_in_domain(const mdemod_stream_state &v)
 }
 
 /* A clock word the reference's loop can hold: timing.c:80-86 keeps it within center / 4096 of the centre, and the kernels' symbol
- * clock counts on it (steps that provably cannot fire: step_fmax, clock_jump.h).  NaN goes through as in the reference. */
+ * clock counts on it (steps that provably cannot fire: step_fmax, clock_jump.h).  NaN is refused like any other word outside (r06: a
+ * NaN clock never fires - every kernel would spin to its watchdog and report an overflow after a full-length run). */
 static bool
 clock_in_domain(const mdemod_ctx *ctx, const mdemod_stream_state &v)
 {
 	const DemodConsts &c = ctx->tab.c;
 	/* (centre + fd is a rounded float sum: the bound carries the same 1e-6 of slack as step_fmax, the one the kernels use) */
 	const double lo = (static_cast<double>(c.t_center) - static_cast<double>(c.t_maxdev)) * (1.0 - 1e-6);
-	return !(v.t_freq > c.step_fmax) && !(static_cast<double>(v.t_freq) < lo);
+	return v.t_freq <= c.step_fmax && static_cast<double>(v.t_freq) >= lo;          /* (positive comparisons: NaN is outside) */
+}
+
+static void
+note_domain(const mdemod_ctx *ctx, const mdemod_stream_state &v)
+{
+	const DemodConsts &c = ctx->tab.c;
+	if (!carrier_in_domain(v))
+		mdm_note_error("carrier state pll_phase %g, pll_freq %g: |phase| + |freq| must stay below 12.5 (pll.c:113 wraps once per symbol)",
+		                  static_cast<double>(v.pll_phase), static_cast<double>(v.pll_freq));
+	else
+		mdm_note_error("symbol-clock word t_freq %.9g is outside what the reference's loop can hold, %.9g +- %.9g (timing.c:80-86)",
+		                  static_cast<double>(v.t_freq), static_cast<double>(c.t_center), static_cast<double>(c.t_maxdev));
 }
 
 int
 mdemod_set_state(mdemod_ctx *ctx, uint32_t stream, const mdemod_stream_state *in, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !in) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	if (in->t_dual_state != 1 && in->t_dual_state != 2) return MDEMOD_ERR_PARAM;
-	if (!carrier_in_domain(*in) || !clock_in_domain(ctx, *in)) return MDEMOD_ERR_PARAM;
+	if (!carrier_in_domain(*in) || !clock_in_domain(ctx, *in)) { note_domain(ctx, *in); return MDEMOD_ERR_PARAM; }
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);
@@ -582,10 +597,10 @@ try {
 
 int
 mdemod_set_state_all(mdemod_ctx *ctx, const mdemod_stream_state *seed, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !seed) return MDEMOD_ERR_PARAM;
 	if (seed->t_dual_state != 1 && seed->t_dual_state != 2) return MDEMOD_ERR_PARAM;
-	if (!carrier_in_domain(*seed) || !clock_in_domain(ctx, *seed)) return MDEMOD_ERR_PARAM;
+	if (!carrier_in_domain(*seed) || !clock_in_domain(ctx, *seed)) { note_domain(ctx, *seed); return MDEMOD_ERR_PARAM; }
 	int rc = select_device(ctx);
 	if (rc) return rc;
 	const int32_t flags = (seed->pll_locked ? MDEMOD_FLAG_LOCKED : 0) | (seed->pll_locked_once ? MDEMOD_FLAG_LOCKED_ONCE : 0) |
@@ -597,7 +612,7 @@ try {
 
 int
 mdemod_rotate_carrier(mdemod_ctx *ctx, const int32_t *quarter_turns_dev, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !quarter_turns_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -607,7 +622,7 @@ try {
 
 int
 mdemod_set_carrier_seeds(mdemod_ctx *ctx, const float *freq_dev, const int32_t *updown_dev, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !freq_dev || !updown_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -617,7 +632,7 @@ try {
 
 int
 mdemod_set_gain_seeds(mdemod_ctx *ctx, const float *gain_dev, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !gain_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -627,7 +642,7 @@ try {
 
 int
 mdemod_set_clock_seeds(mdemod_ctx *ctx, const float *t_freq_dev, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !t_freq_dev) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -641,7 +656,7 @@ try {
 
 int
 mdemod_get_states(mdemod_ctx *ctx, uint32_t first, uint32_t count, mdemod_stream_state *out, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	if (static_cast<uint64_t>(first) + count > ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	if (!count) return MDEMOD_OK;
@@ -673,7 +688,7 @@ try {
 
 int
 mdemod_copy_state(mdemod_ctx *dst, mdemod_ctx *src, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!dst || !src) return MDEMOD_ERR_PARAM;
 	const mdemod_params &a = dst->params, &b = src->params;
 	if (a.n_streams != b.n_streams || a.bps != b.bps || a.device != b.device || dst->tab.use_rw != src->tab.use_rw ||
@@ -702,7 +717,7 @@ mdemod_nominal_pitch(const mdemod_ctx *ctx, uint64_t n_samples)
 int
 mdemod_compact_soft(mdemod_ctx *ctx, const int8_t *soft_dev, uint64_t soft_stride_symbols,
                     int8_t *out_dev, uint64_t out_pitch_symbols, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !soft_dev || !out_dev || (soft_stride_symbols & 7) || (out_pitch_symbols & 7)) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -730,7 +745,7 @@ mdemod_kernel_name(const mdemod_ctx *ctx)
 
 int
 mdemod_plan_kernel(const mdemod_params *params, char *name, uint32_t name_cap, uint32_t *lds_bytes, uint32_t *block_threads)
-try {
+try { MDEMOD_API_ENTER
 	if (!params || !name || name_cap == 0 || params->n_streams == 0) return MDEMOD_ERR_PARAM;
 	mdemod_ctx *ctx = new (std::nothrow) mdemod_ctx();
 	if (!ctx) return MDEMOD_ERR_NOMEM;
@@ -754,7 +769,7 @@ mdemod_history_len(const mdemod_ctx *ctx)
 
 int
 mdemod_get_history(mdemod_ctx *ctx, uint32_t stream, float *iq_pairs, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !iq_pairs) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	int rc = select_device(ctx);
@@ -782,7 +797,7 @@ try {
 
 int
 mdemod_set_history(mdemod_ctx *ctx, uint32_t stream, const float *iq_pairs, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !iq_pairs) return MDEMOD_ERR_PARAM;
 	if (stream >= ctx->params.n_streams) return MDEMOD_ERR_RANGE;
 	int rc = select_device(ctx);
@@ -817,7 +832,7 @@ try {
 
 int
 mdemod_get_rrc_table(const mdemod_ctx *ctx, float *out, uint32_t cap)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	if (cap < ctx->tab.rrc.size()) return MDEMOD_ERR_PARAM;
 	memcpy(out, ctx->tab.rrc.data(), ctx->tab.rrc.size() * sizeof(float));
@@ -826,7 +841,7 @@ try {
 
 int
 mdemod_get_loop_constants(const mdemod_ctx *ctx, float out[8])
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	const DemodConsts &c = ctx->tab.c;
 	const float v[8] = { c.pll_alpha, c.pll_beta, c.pll_fmax, c.t_alpha, c.t_beta, c.t_center, c.t_maxdev, ctx->tab.osf };
@@ -836,7 +851,7 @@ try {
 
 int
 mdemod_get_tanh_lut(const mdemod_ctx *ctx, float out[32])
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !out) return MDEMOD_ERR_PARAM;
 	memcpy(out, ctx->tab.tanh_lut, sizeof(ctx->tab.tanh_lut));
 	return MDEMOD_OK;
@@ -846,7 +861,7 @@ try {
 
 int
 mdemod_selftest_sincos(mdemod_ctx *ctx, const float *x, uint32_t n, float *sin_out, float *cos_out)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !x || !sin_out || !cos_out) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -862,7 +877,7 @@ try {
 
 int
 mdemod_selftest_turncode(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !n_mismatch) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -880,7 +895,7 @@ try {
 
 int
 mdemod_selftest_cabsf(mdemod_ctx *ctx, uint64_t pairs, uint64_t *n_mismatch, uint64_t *n_fallback)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !n_mismatch || !pairs) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -898,7 +913,7 @@ try {
 
 int
 mdemod_selftest_sinlut(mdemod_ctx *ctx, uint64_t *n_checked, uint64_t *n_mismatch)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !n_mismatch) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;
@@ -916,7 +931,7 @@ try {
 
 int
 mdemod_selftest_hypot(mdemod_ctx *ctx, const float *xy, uint32_t n_pairs, float *out)
-try {
+try { MDEMOD_API_ENTER
 	if (!ctx || !xy || !out) return MDEMOD_ERR_PARAM;
 	int rc = select_device(ctx);
 	if (rc) return rc;

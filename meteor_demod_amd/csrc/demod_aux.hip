@@ -98,14 +98,16 @@ gain_seed_kernel(DemodStateSoA st, const float *gain, uint32_t n_streams)
 }
 
 /* Clock words from a device array (the stitcher's per-tile estimates): kept inside what timing.c:80-86 can hold, the range the
- * kernels' symbol clock counts on (step_fmax, clock_jump.h) - the same bounds mdemod_set_state checks on the host.  NaN stays NaN. */
+ * kernels' symbol clock counts on (step_fmax, clock_jump.h) - the same bounds mdemod_set_state checks on the host.  NaN -> the nominal rate. */
 __global__ void
 clock_seed_kernel(DemodStateSoA st, const float *t_freq, float lo, float hi, uint32_t n_streams)
 {
 	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n_streams) return;
 	const float f = t_freq[s];
-	st.t_freq[s] = f < lo ? lo : (f > hi ? hi : f);
+	/* NaN is out of the domain like any other word the loop cannot hold (a NaN clock never fires: the kernel would spin to its
+	 * watchdog): it becomes the nominal rate, the middle of the range */
+	st.t_freq[s] = f != f ? 0.5f * (lo + hi) : (f < lo ? lo : (f > hi ? hi : f));
 }
 
 /* Host path: the demodulator writes its soft symbols with the hard-bound row pitch (one symbol per input sample);

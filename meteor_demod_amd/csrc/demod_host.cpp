@@ -8,8 +8,9 @@
 #include "demod_host.h"
 
 #include <cmath>
-#include <cstdint>
+#include <cstdarg>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -62,20 +63,48 @@ rrc_tap(int stage, unsigned n_taps, float osf, float alpha)
 
 } /* namespace */
 
+/* ---- mdemod_last_error(): the text of the failure, handed back instead of printed (include/meteor_demod_amd.h, ABI 5) ---------- */
+namespace {
+thread_local char tl_error[512];
+thread_local int  tl_depth;
+}
+
+void
+mdm_note_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(tl_error, sizeof tl_error, fmt, ap);
+	va_end(ap);
+	if (getenv("MDEMOD_DEBUG")) fprintf(stderr, "meteor_demod_amd: %s\n", tl_error);
+}
+
+mdm_api_scope::mdm_api_scope() { if (tl_depth++ == 0) tl_error[0] = 0; }
+mdm_api_scope::~mdm_api_scope() { --tl_depth; }
+
+extern "C" const char *
+mdemod_last_error(void)
+{
+	return tl_error;
+}
+
 int
 mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 {
-	if (p.interp_factor < 1 || p.interp_factor > 64) return MDEMOD_ERR_PARAM;
-	if (p.rrc_order < 1 || p.rrc_order > 256) return MDEMOD_ERR_PARAM;
-	if (p.samplerate <= 0 || p.symrate <= 0) return MDEMOD_ERR_PARAM;
+#define REFUSE(...) do { mdm_note_error(__VA_ARGS__); return MDEMOD_ERR_PARAM; } while (0)
+	if (p.interp_factor < 1 || p.interp_factor > 64) REFUSE("-O %d: the interpolation factor must be 1..64", p.interp_factor);
+	if (p.rrc_order < 1 || p.rrc_order > 256) REFUSE("-f %d: the RRC order must be 1..256", p.rrc_order);
+	if (p.samplerate <= 0 || p.symrate <= 0) REFUSE("sample rate %d and symbol rate %d must be positive", p.samplerate, p.symrate);
 	/* Fewer than one input sample per symbol is fine: the reference then fires more than once inside its per-sample loop and keeps
 	 * only the LAST symbol of each sample (demod.c:33-47, 62-90: `ret` and `*sample` are overwritten), and so do the kernels
 	 * (goldens one_per_symbol, sub_sample, sub_sample_oqpsk).  Below a quarter of a sample per firing nothing has been tested. */
-	if (static_cast<double>(p.samplerate) * (p.oqpsk ? 2.0 : 1.0) < static_cast<double>(p.symrate) * 0.25) return MDEMOD_ERR_PARAM;
-	if (p.bps != 8 && p.bps != 16 && p.bps != 32) return MDEMOD_ERR_PARAM;
+	if (static_cast<double>(p.samplerate) * (p.oqpsk ? 2.0 : 1.0) < static_cast<double>(p.symrate) * 0.25)
+		REFUSE("%d samples/s for %d symbols/s: fewer than a quarter of an input sample per firing is untested ground", p.samplerate, p.symrate);
+	if (p.bps != 8 && p.bps != 16 && p.bps != 32) REFUSE("%d bits per sample: 8, 16 or 32 expected", p.bps);
 	/* demod.c:12-13 multiply in int: `multiplier * symrate` and `samplerate * interp_factor`.  Where those overflow the reference is
 	 * undefined; nothing to reproduce, refused. */
-	if (static_cast<int64_t>(p.samplerate) * p.interp_factor > INT32_MAX || static_cast<int64_t>(p.symrate) * 2 > INT32_MAX) return MDEMOD_ERR_PARAM;
+	if (static_cast<int64_t>(p.samplerate) * p.interp_factor > INT32_MAX || static_cast<int64_t>(p.symrate) * 2 > INT32_MAX)
+		REFUSE("sample rate %d x -O %d (or twice the symbol rate %d) overflows the reference's int arithmetic (demod.c:12-13)", p.samplerate, p.interp_factor, p.symrate);
 
 	DemodConsts &c = out.c;
 	c.interp = p.interp_factor;
@@ -100,7 +129,7 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	loop_gains(0.7071067811865475f, pll_bw, c.pll_alpha, c.pll_beta);
 	for (int i = 0; i < 32; i++) out.tanh_lut[i] = static_cast<float>(tanh(static_cast<double>(i - 16)));
 	/* the kernels clamp the LUT argument instead of branching on v > 15 / v < -16 (pll.c:156-157) */
-	if (out.tanh_lut[31] != 1.0f || out.tanh_lut[0] != -1.0f) return MDEMOD_ERR_PARAM;
+	if (out.tanh_lut[31] != 1.0f || out.tanh_lut[0] != -1.0f) REFUSE("this host's tanh() does not saturate to +-1 at +-15: the kernels' clamped table lookup (pll.c:156-157) would differ");
 
 	/* timing.c:19-27 */
 	c.t_center = sym_freq;
@@ -120,9 +149,8 @@ mdemod_host_derive(const mdemod_params &p, HostTables &out, int generation)
 	 * loops and indexes its tanh table with (int)NaN (pll.c:154-159): nothing to reproduce.  Refused, with the way out. */
 	for (float tap : out.rrc)
 		if (!std::isfinite(tap)) {
-			fprintf(stderr, "meteor_demod_amd: the RRC filter for %d samples/s, %d symbols/s, -O %d has a tap that is not finite (filter.c:86-93 divides by "
-			                "zero there; the reference's output is undefined): choose another -O\n", p.samplerate, p.symrate, p.interp_factor);
-			return MDEMOD_ERR_PARAM;
+			REFUSE("the RRC filter for %d samples/s, %d symbols/s, -O %d has a tap that is not finite (filter.c:86-93 divides by "
+			       "zero there; the reference's output is undefined): choose another -O", p.samplerate, p.symrate, p.interp_factor);
 		}
 
 	/* ---- symbol-clock fast path constants ---- */

@@ -49,7 +49,7 @@ namespace {
 	do {                                                                                        \
 		hipError_t e_ = (expr);                                                                 \
 		if (e_ != hipSuccess) {                                                                 \
-			fprintf(stderr, "meteor_demod_amd: %s failed: %s (%s:%d)\n", #expr,                 \
+			mdm_note_error("%s failed: %s (%s:%d)", #expr,                                   \
 			        hipGetErrorString(e_), __FILE__, __LINE__);                                 \
 			return e_ == hipErrorOutOfMemory ? MDEMOD_ERR_NOMEM : MDEMOD_ERR_HIP;               \
 		}                                                                                       \
@@ -204,6 +204,27 @@ mdemod_hostpipe_free(void *opaque)
 	delete p;
 }
 
+/* Does the pinning that holds `b` hold all of [b, b + bytes)?  The runtime knows the allocation a pointer belongs to
+ * (hipMemGetAddressRange: base and size); where it will not say, every 4 KiB page up to the end is asked for its own type - slow
+ * (a microsecond per page) but this is a once-per-buffer call and the answer decides between a copy and a fault. */
+static bool
+pinned_extent_covers(const unsigned char *b, size_t bytes)
+{
+	hipDeviceptr_t abase = nullptr;
+	size_t asize = 0;
+	if (hipMemGetAddressRange(&abase, &asize, const_cast<unsigned char *>(b)) == hipSuccess && abase && asize) {
+		const unsigned char *a0 = static_cast<const unsigned char *>(abase);
+		return a0 <= b && b + bytes <= a0 + asize;
+	}
+	(void)hipGetLastError();
+	const uintptr_t page = 4096;
+	for (uintptr_t at = (reinterpret_cast<uintptr_t>(b) & ~(page - 1)) + page; at < reinterpret_cast<uintptr_t>(b) + bytes; at += page) {
+		hipPointerAttribute_t a;
+		if (hipPointerGetAttributes(&a, reinterpret_cast<const void *>(at)) != hipSuccess || a.type != hipMemoryTypeHost) { (void)hipGetLastError(); return false; }
+	}
+	return true;
+}
+
 /* mdemod_pin_host_buffer / mdemod_unpin_host_buffer (include/meteor_demod_amd.h) */
 int
 mdemod_hostpipe_pin(void **pipe_slot, const void *base, size_t bytes)
@@ -214,18 +235,30 @@ mdemod_hostpipe_pin(void **pipe_slot, const void *base, size_t bytes)
 	const unsigned char *b = static_cast<const unsigned char *>(base);
 	for (const Pin &pin : p->pins)
 		if (b < pin.base + pin.bytes && pin.base < b + bytes) return MDEMOD_ERR_PARAM;       /* overlaps a range that is pinned already */
-	/* memory that is pinned already (hipHostMalloc, or registered by the caller) is taken as it is and left as it is */
+	/* memory that is pinned already (hipHostMalloc, or registered by the caller) is taken as it is and left as it is - if the
+	 * pinning covers ALL of [base, base + bytes): a caller who registered a part of the buffer, or registered it in pieces, gets
+	 * MDEMOD_ERR_PARAM (the direct path would hand hipMemcpy2DAsync pages the runtime never locked); rows outside any pinned
+	 * range take the staged path anyway */
 	hipPointerAttribute_t attr;
 	const hipError_t q = hipPointerGetAttributes(&attr, b);
 	if (q == hipSuccess && attr.type == hipMemoryTypeHost) {
+		if (!pinned_extent_covers(b, bytes)) {
+			mdm_note_error("mdemod_pin_host_buffer: %p is pinned already, but that pinning does not cover all %zu bytes asked for", base, bytes);
+			return MDEMOD_ERR_PARAM;
+		}
 		p->pins.push_back({ b, bytes, false });
 		return MDEMOD_OK;
 	}
 	if (q != hipSuccess) (void)hipGetLastError();                 /* (pageable memory: an error or "unregistered", by runtime version) */
 	const hipError_t e = hipHostRegister(const_cast<unsigned char *>(b), bytes, hipHostRegisterDefault);
-	if (e == hipErrorHostMemoryAlreadyRegistered) (void)hipGetLastError();
-	else PIPE_TRY(e);
-	p->pins.push_back({ b, bytes, e == hipSuccess });
+	if (e == hipErrorHostMemoryAlreadyRegistered) {
+		/* a part of the range (not its first byte: that case is above) belongs to somebody's registration */
+		(void)hipGetLastError();
+		mdm_note_error("mdemod_pin_host_buffer: a part of [%p, +%zu) is registered already, the range as a whole is not", base, bytes);
+		return MDEMOD_ERR_PARAM;
+	}
+	PIPE_TRY(e);
+	p->pins.push_back({ b, bytes, true });
 	return MDEMOD_OK;
 }
 

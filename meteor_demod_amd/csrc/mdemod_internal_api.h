@@ -14,7 +14,14 @@
  * Every int-returning entry is a function-try-block that ends in this: std::bad_alloc from a vector, std::system_error from a thread
  * that could not be started and anything else come back as MDEMOD_ERR_NOMEM - "a resource was not to be had". */
 #include <new>
-#define MDEMOD_API_CATCH catch (...) { return MDEMOD_ERR_NOMEM; }
+/* The text behind mdemod_last_error() (ABI 5): thread-local, written by the entry that fails, never printed unless the environment
+ * has MDEMOD_DEBUG (a library behind someone else's TUI has no business on stderr).  MDEMOD_API_ENTER, first statement of every
+ * int-returning entry, empties it when the OUTERMOST entry on this thread begins, so a text never outlives the call it belongs to
+ * (entries call each other: mdemod_create -> mdemod_reset / mdemod_destroy). */
+void mdm_note_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+struct mdm_api_scope { mdm_api_scope(); ~mdm_api_scope(); };
+#define MDEMOD_API_ENTER mdm_api_scope api_scope_;
+#define MDEMOD_API_CATCH catch (...) { mdm_note_error("a C++ exception reached the boundary (allocation failed, or a thread could not be started)"); return MDEMOD_ERR_NOMEM; }
 extern "C" {
 #endif
 

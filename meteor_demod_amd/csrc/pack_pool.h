@@ -15,6 +15,8 @@
 #include <thread>
 #include <vector>
 #include <unistd.h>
+#include <sched.h>
+#include <cstdio>
 #include <cstring>
 #include <emmintrin.h>
 
@@ -57,13 +59,38 @@ private:
 		uint64_t generation = 0;
 		bool stop = false;
 	};
+public:
+	/* CPUs this process may actually run on at once: the affinity mask (a container's cpuset, taskset) and the cgroup's CPU quota
+	 * (cpu.max "quota period"), not the machine's core count - 12 pack threads time-slicing on a 2-CPU quota are slower than 2. */
+	static unsigned usable_cpus()
+	{
+		unsigned n = std::max(1u, std::thread::hardware_concurrency());
+		cpu_set_t set;
+		CPU_ZERO(&set);
+		if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = std::min<unsigned>(n, static_cast<unsigned>(CPU_COUNT(&set)));
+		if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       /* cgroup v2 */
+			char q[32] = "";
+			long long period = 0;
+			if (fscanf(f, "%31s %lld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) {
+				const long long quota = atoll(q);
+				if (quota > 0) n = std::min<unsigned>(n, static_cast<unsigned>(std::max<long long>(1, (quota + period - 1) / period)));
+			}
+			fclose(f);
+		} else {                                                                     /* cgroup v1 */
+			long long quota = -1, period = 0;
+			if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+			if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+			if (quota > 0 && period > 0) n = std::min<unsigned>(n, static_cast<unsigned>(std::max<long long>(1, (quota + period - 1) / period)));
+		}
+		return std::max(1u, n);
+	}
+private:
 	PackPool() : sh(new Shared)
 	{
 		const char *e = getenv("MDEMOD_PACK_THREADS");
 		int want = e ? atoi(e) : 0;
 		if (want <= 0 || want > 64) want = 12;          /* r05, tools/ubench/h2d_rect.cpp: the pack into the pinned ring keeps up with the link from 8 threads on, best at 12..16 */
-		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-		const unsigned n = std::min<unsigned>(static_cast<unsigned>(want), hw);
+		const unsigned n = std::min<unsigned>(static_cast<unsigned>(want), usable_cpus());
 		Shared *s = sh;
 		for (unsigned i = 1; i < n; i++) workers.emplace_back([s] { loop(*s); });
 	}

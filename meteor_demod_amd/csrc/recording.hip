@@ -537,7 +537,7 @@ struct Ctx {                         /* owns a demodulator context */
 };
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
-#define HTRY(expr) do { if ((expr) != hipSuccess) { fprintf(stderr, "meteor_demod_amd: %s failed (%s:%d)\n", #expr, __FILE__, __LINE__); return MDEMOD_ERR_HIP; } } while (0)
+#define HTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { mdm_note_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return e_ == hipErrorOutOfMemory ? MDEMOD_ERR_NOMEM : MDEMOD_ERR_HIP; } } while (0)
 
 template <typename T>
 int
@@ -653,7 +653,7 @@ extern "C" int
 mdemod_estimate_carrier_chirp(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
                               const uint64_t *starts_dev, const float *chirp_dev, uint32_t n_windows, uint32_t window_samples,
                               float *freq_dev, float *quality_dev, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!params || !iq_dev || !starts_dev || !freq_dev || !quality_dev || n_samples == 0) return MDEMOD_ERR_PARAM;
 	if (params->samplerate <= 0 || params->symrate <= 0 || (params->bps != 8 && params->bps != 16 && params->bps != 32)) return MDEMOD_ERR_PARAM;
 	if (n_windows == 0) return MDEMOD_OK;
@@ -689,7 +689,7 @@ extern "C" int
 mdemod_estimate_carrier(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
                         const uint64_t *starts_dev, uint32_t n_windows, uint32_t window_samples,
                         float *freq_dev, float *quality_dev, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	return mdemod_estimate_carrier_chirp(params, iq_dev, n_samples, starts_dev, nullptr, n_windows, window_samples, freq_dev, quality_dev, hip_stream);
 } MDEMOD_API_CATCH
 
@@ -697,7 +697,7 @@ extern "C" int
 mdemod_estimate_clock(const mdemod_params *params, const void *iq_dev, uint64_t n_samples,
                       const uint64_t *starts_dev, const float *carrier_dev, const float *chirp_dev,
                       uint32_t n_windows, uint32_t window_samples, float *t_freq_dev, float *quality_dev, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	if (!params || !iq_dev || !starts_dev || !t_freq_dev || !quality_dev || n_samples == 0) return MDEMOD_ERR_PARAM;
 	if (params->samplerate <= 0 || params->symrate <= 0 || params->interp_factor <= 0 || (params->bps != 8 && params->bps != 16 && params->bps != 32)) return MDEMOD_ERR_PARAM;
 	if (n_windows == 0) return MDEMOD_OK;
@@ -1689,7 +1689,8 @@ struct Stitcher {
 		HTRY(hipEventCreateWithFlags(&input_ready.ev, hipEventDisableTiming));
 		HTRY(hipEventRecord(input_ready.ev, st));
 		try {
-			est.t = std::thread([this]() { est.rc = estimate_grid(); });    /* joined by estimate_carriers, or by ~EstThread on an early return */
+			/* (a thread's exception is nobody's to catch: std::terminate.  The function-try-blocks of the entries cover the calling thread only) */
+			est.t = std::thread([this]() { try { est.rc = estimate_grid(); } catch (...) { est.rc = MDEMOD_ERR_NOMEM; } });    /* joined by estimate_carriers, or by ~EstThread on an early return */
 		} catch (...) {
 			est.rc = estimate_grid();                                       /* no thread to be had: before the head, then */
 		}
@@ -1738,7 +1739,7 @@ mdemod_demodulate_recording(const mdemod_params *params, const mdemod_recording_
                             const void *iq_dev, uint64_t n_samples,
                             int8_t *soft_dev, uint64_t soft_cap_symbols,
                             mdemod_recording_report *rep, void *hip_stream)
-try {
+try { MDEMOD_API_ENTER
 	return demodulate_recording_impl(params, opts_in, iq_dev, n_samples, soft_dev, soft_cap_symbols, rep, hip_stream, nullptr);
 } MDEMOD_API_CATCH
 
@@ -1750,7 +1751,7 @@ mdemod_demodulate_recording_host(const mdemod_params *params, const mdemod_recor
                                  const void *iq_host, uint64_t n_samples,
                                  int8_t *soft_host, uint64_t soft_cap_symbols,
                                  mdemod_recording_report *rep)
-try {
+try { MDEMOD_API_ENTER
 	if (!params || !iq_host || !soft_host || !rep) return MDEMOD_ERR_PARAM;
 	const bool dbg = opts && opts->debug != 0;
 	const auto t_in = std::chrono::steady_clock::now();
@@ -1773,7 +1774,7 @@ try {
 	struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } copier;
 	if (head < n_samples) {
 		const int device = params->device;
-		copier.t = std::thread([&, device]() {
+		copier.t = std::thread([&, device]() { try {
 			hipStream_t cs = nullptr;
 			if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { copy_failed = 1; there = n_samples; return; }
 			const uint64_t chunk = 1u << 23;                  /* samples per copy: progress in steps of 8-64 MB */
@@ -1786,7 +1787,7 @@ try {
 			mark("recording copied in");
 			there = n_samples;                                /* also after a failure: nobody may wait for ever */
 			(void)hipStreamDestroy(cs);
-		});
+		} catch (...) { copy_failed = 1; there = n_samples; } });          /* (an exception in a thread would be std::terminate) */
 	}
 	const std::function<void(uint64_t)> need = [&](uint64_t upto) {
 		while (there.load() < std::min(upto, n_samples)) std::this_thread::sleep_for(std::chrono::microseconds(50));

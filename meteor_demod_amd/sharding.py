@@ -6,8 +6,9 @@ collective on the data path at all — each rank demodulates its own contiguous
 range of streams from its own HBM.  The only exchange the north star names is the
 optional fan-in of the soft-symbol buffers to one rank, done here with
 `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
-the CPU tests): one all_gather of per-stream symbol counts, then one gather of
-the int8 rows at the nominal symbol pitch (compacted on the device first).
+the CPU tests): one all_gather of per-stream symbol counts, then point-to-point
+send/recv of exactly the int8 rows each rank holds, at the nominal symbol pitch
+(compacted on the device first).
 """
 from __future__ import annotations
 
@@ -38,8 +39,10 @@ def fanin_soft(soft_local, counts_local, n_streams: int, dst: int = 0, group=Non
     counts_local: int32 tensor [n_local], symbols valid per local stream
     Returns on dst: (soft [n_streams, pitch_max, 2], counts [n_streams]); elsewhere (None, None).
 
-    One all_reduce (common pitch), one all_gather (counts), one gather (symbols).  The gather lands directly in the
-    result buffer when the streams divide evenly over the ranks (no staging copy on the root).
+    One all_gather of (streams, pitch) per rank, one all_gather of the symbol counts, then point-to-point transfers of EXACTLY
+    the rows each rank holds ("ncclSend/ncclRecv, variable sizes"): nothing is padded to the largest shard or the
+    longest pitch on the wire (round 6; rounds 1-5 used one padded gather), and a rank whose pitch is the common one lands
+    directly in its slice of the result (no staging copy on the root).
     """
     import torch
     import torch.distributed as dist
@@ -47,46 +50,75 @@ def fanin_soft(soft_local, counts_local, n_streams: int, dst: int = 0, group=Non
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = soft_local.device
-    n_local = soft_local.shape[0]
+    n_local, pitch_local = int(soft_local.shape[0]), int(soft_local.shape[1])
+    lo, hi = shard_range(n_streams, rank, world)
+    if n_local != hi - lo:
+        raise ValueError(f"rank {rank} holds {n_local} streams, its shard of {n_streams} over {world} ranks is {hi - lo}")
     n_max = max(shard_range(n_streams, r, world)[1] - shard_range(n_streams, r, world)[0] for r in range(world))
 
-    # 1) agree on a common row pitch (ranks may have been given different block lengths)
-    cap = torch.tensor([soft_local.shape[1]], dtype=torch.int64, device=dev)
-    dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
-    cap = int(cap.item())
-
+    # 1) who holds what: (streams, pitch) of every rank, and the counts (padded to the largest shard: 4 B per stream)
+    shape = torch.tensor([n_local, pitch_local], dtype=torch.int64, device=dev)
+    shapes = [torch.empty_like(shape) for _ in range(world)]
+    dist.all_gather(shapes, shape, group=group)
+    shapes = [(int(t[0]), int(t[1])) for t in torch.stack(shapes).cpu()]
+    cap = max(p for _, p in shapes)
     cnt_pad = torch.zeros(n_max, dtype=torch.int32, device=dev)
     cnt_pad[:n_local] = counts_local.to(torch.int32)
     all_cnt = [torch.empty_like(cnt_pad) for _ in range(world)]
     dist.all_gather(all_cnt, cnt_pad, group=group)
 
-    # 2) rows: padded only if this rank holds fewer streams or a shorter pitch than the largest shard
-    if n_local == n_max and soft_local.shape[1] == cap and soft_local.is_contiguous():
-        send = soft_local
-    else:
-        send = torch.zeros((n_max, cap, 2), dtype=torch.int8, device=dev)
-        send[:n_local, : soft_local.shape[1]] = soft_local
-    even = n_streams == n_max * world
-    out = torch.empty((n_max * world, cap, 2), dtype=torch.int8, device=dev) if rank == dst else None
-    gathered = [out[r * n_max:(r + 1) * n_max] for r in range(world)] if rank == dst else None
-    dist.gather(send, gathered, dst=dst, group=group)
+    # 2) the rows, point to point, exact sizes
     if rank != dst:
+        if n_local:
+            send = soft_local if soft_local.is_contiguous() else soft_local.contiguous()
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, _global_rank(dst, group), group)]):
+                w.wait()
         return None, None
 
-    if even:
-        return out, torch.cat(all_cnt)
     soft = torch.empty((n_streams, cap, 2), dtype=torch.int8, device=dev)
-    counts = torch.empty(n_streams, dtype=torch.int32, device=dev)
+    ops, staged = [], []
     for r in range(world):
-        lo, hi = shard_range(n_streams, r, world)
-        soft[lo:hi] = gathered[r][: hi - lo]
-        counts[lo:hi] = all_cnt[r][: hi - lo]
+        rlo, rhi = shard_range(n_streams, r, world)
+        n_r, pitch_r = shapes[r]
+        if n_r != rhi - rlo:
+            raise ValueError(f"rank {r} announced {n_r} streams, its shard is {rhi - rlo}")
+        if n_r == 0:
+            continue
+        if r == rank:
+            soft[rlo:rhi, :pitch_r] = soft_local
+            if pitch_r < cap:
+                soft[rlo:rhi, pitch_r:] = 0
+        elif pitch_r == cap:
+            ops.append(dist.P2POp(dist.irecv, soft[rlo:rhi], _global_rank(r, group), group))      # a contiguous slice: lands in place
+        else:
+            tmp = torch.empty((n_r, pitch_r, 2), dtype=torch.int8, device=dev)
+            staged.append((rlo, rhi, pitch_r, tmp))
+            ops.append(dist.P2POp(dist.irecv, tmp, _global_rank(r, group), group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for rlo, rhi, pitch_r, tmp in staged:
+        soft[rlo:rhi, :pitch_r] = tmp
+        soft[rlo:rhi, pitch_r:] = 0
+    counts = torch.cat([all_cnt[r][: shapes[r][0]] for r in range(world)])
     return soft, counts
 
 
-def init_from_env(backend: Optional[str] = None):
-    """torch.distributed init for `python -m torch.distributed.run` launches (env://)."""
+def _global_rank(group_rank: int, group) -> int:
+    import torch.distributed as dist
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
+def fanin_bytes_on_the_wire(shapes, dst: int = 0) -> int:
+    """Bytes the fan-in moves for per-rank (streams, pitch) shapes, the root's own rows excluded: what `fanin_soft` sends, exactly."""
+    return sum(2 * n * p for r, (n, p) in enumerate(shapes) if r != dst)
+
+
+def init_from_env(backend: Optional[str] = None, timeout_s: float = 600.0):
+    """torch.distributed init for `python -m torch.distributed.run` launches (env://).  `timeout_s` bounds every collective
+    (gloo raises after it; RCCL's watchdog aborts the collective): nothing on this path may wait forever for a rank that died."""
     import os
+    from datetime import timedelta
     import torch
     import torch.distributed as dist
 
@@ -99,7 +131,7 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=timedelta(seconds=timeout_s))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timedelta(seconds=timeout_s))
     return rank, local, world

@@ -108,6 +108,7 @@ main(int argc, char **argv)
 	if (argc > 1 && !strcmp(argv[1], "copy")) return copy_check();
 	if (argc > 1 && !strcmp(argv[1], "race")) return race(argc > 2 ? atoi(argv[2]) : 6, argc > 3 ? atoi(argv[3]) : 200);
 	if (argc > 1 && !strcmp(argv[1], "fork")) return fork_exit();
+	if (argc > 1 && !strcmp(argv[1], "cpus")) { printf("usable %u pool %u\n", PackPool::usable_cpus(), PackPool::get().size()); return 0; }
 	fprintf(stderr, "usage: pool_test race [callers] [rounds] | fork | copy\n");
 	return 2;
 }

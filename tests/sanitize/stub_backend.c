@@ -44,6 +44,7 @@ params_ok(const mdemod_params *p)
 
 uint32_t mdemod_abi_version(void) { return MDEMOD_ABI_VERSION; }
 const char *mdemod_strerror(int code) { return code == MDEMOD_OK ? "ok" : (code == MDEMOD_ERR_PARAM ? "bad parameter" : "stub error"); }
+const char *mdemod_last_error(void) { return getenv("STUB_LAST_ERROR") ? getenv("STUB_LAST_ERROR") : ""; }
 int mdemod_init_device(int device) { (void)device; return MDEMOD_OK; }
 int mdemod_device_count(void) { const char *e = getenv("STUB_DEVICES"); return e ? atoi(e) : 1; }
 

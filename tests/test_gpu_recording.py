@@ -317,7 +317,7 @@ def test_bank_primitives_of_the_stitcher(gpu_device):
             assert torch.equal(packed[i, :m1], sa[i, :m1])
         # clock seeds: words the reference's loop can hold (timing.c:80-86: centre +- centre / 4096) pass as they are; anything else -
         # zero, negative, tiny, huge: the words that would spin the closed-form clock's stepping loop - is clamped to that
-        # range on the device, and NaN stays NaN (it ends every loop by itself)
+        # range on the device, and NaN becomes the nominal rate (a NaN clock never fires - the kernels would spin to their watchdog)
         centre = np.float32(0.393382043)
         lo, hi = np.float64(centre) * (1 - 1 / 4096) * (1 - 1e-6), np.float64(centre) * (1 + 1 / 4096) * (1 + 2e-6)
         tf = torch.tensor([0.39, 0.3934, 0.3933, 0.4, 0.0], dtype=torch.float32, device="cuda")
@@ -328,7 +328,16 @@ def test_bank_primitives_of_the_stitcher(gpu_device):
         assert got[0] == got[4] == min(got) and got[3] == max(got)
         a.set_clock_seeds(torch.tensor([-1.0, 1e-30, float("inf"), float("nan"), 0.3934], dtype=torch.float32, device="cuda"))
         got = [np.float32(s.t_freq) for s in a.get_states()]
-        assert np.isnan(got[3]) and all(lo <= np.float64(g) <= hi for g in got[:3] + got[4:]), got
+        assert all(lo <= np.float64(g) <= hi for g in got), got
+        assert abs(np.float64(got[3]) - np.float64(centre)) < 1e-6 * centre and got[0] == got[1] == min(got) and got[2] == max(got)
+        # ... and mdemod_set_state / mdemod_set_state_all, which can refuse, refuse a NaN clock word like any other outside the range
+        from meteor_demod_amd._capi import MdemodError
+        st0 = a.get_states()[0]
+        st0.t_freq = float("nan")
+        with pytest.raises((MdemodError, ValueError)):
+            a.set_state(0, st0)
+        with pytest.raises((MdemodError, ValueError)):
+            a.set_state_all(st0)
         a.process(x[:, :3000].contiguous())                  # and a launch on such seeds ends
         torch.cuda.synchronize()
         with pytest.raises(ValueError):

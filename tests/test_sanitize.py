@@ -98,6 +98,29 @@ def test_pack_pool_under_tsan(bins):
     assert b" 0 bad" in proc.stdout
 
 
+def test_pack_pool_is_sized_by_the_cpus_it_may_use(bins):
+    """the pool was min(12, hardware_concurrency()), which ignores a container's cpuset and the cgroup CPU quota (12 pack
+    threads time-slicing on 2 CPUs are slower than 2).  PackPool::usable_cpus() = affinity mask and cpu.max, whichever is smaller."""
+    import os
+    import shutil
+
+    def quota_cpus():
+        try:
+            q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+            return None if q == "max" else max(1, -(-int(q) // int(per)))
+        except (OSError, ValueError):
+            return None
+    want = min(x for x in (len(os.sched_getaffinity(0)), quota_cpus(), os.cpu_count()) if x)
+    out = _run([bins["pool_asan"], "cpus"], timeout=60).stdout.split()
+    assert int(out[1]) == want and int(out[3]) == min(12, want), (out, want)
+    out = _run([bins["pool_asan"], "cpus"], timeout=60, env=dict(ENV, MDEMOD_PACK_THREADS="3")).stdout.split()
+    assert int(out[3]) == min(3, want)
+    if shutil.which("taskset") and len(os.sched_getaffinity(0)) >= 2:
+        two = sorted(os.sched_getaffinity(0))[:2]
+        out = _run(["taskset", "-c", ",".join(map(str, two)), bins["pool_asan"], "cpus"], timeout=60).stdout.split()
+        assert int(out[1]) == min(2, want) and int(out[3]) == min(2, want), out
+
+
 def test_pack_pool_forked_child_exits(bins):
     """~PackPool in a forked child joined threads that do not exist there.  (The child leaks the pool's state on purpose,
     so LeakSanitizer is off for this one run; ASan and UBSan stay on.)"""
