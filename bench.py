@@ -84,12 +84,21 @@ def bound_block(cfg, tag: str, T: int, L: int, kernel_ms: float) -> dict:
     if fir and pipe_cycles and simd_busy:
         taps = 2 * cfg.rrc_order + 1
         fir_floor = 2 * taps                                   # per firing: one packed multiply and one packed add per tap
-        fir_now, fir_cycles = fir
-        floor_cycles = pipe_cycles - max(0.0, fir_now - fir_floor) * (fir_cycles / fir_now)
-        valu["fir_packed_instructions_per_firing"] = {"issued": fir_now, "floor": fir_floor}
+        fir_static, fir_cycles = fir
+        # what a wave-firing really issues (the wave-agreed padding skips jump over half-chunks): measured in round 6 with two --pmc passes
+        # (profiles/r06_fir_padding.json, tools/fir_dynamic.py) for the std-window kernels; the static count of the code elsewhere
+        fir_dyn = None
+        try:
+            fir_dyn = json.loads((ROOT / "profiles" / "r06_fir_padding.json").read_text()).get(tag, {}).get("fir_packed_dynamic")
+        except Exception:
+            pass
+        fir_now = fir_dyn or fir_static
+        floor_cycles = pipe_cycles - max(0.0, fir_now - fir_floor) * (fir_cycles / fir_static)
+        valu["fir_packed_instructions_per_firing"] = {"static": fir_static, **({"dynamic": fir_dyn} if fir_dyn else {}), "floor": fir_floor}
         valu["pipe_busy_ceiling_hbm_frac"] = round(hbm_frac / simd_busy, 4)
         valu["ceiling_hbm_frac"] = round(hbm_frac * (pipe_cycles / simd_busy) / floor_cycles, 4)
-        valu["ceiling_definition"] = ("pipe 100 % busy and the FIR at 2 packed instructions per tap and firing (no window padding), the other "
+        valu["ceiling_definition"] = ("pipe 100 % busy and the FIR at 2 packed instructions per tap and firing (no window padding: not reachable, the lanes of a wave "
+                                      "sit ~3 slots apart and share one window), the other "
                                       f"{round(valu_per_firing - fir_now, 1)} VALU instructions per wave-firing as measured: {round(floor_cycles)} SIMD cycles of VALU pipe per "
                                       f"wave-firing against the {round(pipe_cycles / simd_busy)} one takes now")
         conv = mix.get("conversion (SDWA)")
