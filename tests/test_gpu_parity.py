@@ -525,6 +525,42 @@ def test_host_buffer_path_from_memory_that_is_pinned_already(gpu_device):
     assert buf_t.is_pinned() and int(buf_t[5, 7, 1]) == int(one[5 + 7, 1])   # still there, still the caller's
 
 
+def test_pinning_that_covers_only_a_part_of_the_range_is_refused(gpu_device):
+    """mdemod_pin_host_buffer took memory as "pinned anyway" on the evidence of its FIRST byte and recorded the caller's
+    full length - the direct path would then hand hipMemcpy2DAsync pages nobody locked.  A range whose existing registration
+    covers only its head, or only its tail, is refused (MDEMOD_ERR_PARAM, mdemod_last_error says why); the rows still go through
+    the staged path and give the oracle's bytes; the caller's own registration is left alone."""
+    import ctypes as C
+    from meteor_demod_amd import _capi
+    torch = _torch()
+    rt = torch.cuda.cudart()
+    ns, n = 32, 1 << 15
+    raw = np.zeros(ns * n * 2 + 8192, dtype=np.int16)
+    off = (-raw.ctypes.data % 4096) // 2                                   # page-aligned start
+    buf = raw[off: off + ns * n * 2].reshape(ns, n, 2)
+    st = synth.make_stream(77, 230000, 72000, f0_hz=90.0, esn0_db=15.0)
+    one = synth.generate_host(st, n + ns)
+    for s in range(ns):
+        buf[s] = one[s: s + n]
+    half = buf.nbytes // 2
+    for lo in (0, half):                                                     # the head, then the tail, registered by the caller
+        assert int(rt.cudaHostRegister(buf.ctypes.data + lo, half, 0)) == 0
+        try:
+            with Demodulator(C1, ns) as d:
+                with pytest.raises(_capi.MdemodError) as e:
+                    d.pin_host(buf)
+                assert e.value.code == _capi.MDEMOD_ERR_PARAM and "mdemod_pin_host_buffer" in e.value.detail, e.value.detail
+                out = d.process_host([buf[s] for s in range(ns)])            # staged: nothing was recorded as pinned
+                for s in (0, 13, ns - 1):
+                    assert np.array_equal(out[s], O.oracle_demod(C1, np.ascontiguousarray(buf[s]))[0]), (lo, s)
+        finally:
+            assert int(rt.cudaHostUnregister(buf.ctypes.data + lo)) == 0
+    with Demodulator(C1, ns) as d:                                           # nobody's registration left: the library's own pin works
+        d.pin_host(buf)
+        out = d.process_host([buf[s] for s in range(ns)])
+        assert np.array_equal(out[5], O.oracle_demod(C1, np.ascontiguousarray(buf[5]))[0])
+
+
 def test_more_symbols_than_the_nominal_rate(gpu_device):
     """While the symbol clock drains a large phase excursion (full-scale burst after silence, wide loop) it fires on
     every sample: more symbols than samples * symrate / samplerate.  mdemod_max_symbols is the hard bound (one per
