@@ -874,15 +874,19 @@ def _fault(stage: str, rank: int) -> None:
 
 
 def device_identity(local: int) -> str:
+    """uuid + PCI address of the device a rank computes on (short: eight of them ride in the line)."""
     import torch
     p = torch.cuda.get_device_properties(local)
-    parts = [p.name]
-    for attr in ("uuid", "pci_bus_id", "pci_device_id"):
-        try:
-            parts.append(f"{attr}={getattr(p, attr)}")
-        except Exception:
-            pass
-    return " ".join(str(x) for x in parts)[:96]
+    parts = []
+    try:
+        parts.append(str(p.uuid))
+    except Exception:
+        parts.append(p.name)
+    try:
+        parts.append(f"pci {int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}")
+    except Exception:
+        pass
+    return " ".join(parts)[:64]
 
 
 def main() -> None:
@@ -1026,7 +1030,7 @@ def main() -> None:
             # did the collective layer see every rank, and which device is each on?
             ones = torch.ones(1, dtype=torch.int32, device=coll_dev)
             dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-            ident = device_identity(local).encode()[:96].ljust(96, b" ")
+            ident = device_identity(local).encode()[:64].ljust(64, b" ")
             mine = torch.tensor(list(ident), dtype=torch.uint8, device=coll_dev)
             every = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
@@ -1036,7 +1040,7 @@ def main() -> None:
                 ver = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:
                 pass
-            full["rccl"] = {"backend": dist.get_backend(), "world": world, "ranks_seen": int(ones[0]), "devices": devs,
+            full["rccl"] = {"backend": dist.get_backend(), "world": world, "ranks_seen": int(ones[0]), "device_name": torch.cuda.get_device_properties(local).name, "devices": devs,
                             "distinct_devices": len(set(devs)), "rccl_version": ver}
         stage("rccl", rccl_facts)
 

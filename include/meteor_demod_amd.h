@@ -239,7 +239,9 @@ int  mdemod_process_host(mdemod_ctx *ctx,
  * staging it through the library's own pinned ring with the CPU.  Any other layout, and anything outside the pinned ranges, takes the
  * staged path; results never depend on it.  The caller keeps the range mapped until mdemod_unpin_host_buffer (with the same base)
  * or mdemod_destroy, which unpins what is left.  MDEMOD_ERR_PARAM for a range that overlaps one pinned already through this call.
- * Memory that is pinned anyway (from hipHostMalloc, or registered by the caller) is accepted and left as it is.
+ * Memory that is pinned anyway (from hipHostMalloc, or registered by the caller) is accepted and left as it is - when that
+ * pinning holds ALL of [base, base + bytes); one that starts at `base` and stops short of the end is MDEMOD_ERR_PARAM (r06: the direct
+ * copy would touch pages nobody locked), and such rows simply keep taking the staged path.
  */
 int  mdemod_pin_host_buffer(mdemod_ctx *ctx, const void *base, size_t bytes);
 int  mdemod_unpin_host_buffer(mdemod_ctx *ctx, const void *base);

@@ -205,8 +205,10 @@ mdemod_hostpipe_free(void *opaque)
 }
 
 /* Does the pinning that holds `b` hold all of [b, b + bytes)?  The runtime knows the allocation a pointer belongs to
- * (hipMemGetAddressRange: base and size); where it will not say, every 4 KiB page up to the end is asked for its own type - slow
- * (a microsecond per page) but this is a once-per-buffer call and the answer decides between a copy and a fault. */
+ * (hipMemGetAddressRange: base and size) - for hipHostMalloc memory; for memory somebody hipHostRegister'ed, ROCm 7.2 answers with a
+ * NULL base and the registration's size (measured, r06: gpurun_exp/pin_probe.py), which says nothing about where `b` lies in it.
+ * Then every 4 KiB page up to the end is asked for its own type: slow (a fraction of a microsecond per page) but this is a
+ * once-per-buffer call and the answer decides between a copy and a fault. */
 static bool
 pinned_extent_covers(const unsigned char *b, size_t bytes)
 {
