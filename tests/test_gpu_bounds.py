@@ -169,3 +169,39 @@ def test_recording_entry_stays_inside_its_output(tag, cfg, log2n, gpu_device):
         assert (got[:pad] == CANARY).all() and (got[pad + 2 * cap:] == CANARY).all(), (cap, ok)
         if ok:
             assert (got[pad + 2 * m: pad + 2 * cap] == CANARY).all(), "bytes written behind the recording's own symbols"
+
+
+def test_failures_come_back_as_text_not_on_stderr(gpu_device, capfd):
+    """VERDICT r05 item 6 on the device side: a HIP failure (a device that does not exist) and the refusals that need a context (a
+    clock word / carrier state the reference's loop cannot hold, an overlapping pin) return their code, leave the words in
+    mdemod_last_error() and print nothing; the next successful entry empties the text."""
+    import torch
+    from meteor_demod_amd import _capi
+    lib = _capi.lib()
+    capfd.readouterr()
+    p = DemodConfig(samplerate=230000).to_c(4, torch.cuda.device_count() + 7)
+    ctx = C.c_void_p()
+    assert lib.mdemod_create(C.byref(p), C.byref(ctx)) == _capi.MDEMOD_ERR_HIP and not ctx.value
+    said = _capi.last_error()
+    assert "no usable HIP device" in said and str(torch.cuda.device_count() + 7) in said, said
+    with Demodulator(DemodConfig(samplerate=230000), 4) as d:
+        assert _capi.last_error() == ""                                  # mdemod_create succeeded: nothing left from the failure before
+        st = d.get_states()[0]
+        st.t_freq = 0.5
+        with pytest.raises(_capi.MdemodError) as e:
+            d.set_state(0, st)
+        assert "t_freq" in e.value.detail and "timing.c:80-86" in e.value.detail
+        st = d.get_states()[0]
+        st.pll_phase = 20.0
+        with pytest.raises(_capi.MdemodError) as e:
+            d.set_state_all(st)
+        assert "pll_phase" in e.value.detail
+        buf = np.zeros((4, 4096, 2), dtype=np.int16)
+        d.pin_host(buf)
+        with pytest.raises(_capi.MdemodError):
+            d.pin_host(buf[1:3])
+        d.unpin_host(buf)
+        d.status()
+        assert _capi.last_error() == ""
+    out = capfd.readouterr()
+    assert "meteor_demod_amd" not in out.err and "failed" not in out.err, out.err
