@@ -236,7 +236,10 @@ mdemod_hostpipe_pin(void **pipe_slot, const void *base, size_t bytes)
 	HostPipe *p = static_cast<HostPipe *>(*pipe_slot);
 	const unsigned char *b = static_cast<const unsigned char *>(base);
 	for (const Pin &pin : p->pins)
-		if (b < pin.base + pin.bytes && pin.base < b + bytes) return MDEMOD_ERR_PARAM;       /* overlaps a range that is pinned already */
+		if (b < pin.base + pin.bytes && pin.base < b + bytes) {                                /* overlaps a range that is pinned already */
+			mdm_note_error("mdemod_pin_host_buffer: [%p, +%zu) overlaps [%p, +%zu), pinned through this context already", base, bytes, static_cast<const void *>(pin.base), pin.bytes);
+			return MDEMOD_ERR_PARAM;
+		}
 	/* memory that is pinned already (hipHostMalloc, or registered by the caller) is taken as it is and left as it is - if the
 	 * pinning covers ALL of [base, base + bytes): a caller who registered a part of the buffer, or registered it in pieces, gets
 	 * MDEMOD_ERR_PARAM (the direct path would hand hipMemcpy2DAsync pages the runtime never locked); rows outside any pinned
@@ -276,6 +279,7 @@ mdemod_hostpipe_unpin(void *opaque, const void *base)
 			p->pins.erase(p->pins.begin() + static_cast<long>(i));
 			return MDEMOD_OK;
 		}
+	mdm_note_error("mdemod_unpin_host_buffer: %p is not the base of a range pinned through this context", base);
 	return MDEMOD_ERR_PARAM;
 }
 
