@@ -7,6 +7,7 @@
 #define MDEMOD_PACK_POOL_H
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -24,11 +25,68 @@ namespace {
 
 /* A few persistent worker threads for the packing and unpacking of the sub-blocks (memcpy between the caller's buffers and the
  * pinned ring).  Round 3 started fresh std::threads for every sub-block - 2 x 16 spawns of 4..8 threads per call, ~10 ms of a 64 ms
- * call, and the reason MORE threads were slower (measured r04: 4 threads 34.5 GB/s of input, 8..24 threads 30..31).  One pool per
- * process, created on first use, parked on a condition variable between jobs. */
+ * call, and the reason MORE threads were slower (measured r04: 4 threads 34.5 GB/s of input, 8..24 threads 30..31).  Pools are created
+ * on first use and parked on a condition variable between jobs.  ONE pool serves a process with one caller; callers that arrive while
+ * it is busy - one library context per GPU is one host thread each, all packing at once - get a pool of their own, up to as many as
+ * the CPUs this process may use have room for (usable_cpus() / threads per pool, at most 8; MDEMOD_PACK_POOLS overrides): round 6,
+ * ADVICE r05 - until then every caller queued on the one pool's mutex and eight GPUs shared one pack at a time. */
 class PackPool {
 public:
-	static PackPool &get() { static PackPool p; return p; }
+	static constexpr unsigned kMaxPools = 8;
+	/* pool i, created on first use (0: the one a process with a single caller ever sees) */
+	static PackPool &get(unsigned i = 0)
+	{
+		static Slots slots;
+		PackPool *q = slots.p[i].load(std::memory_order_acquire);
+		if (!q) {
+			PackPool *fresh = new PackPool;
+			if (slots.p[i].compare_exchange_strong(q, fresh, std::memory_order_acq_rel)) q = fresh;
+			else delete fresh;                                   /* somebody else was first: theirs it is */
+		}
+		return *q;
+	}
+	static unsigned max_pools()
+	{
+		static const unsigned n = [] {
+			const char *e = getenv("MDEMOD_PACK_POOLS");
+			const int want = e ? atoi(e) : 0;
+			if (want >= 1 && want <= static_cast<int>(kMaxPools)) return static_cast<unsigned>(want);
+			return std::max(1u, std::min(kMaxPools, usable_cpus() / std::max(1u, get(0).size())));
+		}();
+		return n;
+	}
+	/* a pool nobody else is running a job on right now (its run mutex held until the lease goes): the first idle one, created if need
+	   be, or - all busy - a wait for the first.  A forked child has the pool objects but not their threads, and their mutexes in
+	   whatever state the fork caught them: it takes no lock and works alone. */
+	class Lease {
+	public:
+		unsigned size() const { return alone ? 1u : pool->size(); }
+		void run(unsigned n_jobs, const std::function<void(unsigned)> &job)
+		{
+			if (alone) { for (unsigned i = 0; i < n_jobs; i++) job(i); return; }
+			pool->run_locked(n_jobs, job);
+		}
+	private:
+		friend class PackPool;
+		PackPool *pool = nullptr;
+		std::unique_lock<std::mutex> lk;
+		bool alone = false;
+	};
+	static Lease lease()
+	{
+		Lease l;
+		PackPool &first = get(0);
+		if (getpid() != first.owner) { l.alone = true; return l; }
+		const unsigned np = max_pools();
+		for (unsigned i = 0; i < np; i++) {
+			PackPool &p = get(i);
+			std::unique_lock<std::mutex> lk(p.sh->run_m, std::try_to_lock);
+			if (lk.owns_lock()) { l.pool = &p; l.lk = std::move(lk); return l; }
+		}
+		l.pool = &first;
+		l.lk = std::unique_lock<std::mutex>(first.sh->run_m);
+		return l;
+	}
 	unsigned size() const { return static_cast<unsigned>(workers.size()) + 1; }          /* + the calling thread */
 	/* run job(i) for i in [0, n_jobs): the workers take jobs off a shared counter, the caller takes its share too and returns when all are done */
 	void run(unsigned n_jobs, const std::function<void(unsigned)> &job)
@@ -36,8 +94,20 @@ public:
 		if (n_jobs == 0) return;
 		/* (a forked child has the pool object but not its threads: it works alone) */
 		if (n_jobs == 1 || workers.empty() || getpid() != owner) { for (unsigned i = 0; i < n_jobs; i++) job(i); return; }
+		std::lock_guard<std::mutex> one_at_a_time(sh->run_m);          /* callers on several host threads may share this pool */
+		run_locked(n_jobs, job);
+	}
+private:
+	struct Slots {
+		std::atomic<PackPool *> p[kMaxPools];
+		Slots() { for (auto &q : p) q.store(nullptr, std::memory_order_relaxed); }
+		~Slots() { for (auto &q : p) delete q.load(std::memory_order_acquire); }          /* (~PackPool knows what to do in a forked child) */
+	};
+	void run_locked(unsigned n_jobs, const std::function<void(unsigned)> &job)           /* sh->run_m is held by the caller */
+	{
+		if (n_jobs == 0) return;
+		if (n_jobs == 1 || workers.empty()) { for (unsigned i = 0; i < n_jobs; i++) job(i); return; }
 		Shared &s = *sh;
-		std::lock_guard<std::mutex> one_at_a_time(s.run_m);            /* contexts on several host threads (one per GPU) share the pool */
 		{
 			std::lock_guard<std::mutex> lk(s.m);
 			s.cur = &job; s.total = n_jobs; s.next = 0; s.pending = n_jobs; s.generation++;
@@ -145,13 +215,14 @@ void
 parallel_streams(uint32_t n, const std::vector<uint64_t> &weight_prefix, F fn)
 {
 	const uint64_t total = weight_prefix.empty() ? 0 : weight_prefix.back();
-	PackPool &pool = PackPool::get();
 	/* small jobs are not worth waking anybody - but "small" is a megabyte, not eight: the last (quarter) sub-block of a pipelined call is
 	   4.6 MB of 640-byte pieces at the bench shape, and one thread took a millisecond over it with nothing left to hide it behind (r05) */
 #ifndef MDEMOD_POOL_MIN_BYTES
 #define MDEMOD_POOL_MIN_BYTES (1u << 20)
 #endif
-	if (total < MDEMOD_POOL_MIN_BYTES || pool.size() == 1) { fn(0u, n); return; }
+	if (total < MDEMOD_POOL_MIN_BYTES) { fn(0u, n); return; }
+	PackPool::Lease pool = PackPool::lease();                /* an idle pool (this caller's alone until the lease goes out of scope) */
+	if (pool.size() == 1) { fn(0u, n); return; }
 	const unsigned pieces = pool.size() * 4;
 	std::vector<uint32_t> cut(pieces + 1, n);
 	cut[0] = 0;

@@ -43,7 +43,29 @@ race(int callers, int rounds)
 		}
 	});
 	for (auto &t : th) t.join();
-	printf("race: %d callers x %d rounds on a pool of %u, %d bad\n", callers, rounds, PackPool::get().size(), bad.load());
+	printf("race: %d callers x %d rounds on up to %u pools of %u, %d bad\n", callers, rounds, PackPool::max_pools(), PackPool::get().size(), bad.load());
+	return bad.load() ? 1 : 0;
+}
+
+/* `callers` threads each hold a lease while all of them are inside a job at the same time (a barrier inside the jobs): possible only
+ * if every caller got a pool of its own - with one shared pool the second caller would wait for the first one's job to end, which
+ * waits for the second to arrive: this test would hang (the harness bounds it). */
+static int
+overlap(int callers)
+{
+	std::atomic<int> inside{ 0 }, bad{ 0 };
+	std::vector<std::thread> th;
+	for (int c = 0; c < callers; c++) th.emplace_back([&] {
+		PackPool::Lease l = PackPool::lease();
+		std::vector<int> hits(8, 0);
+		l.run(8, [&](unsigned i) {
+			if (i == 0) { inside++; while (inside.load() < callers) std::this_thread::yield(); }
+			hits[i]++;
+		});
+		for (int h : hits) if (h != 1) bad++;
+	});
+	for (auto &t : th) t.join();
+	printf("overlap: %d callers inside their jobs at once on %u pools, %d bad\n", callers, PackPool::max_pools(), bad.load());
 	return bad.load() ? 1 : 0;
 }
 
@@ -108,7 +130,8 @@ main(int argc, char **argv)
 	if (argc > 1 && !strcmp(argv[1], "copy")) return copy_check();
 	if (argc > 1 && !strcmp(argv[1], "race")) return race(argc > 2 ? atoi(argv[2]) : 6, argc > 3 ? atoi(argv[3]) : 200);
 	if (argc > 1 && !strcmp(argv[1], "fork")) return fork_exit();
-	if (argc > 1 && !strcmp(argv[1], "cpus")) { printf("usable %u pool %u\n", PackPool::usable_cpus(), PackPool::get().size()); return 0; }
+	if (argc > 1 && !strcmp(argv[1], "cpus")) { printf("usable %u pool %u pools %u\n", PackPool::usable_cpus(), PackPool::get().size(), PackPool::max_pools()); return 0; }
+	if (argc > 1 && !strcmp(argv[1], "overlap")) return overlap(argc > 2 ? atoi(argv[2]) : 3);
 	fprintf(stderr, "usage: pool_test race [callers] [rounds] | fork | copy\n");
 	return 2;
 }

@@ -113,12 +113,27 @@ def test_pack_pool_is_sized_by_the_cpus_it_may_use(bins):
     want = min(x for x in (len(os.sched_getaffinity(0)), quota_cpus(), os.cpu_count()) if x)
     out = _run([bins["pool_asan"], "cpus"], timeout=60).stdout.split()
     assert int(out[1]) == want and int(out[3]) == min(12, want), (out, want)
+    assert int(out[5]) == max(1, min(8, want // min(12, want)))            # pools: as many as the usable CPUs have room for
     out = _run([bins["pool_asan"], "cpus"], timeout=60, env=dict(ENV, MDEMOD_PACK_THREADS="3")).stdout.split()
     assert int(out[3]) == min(3, want)
     if shutil.which("taskset") and len(os.sched_getaffinity(0)) >= 2:
         two = sorted(os.sched_getaffinity(0))[:2]
         out = _run(["taskset", "-c", ",".join(map(str, two)), bins["pool_asan"], "cpus"], timeout=60).stdout.split()
         assert int(out[1]) == min(2, want) and int(out[3]) == min(2, want), out
+
+
+def test_pack_pool_gives_concurrent_callers_pools_of_their_own(bins):
+    """ADVICE r05, second half: the pool was process-wide and one job at a time - one library context per GPU is one host thread,
+    so eight GPUs shared a single pack.  Callers that find a pool busy now get another one (up to usable CPUs / threads per pool;
+    here forced: 3 pools of 2 threads).  `overlap` needs three callers INSIDE their jobs at the same moment; under TSan, and the
+    race test on three pools."""
+    env = dict(ENV, MDEMOD_PACK_POOLS="3", MDEMOD_PACK_THREADS="2")
+    proc = _run([bins["pool_tsan"], "overlap", 3], timeout=120, env=env)
+    assert proc.returncode == 0 and b"on 3 pools, 0 bad" in proc.stdout, proc.stdout
+    proc = _run([bins["pool_tsan"], "race", 6, 150], timeout=300, env=env)
+    assert proc.returncode == 0 and b"up to 3 pools of 2, 0 bad" in proc.stdout, proc.stdout
+    proc = _run([bins["pool_asan"], "fork"], timeout=60, env=dict(env, ASAN_OPTIONS="detect_leaks=0"))     # (the child leaks on purpose: see the next test)
+    assert proc.returncode == 0, proc.stdout
 
 
 def test_pack_pool_forked_child_exits(bins):
