@@ -47,6 +47,7 @@ namespace {
 		if (e_ != hipSuccess) {                                                         \
 			mdm_note_error("%s failed: %s (%s:%d)", #expr,                           \
 			        hipGetErrorString(e_), __FILE__, __LINE__);                         \
+			(void)hipGetLastError();   /* reported: it must not be read again as the status of somebody's next launch */ \
 			return e_ == hipErrorOutOfMemory ? MDEMOD_ERR_NOMEM : MDEMOD_ERR_HIP;       \
 		}                                                                               \
 	} while (0)
@@ -98,6 +99,11 @@ wants_latency_kernel(const mdemod_ctx *ctx)
 int
 select_device(const mdemod_ctx *ctx)
 {
+	/* Every device entry begins here.  The launch wrappers report hipGetLastError() after their launch: an error some EARLIER call of
+	 * this thread left behind (the caller's own, another library's, a refused hipSetDevice) would come back as the status of a launch
+	 * that went through (r06: a context made right after mdemod_create had refused a device that does not exist failed in
+	 * mdemod_launch_reset with that device's error).  A launch's status is the launch's: what is pending is dropped first. */
+	(void)hipGetLastError();
 	HIP_TRY(hipSetDevice(ctx->params.device));
 	return MDEMOD_OK;
 }
@@ -230,11 +236,12 @@ mdemod_abi_version(void)
 int
 mdemod_init_device(int device)
 try { MDEMOD_API_ENTER
-	if (hipSetDevice(device) != hipSuccess) return MDEMOD_ERR_HIP;
-	if (hipFree(nullptr) != hipSuccess) return MDEMOD_ERR_HIP;             /* forces the context */
+	(void)hipGetLastError();                                               /* (see select_device) */
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(hipFree(nullptr));                                             /* forces the context */
 	/* ... and the code objects (loaded at the first launch of a process), on a stream of its own */
 	hipStream_t s = nullptr;
-	if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return MDEMOD_ERR_HIP;
+	HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
 	const bool ok = mdemod_launch_warm(s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
 	(void)hipStreamDestroy(s);
 	return ok ? MDEMOD_OK : MDEMOD_ERR_HIP;
@@ -299,9 +306,11 @@ mdemod_create(const mdemod_params *params, mdemod_ctx **out)
 
 #define CREATE_TRY(expr) do { rc = (expr); if (rc) { mdemod_destroy(ctx); return rc; } } while (0)
 	{
+		(void)hipGetLastError();                       /* (see select_device) */
 		hipError_t e = hipSetDevice(params->device);
 		if (e != hipSuccess) {
 			mdm_note_error("no usable HIP device %d: %s", params->device, hipGetErrorString(e));
+			(void)hipGetLastError();
 			delete ctx;
 			return MDEMOD_ERR_HIP;
 		}

@@ -51,6 +51,7 @@ namespace {
 		if (e_ != hipSuccess) {                                                                 \
 			mdm_note_error("%s failed: %s (%s:%d)", #expr,                                   \
 			        hipGetErrorString(e_), __FILE__, __LINE__);                                 \
+			(void)hipGetLastError();                                                            \
 			return e_ == hipErrorOutOfMemory ? MDEMOD_ERR_NOMEM : MDEMOD_ERR_HIP;               \
 		}                                                                                       \
 	} while (0)

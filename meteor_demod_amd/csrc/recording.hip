@@ -537,7 +537,7 @@ struct Ctx {                         /* owns a demodulator context */
 };
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
-#define HTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { mdm_note_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return e_ == hipErrorOutOfMemory ? MDEMOD_ERR_NOMEM : MDEMOD_ERR_HIP; } } while (0)
+#define HTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { mdm_note_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); (void)hipGetLastError(); return e_ == hipErrorOutOfMemory ? MDEMOD_ERR_NOMEM : MDEMOD_ERR_HIP; } } while (0)
 
 template <typename T>
 int
@@ -1123,7 +1123,7 @@ struct Stitcher {
 	 * (mdemod_estimate_clock) of the estimator's longest windows (2^18 samples: 5e-8 of the rate), side by side as well. */
 	int estimate_grid()
 	{
-		if (hipSetDevice(params->device) != hipSuccess) return MDEMOD_ERR_HIP;
+		(void)hipGetLastError(); HTRY(hipSetDevice(params->device));      /* (what an earlier call left pending is not this call's: demod_api.cpp select_device) */
 		struct OwnStream { hipStream_t s = nullptr; ~OwnStream() { if (s) (void)hipStreamDestroy(s); } } own;
 		{
 			int least = 0, greatest = 0;                          /* behind the head's launches in the queues */
@@ -1758,7 +1758,7 @@ try { MDEMOD_API_ENTER
 	auto mark = [&](const char *what) {
 		if (dbg) fprintf(stderr, "[recording host] %8.2f ms  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count() * 1e3, what);
 	};
-	if (hipSetDevice(params->device) != hipSuccess) return MDEMOD_ERR_HIP;
+	(void)hipGetLastError(); HTRY(hipSetDevice(params->device));      /* (what an earlier call left pending is not this call's: demod_api.cpp select_device) */
 	mark("device set");
 	const size_t sb = 2 * static_cast<size_t>(params->bps) / 8;
 	DevMem mem;

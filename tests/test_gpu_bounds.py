@@ -203,5 +203,14 @@ def test_failures_come_back_as_text_not_on_stderr(gpu_device, capfd):
         d.unpin_host(buf)
         d.status()
         assert _capi.last_error() == ""
+        # an error the CALLER's own HIP code left pending on this thread is not the status of the library's next launch (the launch
+        # wrappers read hipGetLastError() after their launch; r06: select_device drops what is pending first)
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipSetDevice(torch.cuda.device_count() + 7) != 0
+        x = synth.generate_device([synth.make_stream(5 + i, 230000, 72000) for i in range(4)], 6000)
+        soft = d.process(x)
+        torch.cuda.synchronize()
+        want = O.oracle_demod(DemodConfig(samplerate=230000), x[2].cpu().numpy())[0]
+        assert np.array_equal(soft[2, : len(want)].cpu().numpy(), want)
     out = capfd.readouterr()
     assert "meteor_demod_amd" not in out.err and "failed" not in out.err, out.err
