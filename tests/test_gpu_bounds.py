@@ -205,10 +205,12 @@ def test_failures_come_back_as_text_not_on_stderr(gpu_device, capfd):
         assert _capi.last_error() == ""
         # an error the CALLER's own HIP code left pending on this thread is not the status of the library's next launch (the launch
         # wrappers read hipGetLastError() after their launch; r06: select_device drops what is pending first)
-        hip = C.CDLL("libamdhip64.so")
-        assert hip.hipSetDevice(torch.cuda.device_count() + 7) != 0
         x = synth.generate_device([synth.make_stream(5 + i, 230000, 72000) for i in range(4)], 6000)
-        soft = d.process(x)
+        soft = torch.empty((4, d.max_symbols(6000), 2), dtype=torch.int8, device="cuda")
+        torch.cuda.synchronize()
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipSetDevice(torch.cuda.device_count() + 7) != 0         # (torch's own next call would raise on this pending error)
+        d.process(x, soft=soft)
         torch.cuda.synchronize()
         want = O.oracle_demod(DemodConfig(samplerate=230000), x[2].cpu().numpy())[0]
         assert np.array_equal(soft[2, : len(want)].cpu().numpy(), want)
