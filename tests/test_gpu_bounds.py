@@ -216,3 +216,38 @@ def test_failures_come_back_as_text_not_on_stderr(gpu_device, capfd):
         assert np.array_equal(soft[2, : len(want)].cpu().numpy(), want)
     out = capfd.readouterr()
     assert "meteor_demod_amd" not in out.err and "failed" not in out.err, out.err
+
+
+def test_a_context_the_device_has_no_room_for_and_indices_out_of_range(gpu_device, capfd):
+    """MDEMOD_ERR_NOMEM from mdemod_create (600 M streams: the history alone is 384 GB), with the failing hipMalloc named in
+    mdemod_last_error(), everything allocated before it given back (a normal context fits right afterwards and gives the oracle's
+    bytes); MDEMOD_ERR_RANGE for stream indices beyond the context from every per-stream entry; nothing printed."""
+    import torch
+    from meteor_demod_amd import _capi
+    lib = _capi.lib()
+    capfd.readouterr()
+    free0 = torch.cuda.mem_get_info()[0]
+    p = DemodConfig(samplerate=230000).to_c(600_000_000, 0)
+    ctx = C.c_void_p()
+    assert lib.mdemod_create(C.byref(p), C.byref(ctx)) == _capi.MDEMOD_ERR_NOMEM and not ctx.value
+    said = _capi.last_error()
+    assert "hipMalloc" in said and ("memory" in said.lower()), said
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)            # what had been allocated was given back
+    with Demodulator(DemodConfig(samplerate=230000), 8) as d:
+        x = synth.generate_device([synth.make_stream(50 + i, 230000, 72000) for i in range(8)], 5000)
+        soft = d.process(x)
+        torch.cuda.synchronize()
+        want = O.oracle_demod(DemodConfig(samplerate=230000), x[7].cpu().numpy())[0]
+        assert np.array_equal(soft[7, : len(want)].cpu().numpy(), want)
+        st = d.get_state(7)
+        for call in (lambda: d.get_state(8), lambda: d.set_state(8, st), lambda: d.status(4, 5), lambda: d.status(8, 1)):
+            with pytest.raises(_capi.MdemodError) as e:
+                call()
+            assert e.value.code == _capi.MDEMOD_ERR_RANGE, e.value
+        ev = (_capi.MdemodLockEvent * 4)() if hasattr(_capi, "MdemodLockEvent") else None
+        if ev is not None:
+            n = C.c_uint32()
+            assert lib.mdemod_get_lock_events(d._ctx, 8, ev, 4, C.byref(n)) == _capi.MDEMOD_ERR_RANGE
+        assert d.get_state(0).n_samples == 5000                             # the context is unharmed
+    out = capfd.readouterr()
+    assert "meteor_demod_amd" not in out.err, out.err
