@@ -247,7 +247,7 @@ def test_a_context_the_device_has_no_room_for_and_indices_out_of_range(gpu_devic
         ev = (_capi.MdemodLockEvent * 4)() if hasattr(_capi, "MdemodLockEvent") else None
         if ev is not None:
             n = C.c_uint32()
-            assert lib.mdemod_get_lock_events(d._ctx, 8, ev, 4, C.byref(n)) == _capi.MDEMOD_ERR_RANGE
+            assert lib.mdemod_get_lock_events(d._ctx, 8, ev, 4, C.byref(n), None) == _capi.MDEMOD_ERR_RANGE
         assert d.get_state(0).n_samples == 5000                             # the context is unharmed
     out = capfd.readouterr()
     assert "meteor_demod_amd" not in out.err, out.err
