@@ -29,6 +29,7 @@
  */
 #include <getopt.h>
 #include <math.h>
+#include <errno.h>
 #include <stdint.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -160,14 +161,27 @@ write_gated(struct stream_io *io, const int8_t *soft, uint32_t n, int64_t first_
 	}
 }
 
+/* The reference never looks at what fwrite / fclose return (main.c:314,321,274): a full disk ends in a short file and exit status 0.
+ * The status stays the reference's; the loss is said, once per file, on stderr. */
+static void
+close_output(struct stream_io *o)
+{
+	if (!o->out) return;
+	int failed = ferror(o->out);
+	if (o->out == stdout) failed |= fflush(stdout) != 0;
+	else failed |= fclose(o->out) != 0;
+	if (failed) fprintf(stderr, "%s: writing the soft symbols failed (%s): the output is incomplete\n", o->out_name ? o->out_name : "(stdout)", strerror(errno));
+	o->out = NULL;
+}
+
 /* error exits: whatever was written so far is flushed and closed */
 static void
 close_all(struct stream_io *io, int n)
 {
 	for (int i = 0; i < n; i++) {
-		if (io[i].out && io[i].out != stdout) fclose(io[i].out);
+		close_output(&io[i]);
 		if (io[i].in && io[i].in != stdin) fclose(io[i].in);
-		io[i].out = NULL; io[i].in = NULL;
+		io[i].in = NULL;
 	}
 }
 
@@ -324,9 +338,9 @@ tiled_one_file(struct worker *w, int f)
 	size_t tail = 2 * (size_t)io[f].ring_idx;                       /* main.c:321 */
 	if (tail > sizeof(io[f].ring)) tail = sizeof(io[f].ring);
 	fwrite(io[f].ring, 1, tail, io[f].out);
-	if (io[f].out != stdout) fclose(io[f].out);
+	close_output(&io[f]);
 	if (io[f].in != stdin) fclose(io[f].in);
-	io[f].out = NULL; io[f].in = NULL;
+	io[f].in = NULL;
 	free(data); free(soft_all);
 	if (timing)
 		fprintf(stderr, "%s: read %.0f ms, library call %.0f ms (pilot %.0f + tiles %.0f on the device), write %.0f ms\n", io[f].in_name,
@@ -492,8 +506,9 @@ run_exact(struct worker *w)
 		if (tail > sizeof(io[i].ring)) tail = sizeof(io[i].ring);
 		fwrite(io[i].ring, 1, tail, io[i].out);
 		io[i].bytes_out += io[i].ring_idx;
-		if (io[i].out != stdout) fclose(io[i].out);
+		close_output(&io[i]);
 		if (io[i].in != stdin) fclose(io[i].in);
+		io[i].in = NULL;
 	}
 	mdemod_destroy(ctx);                                                          /* demod_deinit: main.c:273 */
 	FREE_BLOCKS();
