@@ -251,3 +251,53 @@ def test_a_context_the_device_has_no_room_for_and_indices_out_of_range(gpu_devic
         assert d.get_state(0).n_samples == 5000                             # the context is unharmed
     out = capfd.readouterr()
     assert "meteor_demod_amd" not in out.err, out.err
+
+
+@pytest.mark.parametrize("pools", ["", "3"], ids=["default-pools", "3-pools-of-4"])
+def test_host_entry_from_concurrent_host_threads(gpu_device, pools):
+    """One library context per host thread (the C host's --devices workers; here three threads on one GPU), all inside
+    mdemod_process_host at once, staged and pinned rows alike: every thread gets byte for byte what it gets alone.  Run in a child
+    process, once with the pack pools as the host allows and once forced to three pools of four threads (r06: callers that find
+    the pool busy get one of their own)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    code = r'''
+import threading, numpy as np, torch
+from meteor_demod_amd import DemodConfig, Demodulator, synth
+cfg = DemodConfig(samplerate=230000)
+ns, n = 96, 60000                      # 23 MB of input per call: well above the pool's 1 MB threshold, several sub-blocks
+one = [synth.generate_host(synth.make_stream(700 + k, 230000, 72000, f0_hz=40.0 * k), n + ns) for k in range(3)]
+bufs = [np.stack([o[s: s + n] for s in range(ns)]) for o in one]
+def run(k, pin):
+    with Demodulator(cfg, ns) as d:
+        if pin:
+            d.pin_host(bufs[k])
+        a = d.process_host([bufs[k][s] for s in range(ns)])
+        b = d.process_host([bufs[k][s][: 20000 + 13 * s] for s in range(ns)])        # ragged, chained on the first call
+        return a, b
+alone = [run(k, False) for k in range(3)]
+for pin in (False, True):
+    out, err = [None] * 3, []
+    def work(k):
+        try:
+            out[k] = run(k, pin)
+        except Exception as e:
+            err.append((k, repr(e)))
+    for rounds in range(3):
+        th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not err, err
+        for k in range(3):
+            for x, y in zip(out[k][0] + out[k][1], alone[k][0] + alone[k][1]):
+                assert np.array_equal(x, y), (pin, rounds, k)
+print("OK")
+'''
+    env = dict(os.environ)
+    if pools:
+        env.update(MDEMOD_PACK_POOLS=pools, MDEMOD_PACK_THREADS="4")
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(root), env=env, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-2000:])
