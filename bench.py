@@ -100,7 +100,8 @@ def bound_block(cfg, tag: str, T: int, L: int, kernel_ms: float) -> dict:
         valu["ceiling_definition"] = ("pipe 100 % busy and the FIR at 2 packed instructions per tap and firing (no window padding: not reachable, the lanes of a wave "
                                       "sit ~3 slots apart and share one window), the other "
                                       f"{round(valu_per_firing - fir_now, 1)} VALU instructions per wave-firing as measured: {round(floor_cycles)} SIMD cycles of VALU pipe per "
-                                      f"wave-firing against the {round(pipe_cycles / simd_busy)} one takes now")
+                                      f"wave-firing against the {round(pipe_cycles / simd_busy)} one takes now; scaled from THIS run's kernel time, so it moves "
+                                      "with the box's sustained clock like `frac` does (250-269 GS/s across boxes: 0.183-0.197)")
         conv = mix.get("conversion (SDWA)")
         if conv and conv[0] > 100:
             valu["conversions_note"] = (f"{conv[0]:.0f} of the instructions are v_cvt_f32_i32_sdwa: the packed s16 window is converted at use, every sample "
