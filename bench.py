@@ -838,7 +838,17 @@ class Emitter:
             if self.done or self.rank != 0:
                 self.done = True
                 return
-            full = self.full
+            # a snapshot: from the watchdog or the signal thread the main thread may still be adding to the record
+            full = None
+            for _ in range(20):
+                try:
+                    full = json.loads(json.dumps(self.full, default=str))
+                    break
+                except RuntimeError:                 # "dictionary changed size during iteration"
+                    time.sleep(0.02)
+            if full is None:
+                full = {k: self.full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                                      "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "errors")}
             try:
                 EXTRAS_FILE.write_text(json.dumps(full, indent=1, default=str))
                 full["extras"] = EXTRAS_FILE.name + " (next to bench.py; also on stderr)"
