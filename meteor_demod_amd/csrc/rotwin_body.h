@@ -243,7 +243,7 @@ rotwin_demod(const DemodLaunch &L)
 	}
 
 	__syncthreads();                                       /* coefficient rows + LUT visible */
-#ifdef ROT_EXP_PHASE             /* experiment (r06, profiles/r06_kernels.md): the waves of a block selected by ROT_EXP_PHASE_MASK start ROT_EXP_PHASE x 64 cycles late -
+#ifdef ROT_EXP_PHASE             /* experiment (r06, NOTEBOOK R6.3): the waves of a block selected by ROT_EXP_PHASE_MASK start ROT_EXP_PHASE x 64 cycles late -
                                     do two waves of a SIMD that are out of step (one in its FIR while the other is in its scalar stage) fill each other's bubbles?
                                     Measured: no - offsets of 900 / 1 800 / 3 600 cycles on waves 4-7, odd waves or waves 2-3, 6-7: +-0.3 % on configs[1], -1 % on configs[2] (NOTEBOOK R6.3) */
 	if ((threadIdx.x >> 6) & ROT_EXP_PHASE_MASK) __builtin_amdgcn_s_sleep(ROT_EXP_PHASE);
