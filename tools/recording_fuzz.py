@@ -37,6 +37,13 @@ for ci in range(n_cases):
     if os.environ.get("FUZZ_SYMBOLS"):                     # e.g. 42e6,83e6: the 2 048-wave-tile grid of round 5
         lo_s, hi_s = (float(v) for v in os.environ["FUZZ_SYMBOLS"].split(","))
         n = int(rng.uniform(lo_s, hi_s) * osf)
+    # a ramp that walks the carrier out of the reference's own sweep range (+-fmax: 3.4 kHz QPSK 72k, 1.9 kHz OQPSK 80k) over the
+    # recording leaves nothing to compare with - the serial run loses lock for good (r06: FUZZ_SYMBOLS without FUZZ_RAMPS gave
+    # 40 Hz/s x 900 s and six "failures" that were the oracle's): the drift over the recording is kept within 1.2 kHz
+    drift_max = 1200.0
+    dur = n / samplerate
+    if abs(ramp) * dur > drift_max:
+        ramp = float(np.sign(ramp) * drift_max / dur)
     # s16 amplitude scaled down with the oversampling: at 1 MS/s an RMS of 6000 LSB drives the reference's AGC into a
     # 0 <-> 0.019 limit cycle (its step is absolute, agc.c:13-25), where no two runs agree on anything
     amp = {8: dict(rms=40.0, dc=(1.5, -1.0)), 16: dict(rms=float(rng.choice([1500.0, 6000.0])) * min(1.0, 3.2 / osf)),
