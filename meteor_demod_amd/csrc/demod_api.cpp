@@ -700,8 +700,14 @@ mdemod_copy_state(mdemod_ctx *dst, mdemod_ctx *src, void *hip_stream)
 try { MDEMOD_API_ENTER
 	if (!dst || !src) return MDEMOD_ERR_PARAM;
 	const mdemod_params &a = dst->params, &b = src->params;
+	/* the same layout (streams, sample format, history) - and the same meaning: a QPSK bank's state words are not an OQPSK bank's (the
+	 * rail of timing.c:43 lives in the flags), nor one filter's history another's */
 	if (a.n_streams != b.n_streams || a.bps != b.bps || a.device != b.device || dst->tab.use_rw != src->tab.use_rw ||
-	    dst->tab.c.hpad != src->tab.c.hpad) return MDEMOD_ERR_PARAM;
+	    dst->tab.c.hpad != src->tab.c.hpad || (a.oqpsk != 0) != (b.oqpsk != 0) || a.rrc_order != b.rrc_order || a.interp_factor != b.interp_factor) {
+		mdm_note_error("mdemod_copy_state: the two contexts differ in streams (%u / %u), sample format, device, modulation, -f or -O: a bank's state only fits a bank made from the same parameters",
+		               a.n_streams, b.n_streams);
+		return MDEMOD_ERR_PARAM;
+	}
 	int rc = select_device(dst);
 	if (rc) return rc;
 	hipStream_t st = static_cast<hipStream_t>(hip_stream);

@@ -301,3 +301,51 @@ print("OK")
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(root), env=env, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_misuse_comes_back_as_a_code_and_harms_nobody(gpu_device):
+    """Entries handed the wrong things: a bank's state into a bank of another size / modulation / filter, histories of the wrong
+    length, NULL contexts, a soft buffer that is too small, a row pitch below the symbol counts, seeds of the wrong size.  Every one
+    is a code (or the Python mirror's own refusal), and a neighbouring context - and the abused one after a reset - still gives the
+    oracle's bytes."""
+    import torch
+    from meteor_demod_amd import _capi
+    lib = _capi.lib()
+    C1 = DemodConfig(samplerate=230000)
+    C3 = DemodConfig(samplerate=230000, symrate=80000, oqpsk=True)
+    CF = DemodConfig(samplerate=230000, rrc_order=24)
+    x = synth.generate_device([synth.make_stream(5 + i, 230000, 72000) for i in range(8)], 6000)
+    want = [O.oracle_demod(C1, x[i].cpu().numpy())[0] for i in (0, 3, 7)]
+    with Demodulator(C1, 8) as a, Demodulator(C1, 4) as b, Demodulator(C3, 8) as c, Demodulator(CF, 8) as f, Demodulator(C1, 8) as twin:
+        a.process(x)
+        torch.cuda.synchronize()
+        for other in (b, c, f):
+            assert lib.mdemod_copy_state(other._ctx, a._ctx, None) == _capi.MDEMOD_ERR_PARAM
+            assert "mdemod_copy_state" in _capi.last_error()
+        assert lib.mdemod_copy_state(twin._ctx, a._ctx, None) == 0 and lib.mdemod_copy_state(a._ctx, a._ctx, None) == 0
+        assert lib.mdemod_get_status(None, 0, 1, None, None) == _capi.MDEMOD_ERR_PARAM
+        assert lib.mdemod_copy_state(None, a._ctx, None) == _capi.MDEMOD_ERR_PARAM
+        lib.mdemod_destroy(None)                                            # a no-op, like free(NULL)
+        h = a.get_history(0)
+        with pytest.raises((ValueError, _capi.MdemodError)):
+            a.set_history(0, h[:10])
+        with pytest.raises((ValueError, _capi.MdemodError)):
+            f.set_history(0, h)                                             # 65 taps' history into a 49-tap filter
+        small = torch.empty((8, 16, 2), dtype=torch.int8, device="cuda")
+        a.reset()
+        with pytest.raises((RuntimeError, ValueError)):
+            a.process(x, soft=small)                                        # MDEMOD_ERR_OVERFLOW (or refused by the mirror)
+        with pytest.raises((AssertionError, ValueError, _capi.MdemodError)):
+            a.rotate_carrier(torch.zeros(3, dtype=torch.int32, device="cuda"))
+        with pytest.raises((AssertionError, ValueError, _capi.MdemodError)):
+            a.set_clock_seeds(torch.zeros(3, dtype=torch.float32, device="cuda"))
+        a.reset()
+        s2 = a.process(x)
+        st = twin.process(x[:, :10])                                        # the twin took a's state after 6000 samples: it continues, untouched by the abuse
+        torch.cuda.synchronize()
+        for k, i in enumerate((0, 3, 7)):
+            assert np.array_equal(s2[i, : len(want[k])].cpu().numpy(), want[k]), i
+        assert twin.get_state(0).n_samples == 6010
+        counts = a.symbol_counts()
+        packed = a.compact(s2, 8)                                           # a pitch below the counts: rows are cut, nothing is written past them
+        assert packed.shape == (8, 8, 2) and torch.equal(packed[5], s2[5, :8]) and int(counts.min()) > 8
