@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define MDEMOD_ABI_VERSION 5    /* 5 (r06): + mdemod_last_error; the library no longer writes to stderr.  4 (r05): + mdemod_pin_host_buffer / mdemod_unpin_host_buffer; settings with a non-finite RRC tap refused */
+#define MDEMOD_ABI_VERSION 5    /* 5 (r06): + mdemod_last_error, + mdemod_fanin_peer; the library no longer writes to stderr.  4 (r05): + mdemod_pin_host_buffer / mdemod_unpin_host_buffer; settings with a non-finite RRC tap refused */
 
 /* Error codes (the reference surfaces none: demod_init returns void and drops
  * filter_init_rrc's status, demod.c:14).  Nothing in the library calls exit() or abort(), and no C++ exception leaves it: an
@@ -195,6 +195,16 @@ uint64_t mdemod_nominal_pitch(const mdemod_ctx *ctx, uint64_t n_samples);
  * RCCL fan-in of soft-symbol buffers (main.c:305-315 writes symbols back to back; the hard-bound pitch is a GPU artefact). */
 int  mdemod_compact_soft(mdemod_ctx *ctx, const int8_t *soft_dev, uint64_t soft_stride_symbols,
                          int8_t *out_dev, uint64_t out_pitch_symbols, void *hip_stream);
+/* The fan-in of soft-symbol buffers for a host that drives several GPUs from ONE process (host/meteor_demod_amd.c --devices: one worker
+ * thread and one context per GPU; the reference has one demodulator thread, main.c:218, and nothing to gather).  The symbols of src's LAST
+ * process call, compacted as by mdemod_compact_soft to rows of pitch_symbols, are written by src's GPU straight into memory of dst_device:
+ * rows first_row .. first_row + n_streams - 1 of dst_soft_dev, and - dst_counts_dev may be NULL - the per-stream symbol counts to
+ * dst_counts_dev[first_row ...].  The compaction kernel's own stores cross xGMI (peer access from src's device to dst_device is switched
+ * on at the first call; dst_device may be src's own, then this is mdemod_compact_soft plus the counts): no staging buffer, no second copy,
+ * no RCCL - that one serves the one-process-per-GPU layout (meteor_demod_amd.sharding.fanin_soft).  MDEMOD_ERR_HIP when the two devices have
+ * no peer access to each other.  Asynchronous on hip_stream, a stream of src's device; the caller orders it against the consumer on dst_device. */
+int  mdemod_fanin_peer(mdemod_ctx *src, const int8_t *soft_dev, uint64_t soft_stride_symbols, int dst_device,
+                       int8_t *dst_soft_dev, uint64_t pitch_symbols, uint64_t first_row, uint32_t *dst_counts_dev, void *hip_stream);
 
 /* ---- the hot path (replaces the main.c:303-306 loop body) ---------------- */
 

@@ -125,6 +125,7 @@ SIGNATURES = {
     "mdemod_copy_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdemod_nominal_pitch": (C.c_uint64, [C.c_void_p, C.c_uint64]),
     "mdemod_compact_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mdemod_fanin_peer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mdemod_carrier_window_samples": (C.c_uint32, [C.c_void_p, C.c_uint32]),
     "mdemod_estimate_carrier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -741,6 +741,35 @@ try { MDEMOD_API_ENTER
 	return MDEMOD_OK;
 } MDEMOD_API_CATCH
 
+int
+mdemod_fanin_peer(mdemod_ctx *src, const int8_t *soft_dev, uint64_t soft_stride_symbols, int dst_device,
+                  int8_t *dst_soft_dev, uint64_t pitch_symbols, uint64_t first_row, uint32_t *dst_counts_dev, void *hip_stream)
+try { MDEMOD_API_ENTER
+	if (!src || !soft_dev || !dst_soft_dev || (soft_stride_symbols & 7) || (pitch_symbols & 7) || dst_device < 0) return MDEMOD_ERR_PARAM;
+	int rc = select_device(src);
+	if (rc) return rc;
+	const int src_device = src->params.device;
+	if (dst_device != src_device) {
+		/* the compaction kernel runs on src's GPU and stores into dst's memory: the stores themselves cross xGMI */
+		int can = 0;
+		HIP_TRY(hipDeviceCanAccessPeer(&can, src_device, dst_device));
+		if (!can) {
+			mdm_note_error("mdemod_fanin_peer: device %d cannot reach the memory of device %d (no peer access between them)", src_device, dst_device);
+			return MDEMOD_ERR_HIP;
+		}
+		const hipError_t e = hipDeviceEnablePeerAccess(dst_device, 0);
+		if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+		else HIP_TRY(e);
+	}
+	hipStream_t st = static_cast<hipStream_t>(hip_stream);
+	const uint32_t n = src->params.n_streams;
+	HIP_TRY(mdemod_launch_compact_rows(soft_dev, soft_stride_symbols, dst_soft_dev + 2 * first_row * pitch_symbols, pitch_symbols,
+	                                   src->st.sym_this_call, n, st));
+	if (dst_counts_dev)
+		HIP_TRY(hipMemcpyPeerAsync(dst_counts_dev + first_row, dst_device, src->st.sym_this_call, src_device, sizeof(uint32_t) * n, st));
+	return MDEMOD_OK;
+} MDEMOD_API_CATCH
+
 const char *
 mdemod_kernel_name(const mdemod_ctx *ctx)
 {

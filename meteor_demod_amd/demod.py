@@ -151,6 +151,26 @@ class Demodulator:
                                             int(pitch), self._stream()), "mdemod_compact_soft")
         return out
 
+    def fanin_peer(self, soft, pitch: int, dst_soft, first_row: int, dst_counts=None) -> None:
+        """``mdemod_fanin_peer``: this context's last symbols, compacted to ``pitch``, written by THIS GPU into rows
+        ``first_row ...`` of ``dst_soft`` ([rows, pitch, 2] int8, on any GPU this one has peer access to - or its own) and the
+        symbol counts into ``dst_counts[first_row ...]`` (uint32 / int32 tensor on the same device as ``dst_soft``).  The fan-in
+        of a host with several GPUs in one process; asynchronous on this device's current stream."""
+        import torch
+        self._check_soft(soft)
+        if pitch % 8 or soft.shape[1] % 8:
+            raise ValueError("pitches must be multiples of 8 symbols")
+        if (not dst_soft.is_cuda or dst_soft.dtype != torch.int8 or dst_soft.dim() != 3 or dst_soft.shape[1] != pitch or dst_soft.shape[2] != 2
+                or not dst_soft.is_contiguous() or first_row < 0 or first_row + self.n_streams > dst_soft.shape[0]):
+            raise ValueError(f"dst_soft must be a contiguous int8 [rows >= {first_row + self.n_streams}, {pitch}, 2] tensor on a GPU")
+        if dst_counts is not None and (dst_counts.device != dst_soft.device or dst_counts.element_size() != 4 or dst_counts.dim() != 1
+                                       or dst_counts.numel() < first_row + self.n_streams or not dst_counts.is_contiguous()):
+            raise ValueError("dst_counts: a contiguous 32-bit tensor with a word per row, on dst_soft's device")
+        check(self._lib.mdemod_fanin_peer(self._ctx, C.c_void_p(soft.data_ptr()), soft.shape[1], int(dst_soft.device.index),
+                                          C.c_void_p(dst_soft.data_ptr()), int(pitch), int(first_row),
+                                          C.c_void_p(dst_counts.data_ptr()) if dst_counts is not None else None, self._stream()),
+              "mdemod_fanin_peer")
+
     # -- hot path -------------------------------------------------------------
     def process(self, iq, n_samples: int | None = None, soft=None):
         """Demodulate one block per stream from a device tensor.

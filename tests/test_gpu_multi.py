@@ -96,3 +96,50 @@ def test_bench_default_line_is_compact(gpu_device):
     full = json.loads((ROOT / "bench_extras.json").read_text())
     assert full["value"] == d["value"] and "other_configs" in full and "host_fed" in full
     assert "bench.py full record: {" in r.stderr
+
+
+def test_fanin_peer_gathers_the_rows_of_several_contexts(gpu_device):
+    """mdemod_fanin_peer - the fan-in of a host that drives several GPUs from one process (the C host's --devices layout): every
+    context's GPU writes its compacted rows and counts straight into ONE buffer.  Two contexts of uneven size; both on this box's
+    one GPU, the second on device 1 where there is one (then its stores cross xGMI).  The gathered rows are the oracle's bytes, the
+    counts the contexts' own, nothing lands outside the rows a context was given."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_py as O
+    from meteor_demod_amd import DemodConfig, Demodulator, synth, _capi
+    cfg = DemodConfig(samplerate=230000)
+    n, sizes = 9000, (5, 3)
+    devs = (0, 1 if torch.cuda.device_count() >= 2 else 0)
+    streams = [synth.make_stream(60 + i, 230000, 72000, f0_hz=70.0 * i, esn0_db=18.0) for i in range(sum(sizes))]
+    ctxs = [Demodulator(cfg, sizes[k], device=devs[k]) for k in range(2)]
+    try:
+        pitch = ctxs[0].nominal_pitch(n)
+        rows = sum(sizes)
+        CAN = 0x5A
+        big = torch.full((rows + 2, pitch, 2), CAN, dtype=torch.int8, device="cuda:0")     # one canary row either side
+        counts = torch.full((rows + 2,), 0x7FFFFFFF, dtype=torch.int32, device="cuda:0")
+        at = 0
+        for k, d in enumerate(ctxs):
+            with torch.cuda.device(devs[k]):
+                x = synth.generate_device(streams[at: at + sizes[k]], n, device=devs[k])
+                soft = d.process(x)
+                d.fanin_peer(soft, pitch, big, 1 + at, counts)
+                torch.cuda.synchronize(devs[k])
+            at += sizes[k]
+        got, cnt = big.cpu().numpy(), counts.cpu().numpy()
+        assert (got[0] == CAN).all() and (got[-1] == CAN).all() and cnt[0] == 0x7FFFFFFF and cnt[-1] == 0x7FFFFFFF
+        for i, st in enumerate(streams):
+            want = O.oracle_demod(cfg, synth.generate_host(st, n))[0]
+            assert cnt[1 + i] == want.shape[0] and np.array_equal(got[1 + i, : want.shape[0]], want), i
+        # refusals: a pitch that is not a multiple of 8, rows that do not fit, a device that is not there
+        with pytest.raises(ValueError):
+            ctxs[0].fanin_peer(soft if devs[1] == 0 else ctxs[0].process(synth.generate_device(streams[:5], n)), pitch, big, rows, counts)
+        lib = _capi.lib()
+        s0 = ctxs[0].process(synth.generate_device(streams[:5], n, device=0))
+        assert lib.mdemod_fanin_peer(ctxs[0]._ctx, s0.data_ptr(), s0.shape[1], 0, big.data_ptr(), pitch + 4, 1, None, None) == _capi.MDEMOD_ERR_PARAM
+        assert lib.mdemod_fanin_peer(ctxs[0]._ctx, s0.data_ptr(), s0.shape[1], torch.cuda.device_count() + 3, big.data_ptr(), pitch, 1, None, None) == _capi.MDEMOD_ERR_HIP
+        assert _capi.last_error() != ""
+    finally:
+        for d in ctxs:
+            d.close()

@@ -33,7 +33,7 @@ def test_header_symbols_are_all_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/meteor_demod_amd.h but not exported"
     # the drop-in boundary stays small: what replaces demod.h:29-50 and the five getters, the batch calls, one recording entry
-    assert len(names) <= 27, names            # (27th, r06: mdemod_last_error)
+    assert len(names) <= 28, names            # (r06: + mdemod_last_error, + mdemod_fanin_peer)
     # and the python binding table covers exactly the public header plus the internal one (stitcher primitives, self-tests)
     internal = _symbols_of(ROOT / "meteor_demod_amd" / "csrc" / "mdemod_internal_api.h")
     for n in internal:
