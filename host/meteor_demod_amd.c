@@ -168,9 +168,12 @@ close_output(struct stream_io *o)
 {
 	if (!o->out) return;
 	int failed = ferror(o->out);
+	errno = 0;
 	if (o->out == stdout) failed |= fflush(stdout) != 0;
 	else failed |= fclose(o->out) != 0;
-	if (failed) fprintf(stderr, "%s: writing the soft symbols failed (%s): the output is incomplete\n", o->out_name ? o->out_name : "(stdout)", strerror(errno));
+	const int why = errno;                                       /* (of the flush / close; an earlier fwrite's is long overwritten) */
+	if (failed) fprintf(stderr, "%s: writing the soft symbols failed (%s): the output is incomplete\n", o->out_name ? o->out_name : "(stdout)",
+	                    why ? strerror(why) : "a write was refused");
 	o->out = NULL;
 }
 
