@@ -740,6 +740,9 @@ def compact_line(full: dict) -> dict:
                        "kernel": _clip(r.get("kernel"), 80), "kernel_ms": r.get("kernel_ms"), **_pick(r, "kernel_ms_over_ranks"),
                        "algorithmic_bytes_per_sample": r.get("algorithmic_bytes_per_sample"),
                        "ceiling_hbm_frac": v.get("ceiling_hbm_frac"), **_pick(r, "profile_round"),
+                       # (scalars at this level too: a reader that keeps only the flat keys of `roofline` still sees what binds)
+                       "simd_valu_busy_frac": v.get("simd_valu_busy_frac"), "valu_per_wave_firing": v.get("valu_instructions_per_wave_firing"),
+                       **({"fir_packed_dynamic_per_firing": fir.get("dynamic"), "fir_packed_floor_per_firing": fir.get("floor")} if isinstance(fir, dict) and fir.get("dynamic") else {}),
                        "valu": {**_pick(v, "frac", "frac_of_measured", "simd_valu_busy_frac", "valu_instructions_per_wave_firing"),
                                 **({"fir_packed_per_firing": fir} if fir else {})}}
     c = full.get("cpu_baseline")
