@@ -208,8 +208,14 @@ def test_failures_come_back_as_text_not_on_stderr(gpu_device, capfd):
         x = synth.generate_device([synth.make_stream(5 + i, 230000, 72000) for i in range(4)], 6000)
         soft = torch.empty((4, d.max_symbols(6000), 2), dtype=torch.int8, device="cuda")
         torch.cuda.synchronize()
-        hip = C.CDLL("libamdhip64.so")
+        # THE runtime this process already runs on (torch's own copy of libamdhip64, which serves the library too: _capi.hip_runtime_first) -
+        # by the path it is mapped from; dlopen("libamdhip64.so") by name would bring the system's copy in as a SECOND runtime
+        # (r06: that is what this test did at first - it then proved nothing, and the process crashed at exit once in five runs)
+        mapped = sorted({line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64.so" in line})
+        assert len(mapped) == 1, mapped
+        hip = C.CDLL(mapped[0])
         assert hip.hipSetDevice(torch.cuda.device_count() + 7) != 0         # (torch's own next call would raise on this pending error)
+        assert hip.hipPeekAtLastError() != 0                                 # it IS pending in the runtime the library launches on
         d.process(x, soft=soft)
         torch.cuda.synchronize()
         want = O.oracle_demod(DemodConfig(samplerate=230000), x[2].cpu().numpy())[0]
