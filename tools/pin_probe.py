@@ -1,6 +1,7 @@
 import ctypes as C, numpy as np, torch
 torch.cuda.init()
-hip = C.CDLL("libamdhip64.so")
+# the runtime this process already runs on (torch's copy), by the path it is mapped from - by NAME the system's copy would come in as a second runtime
+hip = C.CDLL(sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64.so" in l})[0])
 class Attr(C.Structure):
     _fields_ = [("type", C.c_int), ("device", C.c_int), ("devicePointer", C.c_void_p), ("hostPointer", C.c_void_p), ("isManaged", C.c_int), ("allocationFlags", C.c_uint)]
 raw = np.zeros(1 << 24, dtype=np.uint8)
